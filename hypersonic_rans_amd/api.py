@@ -1,0 +1,301 @@
+"""ctypes binding of include/hsrans_hip.h.
+
+Mirrors the reference's codec interface (src/main.cpp:146-155): ``encode(bytes) -> stream`` and
+``decode(stream) -> bytes`` selected by container (raw / block_ / mt_), state count (32 / 64) and histogram bits
+(10..15) — the three things the reference encodes in its function names
+(``rANS32x64_16w_decode_scalar_11``, ``mt_rANS32x32_16w_decode_14`` …).  Failure (the reference's ``return 0``) raises
+``HsransError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+import torch  # first: pins the HIP runtime (libamdhip64.so.7) this process uses before our library is loaded
+
+RAW, BLOCK, MT = 0, 1, 2
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_sz, _vp, _i, _u32 = ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32
+
+
+class HsransError(RuntimeError):
+    pass
+
+
+class Hist(ctypes.Structure):
+    """reference hist_t (src/hist.h:16-20)"""
+    _fields_ = [("symbolCount", ctypes.c_uint16 * 256), ("cumul", ctypes.c_uint16 * 256)]
+
+
+class EncodeOpts(ctypes.Structure):
+    _fields_ = [("block_size", _u32), ("index_interval", _u32), ("plan_out", _vp), ("plan_capacity", _sz), ("plan_size", _sz)]
+
+
+class LaunchInfo(ctypes.Structure):
+    _fields_ = [(n, _u32) for n in ("grid", "block", "lds_bytes", "waves_per_block", "chains", "shared_table", "walk", "two_level")]
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "lib", "libhsrans_hip.so")
+
+
+_LIB = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Loads lib/libhsrans_hip.so.  Fails loudly when it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` (there is no fallback implementation)")
+    L = ctypes.CDLL(path)
+    L.hsrans_version.restype = ctypes.c_char_p
+    L.hsrans_capacity.restype = _sz
+    L.hsrans_capacity.argtypes = [_i, _i, _sz]
+    L.hsrans_make_hist.restype = None
+    L.hsrans_make_hist.argtypes = [ctypes.POINTER(Hist), _vp, _sz, _u32]
+    L.hsrans_encode.restype = _sz
+    L.hsrans_encode.argtypes = [_i, _i, _u32, _vp, _sz, _vp, _sz, ctypes.POINTER(Hist)]
+    L.hsrans_encode_ex.restype = _sz
+    L.hsrans_encode_ex.argtypes = [_i, _i, _u32, _vp, _sz, _vp, _sz, ctypes.POINTER(Hist), ctypes.POINTER(EncodeOpts)]
+    L.hsrans_plan_capacity.restype = _sz
+    L.hsrans_plan_capacity.argtypes = [_i, _i, _sz, _u32, _u32]
+    L.hsrans_plan_build.restype = _sz
+    L.hsrans_plan_build.argtypes = [_i, _i, _u32, _vp, _sz, _sz, _vp, _sz]
+    L.hsrans_plan_chain_count.restype = _u32
+    L.hsrans_plan_chain_count.argtypes = [_vp, _sz]
+    L.hsrans_plan_decoded_length.restype = ctypes.c_uint64
+    L.hsrans_plan_decoded_length.argtypes = [_vp, _sz]
+    L.hsrans_plan_slice.restype = _sz
+    L.hsrans_plan_slice.argtypes = [_vp, _sz, _u32, _u32, _vp, _sz]
+    L.hsrans_plan_chain_range.restype = _i
+    L.hsrans_plan_chain_range.argtypes = [_vp, _sz, _u32, _u32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    L.hsrans_ctx_create.restype = _i
+    L.hsrans_ctx_create.argtypes = [_i, ctypes.POINTER(_vp)]
+    L.hsrans_ctx_destroy.restype = None
+    L.hsrans_ctx_destroy.argtypes = [_vp]
+    L.hsrans_ctx_device_name.restype = ctypes.c_char_p
+    L.hsrans_ctx_device_name.argtypes = [_vp]
+    L.hsrans_decode_host.restype = _sz
+    L.hsrans_decode_host.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _vp, _sz, _vp, _sz]
+    L.hsrans_dplan_create.restype = _i
+    L.hsrans_dplan_create.argtypes = [_vp, _vp, _sz, ctypes.POINTER(_vp)]
+    L.hsrans_dplan_destroy.restype = None
+    L.hsrans_dplan_destroy.argtypes = [_vp]
+    L.hsrans_decode_device.restype = _i
+    L.hsrans_decode_device.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp]
+    L.hsrans_dplan_status.restype = _i
+    L.hsrans_dplan_status.argtypes = [_vp, _vp, _vp]
+    L.hsrans_dplan_launch_info.restype = _i
+    L.hsrans_dplan_launch_info.argtypes = [_vp, ctypes.POINTER(LaunchInfo)]
+    L.hsrans_index_build.restype = _sz
+    L.hsrans_index_build.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _u32, _vp, _sz]
+    _LIB = L
+    return L
+
+
+def _u8(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8) if not isinstance(a, (bytes, bytearray, memoryview)) else np.frombuffer(a, dtype=np.uint8)
+    return a
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(_vp)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# host-side format functions
+# ---------------------------------------------------------------------------------------------------------------------
+def capacity(container: int, states: int, n: int) -> int:
+    return load_library().hsrans_capacity(container, states, n)
+
+
+def make_hist(data, bits: int) -> Hist:
+    data = _u8(data)
+    h = Hist()
+    load_library().hsrans_make_hist(ctypes.byref(h), _p(data), data.size, bits)
+    return h
+
+
+def hist_from_counts(counts) -> Hist:
+    h = Hist()
+    run = 0
+    for k in range(256):
+        h.symbolCount[k] = int(counts[k])
+        h.cumul[k] = run & 0xFFFF
+        run += int(counts[k])
+    return h
+
+
+def encode(container: int, states: int, bits: int, data, hist: Hist | None = None, block_size: int = 0, index_interval: int = 0):
+    """Returns ``stream`` (np.uint8) or ``(stream, plan)`` when ``index_interval`` != 0."""
+    L = load_library()
+    data = _u8(data)
+    cap = L.hsrans_capacity(container, states, data.size)
+    out = np.zeros(cap, np.uint8)
+    hp = ctypes.byref(hist) if hist is not None else None
+    if index_interval == 0 and block_size == 0:
+        m = L.hsrans_encode(container, states, bits, _p(data), data.size, _p(out), cap, hp)
+        if m == 0:
+            raise HsransError("encode failed")
+        return out[:m].copy()
+    pcap = L.hsrans_plan_capacity(container, states, data.size, index_interval, block_size) if index_interval else 0
+    plan = np.zeros(max(pcap, 1), np.uint8)
+    opts = EncodeOpts(block_size, index_interval, plan.ctypes.data if index_interval else None, pcap, 0)
+    m = L.hsrans_encode_ex(container, states, bits, _p(data), data.size, _p(out), cap, hp, ctypes.byref(opts))
+    if m == 0:
+        raise HsransError("encode failed")
+    if index_interval == 0:
+        return out[:m].copy()
+    return out[:m].copy(), plan[:opts.plan_size].copy()
+
+
+def plan_build(container: int, states: int, bits: int, stream, out_capacity: int | None = None) -> np.ndarray:
+    L = load_library()
+    stream = _u8(stream)
+    if stream.size < 16:
+        raise HsransError("stream too short")
+    out_len = int(stream[:8].view(np.uint64)[0])
+    if out_capacity is None:
+        out_capacity = out_len
+    pcap = L.hsrans_plan_capacity(container, states, min(out_len, 1 << 40), 0, 0)
+    plan = np.zeros(pcap, np.uint8)
+    n = L.hsrans_plan_build(container, states, bits, _p(stream), stream.size, out_capacity, _p(plan), pcap)
+    if n == 0:
+        raise HsransError("malformed stream (plan_build returned 0)")
+    return plan[:n].copy()
+
+
+def plan_chain_count(plan) -> int:
+    plan = _u8(plan)
+    return load_library().hsrans_plan_chain_count(_p(plan), plan.size)
+
+
+def plan_decoded_length(plan) -> int:
+    plan = _u8(plan)
+    return load_library().hsrans_plan_decoded_length(_p(plan), plan.size)
+
+
+def plan_slice(plan, first: int, count: int) -> np.ndarray:
+    plan = _u8(plan)
+    out = np.zeros(plan.size, np.uint8)
+    n = load_library().hsrans_plan_slice(_p(plan), plan.size, first, count, _p(out), out.size)
+    if n == 0:
+        raise HsransError("plan_slice failed")
+    return out[:n].copy()
+
+
+def plan_chain_range(plan, first: int, count: int) -> tuple[int, int]:
+    plan = _u8(plan)
+    b, e = ctypes.c_uint64(), ctypes.c_uint64()
+    if load_library().hsrans_plan_chain_range(_p(plan), plan.size, first, count, ctypes.byref(b), ctypes.byref(e)) != 0:
+        raise HsransError("plan_chain_range failed")
+    return b.value, e.value
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU side
+# ---------------------------------------------------------------------------------------------------------------------
+class DevicePlan:
+    def __init__(self, ctx: "Context", handle):
+        self.ctx, self.handle = ctx, handle
+
+    def launch_info(self) -> dict:
+        info = LaunchInfo()
+        load_library().hsrans_dplan_launch_info(self.handle, ctypes.byref(info))
+        return {n: getattr(info, n) for n, _ in LaunchInfo._fields_}
+
+    def close(self):
+        if self.handle:
+            load_library().hsrans_dplan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """hsrans_ctx: one per GPU.  Raises if no gfx950 device is usable (there is no CPU decode path)."""
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        h = _vp()
+        rc = self.L.hsrans_ctx_create(device, ctypes.byref(h))
+        if rc != 0:
+            raise HsransError(f"hsrans_ctx_create(device={device}) failed with code {rc}: a gfx950 GPU is required")
+        self.handle = h
+        self.device = device
+
+    @property
+    def device_name(self) -> str:
+        return self.L.hsrans_ctx_device_name(self.handle).decode()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.hsrans_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host-pointer drop-in: decodeFunc(pInData, inLength, pOutData, outCapacity) ------------------------------
+    def decode_host(self, container: int, states: int, bits: int, stream, out_capacity: int, plan=None, in_length: int | None = None):
+        """Returns (returned_length, out) like the reference's decoders: returned_length == 0 means failure."""
+        stream = _u8(stream)
+        out = np.full(max(out_capacity, 1), 0xCC, np.uint8)
+        pp, pn = (None, 0)
+        if plan is not None:
+            plan = _u8(plan)
+            pp, pn = _p(plan), plan.size
+        r = self.L.hsrans_decode_host(self.handle, container, states, bits, _p(stream), stream.size if in_length is None else in_length, _p(out),
+                                      out_capacity, pp, pn)
+        return r, out[:out_capacity]
+
+    def decode(self, container: int, states: int, bits: int, stream, plan=None) -> np.ndarray:
+        stream = _u8(stream)
+        n = int(stream[:8].view(np.uint64)[0]) if stream.size >= 8 else 0
+        r, out = self.decode_host(container, states, bits, stream, n, plan)
+        if r == 0:
+            raise HsransError("decode failed (malformed stream or no device)")
+        return out[:r]
+
+    # -- device-resident path ------------------------------------------------------------------------------------
+    def make_device_plan(self, plan) -> DevicePlan:
+        plan = _u8(plan)
+        h = _vp()
+        rc = self.L.hsrans_dplan_create(self.handle, _p(plan), plan.size, ctypes.byref(h))
+        if rc != 0:
+            raise HsransError(f"hsrans_dplan_create failed with code {rc}")
+        return DevicePlan(self, h)
+
+    def decode_device(self, dplan: DevicePlan, d_stream: torch.Tensor, d_out: torch.Tensor, stream: torch.cuda.Stream | None = None,
+                      stream_length: int | None = None):
+        """Asynchronous launch on ``stream`` (default: torch's current stream).  Tensors are uint8, on this context's GPU."""
+        s = stream if stream is not None else torch.cuda.current_stream(d_stream.device)
+        rc = self.L.hsrans_decode_device(self.handle, dplan.handle, d_stream.data_ptr(), d_stream.numel() if stream_length is None else stream_length,
+                                         d_out.data_ptr(), d_out.numel(), ctypes.c_void_p(s.cuda_stream))
+        if rc != 0:
+            raise HsransError(f"hsrans_decode_device failed with code {rc}")
+
+    def status(self, dplan: DevicePlan, stream: torch.cuda.Stream | None = None) -> int:
+        s = stream if stream is not None else torch.cuda.current_stream()
+        return self.L.hsrans_dplan_status(self.handle, dplan.handle, ctypes.c_void_p(s.cuda_stream))
+
+    def index_build(self, container: int, states: int, bits: int, stream, index_interval: int) -> np.ndarray:
+        stream = _u8(stream)
+        out_len = int(stream[:8].view(np.uint64)[0])
+        pcap = self.L.hsrans_plan_capacity(container, states, out_len, index_interval, 0)
+        plan = np.zeros(pcap, np.uint8)
+        n = self.L.hsrans_index_build(self.handle, container, states, bits, _p(stream), stream.size, index_interval, _p(plan), pcap)
+        if n == 0:
+            raise HsransError("hsrans_index_build failed")
+        return plan[:n].copy()

@@ -1,0 +1,413 @@
+// C ABI of libhsrans_hip.so (declared in include/hsrans_hip.h).  Nothing here decodes on the CPU: every decode entry
+// ends in a launch of the gfx950 kernels in hsrans_kernels.hip and fails when no usable device exists.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/hsrans_hip.h"
+#include "hsrans_host.h"
+#include "hsrans_kernels.h"
+
+using namespace hsrans;
+
+struct hsrans_ctx
+{
+  int device = 0;
+  char name[256] = {};
+  std::mutex lock; // guards the staging buffers of the host-pointer entry
+  hipStream_t stream = nullptr;
+  uint8_t *d_in = nullptr;
+  size_t d_in_cap = 0;
+  uint8_t *d_out = nullptr;
+  size_t d_out_cap = 0;
+  uint8_t *d_plan = nullptr;
+  size_t d_plan_cap = 0;
+  uint32_t *d_status = nullptr;
+};
+
+struct hsrans_dplan
+{
+  hsrans_ctx *ctx = nullptr;
+  PlanHeader hdr{};
+  uint8_t *d_plan = nullptr;
+  uint32_t *d_status = nullptr;
+  LaunchInfo info{};
+};
+
+namespace
+{
+bool grow(uint8_t **p, size_t *cap, size_t need)
+{
+  if (need <= *cap)
+    return true;
+  if (*p)
+    (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  const size_t want = need + need / 8 + 4096;
+  if (hipMalloc((void **)p, want) != hipSuccess)
+    return false;
+  *cap = want;
+  return true;
+}
+
+bool read_header(const uint8_t *plan, size_t size, PlanHeader *h)
+{
+  if (plan == nullptr || size < sizeof(PlanHeader))
+    return false;
+  memcpy(h, plan, sizeof(PlanHeader));
+  return memcmp(h->magic, "HSRPLAN1", 8) == 0;
+}
+} // namespace
+
+extern "C"
+{
+
+const char *hsrans_version(void) { return "hsrans-hip 0.1 (gfx950)"; }
+
+// ---- host-side format functions ---------------------------------------------------------------------------------
+size_t hsrans_capacity(int container, int states, size_t input_size)
+{
+  if (!valid_codec(container, states, 10))
+    return 0;
+  return capacity(container, states, input_size);
+}
+
+void hsrans_make_hist(hsrans_hist *hist, const uint8_t *data, size_t size, uint32_t bits)
+{
+  if (hist && data && size && bits >= 10 && bits <= 15)
+    make_hist(hist, data, size, bits);
+}
+
+size_t hsrans_encode(int container, int states, uint32_t bits, const uint8_t *in, size_t length, uint8_t *out, size_t out_capacity, const hsrans_hist *hist)
+{
+  return encode(container, states, bits, in, length, out, out_capacity, hist, nullptr);
+}
+
+size_t hsrans_encode_ex(int container, int states, uint32_t bits, const uint8_t *in, size_t length, uint8_t *out, size_t out_capacity,
+                        const hsrans_hist *hist, hsrans_encode_opts *opts)
+{
+  if (opts)
+    opts->plan_size = 0;
+  return encode(container, states, bits, in, length, out, out_capacity, hist, opts);
+}
+
+size_t hsrans_plan_capacity(int container, int states, size_t decoded_size, uint32_t index_interval, uint32_t block_size)
+{
+  if (!valid_codec(container, states, 10))
+    return 0;
+  return plan_capacity(container, states, decoded_size, index_interval, block_size);
+}
+
+size_t hsrans_plan_build(int container, int states, uint32_t bits, const uint8_t *stream, size_t stream_length, size_t out_capacity, uint8_t *plan_out,
+                         size_t plan_capacity)
+{
+  if (plan_out == nullptr)
+    return 0;
+  return plan_build(container, states, bits, stream, stream_length, out_capacity, plan_out, plan_capacity);
+}
+
+uint32_t hsrans_plan_chain_count(const uint8_t *plan, size_t plan_size)
+{
+  PlanHeader h;
+  return read_header(plan, plan_size, &h) ? h.n_chains : 0;
+}
+
+uint64_t hsrans_plan_decoded_length(const uint8_t *plan, size_t plan_size)
+{
+  PlanHeader h;
+  return read_header(plan, plan_size, &h) ? h.decoded_len : 0;
+}
+
+size_t hsrans_plan_slice(const uint8_t *plan, size_t plan_size, uint32_t first_chain, uint32_t chain_count, uint8_t *out, size_t out_capacity)
+{
+  if (out == nullptr)
+    return 0;
+  return plan_slice(plan, plan_size, first_chain, chain_count, out, out_capacity);
+}
+
+int hsrans_plan_chain_range(const uint8_t *plan, size_t plan_size, uint32_t first_chain, uint32_t chain_count, uint64_t *begin, uint64_t *end)
+{
+  if (begin == nullptr || end == nullptr)
+    return HSRANS_E_ARG;
+  return plan_chain_range(plan, plan_size, first_chain, chain_count, begin, end) ? HSRANS_OK : HSRANS_E_FORMAT;
+}
+
+// ---- GPU side ---------------------------------------------------------------------------------------------------
+int hsrans_ctx_create(int device, hsrans_ctx **out_ctx)
+{
+  if (out_ctx == nullptr)
+    return HSRANS_E_ARG;
+  *out_ctx = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+    return HSRANS_E_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess)
+    return HSRANS_E_HIP;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+    return HSRANS_E_HIP;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) // the code object holds gfx950 ISA only
+    return HSRANS_E_NO_DEVICE;
+  hsrans_ctx *ctx = new (std::nothrow) hsrans_ctx;
+  if (ctx == nullptr)
+    return HSRANS_E_HIP;
+  ctx->device = device;
+  strncpy(ctx->name, prop.name, sizeof(ctx->name) - 1);
+  if (prepare_kernels() != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_status, 64) != hipSuccess)
+  {
+    hsrans_ctx_destroy(ctx);
+    return HSRANS_E_HIP;
+  }
+  *out_ctx = ctx;
+  return HSRANS_OK;
+}
+
+void hsrans_ctx_destroy(hsrans_ctx *ctx)
+{
+  if (ctx == nullptr)
+    return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream)
+    (void)hipStreamDestroy(ctx->stream);
+  if (ctx->d_in)
+    (void)hipFree(ctx->d_in);
+  if (ctx->d_out)
+    (void)hipFree(ctx->d_out);
+  if (ctx->d_plan)
+    (void)hipFree(ctx->d_plan);
+  if (ctx->d_status)
+    (void)hipFree(ctx->d_status);
+  delete ctx;
+}
+
+const char *hsrans_ctx_device_name(const hsrans_ctx *ctx) { return ctx ? ctx->name : ""; }
+
+size_t hsrans_decode_host(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out, size_t out_capacity,
+                          const uint8_t *plan, size_t plan_size)
+{
+  if (ctx == nullptr || in == nullptr || out == nullptr || !valid_codec(container, states, bits))
+    return 0;
+
+  std::vector<uint8_t> own_plan;
+  if (plan == nullptr)
+  {
+    // header-only peek to size the plan, then the real planner (which repeats the reference's entry checks)
+    if (in_length < 16)
+      return 0;
+    uint64_t out_len;
+    memcpy(&out_len, in, 8);
+    if (out_len > out_capacity)
+      return 0;
+    own_plan.resize(plan_capacity(container, states, (size_t)out_len, 0, 0));
+    const size_t n = plan_build(container, states, bits, in, in_length, out_capacity, own_plan.data(), own_plan.size());
+    if (n == 0)
+      return 0;
+    plan = own_plan.data();
+    plan_size = n;
+  }
+  PlanHeader h;
+  if (!read_header(plan, plan_size, &h) || (int)h.container != container || (int)h.states != states || h.bits != bits)
+    return 0;
+  if (!plan_validate(plan, plan_size, in_length, out_capacity))
+    return 0;
+
+  std::lock_guard<std::mutex> guard(ctx->lock);
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return 0;
+  const size_t in_pad = (in_length + 15) / 16 * 16;
+  if (!grow(&ctx->d_in, &ctx->d_in_cap, in_pad) || !grow(&ctx->d_out, &ctx->d_out_cap, (size_t)h.decoded_len + 16) ||
+      !grow(&ctx->d_plan, &ctx->d_plan_cap, plan_size))
+    return 0;
+  hipStream_t s = ctx->stream;
+  if (hipMemcpyAsync(ctx->d_in, in, in_length, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(ctx->d_plan, plan, plan_size, hipMemcpyHostToDevice, s) != hipSuccess || hipMemsetAsync(ctx->d_status, 0, 4, s) != hipSuccess)
+    return 0;
+  KParams kp{};
+  kp.stream = ctx->d_in;
+  kp.stream_len = in_length;
+  kp.out = ctx->d_out;
+  kp.out_cap = h.decoded_len;
+  kp.plan = ctx->d_plan;
+  kp.status = ctx->d_status;
+  if (launch_decode(kp, h, s, nullptr) != hipSuccess)
+    return 0;
+  uint32_t status = 0xFFFFFFFF;
+  if (hipMemcpyAsync(out, ctx->d_out, (size_t)h.decoded_len, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipMemcpyAsync(&status, ctx->d_status, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    return 0;
+  return status == 0 ? (size_t)h.decoded_len : 0;
+}
+
+int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, hsrans_dplan **out_dplan)
+{
+  if (ctx == nullptr || out_dplan == nullptr)
+    return HSRANS_E_ARG;
+  *out_dplan = nullptr;
+  PlanHeader h;
+  if (!read_header(plan, plan_size, &h) || !plan_validate(plan, plan_size, h.stream_len, h.decoded_len))
+    return HSRANS_E_FORMAT;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return HSRANS_E_HIP;
+  hsrans_dplan *d = new (std::nothrow) hsrans_dplan;
+  if (d == nullptr)
+    return HSRANS_E_HIP;
+  d->ctx = ctx;
+  d->hdr = h;
+  if (hipMalloc((void **)&d->d_plan, plan_size) != hipSuccess || hipMalloc((void **)&d->d_status, 64) != hipSuccess ||
+      hipMemcpy(d->d_plan, plan, plan_size, hipMemcpyHostToDevice) != hipSuccess || hipMemset(d->d_status, 0, 64) != hipSuccess)
+  {
+    hsrans_dplan_destroy(d);
+    return HSRANS_E_HIP;
+  }
+  *out_dplan = d;
+  return HSRANS_OK;
+}
+
+void hsrans_dplan_destroy(hsrans_dplan *d)
+{
+  if (d == nullptr)
+    return;
+  if (d->d_plan)
+    (void)hipFree(d->d_plan);
+  if (d->d_status)
+    (void)hipFree(d->d_status);
+  delete d;
+}
+
+int hsrans_decode_device(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity, void *hip_stream)
+{
+  if (ctx == nullptr || d == nullptr || d_stream == nullptr || d_out == nullptr)
+    return HSRANS_E_ARG;
+  if (((uintptr_t)d_stream & 15) != 0 || ((uintptr_t)d_out & 3) != 0)
+    return HSRANS_E_ARG;
+  if (stream_length < d->hdr.stream_len || out_capacity < d->hdr.decoded_len)
+    return HSRANS_E_FORMAT;
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (hipMemsetAsync(d->d_status, 0, 4, s) != hipSuccess)
+    return HSRANS_E_HIP;
+  KParams kp{};
+  kp.stream = (const uint8_t *)d_stream;
+  kp.stream_len = stream_length;
+  kp.out = (uint8_t *)d_out;
+  kp.out_cap = out_capacity;
+  kp.plan = d->d_plan;
+  kp.status = d->d_status;
+  return launch_decode(kp, d->hdr, s, &d->info) == hipSuccess ? HSRANS_OK : HSRANS_E_HIP;
+}
+
+int hsrans_dplan_status(hsrans_ctx *ctx, hsrans_dplan *d, void *hip_stream)
+{
+  if (ctx == nullptr || d == nullptr)
+    return HSRANS_E_ARG;
+  uint32_t status = 0xFFFFFFFF;
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (hipMemcpyAsync(&status, d->d_status, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    return HSRANS_E_HIP;
+  return status == 0 ? HSRANS_OK : HSRANS_E_DEVICE;
+}
+
+int hsrans_dplan_launch_info(const hsrans_dplan *d, hsrans_launch_info *info)
+{
+  if (d == nullptr || info == nullptr)
+    return HSRANS_E_ARG;
+  info->grid = d->info.grid;
+  info->block = d->info.block;
+  info->lds_bytes = d->info.lds_bytes;
+  info->waves_per_block = d->info.waves_per_block;
+  info->chains = d->info.chains;
+  info->shared_table = d->info.shared_table;
+  info->walk = d->info.walk;
+  info->two_level = d->info.two_level;
+  return HSRANS_OK;
+}
+
+size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint32_t index_interval,
+                          uint8_t *plan_out, size_t plan_capacity)
+{
+  // One sequential single-wavefront pass over a raw stream that records {states, read cursor} every
+  // `index_interval` groups; the checkpoints then become the chains of a parallel plan.
+  if (ctx == nullptr || in == nullptr || plan_out == nullptr || container != HSRANS_RAW || !valid_codec(container, states, bits))
+    return 0;
+  if (index_interval == 0 || index_interval % 4 != 0 || in_length < 16)
+    return 0;
+  uint64_t out_len;
+  memcpy(&out_len, in, 8);
+  std::vector<uint8_t> base(hsrans::plan_capacity(container, states, (size_t)out_len, 0, 0));
+  const size_t base_size = plan_build(container, states, bits, in, in_length, (size_t)out_len, base.data(), base.size());
+  if (base_size == 0)
+    return 0;
+  PlanHeader h;
+  memcpy(&h, base.data(), sizeof(h));
+  const Piece *p0 = (const Piece *)(base.data() + plan_pieces_off(h.n_chains));
+  const uint32_t *st0 = (const uint32_t *)(base.data() + plan_states_off(h.n_chains, h.n_pieces));
+  const uint32_t S = (uint32_t)states;
+  const uint64_t T = p0->steps;
+  const uint64_t n_ck = T / index_interval + 1; // slot 0 unused (= stream start)
+
+  std::lock_guard<std::mutex> guard(ctx->lock);
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return 0;
+  const size_t in_pad = (in_length + 15) / 16 * 16;
+  if (!grow(&ctx->d_in, &ctx->d_in_cap, in_pad) || !grow(&ctx->d_out, &ctx->d_out_cap, (size_t)out_len + 16) || !grow(&ctx->d_plan, &ctx->d_plan_cap, base_size))
+    return 0;
+  uint32_t *d_ck_states = nullptr;
+  uint64_t *d_ck_words = nullptr;
+  size_t result = 0;
+  hipStream_t s = ctx->stream;
+  std::vector<uint32_t> ck_states(n_ck * S);
+  std::vector<uint64_t> ck_words(n_ck);
+  uint32_t status = 0xFFFFFFFF;
+  do
+  {
+    if (hipMalloc((void **)&d_ck_states, n_ck * S * 4) != hipSuccess || hipMalloc((void **)&d_ck_words, n_ck * 8) != hipSuccess)
+      break;
+    if (hipMemcpyAsync(ctx->d_in, in, in_length, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(ctx->d_plan, base.data(), base_size, hipMemcpyHostToDevice, s) != hipSuccess || hipMemsetAsync(ctx->d_status, 0, 4, s) != hipSuccess)
+      break;
+    KParams kp{};
+    kp.stream = ctx->d_in;
+    kp.stream_len = in_length;
+    kp.out = ctx->d_out;
+    kp.out_cap = out_len;
+    kp.plan = ctx->d_plan;
+    kp.status = ctx->d_status;
+    kp.ckpt_states = d_ck_states;
+    kp.ckpt_words = d_ck_words;
+    kp.ckpt_interval = index_interval;
+    if (launch_decode(kp, h, s, nullptr) != hipSuccess)
+      break;
+    if (hipMemcpyAsync(ck_states.data(), d_ck_states, n_ck * S * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(ck_words.data(), d_ck_words, n_ck * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(&status, ctx->d_status, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      break;
+    if (status != 0)
+      break;
+    PlanBuilder pb;
+    pb.begin(container, states, bits, out_len, in_length);
+    pb.hdr.interval = index_interval;
+    for (uint64_t g = 0; g < T || g == 0; g += index_interval)
+    {
+      Piece p{};
+      p.hist_off = p0->hist_off;
+      p.out_off = g * S;
+      p.words_off = g == 0 ? p0->words_off : ck_words[g / index_interval];
+      const uint64_t steps = T - g < index_interval ? T - g : index_interval;
+      p.steps = (uint32_t)steps;
+      p.tail = (uint16_t)(g + steps == T ? p0->tail : 0);
+      pb.add_chain(p, g == 0 ? st0 : &ck_states[(g / index_interval) * S]);
+    }
+    result = pb.serialize(plan_out, plan_capacity);
+  } while (false);
+  if (d_ck_states)
+    (void)hipFree(d_ck_states);
+  if (d_ck_words)
+    (void)hipFree(d_ck_words);
+  return result;
+}
+
+} // extern "C"

@@ -1,0 +1,802 @@
+// Host-side format layer of the MI355X hypersonic-rANS decode path: capacity, histogram normalisation, the scalar
+// encoders that produce the reference's byte formats (and, optionally, a sidecar decode plan), and the planner that
+// turns a stream into the list of chains the GPU kernels execute.  No decoding happens on the host.
+//
+// Wire formats (little-endian, 2-byte aligned; SURVEY.md §8, reference files under /root/reference/src):
+//   raw    : u64 decodedLen | u64 streamLen | u16 count[256] | u32 state[S] | u16 words...   (rANS32x64_16w.cpp:137-165)
+//   block_ : u64 decodedLen | u64 streamLen | u32 state[S] | { u64 size ; u16 count[256] ; words }...   with bit 63 of
+//            size marking a single-symbol block (symbol in bits 54..61, no counts/words) (block_rANS32x64_16w_encode.cpp:256-373)
+//   mt_    : u64 decodedLen | u64 streamLen | { u64 size ; u64 skip ; u32 state[S] ; u16 count[256] ; words }...
+//            next header = &state[0] + 2*(skip+1) bytes                                  (mt_rANS32x64_16w_encode.cpp:266-298)
+#include "hsrans_host.h"
+
+#include <string.h>
+
+#include <algorithm>
+
+namespace hsrans
+{
+
+namespace
+{
+inline uint64_t rd64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+inline uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline uint16_t rd16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+inline void wr64(uint8_t *p, uint64_t v) { memcpy(p, &v, 8); }
+
+// lane -> byte position inside a group (reference table rANS32x64_16w.cpp:210-216, generated arithmetically)
+inline uint32_t lane_to_byte(uint32_t j) { return (j & 0x23u) | ((j & 0x04u) << 2) | ((j & 0x18u) >> 1); }
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// capacity  (rANS32x64_16w.cpp:10-13, block_rANS32x64_16w_encode.cpp:47-54, mt_rANS32x64_16w_encode.cpp:50-57)
+// ---------------------------------------------------------------------------------------------------------------
+size_t capacity(int container, int states, size_t n)
+{
+  const size_t S = (size_t)states;
+  const size_t header = 16 + 512 + 4 * S;
+  if (container == HSRANS_RAW)
+    return n + S + header;
+  const size_t blocks = (n + 32768) / 32768 + 1; // the reference sizes for 32 KiB blocks
+  const size_t per_block = container == HSRANS_BLOCK ? 8 + 512 : 16 + 512 + 4 * S;
+  return header + n + blocks * per_block;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// histogram normalisation: counts scaled to sum 2^bits, every present symbol keeps >= 1 (hist.cpp:16-215)
+// ---------------------------------------------------------------------------------------------------------------
+namespace
+{
+// textbook heap sort of symbol ids by ascending count; the tie order it produces decides which symbols are adjusted
+void heap_sift(uint8_t *ids, const uint16_t *key, int n, int root)
+{
+  while (true)
+  {
+    int big = root;
+    const int l = 2 * root + 1, r = l + 1;
+    if (l < n && key[ids[l]] > key[ids[big]])
+      big = l;
+    if (r < n && key[ids[r]] > key[ids[big]])
+      big = r;
+    if (big == root)
+      break;
+    std::swap(ids[root], ids[big]);
+    root = big;
+  }
+}
+
+int first_at_least_two(const uint8_t *ids, const uint16_t *key, int from, int fallback)
+{
+  for (int i = from; i < 256; i++)
+    if (key[ids[i]] >= 2)
+      return i;
+  return fallback;
+}
+} // namespace
+
+void normalize_counts(hsrans_hist *hist, const uint32_t raw[256], size_t data_bytes, uint32_t bits)
+{
+  const uint32_t target = 1u << bits;
+  uint16_t scaled[256];
+  uint64_t sum = 0;
+  const float factor = (float)target / (float)data_bytes;
+  for (int s = 0; s < 256; s++)
+  {
+    volatile float v = (float)raw[s] * factor; // single rounding per operation (no fused multiply-add)
+    uint16_t c = (uint16_t)(v + 0.5f);
+    if (c == 0 && raw[s] != 0)
+      c = 1;
+    scaled[s] = c;
+    sum += c;
+  }
+
+  if (sum != target)
+  {
+    uint8_t order[256];
+    for (int s = 0; s < 256; s++)
+      order[s] = (uint8_t)s;
+    for (int i = 127; i >= 0; i--)
+      heap_sift(order, scaled, 256, i);
+    for (int i = 255; i >= 0; i--)
+    {
+      std::swap(order[0], order[i]);
+      heap_sift(order, scaled, i, 0);
+    }
+
+    int lo = first_at_least_two(order, scaled, 0, 0);
+    while (sum > target) // take one from every symbol that can spare it, smallest first, as often as needed
+    {
+      bool done = false;
+      for (int i = lo; i < 256 && !done; i++)
+      {
+        scaled[order[i]]--;
+        done = --sum == target;
+      }
+      if (!done)
+        lo = first_at_least_two(order, scaled, lo, lo);
+    }
+    while (sum < target) // hand one to every symbol with count >= 2, largest first
+    {
+      bool done = false;
+      for (int i = 255; i >= lo && !done; i--)
+      {
+        scaled[order[i]]++;
+        done = ++sum == target;
+      }
+      if (!done)
+        lo = first_at_least_two(order, scaled, lo, lo);
+    }
+  }
+
+  uint32_t run = 0;
+  for (int s = 0; s < 256; s++)
+  {
+    hist->symbolCount[s] = scaled[s];
+    hist->cumul[s] = (uint16_t)run;
+    run += scaled[s];
+  }
+}
+
+void make_hist(hsrans_hist *hist, const uint8_t *data, size_t size, uint32_t bits)
+{
+  uint32_t raw[256] = {};
+  for (size_t i = 0; i < size; i++)
+    raw[data[i]]++;
+  normalize_counts(hist, raw, size, bits);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// scalar encoders.  rANS encodes backwards: symbols last-to-first, uint16 words written from the end of `out`
+// towards the front, then the finished payload is moved behind the header (rANS32x64_16w.cpp:34-166).
+// ---------------------------------------------------------------------------------------------------------------
+namespace
+{
+
+struct Checkpoint
+{
+  uint64_t group;          // absolute group index the decoder is about to start when it is in this state
+  uint64_t words_from_end; // bytes between the decoder's read cursor at that moment and the end of the stream
+  uint64_t hist_from_end;  // bytes between the active histogram's counts and the end of the stream (block_/mt_)
+  uint32_t states[64];
+};
+
+struct Coder
+{
+  uint32_t S, bits;
+  uint32_t x[64];
+  uint8_t *begin; // start of the output buffer
+  uint8_t *end;   // one past the last byte of the output buffer
+  uint8_t *p;     // lowest byte written so far
+  size_t reserve; // bytes the front header will need
+  bool overflow;  // the payload ran into the front of the buffer (histogram does not fit the data)
+  hsrans_hist hist;
+
+  void init(uint32_t S_, uint32_t bits_, uint8_t *out, size_t cap)
+  {
+    S = S_;
+    bits = bits_;
+    begin = out;
+    end = p = out + cap;
+    overflow = false;
+    for (uint32_t j = 0; j < 64; j++)
+      x[j] = kConsumePoint16;
+  }
+  size_t written() const { return (size_t)(end - p); }
+  void push_bytes(const void *src, size_t n)
+  {
+    if ((size_t)(p - begin) < n + reserve) // keep room for the front header
+    {
+      overflow = true;
+      return;
+    }
+    p -= n;
+    memcpy(p, src, n);
+  }
+  // encode the symbols of one group that exist (pos < n), highest lane first (rANS32x64_16w.cpp:65-99)
+  void put_group(const uint8_t *in, size_t group_start, size_t n)
+  {
+    const uint32_t emit_scale = (kConsumePoint16 >> bits) << 16;
+    for (int j = (int)S - 1; j >= 0; j--)
+    {
+      const size_t pos = group_start + lane_to_byte((uint32_t)j);
+      if (pos >= n)
+        continue;
+      const uint8_t sym = in[pos];
+      const uint32_t freq = hist.symbolCount[sym];
+      if (freq == 0) // symbol missing from the histogram: not encodable
+      {
+        overflow = true;
+        return;
+      }
+      uint32_t v = x[j];
+      if (v >= emit_scale * freq)
+      {
+        const uint16_t w = (uint16_t)v;
+        push_bytes(&w, 2);
+        v >>= 16;
+      }
+      x[j] = ((v / freq) << bits) + hist.cumul[sym] + (v % freq);
+    }
+  }
+};
+
+struct BlockSpan
+{
+  size_t begin, end;
+  bool single;
+};
+
+// fixed-size blocks; the last one absorbs a remainder shorter than S so that the reference decoders' loop condition
+// (`i < outLen - S + 1`, block_…decode.cpp:90) always reaches its header
+std::vector<BlockSpan> split_blocks(const uint8_t *in, size_t n, size_t block, uint32_t S)
+{
+  std::vector<BlockSpan> v;
+  size_t count = (n + block - 1) / block;
+  if (count > 1 && n - (count - 1) * block < S)
+    count--;
+  for (size_t b = 0; b < count; b++)
+  {
+    BlockSpan s;
+    s.begin = b * block;
+    s.end = b + 1 == count ? n : (b + 1) * block;
+    s.single = true;
+    for (size_t i = s.begin + 1; i < s.end && s.single; i++)
+      s.single = in[i] == in[s.begin];
+    v.push_back(s);
+  }
+  return v;
+}
+
+} // namespace
+
+size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_t n, uint8_t *out, size_t cap, const hsrans_hist *hist,
+              hsrans_encode_opts *opts)
+{
+  if (!valid_codec(container, states, bits) || n == 0 || in == nullptr || out == nullptr)
+    return 0;
+  if (cap < capacity(container, states, n))
+    return 0;
+  const uint32_t S = (uint32_t)states;
+  const uint32_t interval = opts ? opts->index_interval : 0;
+  if (interval != 0 && (interval % 4 != 0 || opts->plan_out == nullptr))
+    return 0;
+  size_t block = opts && opts->block_size ? opts->block_size : 65536;
+  if (block % 64 != 0)
+    return 0;
+
+  // decoder view of the whole file: T whole groups then `tail` symbols (rANS32x64_16w.cpp:220-250)
+  const uint64_t T = n + 1 >= S ? (n - S + 1 + S - 1) / S : 0;
+  const uint32_t tail = (uint32_t)(n - T * S);
+  const size_t last_group_start = (n - 1) / S * S;
+
+  const size_t header_bytes = container == HSRANS_RAW ? 16 + 512 + 4 * (size_t)S : container == HSRANS_BLOCK ? 16 + 4 * (size_t)S : 16;
+  Coder c;
+  c.init(S, bits, out, cap);
+  c.reserve = header_bytes;
+  std::vector<Checkpoint> cps; // recorded back to front
+
+  auto checkpoint = [&](uint64_t group, uint64_t hist_from_end) {
+    Checkpoint cp;
+    cp.group = group;
+    cp.words_from_end = c.written();
+    cp.hist_from_end = hist_from_end;
+    memcpy(cp.states, c.x, sizeof(cp.states));
+    cps.push_back(cp);
+  };
+
+  struct BlockMeta
+  {
+    BlockSpan span;
+    uint64_t header_from_end; // bytes from the block header to the end of the stream
+    uint64_t hist_from_end;
+    uint64_t words_from_end; // decoder cursor at block start
+    uint32_t start_states[64];
+  };
+  std::vector<BlockMeta> metas; // back to front
+
+  if (container == HSRANS_RAW)
+  {
+    hsrans_hist own;
+    if (hist == nullptr)
+    {
+      make_hist(&own, in, n, bits);
+      hist = &own;
+    }
+    c.hist = *hist;
+    for (size_t g = last_group_start / S + 1; g-- > 0;)
+    {
+      c.put_group(in, g * S, n);
+      if (interval != 0 && g != 0 && g % interval == 0 && g < T)
+        checkpoint(g, 0);
+    }
+  }
+  else
+  {
+    const std::vector<BlockSpan> spans = split_blocks(in, n, block, S);
+    uint64_t next_header_from_end = 0;
+    for (size_t b = spans.size(); b-- > 0;)
+    {
+      const BlockSpan &sp = spans[b];
+      BlockMeta m;
+      m.span = sp;
+      m.hist_from_end = 0;
+      const uint64_t size = sp.end - sp.begin;
+      if (sp.single)
+      {
+        // single-symbol block: only the marker word, states untouched (mt_rANS32x64_16w_encode.cpp:289-295)
+        const uint64_t marker = size | ((uint64_t)1 << 63) | ((uint64_t)in[sp.begin] << 54);
+        m.words_from_end = c.written();
+        memcpy(m.start_states, c.x, sizeof(m.start_states));
+        c.push_bytes(&marker, 8);
+      }
+      else
+      {
+        uint32_t raw[256] = {};
+        for (size_t i = sp.begin; i < sp.end; i++)
+          raw[in[i]]++;
+        normalize_counts(&c.hist, raw, size, bits);
+        const size_t g_first = sp.begin / S;
+        const size_t g_last = (sp.end - 1) / S; // inclusive; may be the file's partial group
+        // positions of this block's counts are only known once its words are written: checkpoints inside the
+        // block are patched below
+        const size_t cp_mark = cps.size();
+        for (size_t g = g_last + 1; g-- > g_first;)
+        {
+          c.put_group(in, g * S, n);
+          if (interval != 0 && g != g_first && (g - g_first) % interval == 0 && g < T)
+            checkpoint(g, 0);
+        }
+        m.words_from_end = c.written();
+        memcpy(m.start_states, c.x, sizeof(m.start_states));
+        c.push_bytes(c.hist.symbolCount, 512);
+        m.hist_from_end = c.written();
+        for (size_t k = cp_mark; k < cps.size(); k++)
+          cps[k].hist_from_end = m.hist_from_end;
+        if (container == HSRANS_MT)
+        {
+          c.push_bytes(c.x, 4 * (size_t)S);
+          const uint64_t states_from_end = c.written();
+          // skip: uint16 units from the state array to the next block header, minus one (mt_…decode.cpp:59)
+          const uint64_t skip = (states_from_end - next_header_from_end) / 2 - 1;
+          c.push_bytes(&skip, 8);
+        }
+        c.push_bytes(&size, 8);
+      }
+      m.header_from_end = c.written();
+      next_header_from_end = m.header_from_end;
+      metas.push_back(m);
+    }
+  }
+
+  if (c.overflow)
+    return 0;
+  // front header, then the payload moves up behind it
+  const size_t payload = c.written();
+  const size_t total = header_bytes + payload;
+  uint8_t *w = out;
+  wr64(w, (uint64_t)n);
+  wr64(w + 8, (uint64_t)total);
+  w += 16;
+  if (container == HSRANS_RAW)
+  {
+    memcpy(w, c.hist.symbolCount, 512);
+    w += 512;
+  }
+  if (container != HSRANS_MT)
+  {
+    memcpy(w, c.x, 4 * (size_t)S);
+    w += 4 * (size_t)S;
+  }
+  memmove(w, c.p, payload);
+
+  if (interval == 0)
+    return total;
+
+  // ---- sidecar plan: chains in output order ----
+  PlanBuilder pb;
+  pb.begin(container, states, bits, n, total);
+  pb.hdr.interval = interval;
+  auto rans_piece = [&](uint64_t g_begin, uint64_t g_end_excl, uint64_t words_from_end, uint64_t hist_off) {
+    // groups [g_begin, g_end_excl) of the file; only those below T are whole groups (the caller adds the tail)
+    Piece p{};
+    p.words_off = total - words_from_end;
+    p.out_off = g_begin * S;
+    p.hist_off = hist_off;
+    const uint64_t whole_end = std::min<uint64_t>(g_end_excl, T);
+    p.steps = (uint32_t)(whole_end > g_begin ? whole_end - g_begin : 0);
+    return p;
+  };
+  std::reverse(cps.begin(), cps.end()); // now ascending by group
+  if (container == HSRANS_RAW)
+  {
+    const uint64_t G_total = last_group_start / S + 1; // groups incl. a partial one
+    uint64_t g = 0;
+    size_t k = 0;
+    const uint32_t *st = c.x;
+    uint64_t wfe = payload;
+    while (true)
+    {
+      const uint64_t g_next = k < cps.size() ? cps[k].group : G_total;
+      Piece p = rans_piece(g, g_next, wfe, 16);
+      p.tail = (uint16_t)(g_next == G_total ? tail : 0);
+      p.flags = kPieceChainStart;
+      pb.add_chain(p, st);
+      if (k == cps.size())
+        break;
+      g = g_next;
+      st = cps[k].states;
+      wfe = cps[k].words_from_end;
+      k++;
+    }
+  }
+  else
+  {
+    size_t k = 0;
+    for (size_t b = metas.size(); b-- > 0;) // metas are back to front: walk in output order
+    {
+      const BlockMeta &m = metas[b];
+      if (m.span.single)
+      {
+        Piece p{};
+        p.out_off = m.span.begin;
+        p.hist_off = in[m.span.begin];
+        p.fill_len = m.span.end - m.span.begin;
+        p.flags = kPieceChainStart | kPieceFill;
+        pb.add_chain(p, nullptr);
+        continue;
+      }
+      const uint64_t g_first = m.span.begin / S;
+      const uint64_t g_last_excl = (m.span.end - 1) / S + 1;
+      const bool is_last_block = m.span.end == n;
+      uint64_t g = g_first;
+      const uint32_t *st = m.start_states;
+      uint64_t wfe = m.words_from_end;
+      while (true)
+      {
+        const bool more = k < cps.size() && cps[k].group < g_last_excl && cps[k].group > g_first;
+        const uint64_t g_next = more ? cps[k].group : g_last_excl;
+        Piece p = rans_piece(g, g_next, wfe, total - m.hist_from_end);
+        p.tail = (uint16_t)((!more && is_last_block) ? tail : 0);
+        p.flags = kPieceChainStart;
+        pb.add_chain(p, st);
+        if (!more)
+          break;
+        g = g_next;
+        st = cps[k].states;
+        wfe = cps[k].words_from_end;
+        k++;
+      }
+    }
+  }
+  const size_t need = pb.serialized_size();
+  if (need > opts->plan_capacity)
+    return 0;
+  opts->plan_size = pb.serialize(opts->plan_out, opts->plan_capacity);
+  return opts->plan_size ? total : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// plan builder / serialisation
+// ---------------------------------------------------------------------------------------------------------------
+void PlanBuilder::begin(int container, int states, uint32_t bits, uint64_t decoded_len, uint64_t stream_len)
+{
+  hdr = PlanHeader{};
+  memcpy(hdr.magic, "HSRPLAN1", 8);
+  hdr.container = (uint32_t)container;
+  hdr.states = (uint32_t)states;
+  hdr.bits = bits;
+  hdr.decoded_len = decoded_len;
+  hdr.stream_len = stream_len;
+  chain_first.clear();
+  pieces.clear();
+  this->states.clear();
+}
+
+void PlanBuilder::add_chain(const Piece &p, const uint32_t *st)
+{
+  Piece q = p;
+  q.flags |= kPieceChainStart;
+  q.state_idx = (uint32_t)chain_first.size();
+  chain_first.push_back((uint32_t)pieces.size());
+  pieces.push_back(q);
+  for (uint32_t j = 0; j < hdr.states; j++)
+    states.push_back(st ? st[j] : 0);
+}
+
+void PlanBuilder::add_piece(const Piece &p)
+{
+  Piece q = p;
+  q.flags &= (uint16_t)~kPieceChainStart;
+  pieces.push_back(q);
+}
+
+size_t PlanBuilder::serialized_size() const { return (size_t)plan_size((uint32_t)chain_first.size(), (uint32_t)pieces.size(), hdr.states); }
+
+size_t PlanBuilder::serialize(uint8_t *out, size_t cap)
+{
+  const uint32_t nc = (uint32_t)chain_first.size(), np = (uint32_t)pieces.size();
+  const size_t need = serialized_size();
+  if (need > cap)
+    return 0;
+  hdr.n_chains = nc;
+  hdr.n_pieces = np;
+  if (!(hdr.flags & kPlanWalk))
+  {
+    bool any = false, same = true;
+    uint64_t h = 0;
+    for (const Piece &p : pieces)
+    {
+      if (p.flags & kPieceFill)
+        continue;
+      if (!any)
+      {
+        h = p.hist_off;
+        any = true;
+      }
+      else if (p.hist_off != h)
+        same = false;
+    }
+    hdr.shared_hist = any && same ? 1 : 0;
+    hdr.aux_off = hdr.shared_hist ? h : 0;
+  }
+  memset(out, 0, need);
+  memcpy(out, &hdr, sizeof(hdr));
+  uint32_t *cf = (uint32_t *)(out + plan_chain_first_off());
+  for (uint32_t i = 0; i < nc; i++)
+    cf[i] = chain_first[i];
+  cf[nc] = np;
+  if (np)
+    memcpy(out + plan_pieces_off(nc), pieces.data(), (size_t)np * sizeof(Piece));
+  if (!states.empty())
+    memcpy(out + plan_states_off(nc, np), states.data(), states.size() * 4);
+  return need;
+}
+
+size_t plan_capacity(int container, int states, size_t decoded_size, uint32_t interval, uint32_t block_size)
+{
+  const size_t S = (size_t)states;
+  const size_t groups = decoded_size / S + 2;
+  size_t chains = 2;
+  if (container != HSRANS_RAW)
+  {
+    const size_t b = block_size ? block_size : 32768; // hsrans_plan_build on foreign streams: reference blocks are >= 32 KiB
+    chains += decoded_size / b + 2;
+  }
+  if (interval)
+    chains += groups / interval + 1;
+  return (size_t)plan_size((uint32_t)chains, (uint32_t)chains + 2, (uint32_t)S);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// planner: derive the chains from the stream alone
+// ---------------------------------------------------------------------------------------------------------------
+size_t plan_build(int container, int states, uint32_t bits, const uint8_t *in, size_t in_len, size_t out_cap, uint8_t *plan_out, size_t plan_cap)
+{
+  if (!valid_codec(container, states, bits) || in == nullptr)
+    return 0;
+  const uint32_t S = (uint32_t)states;
+  // the checks every reference decoder opens with (rANS32x64_16w.cpp:171-187, block_…decode.cpp:15-32, mt_…decode.cpp:15-32)
+  if (in_len < 16 + 4 * (size_t)S + 512)
+    return 0;
+  const uint64_t out_len = rd64(in);
+  if (out_len > out_cap)
+    return 0;
+  const uint64_t stored = rd64(in + 8);
+  if (in_len < stored)
+    return 0;
+  if (out_len == 0)
+    return 0;
+
+  PlanBuilder pb;
+  pb.begin(container, states, bits, out_len, in_len);
+  uint32_t st[64];
+
+  if (container == HSRANS_RAW)
+  {
+    // one chain: there is no restart point in the raw format (rANS32x64_16w.cpp:223-250)
+    for (uint32_t j = 0; j < S; j++)
+      st[j] = rd32(in + 528 + 4 * j);
+    Piece p{};
+    p.hist_off = 16;
+    p.words_off = 528 + 4 * (uint64_t)S;
+    p.out_off = 0;
+    const uint64_t T = out_len + 1 >= S ? (out_len - S + 1 + S - 1) / S : 0; // trip count of the loop at :223
+    if (T > 0xFFFFFFFFull)
+      return 0;
+    p.steps = (uint32_t)T;
+    p.tail = (uint16_t)(out_len - T * S);
+    pb.add_chain(p, st);
+    return pb.serialize(plan_out, plan_cap);
+  }
+
+  if (out_len + 1 < S) // `outLen - StateCount + 1` underflows in the reference (block_…decode.cpp:43): undefined there, rejected here
+    return 0;
+  const uint64_t whole = out_len - S + 1;
+
+  if (container == HSRANS_BLOCK)
+  {
+    // inline headers are only discoverable by decoding (block_…decode.cpp:47-90): the kernel walks them
+    for (uint32_t j = 0; j < S; j++)
+      st[j] = rd32(in + 16 + 4 * j);
+    pb.hdr.flags |= kPlanWalk;
+    pb.hdr.aux_off = 16 + 4 * (uint64_t)S;
+    Piece p{};
+    pb.add_chain(p, st);
+    return pb.serialize(plan_out, plan_cap);
+  }
+
+  // mt_: follow the header chain exactly like mt_rANS32x64_16w_decode.cpp:41-96
+  uint64_t pos = 16, i = 0;
+  bool last_is_rans = false;
+  do
+  {
+    if (pos + 8 > in_len)
+      return 0;
+    const uint64_t size_val = rd64(in + pos);
+    pos += 8;
+    if (size_val >> 63)
+    {
+      const uint64_t len = size_val & (((uint64_t)1 << 54) - 1);
+      if (len == 0 || len > out_len - std::min(i, out_len) || i > out_len)
+        return 0;
+      Piece p{};
+      p.flags = kPieceFill;
+      p.out_off = i;
+      p.fill_len = len;
+      p.hist_off = (size_val >> 54) & 0xFF;
+      pb.add_chain(p, nullptr);
+      i += len;
+      last_is_rans = false;
+    }
+    else
+    {
+      if (pos + 8 + 4 * (uint64_t)S + 512 > in_len)
+        return 0;
+      const uint64_t skip = rd64(in + pos);
+      pos += 8;
+      if (skip > in_len) // keeps `after` from wrapping
+        return 0;
+      const uint64_t after = pos + 2 * (skip + 1);
+      for (uint32_t j = 0; j < S; j++)
+        st[j] = rd32(in + pos + 4 * j);
+      pos += 4 * (uint64_t)S;
+      uint32_t sum = 0;
+      for (uint32_t s = 0; s < 256; s++)
+        sum += rd16(in + pos + 2 * s);
+      if (sum != (1u << bits)) // inplace_complete_hist, hist.cpp:308-324
+        return 0;
+      Piece p{};
+      p.hist_off = pos;
+      pos += 512;
+      p.words_off = pos;
+      p.out_off = i;
+      uint64_t end = i + size_val;
+      if (end > whole || end < i)
+        end = whole;
+      else if (end & (S - 1))
+        return 0;
+      const uint64_t steps = end > i ? (end - i + S - 1) / S : 0; // decode_section: `for (; i < end; i += S)`
+      if (steps > 0xFFFFFFFFull || size_val == 0)
+        return 0;
+      p.steps = (uint32_t)steps;
+      pb.add_chain(p, st);
+      i += steps * S;
+      last_is_rans = true;
+      if (i > whole)
+        break; // both outcomes of mt_…decode.cpp:86-92 leave the loop
+      pos = after;
+    }
+  } while (i < whole);
+
+  if (i < out_len)
+  {
+    // final partial group: decoded with the most recent histogram and the states the last block left behind
+    // (mt_…decode.cpp:99-130) == a tail on the last chain.  A trailing single-symbol block followed by a partial group
+    // cannot be produced by the encoder ("unreachable", :102) and is rejected.
+    if (!last_is_rans || out_len - i >= S)
+      return 0;
+    pb.pieces.back().tail = (uint16_t)(out_len - i);
+  }
+  return pb.serialize(plan_out, plan_cap);
+}
+
+bool plan_validate(const uint8_t *plan, size_t size, uint64_t stream_len, uint64_t out_cap)
+{
+  if (plan == nullptr || size < sizeof(PlanHeader))
+    return false;
+  PlanHeader h;
+  memcpy(&h, plan, sizeof(h));
+  if (memcmp(h.magic, "HSRPLAN1", 8) != 0 || !valid_codec((int)h.container, (int)h.states, h.bits))
+    return false;
+  if (h.n_chains == 0 || h.n_pieces < h.n_chains || plan_size(h.n_chains, h.n_pieces, h.states) != size)
+    return false;
+  if (h.decoded_len > out_cap || h.stream_len > stream_len)
+    return false;
+  const uint32_t *cf = (const uint32_t *)(plan + plan_chain_first_off());
+  const Piece *pc = (const Piece *)(plan + plan_pieces_off(h.n_chains));
+  if (cf[0] != 0 || cf[h.n_chains] != h.n_pieces)
+    return false;
+  for (uint32_t c = 0; c < h.n_chains; c++)
+  {
+    if (cf[c] >= cf[c + 1])
+      return false;
+    if (!(pc[cf[c]].flags & kPieceChainStart) || pc[cf[c]].state_idx >= h.n_chains)
+      return false;
+  }
+  if (h.flags & kPlanWalk)
+    return h.container == HSRANS_BLOCK && h.n_chains == 1 && h.aux_off + 8 <= stream_len && h.decoded_len + 1 >= h.states;
+  for (uint32_t i = 0; i < h.n_pieces; i++)
+  {
+    const Piece &p = pc[i];
+    if (p.flags & kPieceFill)
+    {
+      if (p.out_off > h.decoded_len || p.fill_len > h.decoded_len - p.out_off)
+        return false;
+      continue;
+    }
+    const uint64_t syms = (uint64_t)p.steps * h.states + p.tail;
+    if (p.tail >= h.states || p.out_off > h.decoded_len || syms > h.decoded_len - p.out_off)
+      return false;
+    if ((p.words_off & 1) || p.words_off > stream_len || p.hist_off + 512 > stream_len)
+      return false;
+    if ((p.out_off % 4) != 0)
+      return false;
+  }
+  if (h.shared_hist && h.aux_off + 512 > stream_len)
+    return false;
+  return true;
+}
+
+size_t plan_slice(const uint8_t *plan, size_t size, uint32_t first, uint32_t count, uint8_t *out, size_t cap)
+{
+  if (plan == nullptr || size < sizeof(PlanHeader))
+    return 0;
+  PlanHeader h;
+  memcpy(&h, plan, sizeof(h));
+  if (memcmp(h.magic, "HSRPLAN1", 8) != 0 || (h.flags & kPlanWalk) || count == 0 || first >= h.n_chains || count > h.n_chains - first)
+    return 0;
+  if (plan_size(h.n_chains, h.n_pieces, h.states) != size)
+    return 0;
+  const uint32_t *cf = (const uint32_t *)(plan + plan_chain_first_off());
+  const Piece *pc = (const Piece *)(plan + plan_pieces_off(h.n_chains));
+  const uint32_t *st = (const uint32_t *)(plan + plan_states_off(h.n_chains, h.n_pieces));
+  PlanBuilder pb;
+  pb.hdr = h;
+  for (uint32_t c = first; c < first + count; c++)
+  {
+    for (uint32_t i = cf[c]; i < cf[c + 1]; i++)
+    {
+      if (i == cf[c])
+        pb.add_chain(pc[i], st + (size_t)pc[i].state_idx * h.states);
+      else
+        pb.add_piece(pc[i]);
+    }
+  }
+  return pb.serialize(out, cap);
+}
+
+bool plan_chain_range(const uint8_t *plan, size_t size, uint32_t first, uint32_t count, uint64_t *begin, uint64_t *end)
+{
+  if (plan == nullptr || size < sizeof(PlanHeader))
+    return false;
+  PlanHeader h;
+  memcpy(&h, plan, sizeof(h));
+  if (memcmp(h.magic, "HSRPLAN1", 8) != 0 || (h.flags & kPlanWalk) || count == 0 || first >= h.n_chains || count > h.n_chains - first)
+    return false;
+  if (plan_size(h.n_chains, h.n_pieces, h.states) != size)
+    return false;
+  const uint32_t *cf = (const uint32_t *)(plan + plan_chain_first_off());
+  const Piece *pc = (const Piece *)(plan + plan_pieces_off(h.n_chains));
+  uint64_t lo = ~(uint64_t)0, hi = 0;
+  for (uint32_t i = cf[first]; i < cf[first + count]; i++)
+  {
+    const uint64_t len = (pc[i].flags & kPieceFill) ? pc[i].fill_len : (uint64_t)pc[i].steps * h.states + pc[i].tail;
+    lo = std::min(lo, pc[i].out_off);
+    hi = std::max(hi, pc[i].out_off + len);
+  }
+  *begin = lo;
+  *end = hi;
+  return true;
+}
+
+} // namespace hsrans

@@ -1,0 +1,56 @@
+// Host-side format layer: histogram normalisation, scalar encoders and the decode planner.
+// The C ABI in include/hsrans_hip.h is a thin veneer over these.
+#ifndef HSRANS_HOST_H
+#define HSRANS_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/hsrans_hip.h"
+#include "hsrans_plan.h"
+
+namespace hsrans
+{
+
+constexpr uint32_t kConsumePoint16 = 1u << 15; // reference rans.h:8
+
+inline bool valid_codec(int container, int states, uint32_t bits)
+{
+  return container >= HSRANS_RAW && container <= HSRANS_MT && (states == 32 || states == 64) && bits >= 10 && bits <= 15;
+}
+
+size_t capacity(int container, int states, size_t n);
+void make_hist(hsrans_hist *hist, const uint8_t *data, size_t size, uint32_t bits);
+void normalize_counts(hsrans_hist *hist, const uint32_t raw[256], size_t data_bytes, uint32_t bits);
+
+size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_t n, uint8_t *out, size_t cap, const hsrans_hist *hist,
+              hsrans_encode_opts *opts);
+
+// in-memory plan under construction
+struct PlanBuilder
+{
+  PlanHeader hdr{};
+  std::vector<uint32_t> chain_first; // n_chains entries while building (+1 sentinel on serialise)
+  std::vector<Piece> pieces;
+  std::vector<uint32_t> states; // n_chains * S
+
+  void begin(int container, int states, uint32_t bits, uint64_t decoded_len, uint64_t stream_len);
+  // starts a new chain whose first piece is `p` with start states `st` (S values; may be null for fills)
+  void add_chain(const Piece &p, const uint32_t *st);
+  void add_piece(const Piece &p); // continuation piece of the current chain
+  size_t serialized_size() const;
+  size_t serialize(uint8_t *out, size_t cap); // fills shared_hist / aux_off, returns bytes or 0
+};
+
+// plan derived from the stream alone (mirrors the control flow of the reference decoders; see hsrans_host.cpp)
+size_t plan_build(int container, int states, uint32_t bits, const uint8_t *stream, size_t stream_len, size_t out_cap, uint8_t *plan_out, size_t plan_cap);
+bool plan_validate(const uint8_t *plan, size_t plan_size, uint64_t stream_len, uint64_t out_cap);
+size_t plan_slice(const uint8_t *plan, size_t plan_size, uint32_t first, uint32_t count, uint8_t *out, size_t cap);
+bool plan_chain_range(const uint8_t *plan, size_t plan_size, uint32_t first, uint32_t count, uint64_t *begin, uint64_t *end);
+size_t plan_capacity(int container, int states, size_t decoded_size, uint32_t interval, uint32_t block_size);
+
+} // namespace hsrans
+
+#endif // HSRANS_HOST_H

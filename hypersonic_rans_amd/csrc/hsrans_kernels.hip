@@ -1,0 +1,589 @@
+// gfx950 (MI355X, CDNA4) kernels for the hypersonic-rANS 32-bit-state / 16-bit-word decode path.
+//
+// What is computed (reference: /root/reference/src, scalar form rANS32x64_16w.cpp:223-250 = block_codec64.h:182-213):
+//   for every group of S symbols, for state j = 0..S-1 in order:
+//       slot = x_j & (2^bits - 1);  sym = cumulInv[slot];  out[i + idx2idx[j]] = sym;
+//       x_j  = (x_j >> bits) * freq[sym] + slot - cumul[sym];
+//       if (x_j < 2^15) x_j = (x_j << 16) | *readHead++;
+//
+// How it is mapped to a wave64 (one wavefront = one chain of the decode plan, hsrans_plan.h):
+//   * lane j owns state j.  All S table steps happen at once; the only cross-lane dependency is the read cursor:
+//     `readHead++` in ascending j  ==  lane j reads word[cur + popcount(renorm_mask & lanes_below_j)], i.e.
+//     v_cmp -> SGPR-pair mask, v_mbcnt_lo/hi for the lane's rank, s_bcnt1 to advance the (scalar) cursor.
+//   * decode table lives in LDS.  bits <= 12: one uint32 per slot = sym | (freq-1) << 8 | (slot-cumul) << 20
+//     (freq-1 so that freq == 4096 fits — the reference's own packed table cannot, hist.cpp:304).
+//     bits >= 13: uint8 sym[2^bits] + uint32 {freq | cumul << 16}[256] (two dependent LDS reads, as the reference's
+//     hist_dec2_t path, hist.h:42-47).  The table is built in-kernel from the 256 uint16 counts in the stream.
+//   * the uint16 stream is staged through a 2 KiB LDS ring per wave, refilled 1 KiB at a time by one coalesced,
+//     bounds-checked buffer_load_dwordx4 per lane that is issued ~25 groups before it is needed.
+//   * idx2idx maps 4 consecutive lanes to 4 consecutive output bytes (it is the bit permutation
+//     j -> (j&0x23)|((j&4)<<2)|((j&0x18)>>1)), so a quad assembles one output dword with two DPP quad_perm ORs;
+//     four groups are accumulated so that every lane stores one dword and the wave writes 4*S contiguous bytes.
+//   * no MFMA: this is integer gather work; the roofline that bounds it is HBM (compressed bytes in + decoded bytes out).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hsrans_kernels.h"
+#include "hsrans_plan.h"
+
+namespace hsrans
+{
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t kRingBytes = 2048;  // per wave: two 1 KiB chunks
+constexpr uint32_t kChunkBytes = 1024; // 64 lanes x 16 B
+constexpr uint32_t kChunkWordsLog2 = 9;
+constexpr uint32_t kConsume = 1u << 15; // rans.h:8 DecodeConsumePoint16
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v)
+{
+  return (uint64_t)uni((uint32_t)v) | ((uint64_t)uni((uint32_t)(v >> 32)) << 32);
+}
+
+// idx2idx as arithmetic (rANS32x64_16w.cpp:210-216; the 32-state table rANS32x32_16w.cpp:203 is its first half)
+__device__ __forceinline__ uint32_t lane_to_byte(uint32_t j) { return (j & 0x23u) | ((j & 0x04u) << 2) | ((j & 0x18u) >> 1); }
+
+struct WaveCtx
+{
+  const uint8_t *stream;
+  uint64_t stream_len;
+  uint8_t *out;
+  uint64_t out_cap;
+  uint32_t *status;
+  uint32_t bits, S, lane;
+  uint8_t *ring;    // LDS, kRingBytes
+  uint8_t *table;   // LDS
+  uint16_t *scratch; // LDS, >= 1028 B, only live during table builds (aliases a ring)
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// stream ring
+// ---------------------------------------------------------------------------------------------------------------
+struct Ring
+{
+  __amdgpu_buffer_rsrc_t rs;
+  uint64_t base; // absolute byte offset in the stream of word index 0
+  uint32_t k;    // ring holds chunks k and k+1; `pend` holds chunk k+2
+  uint32_t cur;  // next word to read, counted from `base` (wave-uniform)
+  u32x4 pend;
+};
+
+__device__ __forceinline__ u32x4 ring_load(const Ring &r, uint32_t chunk, uint32_t lane)
+{
+  return __builtin_amdgcn_raw_buffer_load_b128(r.rs, chunk * kChunkBytes + lane * 16, 0, 0);
+}
+
+__device__ __forceinline__ void ring_init(Ring &r, const WaveCtx &c, uint64_t pos)
+{
+  pos = uni64(pos);
+  const uint64_t a0 = pos & ~(uint64_t)15;
+  // range in whole 16-byte lanes: a dwordx4 that straddles num_records is dropped as a whole, and a0 is 16-aligned
+  // inside a 16-aligned allocation, so rounding up never leaves the page the last stream byte is on
+  const uint64_t left = a0 < c.stream_len ? (c.stream_len - a0 + 15) & ~(uint64_t)15 : 0;
+  r.rs =__builtin_amdgcn_make_buffer_rsrc((void *)(c.stream + a0), 0, (uint32_t)(left > 0xFFFFFFFFull ? 0xFFFFFFFFull : left), 0x00020000);
+  r.base = a0;
+  r.cur = (uint32_t)(pos - a0) >> 1;
+  r.k = 0;
+  const u32x4 c0 = ring_load(r, 0, c.lane);
+  const u32x4 c1 = ring_load(r, 1, c.lane);
+  r.pend = ring_load(r, 2, c.lane);
+  *(u32x4 *)(c.ring + c.lane * 16) = c0;
+  *(u32x4 *)(c.ring + kChunkBytes + c.lane * 16) = c1;
+}
+
+// call at least once per 256 consumed words
+__device__ __forceinline__ void ring_advance(Ring &r, const WaveCtx &c)
+{
+  if ((r.cur >> kChunkWordsLog2) > r.k)
+  {
+    *(u32x4 *)(c.ring + (r.k & 1) * kChunkBytes + c.lane * 16) = r.pend; // chunk k+2 replaces chunk k
+    r.k++;
+    r.pend = ring_load(r, r.k + 2, c.lane);
+  }
+}
+
+__device__ __forceinline__ uint64_t ring_pos(const Ring &r) { return r.base + (uint64_t)r.cur * 2; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// decode table build (hist.cpp:291-306 make_dec_pack_hist, :356-384 inplace_make_hist_dec2, :308-324 the sum check)
+// `tid`/`nthreads` = the threads that share this table (one wave, or the whole workgroup); SYNC() orders their LDS traffic.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool TWO_LEVEL, bool BLOCK_SYNC>
+__device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, uint32_t nthreads)
+{
+  auto sync = [&]() {
+    if (BLOCK_SYNC)
+      __syncthreads();
+    else
+    {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  };
+  uint16_t *cnt = c.scratch;       // [256]
+  uint16_t *cum = c.scratch + 256; // [257]
+  const uint32_t total = 1u << c.bits;
+
+  sync(); // scratch aliases a ring: everyone must be done with it
+  const bool in_range = hist_off + 512 <= c.stream_len;
+  for (uint32_t s = tid; s < 256; s += nthreads)
+    cnt[s] = in_range ? *(const uint16_t *)(c.stream + hist_off + 2 * s) : (uint16_t)0;
+  sync();
+  if (tid < 64)
+  {
+    const uint32_t c0 = cnt[4 * tid], c1 = cnt[4 * tid + 1], c2 = cnt[4 * tid + 2], c3 = cnt[4 * tid + 3];
+    const uint32_t mine = c0 + c1 + c2 + c3;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      const uint32_t up = __shfl_up(incl, d, 64);
+      if (tid >= (uint32_t)d)
+        incl += up;
+    }
+    const uint32_t excl = incl - mine;
+    cum[4 * tid] = (uint16_t)excl;
+    cum[4 * tid + 1] = (uint16_t)(excl + c0);
+    cum[4 * tid + 2] = (uint16_t)(excl + c0 + c1);
+    cum[4 * tid + 3] = (uint16_t)(excl + c0 + c1 + c2);
+    if (tid == 63)
+    {
+      cum[256] = (uint16_t)(incl > 0xFFFF ? 0xFFFF : incl); // > 2^15 is invalid anyway; saturate instead of wrapping
+    }
+  }
+  sync();
+  if ((uint32_t)cum[256] != total) // uint32 sum, as inplace_complete_hist (hist.cpp:310)
+  {
+    if (tid == 0)
+      atomicOr(c.status, kStatusBadHist);
+    return false;
+  }
+
+  // slot -> symbol: the largest s with cum[s] <= slot (zero-count symbols share cum with their successor and lose
+  // the tie; trailing zero-count symbols sit at cum == total and are never hit) == hist.cpp:343-351
+  if (!TWO_LEVEL)
+  {
+    uint32_t *tab = (uint32_t *)c.table;
+    for (uint32_t slot = tid; slot < total; slot += nthreads)
+    {
+      uint32_t s = 0;
+#pragma unroll
+      for (uint32_t step = 128; step >= 1; step >>= 1)
+        s += ((uint32_t)cum[s + step] <= slot) ? step : 0;
+      tab[slot] = s | (((uint32_t)cnt[s] - 1) << 8) | ((slot - (uint32_t)cum[s]) << 20);
+    }
+  }
+  else
+  {
+    uint32_t *sym4 = (uint32_t *)c.table;                  // uint8 sym[total], written 4 slots per store
+    uint32_t *symtab = (uint32_t *)(c.table + total);      // freq | cumul << 16
+    for (uint32_t q = tid; q < total / 4; q += nthreads)
+    {
+      uint32_t packed = 0;
+#pragma unroll
+      for (uint32_t b = 0; b < 4; b++)
+      {
+        const uint32_t slot = 4 * q + b;
+        uint32_t s = 0;
+#pragma unroll
+        for (uint32_t step = 128; step >= 1; step >>= 1)
+          s += ((uint32_t)cum[s + step] <= slot) ? step : 0;
+        packed |= s << (8 * b);
+      }
+      sym4[q] = packed;
+    }
+    for (uint32_t s = tid; s < 256; s += nthreads)
+      symtab[s] = (uint32_t)cnt[s] | ((uint32_t)cum[s] << 16);
+  }
+  sync();
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// one group of S symbols: returns this lane's symbol.  `act` = lane takes part (lane < S, and inside the final
+// partial group only lanes whose byte exists, rANS32x64_16w.cpp:256)
+// ---------------------------------------------------------------------------------------------------------------
+template <bool TWO_LEVEL>
+__device__ __forceinline__ uint32_t group_step(uint32_t &x, Ring &r, const WaveCtx &c, bool act)
+{
+  const uint32_t mask = (1u << c.bits) - 1;
+  const uint32_t slot = x & mask;
+  uint32_t sym, nx;
+  if (!TWO_LEVEL)
+  {
+    const uint32_t e = ((const uint32_t *)c.table)[slot];
+    sym = e & 0xFF;
+    nx = (x >> c.bits) * (((e >> 8) & 0xFFF) + 1) + (e >> 20);
+  }
+  else
+  {
+    sym = c.table[slot];
+    const uint32_t fc = ((const uint32_t *)(c.table + mask + 1))[sym];
+    nx = (x >> c.bits) * (fc & 0xFFFF) + slot - (fc >> 16);
+  }
+  const bool need = act && (nx < kConsume);
+  const unsigned long long m = __ballot(need);
+  const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, r.cur));
+  const uint32_t w = *(const uint16_t *)(c.ring + ((idx << 1) & (kRingBytes - 1)));
+  x = act ? (need ? ((nx << 16) | w) : nx) : x;
+  r.cur += (uint32_t)__popcll(m);
+  return sym;
+}
+
+// decode `steps` whole groups starting at output offset `o` (block_codec64.h:173-217)
+template <bool TWO_LEVEL>
+__device__ __forceinline__ void run_groups(uint32_t &x, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps)
+{
+  const uint32_t S = c.S;
+  const bool act = c.lane < S;
+  const uint32_t row = c.lane & 3;
+  const uint32_t quad = c.lane >> 2;
+  const uint32_t dcol = (quad & 8) | ((quad & 1) << 2) | ((quad & 6) >> 1); // dword column of this quad = lane_to_byte(lane) >> 2
+  const uint32_t shift = row * 8;
+  const uint32_t store_off = row * S + dcol * 4;
+
+  for (; steps >= 4; steps -= 4)
+  {
+    uint32_t acc = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < 4; t++)
+    {
+      uint32_t v = group_step<TWO_LEVEL>(x, r, c, act) << shift;
+      v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); // quad_perm [1,0,3,2]
+      v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); // quad_perm [2,3,0,1]
+      acc = (row == t) ? v : acc;
+    }
+    if (act)
+      *(uint32_t *)(c.out + o + store_off) = acc;
+    o += 4 * S;
+    ring_advance(r, c);
+  }
+  const uint32_t p = lane_to_byte(c.lane);
+  for (; steps > 0; steps--)
+  {
+    const uint32_t sym = group_step<TWO_LEVEL>(x, r, c, act);
+    if (act)
+      c.out[o + p] = (uint8_t)sym;
+    o += S;
+  }
+  ring_advance(r, c);
+}
+
+// final partial group (rANS32x64_16w.cpp:252-280): only lanes whose output byte exists take part, in lane order
+template <bool TWO_LEVEL>
+__device__ __forceinline__ void run_tail(uint32_t &x, Ring &r, const WaveCtx &c, uint64_t o, uint32_t tail)
+{
+  if (tail == 0)
+    return;
+  const uint32_t p = lane_to_byte(c.lane);
+  const bool act = c.lane < c.S && p < tail;
+  const uint32_t sym = group_step<TWO_LEVEL>(x, r, c, act);
+  if (act)
+    c.out[o + p] = (uint8_t)sym;
+}
+
+// single-symbol block (block_rANS32x64_16w_decode.cpp:52-60): wave-wide fill
+__device__ void wave_fill(const WaveCtx &c, uint64_t o, uint64_t len, uint32_t symbol)
+{
+  uint8_t *p = c.out + o;
+  uint64_t head = (16 - ((uintptr_t)p & 15)) & 15;
+  if (head > len)
+    head = len;
+  if (c.lane < head)
+    p[c.lane] = (uint8_t)symbol;
+  p += head;
+  len -= head;
+  const uint32_t s4 = symbol * 0x01010101u;
+  const u32x4 v = {s4, s4, s4, s4};
+  const uint64_t vecs = len / 16;
+  for (uint64_t i = c.lane; i < vecs; i += 64)
+    ((u32x4 *)p)[i] = v;
+  const uint64_t done = vecs * 16;
+  if (c.lane < len - done)
+    p[done + c.lane] = (uint8_t)symbol;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// chain runners
+// ---------------------------------------------------------------------------------------------------------------
+struct PlanView
+{
+  const PlanHeader *hdr;
+  const uint32_t *chain_first;
+  const Piece *pieces;
+  const uint32_t *states;
+};
+
+__device__ __forceinline__ PlanView plan_view(const uint8_t *plan)
+{
+  PlanView v;
+  v.hdr = (const PlanHeader *)plan;
+  v.chain_first = (const uint32_t *)(plan + plan_chain_first_off());
+  v.pieces = (const Piece *)(plan + plan_pieces_off(v.hdr->n_chains));
+  v.states = (const uint32_t *)(plan + plan_states_off(v.hdr->n_chains, v.hdr->n_pieces));
+  return v;
+}
+
+// planned chain: pieces [first, last) with absolute offsets.  SHARED: the table was built by the workgroup already.
+template <bool TWO_LEVEL, bool SHARED>
+__device__ void run_planned_chain(const WaveCtx &c, const PlanView &pv, uint32_t chain, const KParams &kp)
+{
+  const uint32_t first = uni(pv.chain_first[chain]);
+  const uint32_t last = uni(pv.chain_first[chain + 1]);
+  uint32_t x = 0;
+  uint64_t have_hist = ~(uint64_t)0;
+  Ring r;
+  for (uint32_t pi = first; pi < last; pi++)
+  {
+    const Piece *pc = pv.pieces + pi;
+    const uint32_t flags = uni(pc->flags);
+    if (flags & kPieceChainStart)
+      x = c.lane < c.S ? pv.states[(uint64_t)uni(pc->state_idx) * c.S + c.lane] : 0;
+    if (flags & kPieceFill)
+    {
+      wave_fill(c, uni64(pc->out_off), uni64(pc->fill_len), (uint32_t)uni64(pc->hist_off) & 0xFF);
+      continue;
+    }
+    const uint64_t hist_off = uni64(pc->hist_off);
+    if (!SHARED && hist_off != have_hist)
+    {
+      if (!build_table<TWO_LEVEL, false>(c, hist_off, c.lane, 64))
+        return;
+      have_hist = hist_off;
+    }
+    ring_init(r, c, uni64(pc->words_off));
+    uint64_t o = uni64(pc->out_off);
+    uint32_t steps = uni(pc->steps);
+
+    if (kp.ckpt_interval != 0)
+    {
+      // index-build pass (hsrans_index_build): record {states, cursor} at every `ckpt_interval`-th group boundary
+      uint32_t g = 0;
+      while (steps > 0)
+      {
+        if (g != 0)
+        {
+          const uint64_t slot = g / kp.ckpt_interval;
+          if (c.lane < c.S)
+            kp.ckpt_states[slot * c.S + c.lane] = x;
+          if (c.lane == 0)
+            kp.ckpt_words[slot] = ring_pos(r);
+        }
+        const uint32_t n = steps < kp.ckpt_interval ? steps : kp.ckpt_interval;
+        run_groups<TWO_LEVEL>(x, r, c, o, n);
+        steps -= n;
+        g += n;
+      }
+    }
+    else
+      run_groups<TWO_LEVEL>(x, r, c, o, steps);
+    run_tail<TWO_LEVEL>(x, r, c, o, uni(pc->tail));
+  }
+}
+
+// block_ container without checkpoints: one wave follows the inline headers exactly like
+// block_rANS32x64_16w_decode.cpp:47-123 (states carry over, histogram swapped per block).
+template <bool TWO_LEVEL>
+__device__ void run_block_walk(const WaveCtx &c, const PlanView &pv)
+{
+  const uint32_t S = c.S;
+  const uint64_t out_len = pv.hdr->decoded_len;
+  const uint64_t whole = out_len - S + 1; // host guarantees out_len >= S - 1
+  uint32_t x = c.lane < S ? pv.states[c.lane] : 0;
+  uint64_t pos = pv.hdr->aux_off;
+  uint64_t i = 0;
+  bool have_table = false;
+  Ring r;
+  do
+  {
+    if (pos + 8 > c.stream_len)
+    {
+      if (c.lane == 0)
+        atomicOr(c.status, kStatusOutOfRange);
+      return;
+    }
+    uint64_t hdr = 0;
+    for (int b = 3; b >= 0; b--) // stream offsets are only 2-byte aligned
+      hdr = (hdr << 16) | *(const uint16_t *)(c.stream + pos + 2 * b);
+    hdr = uni64(hdr);
+    pos += 8;
+    if (hdr >> 63)
+    {
+      const uint64_t len = hdr & (((uint64_t)1 << 54) - 1);
+      if (len == 0 || len > c.out_cap - i) // len == 0 would never terminate
+      {
+        if (c.lane == 0)
+          atomicOr(c.status, kStatusOutOfRange);
+        return;
+      }
+      wave_fill(c, i, len, (uint32_t)(hdr >> 54) & 0xFF);
+      i += len;
+    }
+    else
+    {
+      if (hdr == 0) // empty block: the walk would never terminate
+      {
+        if (c.lane == 0)
+          atomicOr(c.status, kStatusBadBlock);
+        return;
+      }
+      if (!build_table<TWO_LEVEL, false>(c, pos, c.lane, 64))
+        return;
+      have_table = true;
+      pos += 512;
+      uint64_t end = i + hdr;
+      if (end > whole)
+        end = whole;
+      else if (end & (S - 1))
+      {
+        if (c.lane == 0)
+          atomicOr(c.status, kStatusBadBlock);
+        return;
+      }
+      ring_init(r, c, pos);
+      const uint64_t steps = end > i ? (end - i + S - 1) / S : 0;
+      run_groups<TWO_LEVEL>(x, r, c, i, (uint32_t)steps);
+      pos = ring_pos(r);
+    }
+    if (i > whole)
+    {
+      if (i >= out_len)
+        return;
+      break;
+    }
+  } while (i < whole);
+
+  if (i < out_len)
+  {
+    if (!have_table) // tail without any histogram read: inplace_make_hist_dec of all-zero counts fails (decode.cpp:97-98)
+    {
+      if (c.lane == 0)
+        atomicOr(c.status, kStatusBadHist);
+      return;
+    }
+    ring_init(r, c, pos);
+    run_tail<TWO_LEVEL>(x, r, c, i, (uint32_t)(out_len - i));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the kernel: blockDim.x = 64 * waves; wave w of block b runs chain b * waves + w
+// LDS: SHARED  -> [waves x ring][table];   otherwise -> per wave [ring][table]
+// ---------------------------------------------------------------------------------------------------------------
+template <bool TWO_LEVEL, bool SHARED>
+__global__ void __launch_bounds__(1024) k_decode(KParams kp)
+{
+  extern __shared__ u32x4 smem_v[];
+  uint8_t *smem = (uint8_t *)smem_v;
+
+  const PlanView pv = plan_view(kp.plan);
+  const uint32_t waves = blockDim.x >> 6;
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  const uint32_t bits = pv.hdr->bits;
+  const uint32_t table_bytes = TWO_LEVEL ? (1u << bits) + 1024 : 4u << bits;
+
+  WaveCtx c;
+  c.stream = kp.stream;
+  c.stream_len = kp.stream_len;
+  c.out = kp.out;
+  c.out_cap = kp.out_cap;
+  c.status = kp.status;
+  c.bits = bits;
+  c.S = pv.hdr->states;
+  c.lane = threadIdx.x & 63;
+
+  const uint32_t chain = blockIdx.x * waves + wave;
+
+  if (SHARED)
+  {
+    c.ring = smem + wave * kRingBytes;
+    c.table = smem + waves * kRingBytes;
+    c.scratch = (uint16_t *)smem; // ring of wave 0, before any ring is live
+    // every non-fill piece of a shared plan names the same histogram: take it from the first non-fill piece
+    const uint64_t hist_off = pv.hdr->aux_off; // shared plans: the one histogram every chain uses
+    if (!build_table<TWO_LEVEL, true>(c, hist_off, threadIdx.x, blockDim.x))
+      return;
+    if (chain < pv.hdr->n_chains)
+      run_planned_chain<TWO_LEVEL, true>(c, pv, chain, kp);
+  }
+  else
+  {
+    uint8_t *mine = smem + wave * (kRingBytes + table_bytes);
+    c.ring = mine;
+    c.table = mine + kRingBytes;
+    c.scratch = (uint16_t *)mine;
+    if (pv.hdr->flags & kPlanWalk)
+    {
+      if (chain == 0)
+        run_block_walk<TWO_LEVEL>(c, pv);
+    }
+    else if (chain < pv.hdr->n_chains)
+      run_planned_chain<TWO_LEVEL, false>(c, pv, chain, kp);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-side launcher
+// ---------------------------------------------------------------------------------------------------------------
+static uint32_t g_max_lds = 160 * 1024;
+
+hipError_t prepare_kernels()
+{
+  const void *fns[4] = {(const void *)k_decode<false, false>, (const void *)k_decode<false, true>, (const void *)k_decode<true, false>,
+                        (const void *)k_decode<true, true>};
+  for (const void *f : fns)
+  {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_max_lds);
+    if (e != hipSuccess)
+      return e;
+  }
+  return hipSuccess;
+}
+
+hipError_t launch_decode(const KParams &kp, const PlanHeader &h, hipStream_t stream, LaunchInfo *info)
+{
+  const bool two_level = h.bits >= 13;
+  const bool walk = (h.flags & kPlanWalk) != 0;
+  const bool shared = !walk && h.shared_hist != 0 && h.n_chains > 1;
+  const uint32_t table_bytes = two_level ? (1u << h.bits) + 1024 : 4u << h.bits;
+
+  uint32_t waves, lds, grid;
+  if (shared)
+  {
+    waves = 16;
+    while (waves > 1 && waves / 2 >= h.n_chains)
+      waves /= 2;
+    lds = waves * kRingBytes + table_bytes;
+    grid = (h.n_chains + waves - 1) / waves;
+  }
+  else
+  {
+    waves = walk ? 1 : 4;
+    while (waves > 1 && (waves * (kRingBytes + table_bytes) > g_max_lds / 2 || waves / 2 >= h.n_chains))
+      waves /= 2;
+    lds = waves * (kRingBytes + table_bytes);
+    grid = walk ? 1 : (h.n_chains + waves - 1) / waves;
+  }
+  if (grid == 0)
+    grid = 1;
+
+  void (*fn)(KParams) = two_level ? (shared ? k_decode<true, true> : k_decode<true, false>) : (shared ? k_decode<false, true> : k_decode<false, false>);
+  if (info)
+  {
+    info->grid = grid;
+    info->block = waves * 64;
+    info->lds_bytes = lds;
+    info->waves_per_block = waves;
+    info->chains = h.n_chains;
+    info->shared_table = shared;
+    info->walk = walk;
+    info->two_level = two_level;
+  }
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), lds, stream, kp);
+  return hipGetLastError();
+}
+
+} // namespace hsrans

@@ -1,0 +1,140 @@
+/* hsrans_hip.h — C ABI of libhsrans_hip.so: MI355X (gfx950) implementation of the hypersonic-rANS
+ * interleaved 32-bit-state / 16-bit-word decode path (rANS32x32 16w, rANS32x64 16w; raw, block_, mt_ containers).
+ *
+ * The reference (rainerzufalldererste/hypersonic-rANS @ 2024_10_08) has no FFI layer: its boundary is the set of
+ * free C++ functions main.cpp stores in codec_info_t (src/main.cpp:146-155):
+ *     size_t encode(const uint8_t *in, size_t len, uint8_t *out, size_t outCap, const hist_t *hist);
+ *     size_t decode(const uint8_t *in, size_t inLen, uint8_t *out, size_t outCap);      // bytes produced, 0 = failure
+ * This header is the C form of exactly that boundary (container / state count / histogram bits become arguments
+ * instead of name suffixes) plus what a GPU replacement has to add: a context, a device-pointer
+ * entry for device-resident pipelines, and an optional decode plan ("index") that lets many wavefronts work on ONE
+ * stream.  include/hsrans_dropin.hpp declares the same functionality under the reference's own C++ names.
+ *
+ * Conventions kept from the reference: plain pointers + sizes, caller owns all buffers, return = bytes produced,
+ * 0 on any failure, no exceptions cross this boundary, all entry points are re-entrant (per context).
+ * No CPU decode path exists in this library: decoding without a usable GPU fails (returns 0 / an error code).
+ */
+#ifndef HSRANS_HIP_H
+#define HSRANS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSRANS_RAW 0   /* one histogram, one stream:           src/rANS32x64_16w.cpp, src/rANS32x32_16w.cpp        */
+#define HSRANS_BLOCK 1 /* histogram swapped per block, inline: src/block_rANS32x64_16w_{encode,decode}.cpp         */
+#define HSRANS_MT 2    /* independent blocks:                  src/mt_rANS32x64_16w_{encode,decode}.cpp            */
+
+/* = reference hist_t (src/hist.h:16-20) */
+typedef struct hsrans_hist
+{
+  uint16_t symbolCount[256];
+  uint16_t cumul[256];
+} hsrans_hist;
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Host-side format functions (no GPU involved).  The reference's encoders are scalar CPU code too
+ * (README.md:19-27 "all encoders scalar"); these produce streams its decoders accept.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* replaces rANS32x64_16w_capacity (src/rANS32x64_16w.cpp:10), rANS32x32_16w_capacity (src/rANS32x32_16w.cpp:10),
+ * block_rANS32x{32,64}_16w_capacity (src/block_rANS32x64_16w_encode.cpp:47), mt_…_capacity (src/mt_rANS32x64_16w_encode.cpp:50) */
+size_t hsrans_capacity(int container, int states, size_t input_size);
+
+/* replaces make_hist (src/hist.cpp:217): byte histogram normalised to sum 1 << bits */
+void hsrans_make_hist(hsrans_hist *hist, const uint8_t *data, size_t size, uint32_t bits);
+
+/* replaces rANS32x{32,64}_16w_encode_scalar_N (src/rANS32x64_16w.cpp:34), block_…_encode_N
+ * (src/block_rANS32x64_16w_encode.cpp:137), mt_…_encode_N (src/mt_rANS32x64_16w_encode.cpp:140).
+ * `hist` is used by HSRANS_RAW only (NULL = make_hist over the whole input, as src/main.cpp:746 does). */
+size_t hsrans_encode(int container, int states, uint32_t bits, const uint8_t *in, size_t length, uint8_t *out, size_t out_capacity,
+                     const hsrans_hist *hist);
+
+typedef struct hsrans_encode_opts
+{
+  uint32_t block_size;       /* block_/mt_: symbols per block (multiple of 64; 0 = default 65536).                           */
+  uint32_t index_interval;   /* 0 = no plan; else emit a checkpoint every `index_interval` groups of `states` symbols         */
+  uint8_t *plan_out;         /* receives the decode plan (see hsrans_plan_*) when index_interval != 0                         */
+  size_t plan_capacity;      /* bytes available at plan_out (hsrans_plan_capacity)                                            */
+  size_t plan_size;          /* out: bytes written to plan_out                                                                */
+} hsrans_encode_opts;
+
+/* same as hsrans_encode, additionally emitting the sidecar decode plan; the stream bytes are unchanged by it */
+size_t hsrans_encode_ex(int container, int states, uint32_t bits, const uint8_t *in, size_t length, uint8_t *out, size_t out_capacity,
+                        const hsrans_hist *hist, hsrans_encode_opts *opts);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Decode plans.  A plan lists the independent chains (start states, read cursor, output range, histogram location)
+ * one wavefront each will decode.  hsrans_plan_build derives it from the stream alone:
+ *   raw    -> 1 chain (the format has no restart points: src/rANS32x64_16w.cpp:223-250 is one dependent chain);
+ *   mt_    -> 1 chain per block, by following the header chain like src/mt_rANS32x64_16w_decode.cpp:166-227;
+ *   block_ -> 1 chain that parses the inline headers on the device (src/block_rANS32x64_16w_decode.cpp:47-90).
+ * A plan emitted by hsrans_encode_ex (or hsrans_index_build) additionally splits chains every `index_interval`
+ * groups, which is what lets one stream fill the GPU.  Plans are position-independent byte blobs.
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t hsrans_plan_capacity(int container, int states, size_t decoded_size, uint32_t index_interval, uint32_t block_size);
+size_t hsrans_plan_build(int container, int states, uint32_t bits, const uint8_t *stream, size_t stream_length, size_t out_capacity,
+                         uint8_t *plan_out, size_t plan_capacity);
+uint32_t hsrans_plan_chain_count(const uint8_t *plan, size_t plan_size);
+uint64_t hsrans_plan_decoded_length(const uint8_t *plan, size_t plan_size);
+/* restrict a plan to chains [first, first+count): used to shard one stream over several GPUs (each rank decodes its
+ * chains into the same output offsets of its own buffer).  Returns bytes written, 0 on error. */
+size_t hsrans_plan_slice(const uint8_t *plan, size_t plan_size, uint32_t first_chain, uint32_t chain_count, uint8_t *out, size_t out_capacity);
+/* output byte range [*begin, *end) covered by chains [first, first+count) */
+int hsrans_plan_chain_range(const uint8_t *plan, size_t plan_size, uint32_t first_chain, uint32_t chain_count, uint64_t *begin, uint64_t *end);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GPU side
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct hsrans_ctx hsrans_ctx;     /* device id, staging buffers, HIP streams/events */
+typedef struct hsrans_dplan hsrans_dplan; /* a plan resident in device memory + its status word */
+
+#define HSRANS_OK 0
+#define HSRANS_E_NO_DEVICE 1
+#define HSRANS_E_ARG 2
+#define HSRANS_E_FORMAT 3   /* malformed stream / plan (the reference's "return 0" cases) */
+#define HSRANS_E_HIP 4
+#define HSRANS_E_DEVICE 5   /* the kernel reported a malformed histogram / block header */
+
+int hsrans_ctx_create(int device, hsrans_ctx **out_ctx);
+void hsrans_ctx_destroy(hsrans_ctx *ctx);
+const char *hsrans_ctx_device_name(const hsrans_ctx *ctx);
+
+/* Host-pointer drop-in for decodeFunc (src/main.cpp:149): H2D, plan, launch, D2H.  Replaces
+ * rANS32x{32,64}_16w_decode_*_N, block_rANS32x{32,64}_16w_decode_N, mt_rANS32x{32,64}_16w_decode[_mt]_N.
+ * Returns the decoded length, 0 on failure. `plan` may be NULL (derived from the stream). */
+size_t hsrans_decode_host(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out,
+                          size_t out_capacity, const uint8_t *plan, size_t plan_size);
+
+/* Device-resident entry: everything asynchronous on `hip_stream` (a hipStream_t; NULL = default stream), graph-capturable
+ * (no allocation, no synchronisation).  `d_stream` must be 16-byte aligned, `d_out` 4-byte aligned. */
+int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, hsrans_dplan **out_dplan);
+void hsrans_dplan_destroy(hsrans_dplan *dplan);
+int hsrans_decode_device(hsrans_ctx *ctx, hsrans_dplan *dplan, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity,
+                         void *hip_stream);
+/* synchronises `hip_stream` and returns HSRANS_OK or HSRANS_E_DEVICE (kernel found a bad histogram/header) */
+int hsrans_dplan_status(hsrans_ctx *ctx, hsrans_dplan *dplan, void *hip_stream);
+
+/* Build a plan with checkpoints every `index_interval` groups for an EXISTING stream (e.g. one written by the
+ * reference's encoder) by one sequential single-wavefront pass on the GPU; the pass also decodes into d_out.
+ * Returns plan bytes written to plan_out (host memory), 0 on failure. */
+size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length,
+                          uint32_t index_interval, uint8_t *plan_out, size_t plan_capacity);
+
+/* kernel launch geometry of the last hsrans_decode_device call on this plan (for benchmarks / DESIGN.md tables) */
+typedef struct hsrans_launch_info
+{
+  uint32_t grid, block, lds_bytes, waves_per_block, chains, shared_table, walk, two_level;
+} hsrans_launch_info;
+int hsrans_dplan_launch_info(const hsrans_dplan *dplan, hsrans_launch_info *info);
+
+const char *hsrans_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* HSRANS_HIP_H */

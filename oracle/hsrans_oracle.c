@@ -426,3 +426,72 @@ size_t orc_decode(int container, int states, unsigned bits, const uint8_t *in, s
   default: return 0;
   }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Plan interpreter (test infrastructure): executes a product decode plan ("HSRPLAN1", hypersonic_rans_amd/csrc/
+ * hsrans_plan.h) chain by chain with the scalar step above.  It lets the CPU test-suite check the host planner and the
+ * encoders' sidecar plans without a GPU; the GPU tests compare the kernels against the same oracle.
+ * The layout constants are restated here on purpose (the oracle shares no code with the product).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct
+{
+  uint64_t words_off, out_off, hist_off, fill_len;
+  uint32_t steps;
+  uint16_t tail, flags;
+  uint32_t state_idx, reserved;
+} orc_piece_t;
+
+size_t orc_exec_plan(const uint8_t *plan, size_t planLen, const uint8_t *in, size_t inLen, uint8_t *out, size_t outCap)
+{
+  if (planLen < 64 || memcmp(plan, "HSRPLAN1", 8) != 0)
+    return 0;
+  const uint32_t S = ld32(plan + 12), bits = ld32(plan + 16), flags = ld32(plan + 20);
+  const uint64_t outLen = ld64(plan + 24);
+  const uint32_t nChains = ld32(plan + 40), nPieces = ld32(plan + 44);
+  if (flags & 1u) /* walk plans carry no pieces: nothing to interpret */
+    return 0;
+  if (outLen > outCap)
+    return 0;
+  const size_t piecesOff = 64 + (((size_t)nChains + 1) * 4 + 15) / 16 * 16;
+  const size_t statesOff = piecesOff + (size_t)nPieces * sizeof(orc_piece_t);
+  if (statesOff + (size_t)nChains * S * 4 != planLen)
+    return 0;
+  static _Thread_local dec_ctx_t c;
+  uint64_t haveHist = ~(uint64_t)0;
+  for (uint32_t ch = 0; ch < nChains; ch++)
+  {
+    const uint32_t first = ld32(plan + 64 + 4 * (size_t)ch), last = ld32(plan + 64 + 4 * ((size_t)ch + 1));
+    for (uint32_t pi = first; pi < last; pi++)
+    {
+      orc_piece_t p;
+      memcpy(&p, plan + piecesOff + (size_t)pi * sizeof(p), sizeof(p));
+      if (p.flags & 1u)
+        for (uint32_t j = 0; j < S; j++)
+          c.states[j] = ld32(plan + statesOff + ((size_t)p.state_idx * S + j) * 4);
+      if (p.flags & 2u)
+      {
+        if (p.out_off + p.fill_len > outLen)
+          return 0;
+        memset(out + p.out_off, (int)(p.hist_off & 0xFF), (size_t)p.fill_len);
+        continue;
+      }
+      if (p.hist_off + 512 > inLen || p.words_off > inLen)
+        return 0;
+      if (p.hist_off != haveHist)
+      {
+        for (size_t k = 0; k < 256; k++)
+          c.counts[k] = ld16(in + p.hist_off + 2 * k);
+        if (!orc_make_dec_table(bits, c.counts, c.cumul, c.cumulInv, 1))
+          return 0;
+        haveHist = p.hist_off;
+      }
+      c.rd = in + p.words_off;
+      const size_t end = (size_t)p.out_off + (size_t)p.steps * S;
+      if (end + p.tail > outLen)
+        return 0;
+      dec_section(&c, S, bits, out, (size_t)p.out_off, end);
+      dec_tail(&c, S, bits, out, end, end + p.tail);
+    }
+  }
+  return (size_t)outLen;
+}

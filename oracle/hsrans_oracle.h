@@ -57,6 +57,9 @@ size_t orc_mt_decode(int states, unsigned bits, const uint8_t *in, size_t inLen,
 /* dispatch helper for ctypes */
 size_t orc_decode(int container, int states, unsigned bits, const uint8_t *in, size_t inLen, uint8_t *out, size_t outCap);
 
+/* test-only interpreter of the product's decode plans (see hsrans_oracle.c) */
+size_t orc_exec_plan(const uint8_t *plan, size_t planLen, const uint8_t *in, size_t inLen, uint8_t *out, size_t outCap);
+
 #ifdef __cplusplus
 }
 #endif

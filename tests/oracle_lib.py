@@ -49,7 +49,16 @@ class Oracle:
         L.orc_raw_encode.argtypes = [_i, _u, _vp, _sz, _vp, _sz, ctypes.POINTER(OrcHist)]
         L.orc_decode.restype = _sz
         L.orc_decode.argtypes = [_i, _i, _u, _vp, _sz, _vp, _sz]
+        L.orc_exec_plan.restype = _sz
+        L.orc_exec_plan.argtypes = [_vp, _sz, _vp, _sz, _vp, _sz]
         self.L = L
+
+    def exec_plan(self, plan: np.ndarray, stream: np.ndarray, out_cap: int):
+        plan = np.ascontiguousarray(plan, dtype=np.uint8)
+        stream = np.ascontiguousarray(stream, dtype=np.uint8)
+        out = np.full(max(out_cap, 1), 0xCC, np.uint8)
+        r = self.L.orc_exec_plan(_ptr(plan), plan.size, _ptr(stream), stream.size, _ptr(out), out_cap)
+        return r, out[:out_cap]
 
     def idx2idx(self, j):
         return self.L.orc_idx2idx(j)

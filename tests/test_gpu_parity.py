@@ -1,0 +1,129 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.  Bit-exact."""
+import numpy as np
+import pytest
+
+import hypersonic_rans_amd as H
+from hypersonic_rans_amd import synth
+from oracle_lib import BLOCK, MT, RAW
+
+pytestmark = pytest.mark.gpu
+
+LENS_SMALL = (1, 31, 62, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4096, 65536, 65600, 131073)
+
+
+@pytest.fixture(scope="module")
+def zipf():
+    return synth.enwik8_shaped(1 << 20, seed=11)
+
+
+@pytest.fixture(scope="module")
+def nonstat():
+    return synth.nonstationary(3_000_000)
+
+
+@pytest.mark.parametrize("states", (32, 64))
+@pytest.mark.parametrize("bits", (10, 11, 12, 13, 14, 15))
+def test_raw_single_chain_every_length(gpu_ctx, oracle, zipf, states, bits):
+    for n in LENS_SMALL + (1 << 20,):
+        d = zipf[:n]
+        s = H.encode(H.RAW, states, bits, d)
+        r0, want = oracle.decode(RAW, states, bits, s, n)
+        assert r0 == n and np.array_equal(want, d)
+        r, got = gpu_ctx.decode_host(H.RAW, states, bits, s, n)
+        assert r == n, (states, bits, n)
+        assert np.array_equal(got, want), (states, bits, n, int(np.argmax(got != want)))
+
+
+@pytest.mark.parametrize("states", (32, 64))
+@pytest.mark.parametrize("bits", (10, 11, 12, 13, 14, 15))
+@pytest.mark.parametrize("interval", (4, 64, 256))
+def test_raw_indexed(gpu_ctx, oracle, zipf, states, bits, interval):
+    for n in (63, 64, 65, 1000, 65600, 300_001, 1 << 20):
+        d = zipf[:n]
+        s, plan = H.encode(H.RAW, states, bits, d, index_interval=interval)
+        r, got = gpu_ctx.decode_host(H.RAW, states, bits, s, n, plan=plan)
+        assert r == n and np.array_equal(got, d), (states, bits, interval, n)
+
+
+@pytest.mark.parametrize("container", (BLOCK, MT))
+@pytest.mark.parametrize("states", (32, 64))
+@pytest.mark.parametrize("bits", (10, 11, 12, 13, 14, 15))
+def test_containers_own_encoder(gpu_ctx, oracle, zipf, nonstat, container, states, bits):
+    for src, n in ((zipf, 64), (zipf, 1000), (zipf, 65536), (zipf, 65600), (zipf, 200_001), (nonstat, 3_000_000), (nonstat, 1_000_003)):
+        d = src[:n]
+        s = H.encode(container, states, bits, d)
+        r0, want = oracle.decode(container, states, bits, s, n)
+        assert r0 == n and np.array_equal(want, d)
+        r, got = gpu_ctx.decode_host(container, states, bits, s, n)
+        assert r == n and np.array_equal(got, want), (container, states, bits, n)
+        s2, plan = H.encode(container, states, bits, d, index_interval=64, block_size=1 << 16)
+        r, got = gpu_ctx.decode_host(container, states, bits, s2, n, plan=plan)
+        assert r == n and np.array_equal(got, d), ("indexed", container, states, bits, n)
+
+
+@pytest.mark.parametrize("container", (RAW, BLOCK, MT))
+@pytest.mark.parametrize("states", (32, 64))
+def test_reference_encoded_streams(gpu_ctx, oracle, ref, zipf, nonstat, container, states):
+    """Streams written by the REAL reference encoder (only where oracle/_ref is present), incl. the quirk lengths."""
+    for bits in (10, 11, 12, 13, 14, 15):
+        for src, n in ((zipf, 65537), (zipf, 65560), (zipf, 65599), (zipf, 65600), (zipf, 131073), (zipf, 524300), (nonstat, 3_000_000)):
+            d = src[:n]
+            s = ref.encode(container, states, bits, d)
+            r0, want = oracle.decode(container, states, bits, s, n)
+            r, got = gpu_ctx.decode_host(container, states, bits, s, n)
+            assert r == r0 and np.array_equal(got, want), (container, states, bits, n)
+
+
+def test_failure_modes(gpu_ctx, zipf):
+    d = zipf[:10000]
+    s = H.encode(H.RAW, 64, 11, d)
+    assert gpu_ctx.decode_host(H.RAW, 64, 11, s, 9999)[0] == 0  # outCapacity < decodedLength (rANS32x64_16w.cpp:180)
+    assert gpu_ctx.decode_host(H.RAW, 64, 11, s, 10000, in_length=s.size - 1)[0] == 0  # inLength < stored (:186)
+    assert gpu_ctx.decode_host(H.RAW, 64, 11, s[:100], 10000)[0] == 0  # shorter than a header (:171)
+    assert gpu_ctx.decode_host(H.RAW, 64, 12, s, 10000)[0] == 0  # wrong bits: histogram sum check (hist.cpp:340)
+    bad = s.copy()
+    bad[16] ^= 1  # corrupt one count -> sum != 2^bits
+    assert gpu_ctx.decode_host(H.RAW, 64, 11, bad, 10000)[0] == 0
+    for c in (H.BLOCK, H.MT):
+        s = H.encode(c, 64, 11, d)
+        assert gpu_ctx.decode_host(c, 64, 12, s, 10000)[0] == 0
+
+
+def test_index_build_on_gpu(gpu_ctx, oracle, zipf):
+    d = zipf
+    s = H.encode(H.RAW, 64, 11, d)
+    plan = gpu_ctx.index_build(H.RAW, 64, 11, s, 64)
+    s2, plan2 = H.encode(H.RAW, 64, 11, d, index_interval=64)
+    assert np.array_equal(s, s2)
+    assert np.array_equal(plan, plan2), "GPU-built index differs from the encoder's"
+    r, got = gpu_ctx.decode_host(H.RAW, 64, 11, s, d.size, plan=plan)
+    assert r == d.size and np.array_equal(got, d)
+
+
+def test_device_entry_and_graph(gpu_ctx, zipf):
+    import torch
+
+    d = zipf
+    s, plan = H.encode(H.RAW, 64, 11, d, index_interval=64)
+    pad = (-s.size) % 16
+    d_in = torch.from_numpy(np.concatenate([s, np.zeros(pad, np.uint8)])).cuda()
+    d_out = torch.zeros(d.size, dtype=torch.uint8, device="cuda")
+    dp = gpu_ctx.make_device_plan(plan)
+    gpu_ctx.decode_device(dp, d_in, d_out, stream_length=s.size)
+    assert gpu_ctx.status(dp) == 0
+    assert np.array_equal(d_out.cpu().numpy(), d)
+    info = dp.launch_info()
+    assert info["shared_table"] == 1 and info["chains"] == H.plan_chain_count(plan)
+    # hipGraph capture of the launch (no allocation / sync inside hsrans_decode_device)
+    d_out.zero_()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            gpu_ctx.decode_device(dp, d_in, d_out, stream=side, stream_length=s.size)
+    torch.cuda.synchronize()
+    d_out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), d)
