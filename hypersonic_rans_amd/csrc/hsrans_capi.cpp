@@ -288,8 +288,8 @@ int hsrans_decode_device(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_stream,
   if (stream_length < d->hdr.stream_len || out_capacity < d->hdr.decoded_len)
     return HSRANS_E_FORMAT;
   hipStream_t s = (hipStream_t)hip_stream;
-  if (hipMemsetAsync(d->d_status, 0, 4, s) != hipSuccess)
-    return HSRANS_E_HIP;
+  // the status word is sticky: kernels only ever OR error bits into it and hsrans_dplan_status() clears it after
+  // reporting, so the launch path is exactly one kernel node (no memset node in front of it)
   KParams kp{};
   kp.stream = (const uint8_t *)d_stream;
   kp.stream_len = stream_length;
@@ -308,7 +308,11 @@ int hsrans_dplan_status(hsrans_ctx *ctx, hsrans_dplan *d, void *hip_stream)
   hipStream_t s = (hipStream_t)hip_stream;
   if (hipMemcpyAsync(&status, d->d_status, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
     return HSRANS_E_HIP;
-  return status == 0 ? HSRANS_OK : HSRANS_E_DEVICE;
+  if (status == 0)
+    return HSRANS_OK;
+  if (hipMemsetAsync(d->d_status, 0, 4, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    return HSRANS_E_HIP;
+  return HSRANS_E_DEVICE;
 }
 
 int hsrans_dplan_launch_info(const hsrans_dplan *d, hsrans_launch_info *info)

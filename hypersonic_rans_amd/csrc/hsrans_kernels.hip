@@ -31,11 +31,21 @@ namespace hsrans
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr uint32_t kRingBytes = 2048;  // per wave: two 1 KiB chunks
+constexpr uint32_t kRingSlots = 4;
 constexpr uint32_t kChunkBytes = 1024; // 64 lanes x 16 B
+constexpr uint32_t kRingBytes = kRingSlots * kChunkBytes; // per wave
 constexpr uint32_t kChunkWordsLog2 = 9;
 constexpr uint32_t kConsume = 1u << 15; // rans.h:8 DecodeConsumePoint16
 
+// decode-table layouts
+constexpr int kModePack = 0;     // bits <= 11: uint32 per slot = sym | freq << 8 | (slot - cumul) << 20
+constexpr int kModePackM1 = 1;   // bits == 12: same with freq - 1 (freq == 4096 must fit 12 bits)
+constexpr int kModeTwoLevel = 2; // bits >= 13: uint8 sym[2^bits] + uint32 {freq | cumul << 16}[256]
+
+__device__ __forceinline__ uint32_t lds_address(const void *p)
+{
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)p;
+}
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint64_t uni64(uint64_t v)
 {
@@ -53,26 +63,36 @@ struct WaveCtx
   uint64_t out_cap;
   uint32_t *status;
   uint32_t bits, S, lane;
-  uint8_t *ring;    // LDS, kRingBytes
+  uint8_t *ring;    // LDS, kRingBytes, kRingBytes-aligned
+  uint32_t ring_lds; // the same as an LDS byte address (what M0 / ds_read take)
   uint8_t *table;   // LDS
   uint16_t *scratch; // LDS, >= 1028 B, only live during table builds (aliases a ring)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// stream ring
+// stream ring: 4 slots x 1 KiB per wave, filled by LDS-DMA (buffer_load_dwordx4 ... lds: 64 lanes x 16 B land
+// linearly at M0, no VGPR staging, hardware bounds check against the descriptor).
+//
+// Invariant: whenever the cursor is in chunk c, chunks c .. c+2 have been requested, and c, c+1 have landed.
+// ring_advance() runs at least once per 256 consumed words; on entering chunk c it requests chunk c+3 into the
+// slot of the dead chunk c-1 and then waits with vmcnt(2): the two requests younger than chunk c+1's are c+2 and
+// c+3, so "all but the 2 youngest vector-memory operations done" always covers chunk c+1 whatever stores the
+// compiler has interleaved (they only make the wait stricter, never weaker).  The loads are issued from asm, so
+// the compiler never tracks them and never parks the decode loop on vmcnt(0).
 // ---------------------------------------------------------------------------------------------------------------
 struct Ring
 {
-  __amdgpu_buffer_rsrc_t rs;
+  u32x4 rs;      // buffer descriptor (SGPRs): base = stream + `base`, num_records = bytes to the end of the stream
   uint64_t base; // absolute byte offset in the stream of word index 0
-  uint32_t k;    // ring holds chunks k and k+1; `pend` holds chunk k+2
+  uint32_t k;    // chunk the cursor was in at the last ring_advance()
   uint32_t cur;  // next word to read, counted from `base` (wave-uniform)
-  u32x4 pend;
 };
 
-__device__ __forceinline__ u32x4 ring_load(const Ring &r, uint32_t chunk, uint32_t lane)
+__device__ __forceinline__ void ring_request(const Ring &r, const WaveCtx &c, uint32_t chunk)
 {
-  return __builtin_amdgcn_raw_buffer_load_b128(r.rs, chunk * kChunkBytes + lane * 16, 0, 0);
+  const uint32_t voff = chunk * kChunkBytes + c.lane * 16;
+  const uint32_t dst = uni(c.ring_lds + (chunk & (kRingSlots - 1)) * kChunkBytes);
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(voff), "s"(dst), "s"(r.rs) : "memory");
 }
 
 __device__ __forceinline__ void ring_init(Ring &r, const WaveCtx &c, uint64_t pos)
@@ -82,15 +102,19 @@ __device__ __forceinline__ void ring_init(Ring &r, const WaveCtx &c, uint64_t po
   // range in whole 16-byte lanes: a dwordx4 that straddles num_records is dropped as a whole, and a0 is 16-aligned
   // inside a 16-aligned allocation, so rounding up never leaves the page the last stream byte is on
   const uint64_t left = a0 < c.stream_len ? (c.stream_len - a0 + 15) & ~(uint64_t)15 : 0;
-  r.rs =__builtin_amdgcn_make_buffer_rsrc((void *)(c.stream + a0), 0, (uint32_t)(left > 0xFFFFFFFFull ? 0xFFFFFFFFull : left), 0x00020000);
+  const uint64_t addr = (uint64_t)(uintptr_t)c.stream + a0;
+  r.rs.x = uni((uint32_t)addr);
+  r.rs.y = uni((uint32_t)(addr >> 32) & 0xFFFF); // stride 0
+  r.rs.z = uni((uint32_t)(left > 0xFFFFFFFFull ? 0xFFFFFFFFull : left));
+  r.rs.w = 0x00020000;
   r.base = a0;
   r.cur = (uint32_t)(pos - a0) >> 1;
   r.k = 0;
-  const u32x4 c0 = ring_load(r, 0, c.lane);
-  const u32x4 c1 = ring_load(r, 1, c.lane);
-  r.pend = ring_load(r, 2, c.lane);
-  *(u32x4 *)(c.ring + c.lane * 16) = c0;
-  *(u32x4 *)(c.ring + kChunkBytes + c.lane * 16) = c1;
+  // every lane is done with the previous piece's ring contents (its ds_reads returned before their results were used)
+  ring_request(r, c, 0);
+  ring_request(r, c, 1);
+  ring_request(r, c, 2);
+  asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // chunks 0 and 1 have landed
 }
 
 // call at least once per 256 consumed words
@@ -98,9 +122,9 @@ __device__ __forceinline__ void ring_advance(Ring &r, const WaveCtx &c)
 {
   if ((r.cur >> kChunkWordsLog2) > r.k)
   {
-    *(u32x4 *)(c.ring + (r.k & 1) * kChunkBytes + c.lane * 16) = r.pend; // chunk k+2 replaces chunk k
     r.k++;
-    r.pend = ring_load(r, r.k + 2, c.lane);
+    ring_request(r, c, r.k + 2);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); // chunk k+1 has landed (see the invariant above)
   }
 }
 
@@ -110,7 +134,7 @@ __device__ __forceinline__ uint64_t ring_pos(const Ring &r) { return r.base + (u
 // decode table build (hist.cpp:291-306 make_dec_pack_hist, :356-384 inplace_make_hist_dec2, :308-324 the sum check)
 // `tid`/`nthreads` = the threads that share this table (one wave, or the whole workgroup); SYNC() orders their LDS traffic.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool TWO_LEVEL, bool BLOCK_SYNC>
+template <int MODE, bool BLOCK_SYNC>
 __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, uint32_t nthreads)
 {
   auto sync = [&]() {
@@ -164,7 +188,7 @@ __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, u
 
   // slot -> symbol: the largest s with cum[s] <= slot (zero-count symbols share cum with their successor and lose
   // the tie; trailing zero-count symbols sit at cum == total and are never hit) == hist.cpp:343-351
-  if (!TWO_LEVEL)
+  if (MODE != kModeTwoLevel)
   {
     uint32_t *tab = (uint32_t *)c.table;
     for (uint32_t slot = tid; slot < total; slot += nthreads)
@@ -173,7 +197,7 @@ __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, u
 #pragma unroll
       for (uint32_t step = 128; step >= 1; step >>= 1)
         s += ((uint32_t)cum[s + step] <= slot) ? step : 0;
-      tab[slot] = s | (((uint32_t)cnt[s] - 1) << 8) | ((slot - (uint32_t)cum[s]) << 20);
+      tab[slot] = s | (((uint32_t)cnt[s] - (MODE == kModePackM1 ? 1 : 0)) << 8) | ((slot - (uint32_t)cum[s]) << 20);
     }
   }
   else
@@ -203,86 +227,117 @@ __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, u
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// one group of S symbols: returns this lane's symbol.  `act` = lane takes part (lane < S, and inside the final
-// partial group only lanes whose byte exists, rANS32x64_16w.cpp:256)
+// one group of S symbols.  Returns the table word whose low byte is this lane's symbol.
+// `act_mask` = lanes that take part (lane < S; inside the final partial group only lanes whose byte exists,
+// rANS32x64_16w.cpp:256).  Lanes outside it run the arithmetic on junk: they never enter the renormalisation
+// ballot, never store, and their state is never used again.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool TWO_LEVEL>
-__device__ __forceinline__ uint32_t group_step(uint32_t &x, Ring &r, const WaveCtx &c, bool act)
+template <int MODE, bool FULL>
+__device__ __forceinline__ uint32_t group_step(uint32_t &x, Ring &r, const WaveCtx &c, unsigned long long act_mask)
 {
   const uint32_t mask = (1u << c.bits) - 1;
   const uint32_t slot = x & mask;
-  uint32_t sym, nx;
-  if (!TWO_LEVEL)
+  const uint32_t q = x >> c.bits; // < 2^21: the 24-bit multiplier applies (x < 2^31, bits >= 10)
+  uint32_t e, nx;
+  if (MODE == kModePack)
   {
-    const uint32_t e = ((const uint32_t *)c.table)[slot];
-    sym = e & 0xFF;
-    nx = (x >> c.bits) * (((e >> 8) & 0xFFF) + 1) + (e >> 20);
+    e = ((const uint32_t *)c.table)[slot]; // sym | freq << 8 | (slot - cumul) << 20, freq <= 2048
+    nx = __umul24(q, (e >> 8) & 0xFFF) + (e >> 20);
+  }
+  else if (MODE == kModePackM1)
+  {
+    e = ((const uint32_t *)c.table)[slot]; // sym | (freq - 1) << 8 | (slot - cumul) << 20
+    nx = __umul24(q, (e >> 8) & 0xFFF) + q + (e >> 20);
   }
   else
   {
-    sym = c.table[slot];
-    const uint32_t fc = ((const uint32_t *)(c.table + mask + 1))[sym];
-    nx = (x >> c.bits) * (fc & 0xFFFF) + slot - (fc >> 16);
+    e = c.table[slot];
+    const uint32_t fc = ((const uint32_t *)(c.table + mask + 1))[e]; // freq | cumul << 16
+    nx = __umul24(q, fc & 0xFFFF) + slot - (fc >> 16);
   }
-  const bool need = act && (nx < kConsume);
-  const unsigned long long m = __ballot(need);
-  const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, r.cur));
-  const uint32_t w = *(const uint16_t *)(c.ring + ((idx << 1) & (kRingBytes - 1)));
-  x = act ? (need ? ((nx << 16) | w) : nx) : x;
+  const bool low = nx < kConsume;
+  unsigned long long m = __builtin_amdgcn_ballot_w64(low);
+  if (!FULL)
+    m &= act_mask;
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+  uint32_t waddr; // ring base | ((cur + rank) * 2 mod ring size): the ring is kRingBytes-aligned in LDS
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(waddr) : "v"((rank + r.cur) << 1), "s"(kRingBytes - 2), "v"(c.ring_lds));
+  uint32_t w = *(const __attribute__((address_space(3))) uint16_t *)(uintptr_t)waddr;
+  asm volatile("" : "+v"(w)); // keep the read unconditional (no exec-mask branch around it)
+  x = low ? ((nx << 16) | w) : nx;
   r.cur += (uint32_t)__popcll(m);
-  return sym;
+  return e;
+}
+
+// 4x4 byte transpose inside every quad of lanes: in = this lane's symbols of 4 consecutive groups (byte t = group t);
+// out = the 4 symbols of group (lane & 3) for the quad's 4 lanes = one aligned dword of the output row.
+__device__ __forceinline__ uint32_t quad_transpose(uint32_t v, uint32_t sel_a, uint32_t sel_b)
+{
+  const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
+  v = __builtin_amdgcn_perm(p1, v, sel_a);
+  const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
+  return __builtin_amdgcn_perm(p2, v, sel_b);
 }
 
 // decode `steps` whole groups starting at output offset `o` (block_codec64.h:173-217)
-template <bool TWO_LEVEL>
-__device__ __forceinline__ void run_groups(uint32_t &x, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps)
+template <int MODE, bool FULL>
+__device__ __forceinline__ void run_groups_impl(uint32_t &x, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps)
 {
-  const uint32_t S = c.S;
-  const bool act = c.lane < S;
+  const uint32_t S = FULL ? 64 : c.S;
+  const bool act = FULL || c.lane < S;
+  const unsigned long long act_mask = FULL ? ~0ull : __builtin_amdgcn_ballot_w64(act);
   const uint32_t row = c.lane & 3;
   const uint32_t quad = c.lane >> 2;
   const uint32_t dcol = (quad & 8) | ((quad & 1) << 2) | ((quad & 6) >> 1); // dword column of this quad = lane_to_byte(lane) >> 2
-  const uint32_t shift = row * 8;
   const uint32_t store_off = row * S + dcol * 4;
+  const uint32_t sel_a = (c.lane & 1) ? 0x03070105u : 0x06020400u;
+  const uint32_t sel_b = (c.lane & 2) ? 0x03020706u : 0x05040100u;
 
   for (; steps >= 4; steps -= 4)
   {
-    uint32_t acc = 0;
-#pragma unroll
-    for (uint32_t t = 0; t < 4; t++)
-    {
-      uint32_t v = group_step<TWO_LEVEL>(x, r, c, act) << shift;
-      v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); // quad_perm [1,0,3,2]
-      v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); // quad_perm [2,3,0,1]
-      acc = (row == t) ? v : acc;
-    }
+    uint32_t acc;
+    acc = group_step<MODE, FULL>(x, r, c, act_mask);                                       // byte 0 <- group 0
+    acc = __builtin_amdgcn_perm(group_step<MODE, FULL>(x, r, c, act_mask), acc, 0x03020400u); // byte 1 <- group 1
+    acc = __builtin_amdgcn_perm(group_step<MODE, FULL>(x, r, c, act_mask), acc, 0x03040100u); // byte 2 <- group 2
+    acc = __builtin_amdgcn_perm(group_step<MODE, FULL>(x, r, c, act_mask), acc, 0x04020100u); // byte 3 <- group 3
+    acc = quad_transpose(acc, sel_a, sel_b);
+    uint8_t *row_base = c.out + o; // wave-uniform
     if (act)
-      *(uint32_t *)(c.out + o + store_off) = acc;
+      *(uint32_t *)(row_base + store_off) = acc;
     o += 4 * S;
     ring_advance(r, c);
   }
   const uint32_t p = lane_to_byte(c.lane);
   for (; steps > 0; steps--)
   {
-    const uint32_t sym = group_step<TWO_LEVEL>(x, r, c, act);
+    const uint32_t e = group_step<MODE, FULL>(x, r, c, act_mask);
     if (act)
-      c.out[o + p] = (uint8_t)sym;
+      c.out[o + p] = (uint8_t)e;
     o += S;
   }
   ring_advance(r, c);
 }
 
+template <int MODE>
+__device__ __forceinline__ void run_groups(uint32_t &x, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps)
+{
+  if (c.S == 64)
+    run_groups_impl<MODE, true>(x, r, c, o, steps);
+  else
+    run_groups_impl<MODE, false>(x, r, c, o, steps);
+}
+
 // final partial group (rANS32x64_16w.cpp:252-280): only lanes whose output byte exists take part, in lane order
-template <bool TWO_LEVEL>
+template <int MODE>
 __device__ __forceinline__ void run_tail(uint32_t &x, Ring &r, const WaveCtx &c, uint64_t o, uint32_t tail)
 {
   if (tail == 0)
     return;
   const uint32_t p = lane_to_byte(c.lane);
   const bool act = c.lane < c.S && p < tail;
-  const uint32_t sym = group_step<TWO_LEVEL>(x, r, c, act);
+  const uint32_t e = group_step<MODE, false>(x, r, c, __builtin_amdgcn_ballot_w64(act));
   if (act)
-    c.out[o + p] = (uint8_t)sym;
+    c.out[o + p] = (uint8_t)e;
 }
 
 // single-symbol block (block_rANS32x64_16w_decode.cpp:52-60): wave-wide fill
@@ -328,7 +383,7 @@ __device__ __forceinline__ PlanView plan_view(const uint8_t *plan)
 }
 
 // planned chain: pieces [first, last) with absolute offsets.  SHARED: the table was built by the workgroup already.
-template <bool TWO_LEVEL, bool SHARED>
+template <int MODE, bool SHARED>
 __device__ void run_planned_chain(const WaveCtx &c, const PlanView &pv, uint32_t chain, const KParams &kp)
 {
   const uint32_t first = uni(pv.chain_first[chain]);
@@ -350,7 +405,7 @@ __device__ void run_planned_chain(const WaveCtx &c, const PlanView &pv, uint32_t
     const uint64_t hist_off = uni64(pc->hist_off);
     if (!SHARED && hist_off != have_hist)
     {
-      if (!build_table<TWO_LEVEL, false>(c, hist_off, c.lane, 64))
+      if (!build_table<MODE, false>(c, hist_off, c.lane, 64))
         return;
       have_hist = hist_off;
     }
@@ -373,20 +428,20 @@ __device__ void run_planned_chain(const WaveCtx &c, const PlanView &pv, uint32_t
             kp.ckpt_words[slot] = ring_pos(r);
         }
         const uint32_t n = steps < kp.ckpt_interval ? steps : kp.ckpt_interval;
-        run_groups<TWO_LEVEL>(x, r, c, o, n);
+        run_groups<MODE>(x, r, c, o, n);
         steps -= n;
         g += n;
       }
     }
     else
-      run_groups<TWO_LEVEL>(x, r, c, o, steps);
-    run_tail<TWO_LEVEL>(x, r, c, o, uni(pc->tail));
+      run_groups<MODE>(x, r, c, o, steps);
+    run_tail<MODE>(x, r, c, o, uni(pc->tail));
   }
 }
 
 // block_ container without checkpoints: one wave follows the inline headers exactly like
 // block_rANS32x64_16w_decode.cpp:47-123 (states carry over, histogram swapped per block).
-template <bool TWO_LEVEL>
+template <int MODE>
 __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv)
 {
   const uint32_t S = c.S;
@@ -430,7 +485,7 @@ __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv)
           atomicOr(c.status, kStatusBadBlock);
         return;
       }
-      if (!build_table<TWO_LEVEL, false>(c, pos, c.lane, 64))
+      if (!build_table<MODE, false>(c, pos, c.lane, 64))
         return;
       have_table = true;
       pos += 512;
@@ -445,7 +500,7 @@ __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv)
       }
       ring_init(r, c, pos);
       const uint64_t steps = end > i ? (end - i + S - 1) / S : 0;
-      run_groups<TWO_LEVEL>(x, r, c, i, (uint32_t)steps);
+      run_groups<MODE>(x, r, c, i, (uint32_t)steps);
       pos = ring_pos(r);
     }
     if (i > whole)
@@ -465,7 +520,7 @@ __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv)
       return;
     }
     ring_init(r, c, pos);
-    run_tail<TWO_LEVEL>(x, r, c, i, (uint32_t)(out_len - i));
+    run_tail<MODE>(x, r, c, i, (uint32_t)(out_len - i));
   }
 }
 
@@ -473,7 +528,7 @@ __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv)
 // the kernel: blockDim.x = 64 * waves; wave w of block b runs chain b * waves + w
 // LDS: SHARED  -> [waves x ring][table];   otherwise -> per wave [ring][table]
 // ---------------------------------------------------------------------------------------------------------------
-template <bool TWO_LEVEL, bool SHARED>
+template <int MODE, bool SHARED>
 __global__ void __launch_bounds__(1024) k_decode(KParams kp)
 {
   extern __shared__ u32x4 smem_v[];
@@ -483,7 +538,7 @@ __global__ void __launch_bounds__(1024) k_decode(KParams kp)
   const uint32_t waves = blockDim.x >> 6;
   const uint32_t wave = uni(threadIdx.x >> 6);
   const uint32_t bits = pv.hdr->bits;
-  const uint32_t table_bytes = TWO_LEVEL ? (1u << bits) + 1024 : 4u << bits;
+  const uint32_t table_bytes = MODE == kModeTwoLevel ? (1u << bits) + 1024 : 4u << bits;
 
   WaveCtx c;
   c.stream = kp.stream;
@@ -500,28 +555,29 @@ __global__ void __launch_bounds__(1024) k_decode(KParams kp)
   if (SHARED)
   {
     c.ring = smem + wave * kRingBytes;
+    c.ring_lds = lds_address(c.ring);
     c.table = smem + waves * kRingBytes;
     c.scratch = (uint16_t *)smem; // ring of wave 0, before any ring is live
     // every non-fill piece of a shared plan names the same histogram: take it from the first non-fill piece
     const uint64_t hist_off = pv.hdr->aux_off; // shared plans: the one histogram every chain uses
-    if (!build_table<TWO_LEVEL, true>(c, hist_off, threadIdx.x, blockDim.x))
+    if (!build_table<MODE, true>(c, hist_off, threadIdx.x, blockDim.x))
       return;
     if (chain < pv.hdr->n_chains)
-      run_planned_chain<TWO_LEVEL, true>(c, pv, chain, kp);
+      run_planned_chain<MODE, true>(c, pv, chain, kp);
   }
   else
   {
-    uint8_t *mine = smem + wave * (kRingBytes + table_bytes);
-    c.ring = mine;
-    c.table = mine + kRingBytes;
-    c.scratch = (uint16_t *)mine;
+    c.ring = smem + wave * kRingBytes; // all rings first: they stay kRingBytes-aligned and below 64 KiB (M0)
+    c.ring_lds = lds_address(c.ring);
+    c.table = smem + waves * kRingBytes + wave * ((table_bytes + 15) & ~15u);
+    c.scratch = (uint16_t *)c.ring;
     if (pv.hdr->flags & kPlanWalk)
     {
       if (chain == 0)
-        run_block_walk<TWO_LEVEL>(c, pv);
+        run_block_walk<MODE>(c, pv);
     }
     else if (chain < pv.hdr->n_chains)
-      run_planned_chain<TWO_LEVEL, false>(c, pv, chain, kp);
+      run_planned_chain<MODE, false>(c, pv, chain, kp);
   }
 }
 
@@ -530,16 +586,29 @@ __global__ void __launch_bounds__(1024) k_decode(KParams kp)
 // ---------------------------------------------------------------------------------------------------------------
 static uint32_t g_max_lds = 160 * 1024;
 
+typedef void (*KernelFn)(KParams);
+static KernelFn kernel_for(int mode, bool shared)
+{
+  switch (mode * 2 + (shared ? 1 : 0))
+  {
+  case 0: return k_decode<kModePack, false>;
+  case 1: return k_decode<kModePack, true>;
+  case 2: return k_decode<kModePackM1, false>;
+  case 3: return k_decode<kModePackM1, true>;
+  case 4: return k_decode<kModeTwoLevel, false>;
+  default: return k_decode<kModeTwoLevel, true>;
+  }
+}
+
 hipError_t prepare_kernels()
 {
-  const void *fns[4] = {(const void *)k_decode<false, false>, (const void *)k_decode<false, true>, (const void *)k_decode<true, false>,
-                        (const void *)k_decode<true, true>};
-  for (const void *f : fns)
-  {
-    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_max_lds);
-    if (e != hipSuccess)
-      return e;
-  }
+  for (int mode = 0; mode < 3; mode++)
+    for (int shared = 0; shared < 2; shared++)
+    {
+      const hipError_t e = hipFuncSetAttribute((const void *)kernel_for(mode, shared != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_max_lds);
+      if (e != hipSuccess)
+        return e;
+    }
   return hipSuccess;
 }
 
@@ -549,6 +618,7 @@ hipError_t launch_decode(const KParams &kp, const PlanHeader &h, hipStream_t str
   const bool walk = (h.flags & kPlanWalk) != 0;
   const bool shared = !walk && h.shared_hist != 0 && h.n_chains > 1;
   const uint32_t table_bytes = two_level ? (1u << h.bits) + 1024 : 4u << h.bits;
+  const uint32_t wave_bytes = kRingBytes + ((table_bytes + 15) & ~15u); // private ring + table
 
   uint32_t waves, lds, grid;
   if (shared)
@@ -562,15 +632,15 @@ hipError_t launch_decode(const KParams &kp, const PlanHeader &h, hipStream_t str
   else
   {
     waves = walk ? 1 : 4;
-    while (waves > 1 && (waves * (kRingBytes + table_bytes) > g_max_lds / 2 || waves / 2 >= h.n_chains))
+    while (waves > 1 && (waves * wave_bytes > g_max_lds / 2 || waves / 2 >= h.n_chains))
       waves /= 2;
-    lds = waves * (kRingBytes + table_bytes);
+    lds = waves * wave_bytes;
     grid = walk ? 1 : (h.n_chains + waves - 1) / waves;
   }
   if (grid == 0)
     grid = 1;
 
-  void (*fn)(KParams) = two_level ? (shared ? k_decode<true, true> : k_decode<true, false>) : (shared ? k_decode<false, true> : k_decode<false, false>);
+  KernelFn fn = kernel_for(two_level ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : kModePack, shared);
   if (info)
   {
     info->grid = grid;
