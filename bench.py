@@ -83,7 +83,7 @@ def main() -> None:
     ap.add_argument("--size", type=int, default=100_000_000)
     ap.add_argument("--bits", type=int, default=11)
     ap.add_argument("--states", type=int, default=64)
-    ap.add_argument("--interval", type=int, default=64, help="checkpoint interval of the sidecar plan, in groups of `states` symbols")
+    ap.add_argument("--interval", type=int, default=32, help="checkpoint interval of the sidecar plan, in groups of `states` symbols")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-single", action="store_true", help="skip the un-indexed single-wavefront measurement")
     args = ap.parse_args()
@@ -128,20 +128,26 @@ def main() -> None:
     assert torch.equal(d_out, d_ref), "GPU output is not bit-exact"
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides ------------------------------------------
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    # ---- per-launch duration of the decode kernel for the roofline: HIP events on the launch stream (torch's current
+    # stream is the one hsrans_decode_device launches on), outside the timed region so they do not perturb it
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for a, b in ev:
         a.record()
         step()
         b.record()
     torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]  # events sit on the launch stream (torch's current stream)
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
     assert ctx.status(dplan) == 0
     assert torch.equal(d_out, d_ref), "GPU output is not bit-exact after the timed region"
     sha = hashlib.sha256(d_out.cpu().numpy().tobytes()).hexdigest()

@@ -37,7 +37,8 @@ class LaunchInfo(ctypes.Structure):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "lib", "libhsrans_hip.so")
+    # HSRANS_LIB: A/B a differently built libhsrans_hip.so in one process environment (kernel tuning only)
+    return os.environ.get("HSRANS_LIB") or os.path.join(_HERE, "lib", "libhsrans_hip.so")
 
 
 _LIB = None

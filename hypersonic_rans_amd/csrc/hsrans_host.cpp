@@ -538,6 +538,18 @@ size_t PlanBuilder::serialize(uint8_t *out, size_t cap)
     }
     hdr.shared_hist = any && same ? 1 : 0;
     hdr.aux_off = hdr.shared_hist ? h : 0;
+    // mergeable: single-piece rANS chains, one histogram, back-to-back in the output, only the last one has a tail.
+    // Set for raw streams only: there the word stream is one run, so back-to-back output implies back-to-back words.
+    bool merge = hdr.shared_hist && hdr.container == HSRANS_RAW && np == nc && nc > 1;
+    for (uint32_t i = 0; merge && i < np; i++)
+    {
+      const Piece &p = pieces[i];
+      if ((p.flags & kPieceFill) || !(p.flags & kPieceChainStart))
+        merge = false;
+      else if (i + 1 < np && (p.tail != 0 || p.out_off + (uint64_t)p.steps * hdr.states != pieces[i + 1].out_off || p.words_off > pieces[i + 1].words_off))
+        merge = false;
+    }
+    hdr.flags = merge ? (hdr.flags | kPlanMergeable) : (hdr.flags & ~kPlanMergeable);
   }
   memset(out, 0, need);
   memcpy(out, &hdr, sizeof(hdr));

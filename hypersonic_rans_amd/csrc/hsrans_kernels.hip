@@ -41,6 +41,13 @@ constexpr uint32_t kConsume = 1u << 15; // rans.h:8 DecodeConsumePoint16
 constexpr int kModePack = 0;     // bits <= 11: uint32 per slot = sym | freq << 8 | (slot - cumul) << 20
 constexpr int kModePackM1 = 1;   // bits == 12: same with freq - 1 (freq == 4096 must fit 12 bits)
 constexpr int kModeTwoLevel = 2; // bits >= 13: uint8 sym[2^bits] + uint32 {freq | cumul << 16}[256]
+constexpr int kModePack64 = 3;   // bits <= 11, table shared by a workgroup: uint2 per slot = {freq | sym << 24, slot - cumul}:
+                                 // v_mad_u32_u24 takes freq (low 24 bits) and the bias operand as they are, v_perm takes byte 3
+
+__host__ __device__ constexpr uint32_t table_bytes_for(int mode, uint32_t bits)
+{
+  return mode == kModeTwoLevel ? (1u << bits) + 1024 : mode == kModePack64 ? 8u << bits : 4u << bits;
+}
 
 __device__ __forceinline__ uint32_t lds_address(const void *p)
 {
@@ -65,8 +72,9 @@ struct WaveCtx
   uint32_t bits, S, lane;
   uint8_t *ring;    // LDS, kRingBytes, kRingBytes-aligned
   uint32_t ring_lds; // the same as an LDS byte address (what M0 / ds_read take)
+  uint32_t ring_vgpr; // ring_lds held in a VGPR (third operand of v_and_or_b32 beside an SGPR mask)
   uint8_t *table;   // LDS
-  uint16_t *scratch; // LDS, >= 1028 B, only live during table builds (aliases a ring)
+  uint16_t *scratch; // LDS, 1024 B, only live during table builds (aliases the last slot of a ring)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -95,7 +103,7 @@ __device__ __forceinline__ void ring_request(const Ring &r, const WaveCtx &c, ui
   asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(voff), "s"(dst), "s"(r.rs) : "memory");
 }
 
-__device__ __forceinline__ void ring_init(Ring &r, const WaveCtx &c, uint64_t pos)
+__device__ __forceinline__ void ring_begin(Ring &r, const WaveCtx &c, uint64_t pos)
 {
   pos = uni64(pos);
   const uint64_t a0 = pos & ~(uint64_t)15;
@@ -114,7 +122,15 @@ __device__ __forceinline__ void ring_init(Ring &r, const WaveCtx &c, uint64_t po
   ring_request(r, c, 0);
   ring_request(r, c, 1);
   ring_request(r, c, 2);
-  asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // chunks 0 and 1 have landed
+}
+
+// chunks 0 and 1 have landed (anything issued after ring_begin() only makes this wait stricter)
+__device__ __forceinline__ void ring_ready() { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+
+__device__ __forceinline__ void ring_init(Ring &r, const WaveCtx &c, uint64_t pos)
+{
+  ring_begin(r, c, pos);
+  ring_ready();
 }
 
 // call at least once per 256 consumed words
@@ -148,10 +164,13 @@ __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, u
     }
   };
   uint16_t *cnt = c.scratch;       // [256]
-  uint16_t *cum = c.scratch + 256; // [257]
+  uint16_t *cum = c.scratch + 256; // [256] exclusive prefix sums
   const uint32_t total = 1u << c.bits;
+  bool good = true;
 
-  sync(); // scratch aliases a ring: everyone must be done with it
+  if (!BLOCK_SYNC)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // a stream request of the previous piece may still be landing in the scratch slot
+  sync(); // scratch aliases a ring slot: everyone must be done with it
   const bool in_range = hist_off + 512 <= c.stream_len;
   for (uint32_t s = tid; s < 256; s += nthreads)
     cnt[s] = in_range ? *(const uint16_t *)(c.stream + hist_off + 2 * s) : (uint16_t)0;
@@ -173,22 +192,32 @@ __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, u
     cum[4 * tid + 1] = (uint16_t)(excl + c0);
     cum[4 * tid + 2] = (uint16_t)(excl + c0 + c1);
     cum[4 * tid + 3] = (uint16_t)(excl + c0 + c1 + c2);
-    if (tid == 63)
-    {
-      cum[256] = (uint16_t)(incl > 0xFFFF ? 0xFFFF : incl); // > 2^15 is invalid anyway; saturate instead of wrapping
-    }
+    // uint32 sum must be exactly 2^bits, as inplace_complete_hist (hist.cpp:310); the decoder then returns 0.
+    // A workgroup-shared build only raises the status bit and decodes on with the bogus table (every index stays
+    // masked, so that is memory-safe; the host discards the output); a single-wave build stops its chain.
+    good = (uint32_t)__shfl(incl, 63, 64) == total;
+    if (!good && tid == 0)
+      atomicOr(c.status, kStatusBadHist);
   }
   sync();
-  if ((uint32_t)cum[256] != total) // uint32 sum, as inplace_complete_hist (hist.cpp:310)
-  {
-    if (tid == 0)
-      atomicOr(c.status, kStatusBadHist);
+  if (!BLOCK_SYNC && !good)
     return false;
-  }
 
   // slot -> symbol: the largest s with cum[s] <= slot (zero-count symbols share cum with their successor and lose
   // the tie; trailing zero-count symbols sit at cum == total and are never hit) == hist.cpp:343-351
-  if (MODE != kModeTwoLevel)
+  if (MODE == kModePack64)
+  {
+    uint2 *tab = (uint2 *)c.table;
+    for (uint32_t slot = tid; slot < total; slot += nthreads)
+    {
+      uint32_t s = 0;
+#pragma unroll
+      for (uint32_t step = 128; step >= 1; step >>= 1)
+        s += ((uint32_t)cum[s + step] <= slot) ? step : 0;
+      tab[slot] = make_uint2((uint32_t)cnt[s] | (s << 24), slot - (uint32_t)cum[s]);
+    }
+  }
+  else if (MODE != kModeTwoLevel)
   {
     uint32_t *tab = (uint32_t *)c.table;
     for (uint32_t slot = tid; slot < total; slot += nthreads)
@@ -239,7 +268,13 @@ __device__ __forceinline__ uint32_t group_step(uint32_t &x, Ring &r, const WaveC
   const uint32_t slot = x & mask;
   const uint32_t q = x >> c.bits; // < 2^21: the 24-bit multiplier applies (x < 2^31, bits >= 10)
   uint32_t e, nx;
-  if (MODE == kModePack)
+  if (MODE == kModePack64)
+  {
+    const uint2 e2 = ((const uint2 *)c.table)[slot];
+    e = e2.x;                      // symbol in byte 3: the output v_perm selects it from there
+    nx = __umul24(q, e2.x) + e2.y; // the 24-bit multiplier ignores the symbol in bits 24..31
+  }
+  else if (MODE == kModePack)
   {
     e = ((const uint32_t *)c.table)[slot]; // sym | freq << 8 | (slot - cumul) << 20, freq <= 2048
     nx = __umul24(q, (e >> 8) & 0xFFF) + (e >> 20);
@@ -261,10 +296,12 @@ __device__ __forceinline__ uint32_t group_step(uint32_t &x, Ring &r, const WaveC
     m &= act_mask;
   const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
   uint32_t waddr; // ring base | ((cur + rank) * 2 mod ring size): the ring is kRingBytes-aligned in LDS
-  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(waddr) : "v"((rank + r.cur) << 1), "s"(kRingBytes - 2), "v"(c.ring_lds));
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(waddr) : "v"((rank + r.cur) << 1), "s"(kRingBytes - 2), "v"(c.ring_vgpr));
   uint32_t w = *(const __attribute__((address_space(3))) uint16_t *)(uintptr_t)waddr;
-  asm volatile("" : "+v"(w)); // keep the read unconditional (no exec-mask branch around it)
-  x = low ? ((nx << 16) | w) : nx;
+  // x = low ? (nx << 16 | w) : nx, as one VALU op under EXEC = renormalising lanes (EXEC is all ones here: every
+  // caller is in wave-uniform control flow of a full 64-lane wave); the two EXEC writes go to the scalar unit
+  x = nx;
+  asm volatile("s_mov_b64 exec, %2\n\tv_lshl_or_b32 %0, %0, 16, %1\n\ts_mov_b64 exec, -1" : "+v"(x) : "v"(w), "s"(__builtin_amdgcn_ballot_w64(low)));
   r.cur += (uint32_t)__popcll(m);
   return e;
 }
@@ -290,16 +327,20 @@ __device__ __forceinline__ void run_groups_impl(uint32_t &x, Ring &r, const Wave
   const uint32_t quad = c.lane >> 2;
   const uint32_t dcol = (quad & 8) | ((quad & 1) << 2) | ((quad & 6) >> 1); // dword column of this quad = lane_to_byte(lane) >> 2
   const uint32_t store_off = row * S + dcol * 4;
+  constexpr uint32_t kSymByte = MODE == kModePack64 ? 3 : 0; // where group_step's return value holds the symbol
   const uint32_t sel_a = (c.lane & 1) ? 0x03070105u : 0x06020400u;
   const uint32_t sel_b = (c.lane & 2) ? 0x03020706u : 0x05040100u;
 
   for (; steps >= 4; steps -= 4)
   {
-    uint32_t acc;
-    acc = group_step<MODE, FULL>(x, r, c, act_mask);                                       // byte 0 <- group 0
-    acc = __builtin_amdgcn_perm(group_step<MODE, FULL>(x, r, c, act_mask), acc, 0x03020400u); // byte 1 <- group 1
-    acc = __builtin_amdgcn_perm(group_step<MODE, FULL>(x, r, c, act_mask), acc, 0x03040100u); // byte 2 <- group 2
-    acc = __builtin_amdgcn_perm(group_step<MODE, FULL>(x, r, c, act_mask), acc, 0x04020100u); // byte 3 <- group 3
+    // gather this lane's 4 symbols (byte kSymByte of each table word) into one dword, byte t = group t
+    const uint32_t e0 = group_step<MODE, FULL>(x, r, c, act_mask);
+    const uint32_t e1 = group_step<MODE, FULL>(x, r, c, act_mask);
+    const uint32_t lo = __builtin_amdgcn_perm(e1, e0, 0x0c0c0400u + kSymByte * 0x0101u);
+    const uint32_t e2 = group_step<MODE, FULL>(x, r, c, act_mask);
+    const uint32_t e3 = group_step<MODE, FULL>(x, r, c, act_mask);
+    const uint32_t hi = __builtin_amdgcn_perm(e3, e2, 0x0c0c0400u + kSymByte * 0x0101u);
+    uint32_t acc = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
     acc = quad_transpose(acc, sel_a, sel_b);
     uint8_t *row_base = c.out + o; // wave-uniform
     if (act)
@@ -312,7 +353,7 @@ __device__ __forceinline__ void run_groups_impl(uint32_t &x, Ring &r, const Wave
   {
     const uint32_t e = group_step<MODE, FULL>(x, r, c, act_mask);
     if (act)
-      c.out[o + p] = (uint8_t)e;
+      c.out[o + p] = (uint8_t)(e >> (8 * kSymByte));
     o += S;
   }
   ring_advance(r, c);
@@ -337,7 +378,7 @@ __device__ __forceinline__ void run_tail(uint32_t &x, Ring &r, const WaveCtx &c,
   const bool act = c.lane < c.S && p < tail;
   const uint32_t e = group_step<MODE, false>(x, r, c, __builtin_amdgcn_ballot_w64(act));
   if (act)
-    c.out[o + p] = (uint8_t)e;
+    c.out[o + p] = (uint8_t)(e >> (MODE == kModePack64 ? 24 : 0));
 }
 
 // single-symbol block (block_rANS32x64_16w_decode.cpp:52-60): wave-wide fill
@@ -538,7 +579,7 @@ __global__ void __launch_bounds__(1024) k_decode(KParams kp)
   const uint32_t waves = blockDim.x >> 6;
   const uint32_t wave = uni(threadIdx.x >> 6);
   const uint32_t bits = pv.hdr->bits;
-  const uint32_t table_bytes = MODE == kModeTwoLevel ? (1u << bits) + 1024 : 4u << bits;
+  const uint32_t table_bytes = table_bytes_for(MODE, bits);
 
   WaveCtx c;
   c.stream = kp.stream;
@@ -556,12 +597,41 @@ __global__ void __launch_bounds__(1024) k_decode(KParams kp)
   {
     c.ring = smem + wave * kRingBytes;
     c.ring_lds = lds_address(c.ring);
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c.ring_vgpr) : "s"(c.ring_lds));
     c.table = smem + waves * kRingBytes;
-    c.scratch = (uint16_t *)smem; // ring of wave 0, before any ring is live
-    // every non-fill piece of a shared plan names the same histogram: take it from the first non-fill piece
+    c.scratch = (uint16_t *)(smem + (kRingSlots - 1) * kChunkBytes); // last slot of wave 0's ring: free until the first ring_advance
     const uint64_t hist_off = pv.hdr->aux_off; // shared plans: the one histogram every chain uses
-    if (!build_table<MODE, true>(c, hist_off, threadIdx.x, blockDim.x))
+    if (pv.hdr->flags & kPlanMergeable)
+    {
+      // Persistent shape: the grid is sized to the machine and every wave decodes an equal, contiguous run of chains
+      // [first, last) as ONE chain from chain `first`'s start states.  The stream requests and the state load are
+      // in flight while the workgroup builds its table.
+      const uint64_t total_waves = (uint64_t)gridDim.x * waves, n = pv.hdr->n_chains;
+      const uint32_t first = (uint32_t)(chain * n / total_waves), last = (uint32_t)((chain + 1) * n / total_waves);
+      const bool have = first < last;
+      uint32_t x = 0, steps = 0, tail = 0;
+      uint64_t o = 0;
+      Ring r;
+      if (have)
+      {
+        const Piece *p0 = pv.pieces + uni(pv.chain_first[first]);
+        const Piece *p1 = pv.pieces + uni(pv.chain_first[last - 1]);
+        ring_begin(r, c, uni64(p0->words_off));
+        x = c.lane < c.S ? pv.states[(uint64_t)uni(p0->state_idx) * c.S + c.lane] : 0;
+        o = uni64(p0->out_off);
+        steps = (uint32_t)((uni64(p1->out_off) - o) / c.S) + uni(p1->steps);
+        tail = uni(p1->tail);
+      }
+      build_table<MODE, true>(c, hist_off, threadIdx.x, blockDim.x);
+      if (have)
+      {
+        ring_ready();
+        run_groups<MODE>(x, r, c, o, steps);
+        run_tail<MODE>(x, r, c, o, tail);
+      }
       return;
+    }
+    build_table<MODE, true>(c, hist_off, threadIdx.x, blockDim.x);
     if (chain < pv.hdr->n_chains)
       run_planned_chain<MODE, true>(c, pv, chain, kp);
   }
@@ -569,8 +639,9 @@ __global__ void __launch_bounds__(1024) k_decode(KParams kp)
   {
     c.ring = smem + wave * kRingBytes; // all rings first: they stay kRingBytes-aligned and below 64 KiB (M0)
     c.ring_lds = lds_address(c.ring);
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c.ring_vgpr) : "s"(c.ring_lds));
     c.table = smem + waves * kRingBytes + wave * ((table_bytes + 15) & ~15u);
-    c.scratch = (uint16_t *)c.ring;
+    c.scratch = (uint16_t *)(c.ring + (kRingSlots - 1) * kChunkBytes);
     if (pv.hdr->flags & kPlanWalk)
     {
       if (chain == 0)
@@ -585,6 +656,7 @@ __global__ void __launch_bounds__(1024) k_decode(KParams kp)
 // host-side launcher
 // ---------------------------------------------------------------------------------------------------------------
 static uint32_t g_max_lds = 160 * 1024;
+static uint32_t g_num_cus = 256;
 
 typedef void (*KernelFn)(KParams);
 static KernelFn kernel_for(int mode, bool shared)
@@ -596,13 +668,17 @@ static KernelFn kernel_for(int mode, bool shared)
   case 2: return k_decode<kModePackM1, false>;
   case 3: return k_decode<kModePackM1, true>;
   case 4: return k_decode<kModeTwoLevel, false>;
-  default: return k_decode<kModeTwoLevel, true>;
+  case 5: return k_decode<kModeTwoLevel, true>;
+  default: return k_decode<kModePack64, true>;
   }
 }
 
 hipError_t prepare_kernels()
 {
-  for (int mode = 0; mode < 3; mode++)
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+    g_num_cus = (uint32_t)cus;
+  for (int mode = 0; mode < 4; mode++)
     for (int shared = 0; shared < 2; shared++)
     {
       const hipError_t e = hipFuncSetAttribute((const void *)kernel_for(mode, shared != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_max_lds);
@@ -617,7 +693,9 @@ hipError_t launch_decode(const KParams &kp, const PlanHeader &h, hipStream_t str
   const bool two_level = h.bits >= 13;
   const bool walk = (h.flags & kPlanWalk) != 0;
   const bool shared = !walk && h.shared_hist != 0 && h.n_chains > 1;
-  const uint32_t table_bytes = two_level ? (1u << h.bits) + 1024 : 4u << h.bits;
+  // 64-bit entries only where one table serves a whole workgroup (LDS: 16 KiB table + 16 x 4 KiB rings, two per CU)
+  const int mode = two_level ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : shared ? kModePack64 : kModePack;
+  const uint32_t table_bytes = table_bytes_for(mode, h.bits);
   const uint32_t wave_bytes = kRingBytes + ((table_bytes + 15) & ~15u); // private ring + table
 
   uint32_t waves, lds, grid;
@@ -628,6 +706,13 @@ hipError_t launch_decode(const KParams &kp, const PlanHeader &h, hipStream_t str
       waves /= 2;
     lds = waves * kRingBytes + table_bytes;
     grid = (h.n_chains + waves - 1) / waves;
+    if ((h.flags & kPlanMergeable) && kp.ckpt_interval == 0)
+    {
+      const uint32_t per_cu = g_max_lds / lds ? g_max_lds / lds : 1; // workgroups one CU can hold (LDS-limited; 32 waves max)
+      const uint32_t resident = g_num_cus * (per_cu * waves > 32 ? 32 / waves : per_cu);
+      if (grid > resident)
+        grid = resident;
+    }
   }
   else
   {
@@ -640,7 +725,7 @@ hipError_t launch_decode(const KParams &kp, const PlanHeader &h, hipStream_t str
   if (grid == 0)
     grid = 1;
 
-  KernelFn fn = kernel_for(two_level ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : kModePack, shared);
+  KernelFn fn = kernel_for(mode, shared);
   if (info)
   {
     info->grid = grid;

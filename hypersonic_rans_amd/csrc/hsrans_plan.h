@@ -25,6 +25,10 @@ constexpr uint32_t kPieceChainStart = 1; // load start states plan.states[state_
 constexpr uint32_t kPieceFill = 2;       // single-symbol block: fill_len bytes of (hist_off & 0xFF); states untouched
 
 constexpr uint32_t kPlanWalk = 1; // block_ without checkpoints: the kernel parses the inline headers itself
+// every chain is one rANS piece of the same histogram and chain i+1 starts exactly where chain i stops (output AND word
+// stream): any run of consecutive chains can be decoded as one longer chain from the first one's start states.  The
+// kernel uses this to hand every resident wavefront one contiguous, equally long share of the stream.
+constexpr uint32_t kPlanMergeable = 2;
 
 struct Piece
 {
