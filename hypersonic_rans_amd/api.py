@@ -197,6 +197,27 @@ def plan_chain_range(plan, first: int, count: int) -> tuple[int, int]:
     return b.value, e.value
 
 
+PIECE_DTYPE = np.dtype([("words_off", "<u8"), ("out_off", "<u8"), ("hist_off", "<u8"), ("fill_len", "<u8"), ("steps", "<u4"),
+                        ("tail", "<u2"), ("flags", "<u2"), ("state_idx", "<u4"), ("reserved", "<u4")])
+
+
+def plan_tables(plan):
+    """Read-only numpy views of a plan blob (layout: csrc/hsrans_plan.h): (header dict, chain_first[n+1], pieces[n_pieces])."""
+    plan = _u8(plan)
+    if plan.size < 64 or bytes(plan[:8]) != b"HSRPLAN1":
+        raise HsransError("not a plan blob")
+    u32 = plan[8:24].view("<u4")
+    hdr = {"container": int(u32[0]), "states": int(u32[1]), "bits": int(u32[2]), "flags": int(u32[3]),
+           "decoded_len": int(plan[24:32].view("<u8")[0]), "stream_len": int(plan[32:40].view("<u8")[0]),
+           "n_chains": int(plan[40:44].view("<u4")[0]), "n_pieces": int(plan[44:48].view("<u4")[0]),
+           "shared_hist": int(plan[48:52].view("<u4")[0]), "interval": int(plan[52:56].view("<u4")[0])}
+    nc, npc = hdr["n_chains"], hdr["n_pieces"]
+    cf = plan[64:64 + 4 * (nc + 1)].view("<u4")
+    po = 64 + ((nc + 1) * 4 + 15) // 16 * 16
+    pieces = plan[po:po + 48 * npc].view(PIECE_DTYPE)
+    return hdr, cf, pieces
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # GPU side
 # ---------------------------------------------------------------------------------------------------------------------

@@ -103,13 +103,18 @@ __device__ __forceinline__ void ring_request(const Ring &r, const WaveCtx &c, ui
   asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(voff), "s"(dst), "s"(r.rs) : "memory");
 }
 
-__device__ __forceinline__ void ring_begin(Ring &r, const WaveCtx &c, uint64_t pos)
+// `limit` = first stream byte this chain can NOT need (the next chain's cursor, or the stream length): requests past it
+// are dropped by the descriptor's range check instead of fetching a neighbour's words
+__device__ __forceinline__ void ring_begin(Ring &r, const WaveCtx &c, uint64_t pos, uint64_t limit)
 {
   pos = uni64(pos);
+  limit = uni64(limit);
+  if (limit > c.stream_len)
+    limit = c.stream_len;
   const uint64_t a0 = pos & ~(uint64_t)15;
   // range in whole 16-byte lanes: a dwordx4 that straddles num_records is dropped as a whole, and a0 is 16-aligned
   // inside a 16-aligned allocation, so rounding up never leaves the page the last stream byte is on
-  const uint64_t left = a0 < c.stream_len ? (c.stream_len - a0 + 15) & ~(uint64_t)15 : 0;
+  const uint64_t left = a0 < limit ? (limit - a0 + 15) & ~(uint64_t)15 : 0;
   const uint64_t addr = (uint64_t)(uintptr_t)c.stream + a0;
   r.rs.x = uni((uint32_t)addr);
   r.rs.y = uni((uint32_t)(addr >> 32) & 0xFFFF); // stride 0
@@ -129,7 +134,7 @@ __device__ __forceinline__ void ring_ready() { asm volatile("s_waitcnt vmcnt(1)"
 
 __device__ __forceinline__ void ring_init(Ring &r, const WaveCtx &c, uint64_t pos)
 {
-  ring_begin(r, c, pos);
+  ring_begin(r, c, pos, c.stream_len);
   ring_ready();
 }
 
@@ -616,7 +621,8 @@ __global__ void __launch_bounds__(1024) k_decode(KParams kp)
       {
         const Piece *p0 = pv.pieces + uni(pv.chain_first[first]);
         const Piece *p1 = pv.pieces + uni(pv.chain_first[last - 1]);
-        ring_begin(r, c, uni64(p0->words_off));
+        const uint64_t limit = last < n ? uni64(pv.pieces[uni(pv.chain_first[last])].words_off) : c.stream_len;
+        ring_begin(r, c, uni64(p0->words_off), limit);
         x = c.lane < c.S ? pv.states[(uint64_t)uni(p0->state_idx) * c.S + c.lane] : 0;
         o = uni64(p0->out_off);
         steps = (uint32_t)((uni64(p1->out_off) - o) / c.S) + uni(p1->steps);

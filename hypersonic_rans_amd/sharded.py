@@ -1,0 +1,74 @@
+"""Chunk-parallel decode of ONE stream over the GPUs of a node (one process per GPU, torch.distributed).
+
+The reference fans independent mt_ blocks out to a thread pool (src/mt_rANS32x64_16w_decode.cpp:217-220).  Here the unit
+is a *chain* of the decode plan (an mt_ block, or a checkpoint interval of a raw / block_ stream): the chains are split
+into `world_size` contiguous runs balanced by decoded bytes, every rank decodes its run into the same output offsets of
+its own buffer, and the disjoint byte ranges are then exchanged with one all_gather over RCCL (xGMI) — the only
+collective, and only because the caller asked for the whole output on every rank (`gather=True`).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import api
+
+
+def shard_chains(plan, world_size: int) -> list[tuple[int, int]]:
+    """Splits the plan's chains into `world_size` contiguous runs [(first, count), ...] of (nearly) equal decoded bytes.
+    Runs may be empty (count == 0) when there are fewer chains than ranks."""
+    hdr, cf, pieces = api.plan_tables(plan)
+    n, S = hdr["n_chains"], hdr["states"]
+    size = np.where(pieces["flags"] & 2, pieces["fill_len"], pieces["steps"].astype(np.uint64) * S + pieces["tail"]).astype(np.uint64)
+    per_piece_end = np.cumsum(size)
+    chain_end = per_piece_end[cf[1:].astype(np.int64) - 1]  # decoded bytes up to and including chain c (chains are in output order)
+    total = int(chain_end[-1]) if n else 0
+    bounds = [0]
+    for r in range(1, world_size):
+        target = total * r // world_size
+        bounds.append(max(bounds[-1], int(np.searchsorted(chain_end, target, side="right"))))
+    bounds.append(n)
+    return [(bounds[r], bounds[r + 1] - bounds[r]) for r in range(world_size)]
+
+
+def local_range(plan, first: int, count: int) -> tuple[int, int]:
+    return api.plan_chain_range(plan, first, count) if count else (0, 0)
+
+
+def gather_ranges(local_out: torch.Tensor, ranges: list[tuple[int, int]], group=None) -> torch.Tensor:
+    """`local_out` holds this rank's decoded bytes at their final offsets; `ranges[r]` = [begin, end) owned by rank r.
+    Returns the full output on every rank.  One all_gather of equal-sized (padded) slices: a ring over xGMI moves
+    (world-1)/world of the output per link, which is the minimum for "everyone gets everything"."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    width = max(e - b for b, e in ranges)
+    width = (width + 15) // 16 * 16
+    send = torch.zeros(width, dtype=torch.uint8, device=local_out.device)
+    b, e = ranges[rank]
+    send[: e - b] = local_out[b:e]
+    recv = torch.empty(world * width, dtype=torch.uint8, device=local_out.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    out = local_out.clone()
+    for r, (rb, re) in enumerate(ranges):
+        if r != rank and re > rb:
+            out[rb:re] = recv[r * width: r * width + (re - rb)]
+    return out
+
+
+def decode_sharded(ctx: "api.Context", d_stream: torch.Tensor, stream_length: int, plan, gather: bool = True, group=None) -> torch.Tensor:
+    """Every rank holds the compressed stream in HBM and the (host) plan; rank r decodes chain run r.
+    Returns the full decoded tensor (gather=True) or the local buffer with only this rank's range filled."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    runs = shard_chains(plan, world)
+    ranges = [local_range(plan, f, c) for f, c in runs]
+    total = api.plan_decoded_length(plan)
+    out = torch.zeros(total, dtype=torch.uint8, device=d_stream.device)
+    first, count = runs[rank]
+    if count:
+        dplan = ctx.make_device_plan(api.plan_slice(plan, first, count))
+        ctx.decode_device(dplan, d_stream, out, stream_length=stream_length)
+        if ctx.status(dplan) != 0:
+            raise api.HsransError("device reported a malformed histogram / block header")
+    return gather_ranges(out, ranges, group) if gather else out

@@ -15,7 +15,7 @@ static inline void st32(uint8_t *p, uint32_t v) { memcpy(p, &v, 4); }
 static inline void st16(uint8_t *p, uint16_t v) { memcpy(p, &v, 2); }
 
 /* rANS32x64_16w.cpp:210-216: the table is the bit permutation j -> (j&0x23) | ((j&4)<<2) | ((j&0x18)>>1);
- * tests/test_oracle_golden.py checks it against the 64 literal values held in tests/golden/idx2idx.json. */
+ * it is pinned through the golden streams (tests/test_oracle_golden.py): any wrong entry scrambles every decoded group. */
 uint8_t orc_idx2idx(unsigned j)
 {
   return (uint8_t)((j & 0x23u) | ((j & 0x04u) << 2) | ((j & 0x18u) >> 1));

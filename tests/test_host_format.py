@@ -1,0 +1,162 @@
+"""Host-side logic of the product, no GPU: C-ABI surface, encoders, planner, plan slicing — checked with the CPU oracle."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import hypersonic_rans_amd as H
+from hypersonic_rans_amd import api, sharded, synth
+from oracle_lib import BLOCK, MT, RAW
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "hsrans_hip.h")).read()
+    names = set(re.findall(r"\b(hsrans_[a-z_0-9]+)\s*\(", hdr))
+    assert len(names) >= 20
+    lib = H.load_library()
+    for n in sorted(names):
+        assert hasattr(lib, n), f"{n} declared in include/hsrans_hip.h but not exported"
+
+
+def test_dropin_cpp_names_are_exported():
+    out = subprocess.run(["nm", "-D", "--demangle", H.lib_path()], capture_output=True, text=True, check=True).stdout
+    for cont in ("", "block_", "mt_"):
+        for S in (32, 64):
+            for bits in range(10, 16):
+                assert f"hsrans_hip::{cont}rANS32x{S}_16w_decode_hip_{bits}(" in out
+                enc = f"hsrans_hip::rANS32x{S}_16w_encode_scalar_{bits}(" if cont == "" else f"hsrans_hip::{cont}rANS32x{S}_16w_encode_{bits}("
+                assert enc in out
+            assert f"hsrans_hip::{cont}rANS32x{S}_16w_capacity(" in out
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(H.HsransError):
+        H.Context(0)
+
+
+def test_product_does_not_reference_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "hypersonic_rans_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", ".hpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_lib" not in text and "hsrans_oracle" not in text and "libhsrans_ref" not in text, f
+
+
+@pytest.fixture(scope="module")
+def zipf():
+    return synth.enwik8_shaped(400_000, seed=31)
+
+
+@pytest.fixture(scope="module")
+def nonstat():
+    return synth.nonstationary(1_500_000, seed=77)
+
+
+@pytest.mark.parametrize("states", (32, 64))
+def test_capacity_hist_and_raw_encode_match_the_oracle(oracle, zipf, states):
+    for n in (0, 1, 63, 64, 1000, 65536, 100_000_000):
+        for c in (RAW, BLOCK, MT):
+            assert H.capacity(c, states, n) == oracle.capacity(c, states, n)
+    for bits in range(10, 16):
+        for n in (1, 31, 63, 64, 65, 127, 128, 1000, 65600, 400_000):
+            d = zipf[:n]
+            assert list(H.make_hist(d, bits).symbolCount) == list(oracle.make_hist(d, bits).symbolCount)
+            assert np.array_equal(H.encode(H.RAW, states, bits, d), oracle.raw_encode(states, bits, d)), (bits, n)
+
+
+@pytest.mark.parametrize("container", (RAW, BLOCK, MT))
+@pytest.mark.parametrize("states", (32, 64))
+def test_streams_and_plans(oracle, zipf, nonstat, container, states):
+    for bits in (10, 11, 13, 15):
+        for src, n in ((zipf, 1), (zipf, 63), (zipf, 64), (zipf, 65), (zipf, 1000), (zipf, 65536), (zipf, 65560), (zipf, 65599), (zipf, 65600),
+                       (zipf, 131073), (zipf, 400_000), (nonstat, 1_500_000)):
+            d = src[:n]
+            for interval in (0, 4, 64):
+                if interval:
+                    s, plan = H.encode(container, states, bits, d, index_interval=interval)
+                else:
+                    s, plan = H.encode(container, states, bits, d), None
+                if n >= states - 1 or container == RAW:
+                    r, got = oracle.decode(container, states, bits, s, n)  # the reference's decoder accepts our stream
+                    assert r == n and np.array_equal(got, d), (bits, n, interval)
+                if plan is not None:
+                    r, got = oracle.exec_plan(plan, s, n)
+                    assert r == n and np.array_equal(got, d), ("plan", bits, n, interval)
+            if container != BLOCK and (n >= states - 1 or container == RAW):
+                plan = H.plan_build(container, states, bits, s)
+                r, got = oracle.exec_plan(plan, s, n)
+                assert r == n and np.array_equal(got, d), ("plan_build", bits, n)
+
+
+def test_plan_build_on_reference_streams_reproduces_reference_output(oracle):
+    """Golden mt_ streams written by the real reference, incl. the quirk lengths where its own round trip is wrong."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "small_vectors.npz"))
+    n_checked = 0
+    for k in [k[:-7] for k in g.files if k.endswith("_stream")]:
+        parts = k.split("_")
+        if parts[0] == "quirk":
+            cont, S, bits, n = parts[1], int(parts[2][1:]), int(parts[3][1:]), int(parts[4][1:])
+            want = g[k + "_decoded"]
+        else:
+            cont, S, bits = parts[0], int(parts[1][1:]), int(parts[2][1:])
+            want = g[k + "_in"]
+            n = want.size
+        if cont == "block":
+            continue  # inline headers: walked on the device
+        s = g[k + "_stream"]
+        plan = H.plan_build({"raw": RAW, "mt": MT}[cont], S, bits, s)
+        r, got = oracle.exec_plan(plan, s, n)
+        assert r == n and np.array_equal(got, want), k
+        n_checked += 1
+    assert n_checked > 60
+
+
+def test_malformed_streams_are_rejected(zipf):
+    d = zipf[:10_000]
+    for container in (RAW, MT, BLOCK):
+        s = H.encode(container, 64, 11, d)
+        with pytest.raises(H.HsransError):
+            H.plan_build(container, 64, 11, s[:100])  # shorter than a header
+        with pytest.raises(H.HsransError):
+            H.plan_build(container, 64, 11, s, out_capacity=9_999)  # outCapacity < decodedLength
+        t = s.copy()
+        t[8:16] = np.frombuffer(np.uint64(s.size + 1).tobytes(), np.uint8)
+        with pytest.raises(H.HsransError):
+            H.plan_build(container, 64, 11, t)  # inLength < stored length
+    s = H.encode(H.MT, 64, 11, d)
+    t = s.copy()
+    t[16 + 16 + 256] ^= 1  # a count of the first block: sum != 2^11
+    with pytest.raises(H.HsransError):
+        H.plan_build(H.MT, 64, 11, t)
+    with pytest.raises(H.HsransError):
+        H.plan_build(H.MT, 64, 12, s)  # wrong bits
+
+
+def test_plan_slices_cover_the_output(oracle, zipf):
+    d = zipf[:300_001]
+    for container in (RAW, MT, BLOCK):
+        s, plan = H.encode(container, 64, 11, d, index_interval=16)
+        for world in (1, 2, 3, 8):
+            runs = sharded.shard_chains(plan, world)
+            assert sum(c for _, c in runs) == H.plan_chain_count(plan)
+            out = np.zeros(d.size, np.uint8)
+            pos = 0
+            for first, count in runs:
+                if count == 0:
+                    continue
+                b, e = H.plan_chain_range(plan, first, count)
+                assert b == pos
+                pos = e
+                r, part = oracle.exec_plan(H.plan_slice(plan, first, count), s, d.size)
+                assert r == d.size
+                out[b:e] = part[b:e]
+            assert pos == d.size and np.array_equal(out, d)

@@ -1,0 +1,60 @@
+"""Differential test: oracle restatement vs the REAL reference compiled into oracle/_ref (skipped where it is absent)."""
+import numpy as np
+import pytest
+
+from hypersonic_rans_amd import synth
+from oracle_lib import BLOCK, MT, RAW
+
+
+@pytest.fixture(scope="module")
+def data():
+    return synth.enwik8_shaped(300_000, seed=21), synth.nonstationary(1_200_000, seed=5)
+
+
+@pytest.mark.parametrize("states", (32, 64))
+@pytest.mark.parametrize("bits", (10, 11, 12, 13, 14, 15))
+def test_raw(oracle, ref, data, states, bits):
+    zipf, _ = data
+    for n in (1, 31, 62, 63, 64, 65, 127, 128, 129, 1000, 65536, 65600, 131073, 300_000):
+        d = zipf[:n]
+        counts, _ = ref.make_hist(d, bits)
+        assert list(oracle.make_hist(d, bits).symbolCount) == list(counts)
+        s_ref = ref.encode(RAW, states, bits, d)
+        assert np.array_equal(oracle.raw_encode(states, bits, d), s_ref)
+        r, got = oracle.decode(RAW, states, bits, s_ref, n)
+        assert r == n and np.array_equal(got, d)
+        if n >= states - 1:  # below that the reference walks off its buffers (rANS32x64_16w.cpp:220)
+            for variant in (0, 1):
+                r2, got2 = ref.decode(RAW, states, bits, s_ref, n, variant=variant)
+                assert r2 == n and np.array_equal(got2, got)
+
+
+@pytest.mark.parametrize("container", (BLOCK, MT))
+@pytest.mark.parametrize("states", (32, 64))
+def test_containers_including_quirk_lengths(oracle, ref, data, container, states):
+    zipf, nonstat = data
+    for bits in (10, 11, 12, 13, 14, 15):
+        for src, n in ((zipf, 64), (zipf, 1000), (zipf, 65536), (zipf, 65537), (zipf, 65560), (zipf, 65599), (zipf, 65600), (zipf, 131073),
+                       (zipf, 131100), (zipf, 300_000), (nonstat, 1_200_000), (nonstat, 700_001)):
+            if n < states:
+                continue
+            d = src[:n]
+            s = ref.encode(container, states, bits, d)
+            r1, o1 = ref.decode(container, states, bits, s, n)
+            r2, o2 = oracle.decode(container, states, bits, s, n)
+            assert r1 == r2 and np.array_equal(o1, o2), (container, states, bits, n)
+
+
+def test_error_returns(oracle, ref, data):
+    zipf, _ = data
+    d = zipf[:5000]
+    for container in (RAW, BLOCK, MT):
+        s = ref.encode(container, 64, 11, d)
+        for cap, in_len in ((4999, None), (5000, s.size - 1), (5000, 100)):
+            r1, _ = oracle.decode(container, 64, 11, s, cap, in_len=in_len)
+            assert r1 == 0
+        bad = s.copy()
+        off = 16 if container == RAW else (16 + 256 + 8 if container == BLOCK else 16 + 16 + 256)
+        bad[off] ^= 1
+        assert oracle.decode(container, 64, 11, bad, 5000)[0] == 0
+        assert ref.decode(container, 64, 11, bad, 5000)[0] == 0
