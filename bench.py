@@ -64,6 +64,24 @@ def cpu_baseline(stream: np.ndarray, data: np.ndarray, states: int, bits: int, b
             "host_cores": os.cpu_count()}
 
 
+def _pmc_traffic(n: int, states: int, bits: int, interval: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC run of this very workload (profiles/*_pmc.json, written by
+    tools/pmc_summary.py: FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).
+    PMC counters cannot be collected from inside this process, so this is null unless such a run matches the workload."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            j = json.load(open(f))
+            cfg = j["bench_line_under_trace"]["config"]
+            if (cfg["decoded_bytes"], cfg["states"], cfg["bits"], cfg["index_interval_groups"]) == (n, states, bits, interval):
+                best = float(j["hbm_traffic_bytes_per_launch"]["total"])
+        except (KeyError, ValueError, OSError):
+            continue
+    return best
+
+
 def _cpu_model() -> str:
     try:
         with open("/proc/cpuinfo") as f:
@@ -128,20 +146,25 @@ def main() -> None:
     assert torch.equal(d_out, d_ref), "GPU output is not bit-exact"
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides ------------------------------------------
+    # One HIP event pair brackets the K launches ON THE LAUNCH STREAM (hsrans_decode_device launches on torch's current
+    # stream, which is where torch.cuda.Event records): span / K = the kernel's average launch duration for the roofline.
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev_a.record()
     for _ in range(args.steps):
         step()
+    ev_b.record()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    kernel_ms_span = ev_a.elapsed_time(ev_b) / args.steps
 
-    # ---- per-launch duration of the decode kernel for the roofline: HIP events on the launch stream (torch's current
-    # stream is the one hsrans_decode_device launches on), outside the timed region so they do not perturb it
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # per-launch spread (outside the timed region; each pair adds event/launch latency, so only min/max are reported)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 20))]
     for a, b in ev:
         a.record()
         step()
@@ -162,7 +185,7 @@ def main() -> None:
     if rank == 0:
         info = dplan.launch_info()
         ms_per_step = elapsed * 1e3 / args.steps
-        k_avg = float(np.mean(kernel_ms))
+        k_avg = float(kernel_ms_span)
         k_min = float(np.min(kernel_ms))
         alg_bytes = stream.size + n  # compressed bytes read once + decoded bytes written once
         achieved = alg_bytes / (k_avg * 1e-3) / 1e9
@@ -188,9 +211,10 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": k_avg, "kernel_ms_min": k_min,
-                "kernel": "hsrans::k_decode<false,true> (packed table, shared per workgroup)",
+                "traffic": _pmc_traffic(n, S, bits, args.interval),
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": k_avg, "kernel_ms_single_launch_min": k_min,
+                "kernel": "hsrans::k_decode<%d, %s>" % (3 if info["shared_table"] and bits <= 11 else (2 if bits >= 13 else (1 if bits == 12 else 0)),
+                                                        "true" if info["shared_table"] else "false"),
             },
         }
 

@@ -1,14 +1,16 @@
 #!/bin/bash
-# Profiling recipe (run on the GPU box through gpurun): kernel trace + stats, then PMC passes (separate runs).
-# usage: bash tools_profile.sh <tag> [bench args...]
+# Profiling recipe for the decode kernel (run on the GPU box through gpurun, from the repo root):
+#   bash tools/profile.sh <tag> [bench.py args...]
+# 1. kernel trace + stats (rocprofv3 --kernel-trace --stats) of the default bench command;
+# 2. PMC counters in SEPARATE passes (never combined with tracing; FETCH_SIZE and WRITE_SIZE cannot share a pass).
+# Results land in gpurun_out/prof_<tag>/; tools/pmc_summary.py turns them into profiles/<tag>_*.{csv,json}.
 set -u
 TAG=${1:-r01}; shift || true
 export TMPDIR=/tmp
 BARGS="$*"
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
-cd $PWD
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-single "$@" > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 50 --warmup 5 --no-cpu --no-single $BARGS > $OUT/trace.log 2>&1
 pmc() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-single $BARGS > $OUT/pmc_$name.log 2>&1; }
 pmc a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 pmc b SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU
@@ -16,4 +18,5 @@ pmc c SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGN
 pmc d FETCH_SIZE
 pmc e WRITE_SIZE
 pmc f GRBM_GUI_ACTIVE GRBM_COUNT
-ls -R $OUT | head -50
+pmc g TCC_HIT_sum TCC_MISS_sum
+tail -2 $OUT/trace.log
