@@ -1,6 +1,7 @@
 // C ABI of libhsrans_hip.so (declared in include/hsrans_hip.h).  Nothing here decodes on the CPU: every decode entry
 // ends in a launch of the gfx950 kernels in hsrans_kernels.hip and fails when no usable device exists.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -34,11 +35,16 @@ struct hsrans_dplan
   PlanHeader hdr{};
   uint8_t *d_plan = nullptr;
   uint32_t *d_status = nullptr;
+  uint64_t *d_stamps = nullptr; // diagnostics (HSRANS_DEBUG_STAMPS=1)
+  unsigned long long *d_counters = nullptr; // persistent launches: monotonic queue heads
+  PersistentArgs pa{};
   LaunchInfo info{};
 };
 
 namespace
 {
+constexpr size_t kStampWaves = 16384;
+
 bool grow(uint8_t **p, size_t *cap, size_t need)
 {
   if (need <= *cap)
@@ -264,14 +270,53 @@ int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
     hsrans_dplan_destroy(d);
     return HSRANS_E_HIP;
   }
+  if ((h.flags & kPlanMergeable) && h.container == HSRANS_RAW && h.interval != 0)
+  {
+    // persistent launch arguments, taken from the plan once (hsrans_kernels.h PersistentArgs)
+    const Piece *pc = (const Piece *)(plan + plan_pieces_off(h.n_chains));
+    const Piece &first = pc[0], &last = pc[h.n_pieces - 1];
+    bool uniform = h.n_pieces == h.n_chains;
+    for (uint32_t i = 0; uniform && i + 1 < h.n_pieces; i++)
+      uniform = pc[i].steps == h.interval && pc[i].state_idx == i;
+    uniform = uniform && last.steps >= 1 && last.steps <= h.interval && last.state_idx == h.n_pieces - 1;
+    if (uniform && hipMalloc((void **)&d->d_counters, kDynQueues * kDynQueueStride * 8) == hipSuccess &&
+        hipMemset(d->d_counters, 0, kDynQueues * kDynQueueStride * 8) == hipSuccess)
+    {
+      d->pa.pieces = (const Piece *)(d->d_plan + plan_pieces_off(h.n_chains));
+      d->pa.states = (const uint32_t *)(d->d_plan + plan_states_off(h.n_chains, h.n_pieces));
+      d->pa.n_chains = h.n_chains;
+      d->pa.interval = h.interval;
+      d->pa.S = h.states;
+      d->pa.bits = h.bits;
+      d->pa.out_base = first.out_off;
+      d->pa.steps_total = (uint64_t)(h.n_chains - 1) * h.interval + last.steps;
+      d->pa.hist_off = h.aux_off;
+      d->pa.tail = last.tail;
+      d->pa.counters = d->d_counters;
+    }
+  }
+  if (getenv("HSRANS_DEBUG_STAMPS") && hipMalloc((void **)&d->d_stamps, kStampWaves * 4 * 8) == hipSuccess)
+    (void)hipMemset(d->d_stamps, 0, kStampWaves * 4 * 8);
   *out_dplan = d;
   return HSRANS_OK;
+}
+
+size_t hsrans_debug_read_stamps(hsrans_dplan *d, uint64_t *out, size_t capacity_u64)
+{
+  if (d == nullptr || d->d_stamps == nullptr || out == nullptr)
+    return 0;
+  const size_t n = capacity_u64 < kStampWaves * 4 ? capacity_u64 : kStampWaves * 4;
+  return hipMemcpy(out, d->d_stamps, n * 8, hipMemcpyDeviceToHost) == hipSuccess ? n : 0;
 }
 
 void hsrans_dplan_destroy(hsrans_dplan *d)
 {
   if (d == nullptr)
     return;
+  if (d->d_stamps)
+    (void)hipFree(d->d_stamps);
+  if (d->d_counters)
+    (void)hipFree(d->d_counters);
   if (d->d_plan)
     (void)hipFree(d->d_plan);
   if (d->d_status)
@@ -297,6 +342,8 @@ int hsrans_decode_device(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_stream,
   kp.out_cap = out_capacity;
   kp.plan = d->d_plan;
   kp.status = d->d_status;
+  kp.stamps = d->d_stamps;
+  kp.pa = d->pa;
   return launch_decode(kp, d->hdr, s, &d->info) == hipSuccess ? HSRANS_OK : HSRANS_E_HIP;
 }
 

@@ -10,6 +10,21 @@
 namespace hsrans
 {
 
+// Persistent launch of a kPlanMergeable plan: everything a wave needs without a dependent read of the plan header.
+// Chain c (local index) covers groups [c*interval, min((c+1)*interval, steps_total)) of the run that starts at out_base.
+struct PersistentArgs
+{
+  const Piece *pieces;   // null = not a persistent launch
+  const uint32_t *states;
+  uint32_t n_chains, interval, S, bits;
+  uint64_t out_base, steps_total, hist_off;
+  uint32_t tail;            // symbols of the final partial group (after the last chain)
+  uint32_t static_per_wave; // chains every wave decodes as one merged run before it starts pulling single chains
+  unsigned long long *counters; // [kDynQueues * kDynQueueStride] monotonic queue heads (never reset, see run_persistent)
+};
+constexpr uint32_t kDynQueues = 64;
+constexpr uint32_t kDynQueueStride = 32; // in uint64: one head per 256 B, so that heads never share a line / atomic unit
+
 struct KParams
 {
   const uint8_t *stream; // device, 16-byte aligned
@@ -23,6 +38,9 @@ struct KParams
   uint32_t *ckpt_states;
   uint64_t *ckpt_words;
   uint32_t ckpt_interval;
+  // diagnostics only (HSRANS_DEBUG_STAMPS=1): per wave {entry, table built, stream ready, done} s_memtime stamps; null otherwise
+  uint64_t *stamps;
+  PersistentArgs pa;
 };
 
 struct LaunchInfo

@@ -22,6 +22,7 @@
 //   * no MFMA: this is integer gather work; the roofline that bounds it is HBM (compressed bytes in + decoded bytes out).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "hsrans_kernels.h"
 #include "hsrans_plan.h"
@@ -485,6 +486,95 @@ __device__ void run_planned_chain(const WaveCtx &c, const PlanView &pv, uint32_t
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent launch (kPlanMergeable plans): the grid is sized to the machine (2 workgroups per CU).  Every wave first
+// decodes `static_per_wave` consecutive chains as ONE chain (stream requests and state load in flight while the
+// workgroup builds its table), then pulls single chains from one of kDynQueues atomic heads until the stream is done.
+// Why dynamic: the SIMD arbiter favours its oldest wave, so equal static shares finish 2x apart (measured 23..52 us)
+// and the tail runs at one-wave latency; the queues keep every SIMD full until the end.
+// ---------------------------------------------------------------------------------------------------------------
+struct RunGeom
+{
+  uint64_t o;
+  uint32_t steps, tail;
+};
+
+template <int MODE>
+__device__ __forceinline__ RunGeom run_begin(const WaveCtx &c, const PersistentArgs &pa, uint32_t c0, uint32_t c1, uint32_t &x, Ring &r)
+{
+  const uint64_t words = uni64(pa.pieces[c0].words_off);
+  const uint64_t limit = c1 < pa.n_chains ? uni64(pa.pieces[c1].words_off) : c.stream_len;
+  ring_begin(r, c, words, limit);
+  x = c.lane < c.S ? pa.states[(uint64_t)c0 * c.S + c.lane] : 0;
+  RunGeom g;
+  const uint64_t g0 = (uint64_t)c0 * pa.interval;
+  const uint64_t g1 = (uint64_t)c1 * pa.interval < pa.steps_total ? (uint64_t)c1 * pa.interval : pa.steps_total;
+  g.o = pa.out_base + g0 * c.S;
+  g.steps = (uint32_t)(g1 - g0);
+  g.tail = c1 == pa.n_chains ? pa.tail : 0;
+  return g;
+}
+
+template <int MODE>
+__device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t waves, uint32_t w)
+{
+  const PersistentArgs &pa = kp.pa;
+  const uint32_t W = gridDim.x * waves;
+  const uint64_t t_entry = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  uint64_t t_table = 0, t_ready = 0;
+
+  uint32_t x = 0;
+  Ring r;
+  RunGeom g{};
+  const uint32_t q0 = pa.static_per_wave;
+  const bool have_static = q0 != 0; // host guarantees W * q0 <= n_chains
+  if (have_static)
+    g = run_begin<MODE>(c, pa, w * q0, w * q0 + q0, x, r);
+  build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
+  if (kp.stamps)
+    t_table = __builtin_amdgcn_s_memrealtime();
+  if (have_static)
+  {
+    ring_ready();
+    if (kp.stamps)
+      t_ready = __builtin_amdgcn_s_memrealtime();
+    run_groups<MODE>(x, r, c, g.o, g.steps);
+    run_tail<MODE>(x, r, c, g.o, g.tail);
+  }
+
+  // Dynamic part: queue k hands out chains [lo, hi) in order.  Its 64-bit head is never reset: every launch draws
+  // exactly H = (hi - lo) + (waves on this queue) tickets from it (each wave fails exactly once), and launches on one
+  // plan are serialised by their stream, so ticket mod H is this launch's ticket.  No memset node, no exit protocol.
+  const uint32_t dyn0 = W * q0;
+  const uint64_t D = pa.n_chains - dyn0;
+  const uint32_t k = w & (kDynQueues - 1);
+  const uint32_t lo = dyn0 + (uint32_t)(k * D / kDynQueues), hi = dyn0 + (uint32_t)((k + 1) * D / kDynQueues);
+  const uint64_t H = (uint64_t)(hi - lo) + (W - k + kDynQueues - 1) / kDynQueues;
+  while (true)
+  {
+    unsigned long long t = 0;
+    if (c.lane == 0)
+      t = atomicAdd(pa.counters + k * kDynQueueStride, 1ull);
+    t = uni64(t) % H;
+    if (t >= hi - lo)
+      break;
+    const uint32_t ch = lo + (uint32_t)t;
+    g = run_begin<MODE>(c, pa, ch, ch + 1, x, r);
+    ring_ready();
+    run_groups<MODE>(x, r, c, g.o, g.steps);
+    run_tail<MODE>(x, r, c, g.o, g.tail);
+  }
+
+  if (kp.stamps && c.lane == 0)
+  {
+    uint64_t *st = kp.stamps + (uint64_t)w * 4;
+    st[0] = t_entry;
+    st[1] = t_table;
+    st[2] = t_ready;
+    st[3] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
 // block_ container without checkpoints: one wave follows the inline headers exactly like
 // block_rANS32x64_16w_decode.cpp:47-123 (states carry over, histogram swapped per block).
 template <int MODE>
@@ -575,7 +665,7 @@ __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv)
 // LDS: SHARED  -> [waves x ring][table];   otherwise -> per wave [ring][table]
 // ---------------------------------------------------------------------------------------------------------------
 template <int MODE, bool SHARED>
-__global__ void __launch_bounds__(1024) k_decode(KParams kp)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_decode(KParams kp)
 {
   extern __shared__ u32x4 smem_v[];
   uint8_t *smem = (uint8_t *)smem_v;
@@ -606,35 +696,9 @@ __global__ void __launch_bounds__(1024) k_decode(KParams kp)
     c.table = smem + waves * kRingBytes;
     c.scratch = (uint16_t *)(smem + (kRingSlots - 1) * kChunkBytes); // last slot of wave 0's ring: free until the first ring_advance
     const uint64_t hist_off = pv.hdr->aux_off; // shared plans: the one histogram every chain uses
-    if (pv.hdr->flags & kPlanMergeable)
+    if (kp.pa.pieces != nullptr)
     {
-      // Persistent shape: the grid is sized to the machine and every wave decodes an equal, contiguous run of chains
-      // [first, last) as ONE chain from chain `first`'s start states.  The stream requests and the state load are
-      // in flight while the workgroup builds its table.
-      const uint64_t total_waves = (uint64_t)gridDim.x * waves, n = pv.hdr->n_chains;
-      const uint32_t first = (uint32_t)(chain * n / total_waves), last = (uint32_t)((chain + 1) * n / total_waves);
-      const bool have = first < last;
-      uint32_t x = 0, steps = 0, tail = 0;
-      uint64_t o = 0;
-      Ring r;
-      if (have)
-      {
-        const Piece *p0 = pv.pieces + uni(pv.chain_first[first]);
-        const Piece *p1 = pv.pieces + uni(pv.chain_first[last - 1]);
-        const uint64_t limit = last < n ? uni64(pv.pieces[uni(pv.chain_first[last])].words_off) : c.stream_len;
-        ring_begin(r, c, uni64(p0->words_off), limit);
-        x = c.lane < c.S ? pv.states[(uint64_t)uni(p0->state_idx) * c.S + c.lane] : 0;
-        o = uni64(p0->out_off);
-        steps = (uint32_t)((uni64(p1->out_off) - o) / c.S) + uni(p1->steps);
-        tail = uni(p1->tail);
-      }
-      build_table<MODE, true>(c, hist_off, threadIdx.x, blockDim.x);
-      if (have)
-      {
-        ring_ready();
-        run_groups<MODE>(x, r, c, o, steps);
-        run_tail<MODE>(x, r, c, o, tail);
-      }
+      run_persistent<MODE>(c, kp, waves, chain);
       return;
     }
     build_table<MODE, true>(c, hist_off, threadIdx.x, blockDim.x);
@@ -663,6 +727,7 @@ __global__ void __launch_bounds__(1024) k_decode(KParams kp)
 // ---------------------------------------------------------------------------------------------------------------
 static uint32_t g_max_lds = 160 * 1024;
 static uint32_t g_num_cus = 256;
+static uint32_t g_static_percent = 75; // HSRANS_STATIC_PERCENT (tuning): share of the chains handed out statically
 
 typedef void (*KernelFn)(KParams);
 static KernelFn kernel_for(int mode, bool shared)
@@ -681,6 +746,8 @@ static KernelFn kernel_for(int mode, bool shared)
 
 hipError_t prepare_kernels()
 {
+  if (const char *e = getenv("HSRANS_STATIC_PERCENT"))
+    g_static_percent = (uint32_t)atoi(e) > 100 ? 100 : (uint32_t)atoi(e);
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
     g_num_cus = (uint32_t)cus;
@@ -694,8 +761,9 @@ hipError_t prepare_kernels()
   return hipSuccess;
 }
 
-hipError_t launch_decode(const KParams &kp, const PlanHeader &h, hipStream_t stream, LaunchInfo *info)
+hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t stream, LaunchInfo *info)
 {
+  KParams kp = kp_in;
   const bool two_level = h.bits >= 13;
   const bool walk = (h.flags & kPlanWalk) != 0;
   const bool shared = !walk && h.shared_hist != 0 && h.n_chains > 1;
@@ -712,7 +780,7 @@ hipError_t launch_decode(const KParams &kp, const PlanHeader &h, hipStream_t str
       waves /= 2;
     lds = waves * kRingBytes + table_bytes;
     grid = (h.n_chains + waves - 1) / waves;
-    if ((h.flags & kPlanMergeable) && kp.ckpt_interval == 0)
+    if (kp.pa.pieces != nullptr)
     {
       const uint32_t per_cu = g_max_lds / lds ? g_max_lds / lds : 1; // workgroups one CU can hold (LDS-limited; 32 waves max)
       const uint32_t resident = g_num_cus * (per_cu * waves > 32 ? 32 / waves : per_cu);
@@ -731,6 +799,12 @@ hipError_t launch_decode(const KParams &kp, const PlanHeader &h, hipStream_t str
   if (grid == 0)
     grid = 1;
 
+  if (kp.pa.pieces != nullptr)
+  {
+    // static share: a fixed fraction of the chains, split evenly; the rest goes through the queues
+    const uint64_t W = (uint64_t)grid * waves;
+    kp.pa.static_per_wave = (uint32_t)((uint64_t)h.n_chains * g_static_percent / 100 / W);
+  }
   KernelFn fn = kernel_for(mode, shared);
   if (info)
   {

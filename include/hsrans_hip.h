@@ -131,6 +131,10 @@ typedef struct hsrans_launch_info
 } hsrans_launch_info;
 int hsrans_dplan_launch_info(const hsrans_dplan *dplan, hsrans_launch_info *info);
 
+/* diagnostics: with HSRANS_DEBUG_STAMPS=1 in the environment every wavefront of a persistent launch records four
+ * s_memtime stamps {entry, table built, stream ready, done}; copies up to capacity_u64 values to `out`, returns the count */
+size_t hsrans_debug_read_stamps(hsrans_dplan *dplan, uint64_t *out, size_t capacity_u64);
+
 const char *hsrans_version(void);
 
 #ifdef __cplusplus
