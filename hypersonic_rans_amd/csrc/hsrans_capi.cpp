@@ -37,6 +37,7 @@ struct hsrans_dplan
   uint32_t *d_status = nullptr;
   uint64_t *d_stamps = nullptr; // diagnostics (HSRANS_DEBUG_STAMPS=1)
   unsigned long long *d_counters = nullptr; // persistent launches: monotonic queue heads
+  uint2 *d_table = nullptr;                 // host-built decode table (plans that carry their histogram)
   PersistentArgs pa{};
   LaunchInfo info{};
 };
@@ -293,6 +294,32 @@ int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
       d->pa.hist_off = h.aux_off;
       d->pa.tail = last.tail;
       d->pa.counters = d->d_counters;
+      if ((h.flags & kPlanHasHist) && h.bits <= 11)
+      {
+        // decode table for the shared-table kernel (MODE 3): {freq | sym << 24, slot - cumul} per slot, the same
+        // entries build_table<kModePack64> produces (hist.cpp:291-306 / :308-324 for the sum check)
+        const uint16_t *counts = (const uint16_t *)(plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
+        const uint32_t total = 1u << h.bits;
+        std::vector<uint2> tab(total);
+        uint32_t cum = 0;
+        for (uint32_t s = 0; s < 256; s++)
+        {
+          for (uint32_t k = 0; k < counts[s] && cum + k < total; k++)
+            tab[cum + k] = make_uint2((uint32_t)counts[s] | (s << 24), k);
+          cum += counts[s];
+        }
+        if (cum != total)
+        {
+          hsrans_dplan_destroy(d);
+          return HSRANS_E_FORMAT;
+        }
+        if (hipMalloc((void **)&d->d_table, total * sizeof(uint2)) == hipSuccess &&
+            hipMemcpy(d->d_table, tab.data(), total * sizeof(uint2), hipMemcpyHostToDevice) == hipSuccess)
+        {
+          d->pa.table = d->d_table;
+          d->pa.hist_copy = (const uint16_t *)(d->d_plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
+        }
+      }
     }
   }
   if (getenv("HSRANS_DEBUG_STAMPS") && hipMalloc((void **)&d->d_stamps, kStampWaves * 4 * 8) == hipSuccess)
@@ -317,6 +344,8 @@ void hsrans_dplan_destroy(hsrans_dplan *d)
     (void)hipFree(d->d_stamps);
   if (d->d_counters)
     (void)hipFree(d->d_counters);
+  if (d->d_table)
+    (void)hipFree(d->d_table);
   if (d->d_plan)
     (void)hipFree(d->d_plan);
   if (d->d_status)
@@ -441,6 +470,9 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
     PlanBuilder pb;
     pb.begin(container, states, bits, out_len, in_length);
     pb.hdr.interval = index_interval;
+    uint16_t counts[256];
+    memcpy(counts, in + p0->hist_off, 512);
+    pb.set_hist(counts);
     for (uint64_t g = 0; g < T || g == 0; g += index_interval)
     {
       Piece p{};

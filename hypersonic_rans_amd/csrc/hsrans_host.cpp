@@ -409,6 +409,7 @@ size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_
   std::reverse(cps.begin(), cps.end()); // now ascending by group
   if (container == HSRANS_RAW)
   {
+    pb.set_hist(c.hist.symbolCount);
     const uint64_t G_total = last_group_start / S + 1; // groups incl. a partial one
     uint64_t g = 0;
     size_t k = 0;
@@ -468,9 +469,6 @@ size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_
       }
     }
   }
-  const size_t need = pb.serialized_size();
-  if (need > opts->plan_capacity)
-    return 0;
   opts->plan_size = pb.serialize(opts->plan_out, opts->plan_capacity);
   return opts->plan_size ? total : 0;
 }
@@ -490,6 +488,7 @@ void PlanBuilder::begin(int container, int states, uint32_t bits, uint64_t decod
   chain_first.clear();
   pieces.clear();
   this->states.clear();
+  has_hist = false;
 }
 
 void PlanBuilder::add_chain(const Piece &p, const uint32_t *st)
@@ -510,14 +509,20 @@ void PlanBuilder::add_piece(const Piece &p)
   pieces.push_back(q);
 }
 
-size_t PlanBuilder::serialized_size() const { return (size_t)plan_size((uint32_t)chain_first.size(), (uint32_t)pieces.size(), hdr.states); }
+void PlanBuilder::set_hist(const uint16_t counts[256])
+{
+  memcpy(hist_counts, counts, sizeof(hist_counts));
+  has_hist = true;
+}
+
+size_t PlanBuilder::serialized_size() const
+{
+  return (size_t)plan_size((uint32_t)chain_first.size(), (uint32_t)pieces.size(), hdr.states, kPlanHasHist); // upper bound
+}
 
 size_t PlanBuilder::serialize(uint8_t *out, size_t cap)
 {
   const uint32_t nc = (uint32_t)chain_first.size(), np = (uint32_t)pieces.size();
-  const size_t need = serialized_size();
-  if (need > cap)
-    return 0;
   hdr.n_chains = nc;
   hdr.n_pieces = np;
   if (!(hdr.flags & kPlanWalk))
@@ -551,6 +556,11 @@ size_t PlanBuilder::serialize(uint8_t *out, size_t cap)
     }
     hdr.flags = merge ? (hdr.flags | kPlanMergeable) : (hdr.flags & ~kPlanMergeable);
   }
+  const bool with_hist = has_hist && hdr.shared_hist && !(hdr.flags & kPlanWalk);
+  hdr.flags = with_hist ? (hdr.flags | kPlanHasHist) : (hdr.flags & ~kPlanHasHist);
+  const size_t need = (size_t)plan_size(nc, np, hdr.states, hdr.flags);
+  if (need > cap)
+    return 0;
   memset(out, 0, need);
   memcpy(out, &hdr, sizeof(hdr));
   uint32_t *cf = (uint32_t *)(out + plan_chain_first_off());
@@ -561,6 +571,8 @@ size_t PlanBuilder::serialize(uint8_t *out, size_t cap)
     memcpy(out + plan_pieces_off(nc), pieces.data(), (size_t)np * sizeof(Piece));
   if (!states.empty())
     memcpy(out + plan_states_off(nc, np), states.data(), states.size() * 4);
+  if (with_hist)
+    memcpy(out + plan_hist_off(nc, np, hdr.states), hist_counts, 512);
   return need;
 }
 
@@ -576,7 +588,7 @@ size_t plan_capacity(int container, int states, size_t decoded_size, uint32_t in
   }
   if (interval)
     chains += groups / interval + 1;
-  return (size_t)plan_size((uint32_t)chains, (uint32_t)chains + 2, (uint32_t)S);
+  return (size_t)plan_size((uint32_t)chains, (uint32_t)chains + 2, (uint32_t)S, kPlanHasHist);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -618,6 +630,9 @@ size_t plan_build(int container, int states, uint32_t bits, const uint8_t *in, s
     p.steps = (uint32_t)T;
     p.tail = (uint16_t)(out_len - T * S);
     pb.add_chain(p, st);
+    uint16_t counts[256];
+    memcpy(counts, in + 16, 512);
+    pb.set_hist(counts);
     return pb.serialize(plan_out, plan_cap);
   }
 
@@ -720,7 +735,7 @@ bool plan_validate(const uint8_t *plan, size_t size, uint64_t stream_len, uint64
   memcpy(&h, plan, sizeof(h));
   if (memcmp(h.magic, "HSRPLAN1", 8) != 0 || !valid_codec((int)h.container, (int)h.states, h.bits))
     return false;
-  if (h.n_chains == 0 || h.n_pieces < h.n_chains || plan_size(h.n_chains, h.n_pieces, h.states) != size)
+  if (h.n_chains == 0 || h.n_pieces < h.n_chains || plan_size(h.n_chains, h.n_pieces, h.states, h.flags) != size)
     return false;
   if (h.decoded_len > out_cap || h.stream_len > stream_len)
     return false;
@@ -767,13 +782,15 @@ size_t plan_slice(const uint8_t *plan, size_t size, uint32_t first, uint32_t cou
   memcpy(&h, plan, sizeof(h));
   if (memcmp(h.magic, "HSRPLAN1", 8) != 0 || (h.flags & kPlanWalk) || count == 0 || first >= h.n_chains || count > h.n_chains - first)
     return 0;
-  if (plan_size(h.n_chains, h.n_pieces, h.states) != size)
+  if (plan_size(h.n_chains, h.n_pieces, h.states, h.flags) != size)
     return 0;
   const uint32_t *cf = (const uint32_t *)(plan + plan_chain_first_off());
   const Piece *pc = (const Piece *)(plan + plan_pieces_off(h.n_chains));
   const uint32_t *st = (const uint32_t *)(plan + plan_states_off(h.n_chains, h.n_pieces));
   PlanBuilder pb;
   pb.hdr = h;
+  if (h.flags & kPlanHasHist)
+    pb.set_hist((const uint16_t *)(plan + plan_hist_off(h.n_chains, h.n_pieces, h.states)));
   for (uint32_t c = first; c < first + count; c++)
   {
     for (uint32_t i = cf[c]; i < cf[c + 1]; i++)
@@ -795,7 +812,7 @@ bool plan_chain_range(const uint8_t *plan, size_t size, uint32_t first, uint32_t
   memcpy(&h, plan, sizeof(h));
   if (memcmp(h.magic, "HSRPLAN1", 8) != 0 || (h.flags & kPlanWalk) || count == 0 || first >= h.n_chains || count > h.n_chains - first)
     return false;
-  if (plan_size(h.n_chains, h.n_pieces, h.states) != size)
+  if (plan_size(h.n_chains, h.n_pieces, h.states, h.flags) != size)
     return false;
   const uint32_t *cf = (const uint32_t *)(plan + plan_chain_first_off());
   const Piece *pc = (const Piece *)(plan + plan_pieces_off(h.n_chains));

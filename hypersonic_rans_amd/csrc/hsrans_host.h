@@ -35,6 +35,9 @@ struct PlanBuilder
   std::vector<uint32_t> chain_first; // n_chains entries while building (+1 sentinel on serialise)
   std::vector<Piece> pieces;
   std::vector<uint32_t> states; // n_chains * S
+  uint16_t hist_counts[256] = {}; // copy of the shared histogram (kPlanHasHist), set with set_hist()
+  bool has_hist = false;
+  void set_hist(const uint16_t counts[256]);
 
   void begin(int container, int states, uint32_t bits, uint64_t decoded_len, uint64_t stream_len);
   // starts a new chain whose first piece is `p` with start states `st` (S values; may be null for fills)

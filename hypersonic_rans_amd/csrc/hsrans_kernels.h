@@ -20,6 +20,8 @@ struct PersistentArgs
   uint64_t out_base, steps_total, hist_off;
   uint32_t tail;            // symbols of the final partial group (after the last chain)
   uint32_t static_per_wave; // chains every wave decodes as one merged run before it starts pulling single chains
+  const uint2 *table;       // host-built MODE-3 decode table (kPlanHasHist plans, bits <= 11) or null: build it in the kernel
+  const uint16_t *hist_copy; // the 256 counts that table was built from (device copy inside the plan)
   unsigned long long *counters; // [kDynQueues * kDynQueueStride] monotonic queue heads (never reset, see run_persistent)
 };
 constexpr uint32_t kDynQueues = 64;

@@ -530,7 +530,31 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
   const bool have_static = q0 != 0; // host guarantees W * q0 <= n_chains
   if (have_static)
     g = run_begin<MODE>(c, pa, w * q0, w * q0 + q0, x, r);
-  build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
+  if (MODE == kModePack64 && pa.table != nullptr)
+  {
+    // the table was built on the host from the plan's histogram copy: one coalesced 16 B load + LDS store per thread,
+    // while the first wave checks that the stream really carries that histogram (else: status, as a failed sum check)
+    const uint32_t entries = 1u << c.bits;
+    for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
+      *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
+    if (blockIdx.x == 0 && threadIdx.x < 64)
+    {
+      bool same = pa.hist_off + 512 <= c.stream_len;
+      if (same)
+      {
+        const uint64_t mine = *(const uint64_t *)(pa.hist_copy + 4 * c.lane);
+        uint64_t theirs = 0;
+        for (int b = 3; b >= 0; b--) // stream offsets are only 2-byte aligned
+          theirs = (theirs << 16) | *(const uint16_t *)(c.stream + pa.hist_off + 8 * c.lane + 2 * b);
+        same = mine == theirs;
+      }
+      if (__builtin_amdgcn_ballot_w64(!same) != 0 && c.lane == 0)
+        atomicOr(c.status, kStatusBadHist);
+    }
+    __syncthreads();
+  }
+  else
+    build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
   if (kp.stamps)
     t_table = __builtin_amdgcn_s_memrealtime();
   if (have_static)

@@ -2,6 +2,7 @@
 //
 // A plan is one little-endian byte blob:
 //   PlanHeader (64 B) | uint32 chain_first[n_chains + 1] (padded to 16 B) | Piece pieces[n_pieces] | uint32 states[n_chains * S]
+//   | optional uint16 symbolCount[256] (kPlanHasHist)
 // A *chain* is what one wavefront decodes: it loads S start states, then runs its pieces in order, carrying the
 // states from piece to piece.  A *piece* is a run of whole S-symbol groups (+ an optional final masked group) decoded
 // with one histogram from one contiguous span of uint16 words, or a single-symbol fill.
@@ -29,6 +30,10 @@ constexpr uint32_t kPlanWalk = 1; // block_ without checkpoints: the kernel pars
 // stream): any run of consecutive chains can be decoded as one longer chain from the first one's start states.  The
 // kernel uses this to hand every resident wavefront one contiguous, equally long share of the stream.
 constexpr uint32_t kPlanMergeable = 2;
+// the plan carries a copy of the one histogram all its chains use (uint16 symbolCount[256] after the states): lets the
+// host prepare the decode table once per plan instead of every workgroup rebuilding it on every launch.  The kernel
+// still compares the copy with the counts in the stream it is given and flags a mismatch.
+constexpr uint32_t kPlanHasHist = 4;
 
 struct Piece
 {
@@ -59,7 +64,11 @@ static_assert(sizeof(PlanHeader) == 64, "PlanHeader layout");
 __host__ __device__ inline uint64_t plan_chain_first_off() { return sizeof(PlanHeader); }
 __host__ __device__ inline uint64_t plan_pieces_off(uint32_t n_chains) { return sizeof(PlanHeader) + ((uint64_t(n_chains) + 1) * 4 + 15) / 16 * 16; }
 __host__ __device__ inline uint64_t plan_states_off(uint32_t n_chains, uint32_t n_pieces) { return plan_pieces_off(n_chains) + uint64_t(n_pieces) * sizeof(Piece); }
-__host__ __device__ inline uint64_t plan_size(uint32_t n_chains, uint32_t n_pieces, uint32_t S) { return plan_states_off(n_chains, n_pieces) + uint64_t(n_chains) * S * 4; }
+__host__ __device__ inline uint64_t plan_hist_off(uint32_t n_chains, uint32_t n_pieces, uint32_t S) { return plan_states_off(n_chains, n_pieces) + uint64_t(n_chains) * S * 4; }
+__host__ __device__ inline uint64_t plan_size(uint32_t n_chains, uint32_t n_pieces, uint32_t S, uint32_t flags)
+{
+  return plan_hist_off(n_chains, n_pieces, S) + ((flags & kPlanHasHist) ? 512 : 0);
+}
 
 // device status bits (hsrans_dplan status word)
 constexpr uint32_t kStatusBadHist = 1;   // counts do not sum to 1 << bits (hist.cpp:308-324 returns false)

@@ -454,7 +454,7 @@ size_t orc_exec_plan(const uint8_t *plan, size_t planLen, const uint8_t *in, siz
     return 0;
   const size_t piecesOff = 64 + (((size_t)nChains + 1) * 4 + 15) / 16 * 16;
   const size_t statesOff = piecesOff + (size_t)nPieces * sizeof(orc_piece_t);
-  if (statesOff + (size_t)nChains * S * 4 != planLen)
+  if (statesOff + (size_t)nChains * S * 4 + ((flags & 4u) ? 512 : 0) != planLen) /* optional histogram copy */
     return 0;
   static _Thread_local dec_ctx_t c;
   uint64_t haveHist = ~(uint64_t)0;
