@@ -38,6 +38,8 @@ struct hsrans_dplan
   uint64_t *d_stamps = nullptr; // diagnostics (HSRANS_DEBUG_STAMPS=1)
   unsigned long long *d_counters = nullptr; // persistent launches: monotonic queue heads
   uint2 *d_table = nullptr;                 // host-built decode table (plans that carry their histogram)
+  Group *d_groups = nullptr;                // grouped launches (block_/mt_ plans with checkpoints)
+  uint32_t n_groups = 0;
   PersistentArgs pa{};
   LaunchInfo info{};
 };
@@ -322,6 +324,52 @@ int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
       }
     }
   }
+  if (!(h.flags & (kPlanWalk | kPlanMergeable)) && h.n_chains > 1)
+  {
+    // group consecutive chains that decode with the same histogram (= the chains of one block_/mt_ block)
+    const uint32_t *cf = (const uint32_t *)(plan + plan_chain_first_off());
+    const Piece *pc = (const Piece *)(plan + plan_pieces_off(h.n_chains));
+    std::vector<Group> groups;
+    for (uint32_t ch = 0; ch < h.n_chains; ch++)
+    {
+      const Piece &p = pc[cf[ch]];
+      const bool single = cf[ch + 1] - cf[ch] == 1;
+      const bool fill = (p.flags & kPieceFill) != 0;
+      bool joins = false;
+      if (!groups.empty() && single)
+      {
+        Group &g = groups.back();
+        const Piece &q = pc[cf[ch - 1]];
+        if (fill && (g.flags & kGroupFill))
+          joins = true;
+        else if (!fill && !(g.flags & kGroupFill) && g.hist_off == p.hist_off)
+        {
+          joins = true;
+          if (!(cf[ch] - cf[ch - 1] == 1 && q.tail == 0 && q.out_off + (uint64_t)q.steps * h.states == p.out_off && q.words_off <= p.words_off))
+            g.flags &= ~kGroupMergeable;
+        }
+      }
+      if (joins)
+        groups.back().count++;
+      else
+      {
+        Group g{};
+        g.begin = ch;
+        g.count = 1;
+        g.flags = fill ? kGroupFill : (single ? kGroupMergeable : 0);
+        g.hist_off = fill ? 0 : p.hist_off;
+        g.words_end = h.stream_len;
+        // the previous rANS group's words end no later than this group's histogram / header
+        if (!fill && !groups.empty())
+          for (size_t k = groups.size(); k-- > 0 && groups[k].words_end == h.stream_len;)
+            groups[k].words_end = p.hist_off;
+        groups.push_back(g);
+      }
+    }
+    if (groups.size() < h.n_chains && hipMalloc((void **)&d->d_groups, groups.size() * sizeof(Group)) == hipSuccess &&
+        hipMemcpy(d->d_groups, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice) == hipSuccess)
+      d->n_groups = (uint32_t)groups.size();
+  }
   if (getenv("HSRANS_DEBUG_STAMPS") && hipMalloc((void **)&d->d_stamps, kStampWaves * 4 * 8) == hipSuccess)
     (void)hipMemset(d->d_stamps, 0, kStampWaves * 4 * 8);
   *out_dplan = d;
@@ -346,6 +394,8 @@ void hsrans_dplan_destroy(hsrans_dplan *d)
     (void)hipFree(d->d_counters);
   if (d->d_table)
     (void)hipFree(d->d_table);
+  if (d->d_groups)
+    (void)hipFree(d->d_groups);
   if (d->d_plan)
     (void)hipFree(d->d_plan);
   if (d->d_status)
@@ -373,6 +423,11 @@ int hsrans_decode_device(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_stream,
   kp.status = d->d_status;
   kp.stamps = d->d_stamps;
   kp.pa = d->pa;
+  if (d->n_groups)
+  {
+    kp.groups = d->d_groups;
+    kp.n_groups = d->n_groups;
+  }
   return launch_decode(kp, d->hdr, s, &d->info) == hipSuccess ? HSRANS_OK : HSRANS_E_HIP;
 }
 

@@ -27,6 +27,19 @@ struct PersistentArgs
 constexpr uint32_t kDynQueues = 64;
 constexpr uint32_t kDynQueueStride = 32; // in uint64: one head per 256 B, so that heads never share a line / atomic unit
 
+// Grouped launch (block_/mt_ plans with checkpoints): chains [begin, begin+count) share one histogram = one LDS table
+// per workgroup; its waves split the chains evenly (merged into one run per wave when the chains are back to back).
+struct Group
+{
+  uint32_t begin, count;
+  uint32_t flags; // 1: chains are single back-to-back rANS pieces (mergeable); 2: fill chains only (no table)
+  uint32_t reserved;
+  uint64_t hist_off;
+  uint64_t words_end; // first stream byte after the group's words (next group's first header) or the stream length
+};
+constexpr uint32_t kGroupMergeable = 1;
+constexpr uint32_t kGroupFill = 2;
+
 struct KParams
 {
   const uint8_t *stream; // device, 16-byte aligned
@@ -42,7 +55,10 @@ struct KParams
   uint32_t ckpt_interval;
   // diagnostics only (HSRANS_DEBUG_STAMPS=1): per wave {entry, table built, stream ready, done} s_memtime stamps; null otherwise
   uint64_t *stamps;
+  uint32_t exp_flags; // tuning experiments (bit 0: rotate s_setprio)
   PersistentArgs pa;
+  const Group *groups; // null = not a grouped launch
+  uint32_t n_groups;
 };
 
 struct LaunchInfo

@@ -73,6 +73,7 @@ struct WaveCtx
   uint32_t bits, S, lane;
   uint8_t *ring;    // LDS, kRingBytes, kRingBytes-aligned
   uint32_t ring_lds; // the same as an LDS byte address (what M0 / ds_read take)
+  uint32_t prio_rank, prio_rotate; // experiment: s_setprio rotation (HSRANS_PRIO_ROTATE)
   uint32_t ring_vgpr; // ring_lds held in a VGPR (third operand of v_and_or_b32 beside an SGPR mask)
   uint8_t *table;   // LDS
   uint16_t *scratch; // LDS, 1024 B, only live during table builds (aliases the last slot of a ring)
@@ -337,8 +338,20 @@ __device__ __forceinline__ void run_groups_impl(uint32_t &x, Ring &r, const Wave
   const uint32_t sel_a = (c.lane & 1) ? 0x03070105u : 0x06020400u;
   const uint32_t sel_b = (c.lane & 2) ? 0x03020706u : 0x05040100u;
 
+  uint32_t it = c.prio_rank;
   for (; steps >= 4; steps -= 4)
   {
+    if (c.prio_rotate)
+    {
+      // rotate the wave's issue priority so that the 8 waves of a SIMD progress evenly instead of oldest-first
+      switch ((it++ >> 1) & 3)
+      {
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+      }
+    }
     // gather this lane's 4 symbols (byte kSymByte of each table word) into one dword, byte t = group t
     const uint32_t e0 = group_step<MODE, FULL>(x, r, c, act_mask);
     const uint32_t e1 = group_step<MODE, FULL>(x, r, c, act_mask);
@@ -599,6 +612,42 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
   }
 }
 
+// Grouped launch: workgroup b walks groups b, b + gridDim.x, ...; per group one table build, then every wave decodes an
+// equal contiguous share of the group's chains.
+template <int MODE>
+__device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams &kp, uint32_t waves, uint32_t wave)
+{
+  for (uint32_t gi = blockIdx.x; gi < kp.n_groups; gi += gridDim.x)
+  {
+    const Group *G = kp.groups + gi;
+    const uint32_t begin = uni(G->begin), count = uni(G->count), flags = uni(G->flags);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no stream request of the previous group may still land in the scratch slot
+    __syncthreads();                                    // every wave is done with the previous group's table and rings
+    if (!(flags & kGroupFill))
+      build_table<MODE, true>(c, uni64(G->hist_off), threadIdx.x, blockDim.x);
+    const uint32_t first = begin + (uint32_t)((uint64_t)wave * count / waves), last = begin + (uint32_t)((uint64_t)(wave + 1) * count / waves);
+    if (first >= last)
+      continue;
+    if (flags & kGroupMergeable)
+    {
+      const Piece *p0 = pv.pieces + uni(pv.chain_first[first]);
+      const Piece *p1 = pv.pieces + uni(pv.chain_first[last - 1]);
+      const uint64_t limit = last < begin + count ? uni64(pv.pieces[uni(pv.chain_first[last])].words_off) : uni64(G->words_end);
+      uint32_t x = c.lane < c.S ? pv.states[(uint64_t)uni(p0->state_idx) * c.S + c.lane] : 0;
+      Ring r;
+      ring_begin(r, c, uni64(p0->words_off), limit);
+      uint64_t o = uni64(p0->out_off);
+      const uint64_t steps = (uni64(p1->out_off) - o) / c.S + uni(p1->steps);
+      ring_ready();
+      run_groups<MODE>(x, r, c, o, (uint32_t)steps);
+      run_tail<MODE>(x, r, c, o, uni(p1->tail));
+    }
+    else
+      for (uint32_t ch = first; ch < last; ch++)
+        run_planned_chain<MODE, true>(c, pv, ch, kp);
+  }
+}
+
 // block_ container without checkpoints: one wave follows the inline headers exactly like
 // block_rANS32x64_16w_decode.cpp:47-123 (states carry over, histogram swapped per block).
 template <int MODE>
@@ -709,6 +758,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.bits = bits;
   c.S = pv.hdr->states;
   c.lane = threadIdx.x & 63;
+  c.prio_rotate = kp.exp_flags & 1;
+  c.prio_rank = ((threadIdx.x >> 8) + (blockIdx.x >= gridDim.x / 2 ? 4 : 0)) * 2;
 
   const uint32_t chain = blockIdx.x * waves + wave;
 
@@ -723,6 +774,11 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
     if (kp.pa.pieces != nullptr)
     {
       run_persistent<MODE>(c, kp, waves, chain);
+      return;
+    }
+    if (kp.groups != nullptr)
+    {
+      run_grouped<MODE>(c, pv, kp, waves, wave);
       return;
     }
     build_table<MODE, true>(c, hist_off, threadIdx.x, blockDim.x);
@@ -790,7 +846,8 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
   KParams kp = kp_in;
   const bool two_level = h.bits >= 13;
   const bool walk = (h.flags & kPlanWalk) != 0;
-  const bool shared = !walk && h.shared_hist != 0 && h.n_chains > 1;
+  const bool grouped = kp.groups != nullptr && kp.ckpt_interval == 0;
+  const bool shared = !walk && (grouped || (h.shared_hist != 0 && h.n_chains > 1));
   // 64-bit entries only where one table serves a whole workgroup (LDS: 16 KiB table + 16 x 4 KiB rings, two per CU)
   const int mode = two_level ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : shared ? kModePack64 : kModePack;
   const uint32_t table_bytes = table_bytes_for(mode, h.bits);
@@ -804,7 +861,9 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
       waves /= 2;
     lds = waves * kRingBytes + table_bytes;
     grid = (h.n_chains + waves - 1) / waves;
-    if (kp.pa.pieces != nullptr)
+    if (grouped)
+      grid = kp.n_groups;
+    if (kp.pa.pieces != nullptr || grouped)
     {
       const uint32_t per_cu = g_max_lds / lds ? g_max_lds / lds : 1; // workgroups one CU can hold (LDS-limited; 32 waves max)
       const uint32_t resident = g_num_cus * (per_cu * waves > 32 ? 32 / waves : per_cu);
@@ -823,6 +882,8 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
   if (grid == 0)
     grid = 1;
 
+  if (const char *e = getenv("HSRANS_PRIO_ROTATE"))
+    kp.exp_flags |= atoi(e) ? 1 : 0;
   if (kp.pa.pieces != nullptr)
   {
     // static share: a fixed fraction of the chains, split evenly; the rest goes through the queues
