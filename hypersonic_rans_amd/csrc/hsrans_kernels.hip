@@ -33,9 +33,11 @@ namespace hsrans
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kRingSlots = 4;
-constexpr uint32_t kChunkBytes = 1024; // 64 lanes x 16 B
-constexpr uint32_t kRingBytes = kRingSlots * kChunkBytes; // per wave
-constexpr uint32_t kChunkWordsLog2 = 9;
+constexpr uint32_t kChunkBytes = 512; // 32 lanes x 16 B
+constexpr uint32_t kRingBytes = kRingSlots * kChunkBytes; // 2 KiB
+constexpr uint32_t kChunkWordsLog2 = 8;
+// (the mirror is 128 bytes: the first 64 words of the ring, copied behind its end)
+constexpr uint32_t kWaveRingBytes = kRingBytes + 256;     // per wave (ring + mirror, 256-byte granular)
 constexpr uint32_t kConsume = 1u << 15; // rans.h:8 DecodeConsumePoint16
 
 // decode-table layouts
@@ -71,43 +73,63 @@ struct WaveCtx
   uint64_t out_cap;
   uint32_t *status;
   uint32_t bits, S, lane;
-  uint8_t *ring;    // LDS, kRingBytes, kRingBytes-aligned
-  uint32_t ring_lds; // the same as an LDS byte address (what M0 / ds_read take)
-  uint32_t prio_rank, prio_rotate; // experiment: s_setprio rotation (HSRANS_PRIO_ROTATE)
-  uint32_t ring_vgpr; // ring_lds held in a VGPR (third operand of v_and_or_b32 beside an SGPR mask)
-  uint8_t *table;   // LDS
-  uint16_t *scratch; // LDS, 1024 B, only live during table builds (aliases the last slot of a ring)
+  uint8_t *rings;        // LDS, kWaveRingBytes: this wave's stream ring + mirror
+  uint8_t *table;        // LDS
+  uint16_t *scratch_cnt; // LDS, 512 B each, only live during table builds: they alias a ring that has no request in
+  uint16_t *scratch_cum; // flight (build_table is always called before the ring is begun)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// stream ring: 4 slots x 1 KiB per wave, filled by LDS-DMA (buffer_load_dwordx4 ... lds: 64 lanes x 16 B land
-// linearly at M0, no VGPR staging, hardware bounds check against the descriptor).
+// stream ring: 4 slots x 512 B per wave, filled by LDS-DMA (buffer_load_dwordx4 ... lds under EXEC = lanes 0..31:
+// 32 lanes x 16 B land linearly at M0, no VGPR staging, hardware bounds check against the descriptor).  The first 128
+// bytes of the ring are mirrored behind its end (a second, 8-lane request whenever slot 0 is filled), so the up to 64
+// words one group reads never wrap: a lane's address is ring + (cursor mod ring) + 2 * rank, one v_lshl_add_u32.
 //
-// Invariant: whenever the cursor is in chunk c, chunks c .. c+2 have been requested, and c, c+1 have landed.
-// ring_advance() runs at least once per 256 consumed words; on entering chunk c it requests chunk c+3 into the
-// slot of the dead chunk c-1 and then waits with vmcnt(2): the two requests younger than chunk c+1's are c+2 and
-// c+3, so "all but the 2 youngest vector-memory operations done" always covers chunk c+1 whatever stores the
-// compiler has interleaved (they only make the wait stricter, never weaker).  The loads are issued from asm, so
-// the compiler never tracks them and never parks the decode loop on vmcnt(0).
+// Invariant: whenever the cursor is in chunk c (256 words), chunks c .. c+2 have been requested and c, c+1 have landed.
+// ring_advance() runs at least once per 256 consumed words (4 groups of 64), so the cursor crosses at most one chunk
+// boundary between two calls and never needs more than chunks c, c+1 before the next call.  On entering chunk c it
+// requests chunk c+3 into the slot of the dead chunk c-1 and then waits with vmcnt(2): at least two requests of this
+// ring are younger than chunk c+1's (and than its mirror request, if it has one): those for c+2 and c+3.  So "all but
+// the 2 youngest vector-memory operations done" always covers chunk c+1 whatever else (stores, mirror requests) has
+// been issued in between — more young operations only make the wait stricter, never weaker.  The loads are issued
+// from asm, so the compiler never tracks them and never parks the decode loop on vmcnt(0).
 // ---------------------------------------------------------------------------------------------------------------
+struct StreamWin // the stream as the ring's requests see it
+{
+  u32x4 rs;      // buffer descriptor (SGPRs): base = stream + `base`, num_records = bytes up to `limit`
+  uint64_t base; // absolute byte offset in the stream of descriptor offset 0 (16-byte aligned)
+};
+
 struct Ring
 {
-  u32x4 rs;      // buffer descriptor (SGPRs): base = stream + `base`, num_records = bytes to the end of the stream
-  uint64_t base; // absolute byte offset in the stream of word index 0
-  uint32_t k;    // chunk the cursor was in at the last ring_advance()
-  uint32_t cur;  // next word to read, counted from `base` (wave-uniform)
+  uint32_t voff0; // descriptor offset of this chain's word index 0 (16-byte aligned)
+  uint32_t k;     // chunk the cursor was in at the last ring_advance()
+  uint32_t cur;   // next word to read, counted from voff0 (wave-uniform)
+  uint32_t lds;   // LDS byte address of the ring (what M0 / ds_read take)
 };
 
-__device__ __forceinline__ void ring_request(const Ring &r, const WaveCtx &c, uint32_t chunk)
+__device__ __forceinline__ void ring_bind(Ring &r, const uint8_t *lds_ring) { r.lds = uni(lds_address(lds_ring)); }
+
+__device__ __forceinline__ void ring_request(const StreamWin &sw, const Ring &r, const WaveCtx &c, uint32_t chunk)
 {
-  const uint32_t voff = chunk * kChunkBytes + c.lane * 16;
-  const uint32_t dst = uni(c.ring_lds + (chunk & (kRingSlots - 1)) * kChunkBytes);
-  asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(voff), "s"(dst), "s"(r.rs) : "memory");
+  const uint32_t voff = r.voff0 + chunk * kChunkBytes + c.lane * 16;
+  const uint32_t slot = chunk & (kRingSlots - 1);
+  const uint32_t dst = uni(r.lds + slot * kChunkBytes);
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_mov_b32 exec_hi, 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds\n\ts_mov_b32 exec_hi, -1"
+               :
+               : "v"(voff), "s"(dst), "s"(sw.rs)
+               : "memory");
+  if (slot == 0) // wave-uniform: the ring's first 128 bytes once more, behind its end (lanes 0..7)
+    asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 exec, 0xff\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds\n\ts_mov_b64 exec, -1"
+                 :
+                 : "v"(voff), "s"(uni(r.lds + kRingBytes)), "s"(sw.rs)
+                 : "memory");
 }
 
-// `limit` = first stream byte this chain can NOT need (the next chain's cursor, or the stream length): requests past it
-// are dropped by the descriptor's range check instead of fetching a neighbour's words
-__device__ __forceinline__ void ring_begin(Ring &r, const WaveCtx &c, uint64_t pos, uint64_t limit)
+// `pos` = first stream byte the descriptor must reach, `limit` = first stream byte the chain(s) can NOT need (the next
+// chain's cursor, or the stream length): requests past it are dropped by the range check instead of fetching a
+// neighbour's words
+__device__ __forceinline__ void win_open(StreamWin &sw, const WaveCtx &c, uint64_t pos, uint64_t limit)
 {
   pos = uni64(pos);
   limit = uni64(limit);
@@ -118,40 +140,50 @@ __device__ __forceinline__ void ring_begin(Ring &r, const WaveCtx &c, uint64_t p
   // inside a 16-aligned allocation, so rounding up never leaves the page the last stream byte is on
   const uint64_t left = a0 < limit ? (limit - a0 + 15) & ~(uint64_t)15 : 0;
   const uint64_t addr = (uint64_t)(uintptr_t)c.stream + a0;
-  r.rs.x = uni((uint32_t)addr);
-  r.rs.y = uni((uint32_t)(addr >> 32) & 0xFFFF); // stride 0
-  r.rs.z = uni((uint32_t)(left > 0xFFFFFFFFull ? 0xFFFFFFFFull : left));
-  r.rs.w = 0x00020000;
-  r.base = a0;
-  r.cur = (uint32_t)(pos - a0) >> 1;
-  r.k = 0;
-  // every lane is done with the previous piece's ring contents (its ds_reads returned before their results were used)
-  ring_request(r, c, 0);
-  ring_request(r, c, 1);
-  ring_request(r, c, 2);
+  sw.rs.x = uni((uint32_t)addr);
+  sw.rs.y = uni((uint32_t)(addr >> 32) & 0xFFFF); // stride 0
+  sw.rs.z = uni((uint32_t)(left > 0xFFFFFFFFull ? 0xFFFFFFFFull : left));
+  sw.rs.w = 0x00020000;
+  sw.base = a0;
 }
 
-// chunks 0 and 1 have landed (anything issued after ring_begin() only makes this wait stricter)
+// start streaming a chain whose first word is at absolute stream byte `pos` (>= sw.base, < sw.base + 4 GiB)
+__device__ __forceinline__ void ring_begin(const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t pos)
+{
+  pos = uni64(pos);
+  const uint32_t rel = (uint32_t)(pos - sw.base);
+  r.voff0 = rel & ~15u;
+  r.cur = (rel - r.voff0) >> 1;
+  r.k = 0;
+  // every lane is done with the ring's previous contents (its ds_reads returned before their results were used)
+  ring_request(sw, r, c, 0);
+  ring_request(sw, r, c, 1);
+  ring_request(sw, r, c, 2);
+}
+
+// chunks 0 and 1 (and the mirror) have landed: ring_begin issues {chunk 0, mirror, chunk 1, chunk 2} and anything issued
+// after it only makes this wait stricter
 __device__ __forceinline__ void ring_ready() { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
 
-__device__ __forceinline__ void ring_init(Ring &r, const WaveCtx &c, uint64_t pos)
+__device__ __forceinline__ void ring_init(StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t pos)
 {
-  ring_begin(r, c, pos, c.stream_len);
+  win_open(sw, c, pos, c.stream_len);
+  ring_begin(sw, r, c, pos);
   ring_ready();
 }
 
 // call at least once per 256 consumed words
-__device__ __forceinline__ void ring_advance(Ring &r, const WaveCtx &c)
+__device__ __forceinline__ void ring_advance(const StreamWin &sw, Ring &r, const WaveCtx &c)
 {
   if ((r.cur >> kChunkWordsLog2) > r.k)
   {
     r.k++;
-    ring_request(r, c, r.k + 2);
+    ring_request(sw, r, c, r.k + 2);
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); // chunk k+1 has landed (see the invariant above)
   }
 }
 
-__device__ __forceinline__ uint64_t ring_pos(const Ring &r) { return r.base + (uint64_t)r.cur * 2; }
+__device__ __forceinline__ uint64_t ring_pos(const StreamWin &sw, const Ring &r) { return sw.base + r.voff0 + (uint64_t)r.cur * 2; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // decode table build (hist.cpp:291-306 make_dec_pack_hist, :356-384 inplace_make_hist_dec2, :308-324 the sum check)
@@ -170,8 +202,8 @@ __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, u
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   };
-  uint16_t *cnt = c.scratch;       // [256]
-  uint16_t *cum = c.scratch + 256; // [256] exclusive prefix sums
+  uint16_t *cnt = c.scratch_cnt; // [256]
+  uint16_t *cum = c.scratch_cum; // [256] exclusive prefix sums
   const uint32_t total = 1u << c.bits;
   bool good = true;
 
@@ -298,17 +330,17 @@ __device__ __forceinline__ uint32_t group_step(uint32_t &x, Ring &r, const WaveC
     nx = __umul24(q, fc & 0xFFFF) + slot - (fc >> 16);
   }
   const bool low = nx < kConsume;
-  unsigned long long m = __builtin_amdgcn_ballot_w64(low);
-  if (!FULL)
-    m &= act_mask;
+  const unsigned long long m_all = __builtin_amdgcn_ballot_w64(low);
+  const unsigned long long m = FULL ? m_all : (m_all & act_mask);
   const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-  uint32_t waddr; // ring base | ((cur + rank) * 2 mod ring size): the ring is kRingBytes-aligned in LDS
-  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(waddr) : "v"((rank + r.cur) << 1), "s"(kRingBytes - 2), "v"(c.ring_vgpr));
+  // this lane's word: ring + (cursor mod ring) + 2 * rank; the mirror behind the ring's end makes the wrap invisible
+  uint32_t waddr;
+  asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(waddr) : "v"(rank), "s"(r.lds + ((r.cur << 1) & (kRingBytes - 1))));
   uint32_t w = *(const __attribute__((address_space(3))) uint16_t *)(uintptr_t)waddr;
   // x = low ? (nx << 16 | w) : nx, as one VALU op under EXEC = renormalising lanes (EXEC is all ones here: every
   // caller is in wave-uniform control flow of a full 64-lane wave); the two EXEC writes go to the scalar unit
   x = nx;
-  asm volatile("s_mov_b64 exec, %2\n\tv_lshl_or_b32 %0, %0, 16, %1\n\ts_mov_b64 exec, -1" : "+v"(x) : "v"(w), "s"(__builtin_amdgcn_ballot_w64(low)));
+  asm volatile("s_mov_b64 exec, %2\n\tv_lshl_or_b32 %0, %0, 16, %1\n\ts_mov_b64 exec, -1" : "+v"(x) : "v"(w), "s"(m_all));
   r.cur += (uint32_t)__popcll(m);
   return e;
 }
@@ -323,49 +355,55 @@ __device__ __forceinline__ uint32_t quad_transpose(uint32_t v, uint32_t sel_a, u
   return __builtin_amdgcn_perm(p2, v, sel_b);
 }
 
+// per-lane constants of the output path
+struct OutLanes
+{
+  uint32_t store_off, sel_a, sel_b;
+};
+
+__device__ __forceinline__ OutLanes out_lanes(uint32_t lane, uint32_t S)
+{
+  OutLanes ol;
+  const uint32_t row = lane & 3, quad = lane >> 2;
+  const uint32_t dcol = (quad & 8) | ((quad & 1) << 2) | ((quad & 6) >> 1); // dword column of this quad = lane_to_byte(lane) >> 2
+  ol.store_off = row * S + dcol * 4;
+  ol.sel_a = (lane & 1) ? 0x03070105u : 0x06020400u;
+  ol.sel_b = (lane & 2) ? 0x03020706u : 0x05040100u;
+  return ol;
+}
+
+// this lane's symbols of 4 consecutive groups (byte SYM_BYTE of each table word) -> the dword it stores
+template <uint32_t SYM_BYTE>
+__device__ __forceinline__ uint32_t pack4(uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3, const OutLanes &ol)
+{
+  const uint32_t lo = __builtin_amdgcn_perm(e1, e0, 0x0c0c0400u + SYM_BYTE * 0x0101u);
+  const uint32_t hi = __builtin_amdgcn_perm(e3, e2, 0x0c0c0400u + SYM_BYTE * 0x0101u);
+  return quad_transpose(__builtin_amdgcn_perm(hi, lo, 0x05040100u), ol.sel_a, ol.sel_b);
+}
+
 // decode `steps` whole groups starting at output offset `o` (block_codec64.h:173-217)
 template <int MODE, bool FULL>
-__device__ __forceinline__ void run_groups_impl(uint32_t &x, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps)
+__device__ __forceinline__ void run_groups_impl(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o_ref, uint32_t steps)
 {
+  uint64_t o = uni64(o_ref); // wave-uniform by construction; pinned to SGPRs
   const uint32_t S = FULL ? 64 : c.S;
   const bool act = FULL || c.lane < S;
   const unsigned long long act_mask = FULL ? ~0ull : __builtin_amdgcn_ballot_w64(act);
-  const uint32_t row = c.lane & 3;
-  const uint32_t quad = c.lane >> 2;
-  const uint32_t dcol = (quad & 8) | ((quad & 1) << 2) | ((quad & 6) >> 1); // dword column of this quad = lane_to_byte(lane) >> 2
-  const uint32_t store_off = row * S + dcol * 4;
   constexpr uint32_t kSymByte = MODE == kModePack64 ? 3 : 0; // where group_step's return value holds the symbol
-  const uint32_t sel_a = (c.lane & 1) ? 0x03070105u : 0x06020400u;
-  const uint32_t sel_b = (c.lane & 2) ? 0x03020706u : 0x05040100u;
+  const OutLanes ol = out_lanes(c.lane, S);
 
-  uint32_t it = c.prio_rank;
   for (; steps >= 4; steps -= 4)
   {
-    if (c.prio_rotate)
-    {
-      // rotate the wave's issue priority so that the 8 waves of a SIMD progress evenly instead of oldest-first
-      switch ((it++ >> 1) & 3)
-      {
-      case 0: __builtin_amdgcn_s_setprio(0); break;
-      case 1: __builtin_amdgcn_s_setprio(1); break;
-      case 2: __builtin_amdgcn_s_setprio(2); break;
-      default: __builtin_amdgcn_s_setprio(3); break;
-      }
-    }
-    // gather this lane's 4 symbols (byte kSymByte of each table word) into one dword, byte t = group t
     const uint32_t e0 = group_step<MODE, FULL>(x, r, c, act_mask);
     const uint32_t e1 = group_step<MODE, FULL>(x, r, c, act_mask);
-    const uint32_t lo = __builtin_amdgcn_perm(e1, e0, 0x0c0c0400u + kSymByte * 0x0101u);
     const uint32_t e2 = group_step<MODE, FULL>(x, r, c, act_mask);
     const uint32_t e3 = group_step<MODE, FULL>(x, r, c, act_mask);
-    const uint32_t hi = __builtin_amdgcn_perm(e3, e2, 0x0c0c0400u + kSymByte * 0x0101u);
-    uint32_t acc = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
-    acc = quad_transpose(acc, sel_a, sel_b);
+    const uint32_t acc = pack4<kSymByte>(e0, e1, e2, e3, ol);
     uint8_t *row_base = c.out + o; // wave-uniform
     if (act)
-      *(uint32_t *)(row_base + store_off) = acc;
+      *(uint32_t *)(row_base + ol.store_off) = acc;
     o += 4 * S;
-    ring_advance(r, c);
+    ring_advance(sw, r, c);
   }
   const uint32_t p = lane_to_byte(c.lane);
   for (; steps > 0; steps--)
@@ -375,16 +413,17 @@ __device__ __forceinline__ void run_groups_impl(uint32_t &x, Ring &r, const Wave
       c.out[o + p] = (uint8_t)(e >> (8 * kSymByte));
     o += S;
   }
-  ring_advance(r, c);
+  ring_advance(sw, r, c);
+  o_ref = o;
 }
 
 template <int MODE>
-__device__ __forceinline__ void run_groups(uint32_t &x, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps)
+__device__ __forceinline__ void run_groups(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps)
 {
   if (c.S == 64)
-    run_groups_impl<MODE, true>(x, r, c, o, steps);
+    run_groups_impl<MODE, true>(x, sw, r, c, o, steps);
   else
-    run_groups_impl<MODE, false>(x, r, c, o, steps);
+    run_groups_impl<MODE, false>(x, sw, r, c, o, steps);
 }
 
 // final partial group (rANS32x64_16w.cpp:252-280): only lanes whose output byte exists take part, in lane order
@@ -450,7 +489,9 @@ __device__ void run_planned_chain(const WaveCtx &c, const PlanView &pv, uint32_t
   const uint32_t last = uni(pv.chain_first[chain + 1]);
   uint32_t x = 0;
   uint64_t have_hist = ~(uint64_t)0;
+  StreamWin sw;
   Ring r;
+  ring_bind(r, c.rings);
   for (uint32_t pi = first; pi < last; pi++)
   {
     const Piece *pc = pv.pieces + pi;
@@ -469,7 +510,7 @@ __device__ void run_planned_chain(const WaveCtx &c, const PlanView &pv, uint32_t
         return;
       have_hist = hist_off;
     }
-    ring_init(r, c, uni64(pc->words_off));
+    ring_init(sw, r, c, uni64(pc->words_off));
     uint64_t o = uni64(pc->out_off);
     uint32_t steps = uni(pc->steps);
 
@@ -485,16 +526,16 @@ __device__ void run_planned_chain(const WaveCtx &c, const PlanView &pv, uint32_t
           if (c.lane < c.S)
             kp.ckpt_states[slot * c.S + c.lane] = x;
           if (c.lane == 0)
-            kp.ckpt_words[slot] = ring_pos(r);
+            kp.ckpt_words[slot] = ring_pos(sw, r);
         }
         const uint32_t n = steps < kp.ckpt_interval ? steps : kp.ckpt_interval;
-        run_groups<MODE>(x, r, c, o, n);
+        run_groups<MODE>(x, sw, r, c, o, n);
         steps -= n;
         g += n;
       }
     }
     else
-      run_groups<MODE>(x, r, c, o, steps);
+      run_groups<MODE>(x, sw, r, c, o, steps);
     run_tail<MODE>(x, r, c, o, uni(pc->tail));
   }
 }
@@ -502,9 +543,11 @@ __device__ void run_planned_chain(const WaveCtx &c, const PlanView &pv, uint32_t
 // ---------------------------------------------------------------------------------------------------------------
 // Persistent launch (kPlanMergeable plans): the grid is sized to the machine (2 workgroups per CU).  Every wave first
 // decodes `static_per_wave` consecutive chains as ONE chain (stream requests and state load in flight while the
-// workgroup builds its table), then pulls single chains from one of kDynQueues atomic heads until the stream is done.
+// workgroup gets its table), then pulls single chains from one of kDynQueues atomic heads until the stream is done.
 // Why dynamic: the SIMD arbiter favours its oldest wave, so equal static shares finish 2x apart (measured 23..52 us)
 // and the tail runs at one-wave latency; the queues keep every SIMD full until the end.
+// (Keeping two chains in flight per wave was tried and is not faster: the loop is bound by VALU/LDS throughput, not by
+// the latency of the dependent LDS round trips.)
 // ---------------------------------------------------------------------------------------------------------------
 struct RunGeom
 {
@@ -512,12 +555,13 @@ struct RunGeom
   uint32_t steps, tail;
 };
 
+// geometry of the run of chains [c0, c1) and the start of its stream / state loads
 template <int MODE>
-__device__ __forceinline__ RunGeom run_begin(const WaveCtx &c, const PersistentArgs &pa, uint32_t c0, uint32_t c1, uint32_t &x, Ring &r)
+__device__ __forceinline__ RunGeom run_begin(const WaveCtx &c, const PersistentArgs &pa, StreamWin &sw, uint32_t c0, uint32_t c1, uint32_t &x, Ring &r)
 {
   const uint64_t words = uni64(pa.pieces[c0].words_off);
-  const uint64_t limit = c1 < pa.n_chains ? uni64(pa.pieces[c1].words_off) : c.stream_len;
-  ring_begin(r, c, words, limit);
+  win_open(sw, c, words, c1 < pa.n_chains ? uni64(pa.pieces[c1].words_off) : c.stream_len);
+  ring_begin(sw, r, c, words);
   x = c.lane < c.S ? pa.states[(uint64_t)c0 * c.S + c.lane] : 0;
   RunGeom g;
   const uint64_t g0 = (uint64_t)c0 * pa.interval;
@@ -537,13 +581,17 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
   uint64_t t_table = 0, t_ready = 0;
 
   uint32_t x = 0;
+  StreamWin sw;
   Ring r;
+  ring_bind(r, c.rings);
   RunGeom g{};
-  const uint32_t q0 = pa.static_per_wave;
-  const bool have_static = q0 != 0; // host guarantees W * q0 <= n_chains
-  if (have_static)
-    g = run_begin<MODE>(c, pa, w * q0, w * q0 + q0, x, r);
-  if (MODE == kModePack64 && pa.table != nullptr)
+  const uint32_t q0 = pa.static_per_wave; // host guarantees W * q0 <= n_chains
+  const bool host_table = MODE == kModePack64 && pa.table != nullptr;
+  if (!host_table) // the in-kernel build borrows ring space: it has to come before the first stream request
+    build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
+  if (q0 != 0)
+    g = run_begin<MODE>(c, pa, sw, w * q0, w * q0 + q0, x, r);
+  if (host_table)
   {
     // the table was built on the host from the plan's histogram copy: one coalesced 16 B load + LDS store per thread,
     // while the first wave checks that the stream really carries that histogram (else: status, as a failed sum check)
@@ -566,16 +614,14 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
     }
     __syncthreads();
   }
-  else
-    build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
   if (kp.stamps)
     t_table = __builtin_amdgcn_s_memrealtime();
-  if (have_static)
+  if (q0 != 0)
   {
     ring_ready();
     if (kp.stamps)
       t_ready = __builtin_amdgcn_s_memrealtime();
-    run_groups<MODE>(x, r, c, g.o, g.steps);
+    run_groups<MODE>(x, sw, r, c, g.o, g.steps);
     run_tail<MODE>(x, r, c, g.o, g.tail);
   }
 
@@ -596,9 +642,9 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
     if (t >= hi - lo)
       break;
     const uint32_t ch = lo + (uint32_t)t;
-    g = run_begin<MODE>(c, pa, ch, ch + 1, x, r);
+    g = run_begin<MODE>(c, pa, sw, ch, ch + 1, x, r);
     ring_ready();
-    run_groups<MODE>(x, r, c, g.o, g.steps);
+    run_groups<MODE>(x, sw, r, c, g.o, g.steps);
     run_tail<MODE>(x, r, c, g.o, g.tail);
   }
 
@@ -634,12 +680,15 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
       const Piece *p1 = pv.pieces + uni(pv.chain_first[last - 1]);
       const uint64_t limit = last < begin + count ? uni64(pv.pieces[uni(pv.chain_first[last])].words_off) : uni64(G->words_end);
       uint32_t x = c.lane < c.S ? pv.states[(uint64_t)uni(p0->state_idx) * c.S + c.lane] : 0;
+      StreamWin sw;
       Ring r;
-      ring_begin(r, c, uni64(p0->words_off), limit);
+      ring_bind(r, c.rings);
+      win_open(sw, c, uni64(p0->words_off), limit);
+      ring_begin(sw, r, c, uni64(p0->words_off));
       uint64_t o = uni64(p0->out_off);
       const uint64_t steps = (uni64(p1->out_off) - o) / c.S + uni(p1->steps);
       ring_ready();
-      run_groups<MODE>(x, r, c, o, (uint32_t)steps);
+      run_groups<MODE>(x, sw, r, c, o, (uint32_t)steps);
       run_tail<MODE>(x, r, c, o, uni(p1->tail));
     }
     else
@@ -660,7 +709,9 @@ __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv)
   uint64_t pos = pv.hdr->aux_off;
   uint64_t i = 0;
   bool have_table = false;
+  StreamWin sw;
   Ring r;
+  ring_bind(r, c.rings);
   do
   {
     if (pos + 8 > c.stream_len)
@@ -707,10 +758,10 @@ __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv)
           atomicOr(c.status, kStatusBadBlock);
         return;
       }
-      ring_init(r, c, pos);
+      ring_init(sw, r, c, pos);
       const uint64_t steps = end > i ? (end - i + S - 1) / S : 0;
-      run_groups<MODE>(x, r, c, i, (uint32_t)steps);
-      pos = ring_pos(r);
+      run_groups<MODE>(x, sw, r, c, i, (uint32_t)steps);
+      pos = ring_pos(sw, r);
     }
     if (i > whole)
     {
@@ -728,7 +779,7 @@ __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv)
         atomicOr(c.status, kStatusBadHist);
       return;
     }
-    ring_init(r, c, pos);
+    ring_init(sw, r, c, pos);
     run_tail<MODE>(x, r, c, i, (uint32_t)(out_len - i));
   }
 }
@@ -758,18 +809,15 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.bits = bits;
   c.S = pv.hdr->states;
   c.lane = threadIdx.x & 63;
-  c.prio_rotate = kp.exp_flags & 1;
-  c.prio_rank = ((threadIdx.x >> 8) + (blockIdx.x >= gridDim.x / 2 ? 4 : 0)) * 2;
 
   const uint32_t chain = blockIdx.x * waves + wave;
 
   if (SHARED)
   {
-    c.ring = smem + wave * kRingBytes;
-    c.ring_lds = lds_address(c.ring);
-    asm volatile("v_mov_b32 %0, %1" : "=v"(c.ring_vgpr) : "s"(c.ring_lds));
-    c.table = smem + waves * kRingBytes;
-    c.scratch = (uint16_t *)(smem + (kRingSlots - 1) * kChunkBytes); // last slot of wave 0's ring: free until the first ring_advance
+    c.rings = smem + wave * kWaveRingBytes;
+    c.table = smem + waves * kWaveRingBytes;
+    c.scratch_cnt = (uint16_t *)smem;         // wave 0's ring (no request in flight while a table is built)
+    c.scratch_cum = (uint16_t *)(smem + 512);
     const uint64_t hist_off = pv.hdr->aux_off; // shared plans: the one histogram every chain uses
     if (kp.pa.pieces != nullptr)
     {
@@ -787,11 +835,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   }
   else
   {
-    c.ring = smem + wave * kRingBytes; // all rings first: they stay kRingBytes-aligned and below 64 KiB (M0)
-    c.ring_lds = lds_address(c.ring);
-    asm volatile("v_mov_b32 %0, %1" : "=v"(c.ring_vgpr) : "s"(c.ring_lds));
-    c.table = smem + waves * kRingBytes + wave * ((table_bytes + 15) & ~15u);
-    c.scratch = (uint16_t *)(c.ring + (kRingSlots - 1) * kChunkBytes);
+    c.rings = smem + wave * kWaveRingBytes; // all rings first: they stay kRingBytes-aligned
+    c.table = smem + waves * kWaveRingBytes + wave * ((table_bytes + 15) & ~15u);
+    c.scratch_cnt = (uint16_t *)c.rings;
+    c.scratch_cum = (uint16_t *)(c.rings + 512);
     if (pv.hdr->flags & kPlanWalk)
     {
       if (chain == 0)
@@ -807,7 +854,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
 // ---------------------------------------------------------------------------------------------------------------
 static uint32_t g_max_lds = 160 * 1024;
 static uint32_t g_num_cus = 256;
-static uint32_t g_static_percent = 75; // HSRANS_STATIC_PERCENT (tuning): share of the chains handed out statically
+static uint32_t g_static_percent = 100; // HSRANS_STATIC_PERCENT (tuning): share of the chains handed out statically
 
 typedef void (*KernelFn)(KParams);
 static KernelFn kernel_for(int mode, bool shared)
@@ -851,7 +898,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
   // 64-bit entries only where one table serves a whole workgroup (LDS: 16 KiB table + 16 x 4 KiB rings, two per CU)
   const int mode = two_level ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : shared ? kModePack64 : kModePack;
   const uint32_t table_bytes = table_bytes_for(mode, h.bits);
-  const uint32_t wave_bytes = kRingBytes + ((table_bytes + 15) & ~15u); // private ring + table
+  const uint32_t wave_bytes = kWaveRingBytes + ((table_bytes + 15) & ~15u); // private rings + table
 
   uint32_t waves, lds, grid;
   if (shared)
@@ -859,7 +906,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
     waves = 16;
     while (waves > 1 && waves / 2 >= h.n_chains)
       waves /= 2;
-    lds = waves * kRingBytes + table_bytes;
+    lds = waves * kWaveRingBytes + table_bytes;
     grid = (h.n_chains + waves - 1) / waves;
     if (grouped)
       grid = kp.n_groups;
@@ -882,8 +929,6 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
   if (grid == 0)
     grid = 1;
 
-  if (const char *e = getenv("HSRANS_PRIO_ROTATE"))
-    kp.exp_flags |= atoi(e) ? 1 : 0;
   if (kp.pa.pieces != nullptr)
   {
     // static share: a fixed fraction of the chains, split evenly; the rest goes through the queues
