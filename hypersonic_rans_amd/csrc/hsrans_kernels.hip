@@ -88,11 +88,14 @@ struct WaveCtx
 // Invariant: whenever the cursor is in chunk c (256 words), chunks c .. c+2 have been requested and c, c+1 have landed.
 // ring_advance() runs at least once per 256 consumed words (4 groups of 64), so the cursor crosses at most one chunk
 // boundary between two calls and never needs more than chunks c, c+1 before the next call.  On entering chunk c it
-// requests chunk c+3 into the slot of the dead chunk c-1 and then waits with vmcnt(2): at least two requests of this
-// ring are younger than chunk c+1's (and than its mirror request, if it has one): those for c+2 and c+3.  So "all but
-// the 2 youngest vector-memory operations done" always covers chunk c+1 whatever else (stores, mirror requests) has
-// been issued in between — more young operations only make the wait stricter, never weaker.  The loads are issued
-// from asm, so the compiler never tracks them and never parks the decode loop on vmcnt(0).
+// requests chunk c+2 into the slot of the dead chunk c-2 and then waits with vmcnt(2) for chunk c+1.  Why 2 is enough:
+// vmcnt(N) waits until all but the N youngest vector-memory operations are done, in issue order.  Younger than chunk
+// c+1's request (and than its mirror request, if it has one) are (a) the request for c+2 just issued and (b) at least
+// one output store: chunk c+1 was requested at an earlier ring_advance(), the cursor has moved since, every decoded
+// group is followed by its store before the next ring_advance() (run_groups_impl: 4 groups, store, advance; or group,
+// store, ..., advance), so a store sits between the two requests.  More young operations only make the wait stricter,
+// never weaker.  The loads are issued from asm, so the compiler never tracks them and never parks the decode loop on
+// vmcnt(0).  (Requesting one chunk further ahead, which makes the bound independent of the stores, measured 7 % slower.)
 // ---------------------------------------------------------------------------------------------------------------
 struct StreamWin // the stream as the ring's requests see it
 {

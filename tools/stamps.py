@@ -37,3 +37,16 @@ for name, col in (("entry", 0), ("table built", 1), ("stream ready", 2), ("done"
     print(f"{name:13s} min {v.min():8.2f}  p50 {np.median(v):8.2f}  p99 {np.percentile(v, 99):8.2f}  max {v.max():8.2f} us")
 d = rel[:, 3] - rel[:, 2]
 print(f"decode span   min {d.min():8.2f}  p50 {np.median(d):8.2f}  max {d.max():8.2f} us")
+
+# who finishes late?  group by wave slot inside the workgroup and by workgroup half
+w = np.arange(len(buf) // 4)
+valid = buf.reshape(-1, 4)[:, 3] > 0
+done = (buf.reshape(-1, 4)[:, 3].astype(np.int64) - t0) / 100.0
+wave_in_wg = w % 16
+blk = w // 16
+print("done by wave-in-workgroup:", " ".join(f"{done[valid & (wave_in_wg == k)].mean():.1f}" for k in range(16)))
+print("done by SIMD slot (wave%4):", " ".join(f"{done[valid & (wave_in_wg % 4 == k)].mean():.1f}" for k in range(4)))
+print("done by wave//4:", " ".join(f"{done[valid & (wave_in_wg // 4 == k)].mean():.1f}" for k in range(4)))
+nb = blk.max() + 1
+print("done by workgroup half:", f"{done[valid & (blk < nb // 2)].mean():.1f} {done[valid & (blk >= nb // 2)].mean():.1f}")
+print("done by workgroup % 8 (XCD):", " ".join(f"{done[valid & (blk % 8 == k)].mean():.1f}" for k in range(8)))
