@@ -92,6 +92,10 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_dplan_status.argtypes = [_vp, _vp, _vp]
     L.hsrans_dplan_launch_info.restype = _i
     L.hsrans_dplan_launch_info.argtypes = [_vp, ctypes.POINTER(LaunchInfo)]
+    L.hsrans_dplan_create_from_device_stream.restype = _i
+    L.hsrans_dplan_create_from_device_stream.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _sz, _vp, ctypes.POINTER(_vp)]
+    L.hsrans_dplan_read_plan.restype = _sz
+    L.hsrans_dplan_read_plan.argtypes = [_vp, _vp, _sz]
     L.hsrans_index_build.restype = _sz
     L.hsrans_index_build.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _u32, _vp, _sz]
     _LIB = L
@@ -298,6 +302,24 @@ class Context:
         if rc != 0:
             raise HsransError(f"hsrans_dplan_create failed with code {rc}")
         return DevicePlan(self, h)
+
+    def make_device_plan_from_stream(self, container: int, states: int, bits: int, d_stream: torch.Tensor, stream_length: int,
+                                     out_capacity: int, stream: torch.cuda.Stream | None = None) -> DevicePlan:
+        """mt_ only: the header chain is walked on the GPU (no host copy of the stream needed)."""
+        s = stream if stream is not None else torch.cuda.current_stream(d_stream.device)
+        h = _vp()
+        rc = self.L.hsrans_dplan_create_from_device_stream(self.handle, container, states, bits, d_stream.data_ptr(), stream_length, out_capacity,
+                                                           ctypes.c_void_p(s.cuda_stream), ctypes.byref(h))
+        if rc != 0:
+            raise HsransError(f"hsrans_dplan_create_from_device_stream failed with code {rc}")
+        return DevicePlan(self, h)
+
+    def read_device_plan(self, dplan: DevicePlan, capacity: int = 1 << 28) -> np.ndarray:
+        out = np.zeros(capacity, np.uint8)
+        n = self.L.hsrans_dplan_read_plan(dplan.handle, _p(out), out.size)
+        if n == 0:
+            raise HsransError("hsrans_dplan_read_plan failed")
+        return out[:n].copy()
 
     def decode_device(self, dplan: DevicePlan, d_stream: torch.Tensor, d_out: torch.Tensor, stream: torch.cuda.Stream | None = None,
                       stream_length: int | None = None):

@@ -35,6 +35,7 @@ struct hsrans_dplan
   PlanHeader hdr{};
   uint8_t *d_plan = nullptr;
   uint32_t *d_status = nullptr;
+  size_t plan_bytes = 0;
   uint64_t *d_stamps = nullptr; // diagnostics (HSRANS_DEBUG_STAMPS=1)
   unsigned long long *d_counters = nullptr; // persistent launches: monotonic queue heads
   uint2 *d_table = nullptr;                 // host-built decode table (plans that carry their histogram)
@@ -267,6 +268,7 @@ int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
     return HSRANS_E_HIP;
   d->ctx = ctx;
   d->hdr = h;
+  d->plan_bytes = plan_size;
   if (hipMalloc((void **)&d->d_plan, plan_size) != hipSuccess || hipMalloc((void **)&d->d_status, 64) != hipSuccess ||
       hipMemcpy(d->d_plan, plan, plan_size, hipMemcpyHostToDevice) != hipSuccess || hipMemset(d->d_status, 0, 64) != hipSuccess)
   {
@@ -382,6 +384,83 @@ size_t hsrans_debug_read_stamps(hsrans_dplan *d, uint64_t *out, size_t capacity_
     return 0;
   const size_t n = capacity_u64 < kStampWaves * 4 ? capacity_u64 : kStampWaves * 4;
   return hipMemcpy(out, d->d_stamps, n * 8, hipMemcpyDeviceToHost) == hipSuccess ? n : 0;
+}
+
+int hsrans_dplan_create_from_device_stream(hsrans_ctx *ctx, int container, int states, uint32_t bits, const void *d_stream, size_t stream_length,
+                                           size_t out_capacity, void *hip_stream, hsrans_dplan **out_dplan)
+{
+  // K2: the mt_ header chain is followed on the device, so a stream that only exists in HBM can be
+  // planned without a host copy.  Two passes of one single-wavefront kernel (count, then write); the pointer chase costs
+  // about a memory round trip per block.
+  if (ctx == nullptr || out_dplan == nullptr || d_stream == nullptr)
+    return HSRANS_E_ARG;
+  *out_dplan = nullptr;
+  if (container != HSRANS_MT || !valid_codec(container, states, bits) || ((uintptr_t)d_stream & 15) != 0)
+    return HSRANS_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return HSRANS_E_HIP;
+  hipStream_t s = (hipStream_t)hip_stream;
+  WalkResult *d_res = nullptr;
+  WalkResult res{};
+  hsrans_dplan *d = nullptr;
+  int rc = HSRANS_E_HIP;
+  do
+  {
+    if (hipMalloc((void **)&d_res, sizeof(WalkResult)) != hipSuccess)
+      break;
+    if (launch_mt_walk((const uint8_t *)d_stream, stream_length, out_capacity, (uint32_t)states, bits, nullptr, 0, d_res, s) != hipSuccess ||
+        hipMemcpyAsync(&res, d_res, sizeof(res), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      break;
+    if (res.error != 0 || res.n_chains == 0)
+    {
+      rc = HSRANS_E_FORMAT;
+      break;
+    }
+    d = new (std::nothrow) hsrans_dplan;
+    if (d == nullptr)
+      break;
+    d->ctx = ctx;
+    PlanHeader h{};
+    memcpy(h.magic, "HSRPLAN1", 8);
+    h.container = HSRANS_MT;
+    h.states = (uint32_t)states;
+    h.bits = bits;
+    h.decoded_len = res.decoded_len;
+    h.stream_len = stream_length;
+    h.n_chains = h.n_pieces = res.n_chains;
+    const size_t bytes = (size_t)plan_size(h.n_chains, h.n_pieces, h.states, 0);
+    WalkResult res2{};
+    if (hipMalloc((void **)&d->d_plan, bytes) != hipSuccess || hipMalloc((void **)&d->d_status, 64) != hipSuccess ||
+        hipMemsetAsync(d->d_plan, 0, bytes, s) != hipSuccess || hipMemsetAsync(d->d_status, 0, 64, s) != hipSuccess ||
+        hipMemcpyAsync(d->d_plan, &h, sizeof(h), hipMemcpyHostToDevice, s) != hipSuccess ||
+        launch_mt_walk((const uint8_t *)d_stream, stream_length, out_capacity, (uint32_t)states, bits, d->d_plan, h.n_chains, d_res, s) != hipSuccess ||
+        hipMemcpyAsync(&res2, d_res, sizeof(res2), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      break;
+    if (res2.error != 0 || res2.n_chains != res.n_chains)
+    {
+      rc = HSRANS_E_FORMAT;
+      break;
+    }
+    d->hdr = h;
+    d->plan_bytes = bytes;
+    rc = HSRANS_OK;
+  } while (false);
+  if (d_res)
+    (void)hipFree(d_res);
+  if (rc != HSRANS_OK)
+  {
+    hsrans_dplan_destroy(d);
+    return rc;
+  }
+  *out_dplan = d;
+  return HSRANS_OK;
+}
+
+size_t hsrans_dplan_read_plan(hsrans_dplan *d, uint8_t *out, size_t capacity)
+{
+  if (d == nullptr || out == nullptr || d->d_plan == nullptr || d->plan_bytes == 0 || capacity < d->plan_bytes)
+    return 0;
+  return hipMemcpy(out, d->d_plan, d->plan_bytes, hipMemcpyDeviceToHost) == hipSuccess ? d->plan_bytes : 0;
 }
 
 void hsrans_dplan_destroy(hsrans_dplan *d)

@@ -66,6 +66,17 @@ struct LaunchInfo
   uint32_t grid, block, lds_bytes, waves_per_block, chains, shared_table, walk, two_level;
 };
 
+// K2: device-side walk of an mt_ stream's header chain (mt_rANS32x64_16w_decode.cpp:41-96), the device twin of the host
+// planner.  Two passes of the same single-wavefront kernel: count (plan == nullptr), then write the plan blob.
+struct WalkResult
+{
+  uint32_t n_chains; // chains (= pieces) the walk produces
+  uint32_t error;    // 0 ok; else the stream is malformed (the reference's "return 0" cases)
+  uint64_t decoded_len;
+};
+hipError_t launch_mt_walk(const uint8_t *d_stream, uint64_t stream_len, uint64_t out_cap, uint32_t S, uint32_t bits, uint8_t *d_plan, uint32_t n_chains,
+                          WalkResult *d_result, hipStream_t stream);
+
 // one-time per process: raise the dynamic-LDS limit of every kernel variant to the gfx950 maximum (160 KiB)
 hipError_t prepare_kernels();
 // asynchronous on `stream`; no allocation, no synchronisation (graph-capturable)

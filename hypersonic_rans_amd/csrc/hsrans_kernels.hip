@@ -853,6 +853,125 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// K2: mt_ header-chain walk on the device (one wavefront; lane 0 steers, all lanes copy states / sum counts).
+// Mirrors hsrans::plan_build's mt_ branch step by step, which mirrors mt_rANS32x64_16w_decode.cpp:41-96.
+// plan == nullptr: count only.  Otherwise plan is a blob sized for `n_chains` single-piece chains: the kernel fills
+// chain_first, pieces and states (the host writes the 64-byte header).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t load_u64_2b(const uint8_t *p) // stream offsets are only 2-byte aligned
+{
+  uint64_t v = 0;
+  for (int b = 3; b >= 0; b--)
+    v = (v << 16) | *(const uint16_t *)(p + 2 * b);
+  return v;
+}
+
+__global__ void __launch_bounds__(64) k_mt_walk(const uint8_t *in, uint64_t in_len, uint64_t out_cap, uint32_t S, uint32_t bits, uint8_t *plan,
+                                                uint32_t n_chains, WalkResult *result)
+{
+  const uint32_t lane = threadIdx.x;
+  uint32_t *cf = plan ? (uint32_t *)(plan + plan_chain_first_off()) : nullptr;
+  Piece *pieces = plan ? (Piece *)(plan + plan_pieces_off(n_chains)) : nullptr;
+  uint32_t *states = plan ? (uint32_t *)(plan + plan_states_off(n_chains, n_chains)) : nullptr;
+  uint32_t count = 0, error = 0;
+  uint64_t out_len = 0;
+  do
+  {
+    // the checks every reference decoder opens with (mt_…decode.cpp:15-32)
+    if (in_len < 16 + 4 * (uint64_t)S + 512) { error = 1; break; }
+    out_len = uni64(load_u64_2b(in));
+    const uint64_t stored = uni64(load_u64_2b(in + 8));
+    if (out_len > out_cap || in_len < stored || out_len == 0 || out_len + 1 < S) { error = 1; break; }
+    const uint64_t whole = out_len - S + 1;
+    uint64_t pos = 16, i = 0;
+    bool last_is_rans = false;
+    do
+    {
+      if (pos + 8 > in_len) { error = 2; break; }
+      const uint64_t size_val = uni64(load_u64_2b(in + pos));
+      pos += 8;
+      Piece p{};
+      if (size_val >> 63)
+      {
+        const uint64_t len = size_val & (((uint64_t)1 << 54) - 1);
+        if (len == 0 || i > out_len || len > out_len - i) { error = 3; break; }
+        p.flags = kPieceFill | kPieceChainStart;
+        p.out_off = i;
+        p.fill_len = len;
+        p.hist_off = (size_val >> 54) & 0xFF;
+        i += len;
+        last_is_rans = false;
+      }
+      else
+      {
+        if (pos + 8 + 4 * (uint64_t)S + 512 > in_len) { error = 2; break; }
+        const uint64_t skip = uni64(load_u64_2b(in + pos));
+        pos += 8;
+        if (skip > in_len) { error = 2; break; }
+        const uint64_t after = pos + 2 * (skip + 1);
+        if (states && lane < S && count < n_chains)
+          states[(uint64_t)count * S + lane] = (uint32_t)*(const uint16_t *)(in + pos + 4 * lane) | ((uint32_t)*(const uint16_t *)(in + pos + 4 * lane + 2) << 16);
+        pos += 4 * (uint64_t)S;
+        uint32_t sum = 0;
+        for (uint32_t k = 0; k < 4; k++)
+          sum += *(const uint16_t *)(in + pos + 2 * (4 * lane + k));
+        for (int d = 32; d >= 1; d >>= 1)
+          sum += __shfl_xor(sum, d, 64);
+        if (uni(sum) != (1u << bits)) { error = 4; break; } // inplace_complete_hist, hist.cpp:308-324
+        p.flags = kPieceChainStart;
+        p.hist_off = pos;
+        pos += 512;
+        p.words_off = pos;
+        p.out_off = i;
+        uint64_t end = i + size_val;
+        if (end > whole || end < i)
+          end = whole;
+        else if (end & (S - 1)) { error = 5; break; }
+        const uint64_t steps = end > i ? (end - i + S - 1) / S : 0;
+        if (steps > 0xFFFFFFFFull || size_val == 0) { error = 5; break; }
+        p.steps = (uint32_t)steps;
+        i += steps * S;
+        last_is_rans = true;
+        if (i > whole)
+          pos = ~(uint64_t)0; // both outcomes of mt_…decode.cpp:86-92 leave the loop
+        else
+          pos = after;
+      }
+      p.state_idx = count;
+      if (i >= whole && i < out_len)
+      {
+        // final partial group: a tail on the last chain (mt_…decode.cpp:99-130); see hsrans::plan_build for the rejected case
+        if (!last_is_rans || out_len - i >= S) { error = 6; break; }
+        p.tail = (uint16_t)(out_len - i);
+      }
+      if (pieces && lane == 0 && count < n_chains)
+      {
+        pieces[count] = p;
+        cf[count] = count;
+      }
+      count++;
+      if (pos == ~(uint64_t)0)
+        break;
+    } while (i < whole);
+  } while (false);
+  if (lane == 0)
+  {
+    if (cf && error == 0 && count == n_chains)
+      cf[count] = count;
+    result->n_chains = count;
+    result->error = error;
+    result->decoded_len = out_len;
+  }
+}
+
+hipError_t launch_mt_walk(const uint8_t *d_stream, uint64_t stream_len, uint64_t out_cap, uint32_t S, uint32_t bits, uint8_t *d_plan, uint32_t n_chains,
+                          WalkResult *d_result, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_mt_walk, dim3(1), dim3(64), 0, stream, d_stream, stream_len, out_cap, S, bits, d_plan, n_chains, d_result);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------------------------------
 static uint32_t g_max_lds = 160 * 1024;

@@ -115,6 +115,12 @@ int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
 void hsrans_dplan_destroy(hsrans_dplan *dplan);
 int hsrans_decode_device(hsrans_ctx *ctx, hsrans_dplan *dplan, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity,
                          void *hip_stream);
+/* Plan an mt_ stream that only exists in device memory: the header chain (src/mt_rANS32x64_16w_decode.cpp:166-227) is
+ * followed by a device kernel; synchronises `hip_stream` twice (chain count, then the finished plan). HSRANS_MT only. */
+int hsrans_dplan_create_from_device_stream(hsrans_ctx *ctx, int container, int states, uint32_t bits, const void *d_stream, size_t stream_length,
+                                           size_t out_capacity, void *hip_stream, hsrans_dplan **out_dplan);
+/* copies the plan blob a dplan holds in device memory back to the host (inspection / tests); returns its size, 0 on error */
+size_t hsrans_dplan_read_plan(hsrans_dplan *dplan, uint8_t *out, size_t capacity);
 /* synchronises `hip_stream` and returns HSRANS_OK or HSRANS_E_DEVICE (kernel found a bad histogram/header) */
 int hsrans_dplan_status(hsrans_ctx *ctx, hsrans_dplan *dplan, void *hip_stream);
 

@@ -176,3 +176,39 @@ def test_sharded_decode_single_rank(gpu_ctx, zipf):
             assert np.array_equal(out.cpu().numpy(), zipf)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("states", (32, 64))
+def test_device_side_mt_walk_matches_host_planner(gpu_ctx, ref, zipf, nonstat, states):
+    """K2: the mt_ header chain followed on the GPU gives the same chains as the host planner, on streams written by our
+    encoder and by the real reference (incl. a quirk length), and decodes bit-exactly."""
+    import torch
+
+    cases = [(H.encode(H.MT, states, 11, nonstat[:2_000_003]), nonstat[:2_000_003], 11)]
+    for bits, n in ((11, 65560), (14, 1 << 20), (11, 3_000_000)):
+        src = zipf if n <= zipf.size else nonstat
+        cases.append((ref.encode(MT, states, bits, src[:n]), None, bits))
+    for s, data, bits in cases:
+        n = int(s[:8].view(np.uint64)[0])
+        host_plan = H.plan_build(H.MT, states, bits, s)
+        d_in = torch.from_numpy(np.concatenate([s, np.zeros((-s.size) % 16, np.uint8)])).cuda()
+        dp = gpu_ctx.make_device_plan_from_stream(H.MT, states, bits, d_in, s.size, n)
+        dev_plan = gpu_ctx.read_device_plan(dp, capacity=host_plan.size + 4096)
+        _, cf_h, pc_h = H.api.plan_tables(host_plan)
+        hd, cf_d, pc_d = H.api.plan_tables(dev_plan)
+        assert hd["n_chains"] == H.plan_chain_count(host_plan) and np.array_equal(cf_h, cf_d)
+        assert pc_h.tobytes() == pc_d.tobytes()
+        so = 64 + ((hd["n_chains"] + 1) * 4 + 15) // 16 * 16 + 48 * hd["n_pieces"]
+        assert np.array_equal(host_plan[so:so + 4 * states * hd["n_chains"]], dev_plan[so:so + 4 * states * hd["n_chains"]])
+        d_out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        gpu_ctx.decode_device(dp, d_in, d_out, stream_length=s.size)
+        assert gpu_ctx.status(dp) == 0
+        r, want = gpu_ctx.decode_host(H.MT, states, bits, s, n)
+        assert r == n and np.array_equal(d_out.cpu().numpy(), want)
+        if data is not None:
+            assert np.array_equal(want, data)
+    bad = cases[0][0].copy()
+    bad[16 + 16 + 4 * states] ^= 1  # first block's first count
+    d_bad = torch.from_numpy(np.concatenate([bad, np.zeros((-bad.size) % 16, np.uint8)])).cuda()
+    with pytest.raises(H.HsransError):
+        gpu_ctx.make_device_plan_from_stream(H.MT, states, 11, d_bad, bad.size, 2_000_003)
