@@ -10,6 +10,7 @@
 //            next header = &state[0] + 2*(skip+1) bytes                                  (mt_rANS32x64_16w_encode.cpp:266-298)
 #include "hsrans_host.h"
 
+#include <math.h>
 #include <string.h>
 
 #include <algorithm>
@@ -224,11 +225,12 @@ struct BlockSpan
 {
   size_t begin, end;
   bool single;
+  hsrans_hist hist; // histogram the block is coded with (unused for single-symbol blocks)
 };
 
 // fixed-size blocks; the last one absorbs a remainder shorter than S so that the reference decoders' loop condition
 // (`i < outLen - S + 1`, block_…decode.cpp:90) always reaches its header
-std::vector<BlockSpan> split_blocks(const uint8_t *in, size_t n, size_t block, uint32_t S)
+std::vector<BlockSpan> split_blocks(const uint8_t *in, size_t n, size_t block, uint32_t S, uint32_t bits)
 {
   std::vector<BlockSpan> v;
   size_t count = (n + block - 1) / block;
@@ -242,9 +244,159 @@ std::vector<BlockSpan> split_blocks(const uint8_t *in, size_t n, size_t block, u
     s.single = true;
     for (size_t i = s.begin + 1; i < s.end && s.single; i++)
       s.single = in[i] == in[s.begin];
+    if (!s.single)
+    {
+      uint32_t raw[256] = {};
+      for (size_t i = s.begin; i < s.end; i++)
+        raw[in[i]]++;
+      normalize_counts(&s.hist, raw, s.end - s.begin, bits);
+    }
     v.push_back(s);
   }
   return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The reference's adaptive block policy (block_rANS32x64_16w_encode.cpp:137-349, mt_rANS32x64_16w_encode.cpp:140-356 and
+// their 32-state twins), restated: blocks are chosen back to front in units of MinBlockSize; a block keeps growing
+// towards the front while a cost model (order-0 code length under the block's histogram vs. a fresh histogram for the
+// next unit) says one histogram is cheaper than two; runs of one symbol become single-symbol blocks.
+// Reproduces the reference's choices byte for byte, including two things that look like accidents: every block but the
+// last is modelled on the bytes up to the END of the block behind it (`blockBackPoint` is updated late, :344), and the
+// mt_ size cap is measured against that stale end too.  One deliberate deviation: the reference can leave a last block
+// shorter than S symbols (MinBlockSize < n < MinBlockSize + S), which its own decoders then mis-decode (SURVEY.md §8
+// quirks); here that remainder is merged into the block before it.
+// ---------------------------------------------------------------------------------------------------------------
+struct Policy
+{
+  uint32_t min_block_bits;
+  uint32_t replace_mul; // HistReplaceMul
+  size_t max_block;     // mt_: 1 << 25; block_: unlimited
+};
+
+Policy reference_policy(int container, uint32_t S, uint32_t bits)
+{
+  Policy p;
+  if (container == HSRANS_MT) // mt_rANS32x64_16w_encode.cpp:21-48 (same in the 32-state file)
+  {
+    p.min_block_bits = 16;
+    p.replace_mul = bits == 15 ? 50 : 500;
+    p.max_block = (size_t)1 << 25;
+    return p;
+  }
+  // block_rANS32x64_16w_encode.cpp:21-39 / block_rANS32x32_16w_encode.cpp:21-39
+  static const uint32_t mul64[6] = {4000, 7730, 5600, 2500, 1500, 850}, mul32[6] = {4000, 7730, 5600, 3120, 2087, 822};
+  static const uint32_t min64[6] = {20, 19, 16, 17, 17, 16}, min32[6] = {20, 19, 15, 17, 17, 18};
+  p.replace_mul = (S == 64 ? mul64 : mul32)[bits - 10];
+  p.min_block_bits = (S == 64 ? min64 : min32)[bits - 10];
+  p.max_block = ~(size_t)0;
+  return p;
+}
+
+// _CanExtendHist (mt_…encode.cpp:61-136): would coding [start, start+size) with `old` cost less than 8 x replace_mul/4096
+// x 2^bits bits more than with a histogram of its own?  `counts` receives the unit's raw counts.
+bool can_extend(const uint8_t *in, size_t start, size_t size, const hsrans_hist &old, uint32_t bits, const Policy &pol, uint32_t S)
+{
+  uint32_t counts[256] = {};
+  for (size_t i = start; i < start + size; i++)
+    counts[in[i]]++;
+  hsrans_hist fresh;
+  normalize_counts(&fresh, counts, (size_t)1 << pol.min_block_bits, bits);
+  const float total = (float)(1u << bits);
+  const size_t replace_point = ((size_t)(1u << bits) * pol.replace_mul) >> 12;
+  float cost_old = 0;
+  float cost_new = (float)(2 * 256 + S * 4 + 8 * 2) * 0.5f;
+  for (int s = 0; s < 256; s++)
+  {
+    if (counts[s] == 0)
+      continue;
+    const float before = (float)(counts[s] - 1) * log2f((float)old.symbolCount[s] / total);
+    const float after = (float)counts[s] * log2f((float)fresh.symbolCount[s] / total);
+    cost_old -= before;
+    cost_new -= after;
+  }
+  return cost_old - cost_new < (float)replace_point;
+}
+
+void count_range(uint32_t counts[256], const uint8_t *in, size_t begin, size_t end, uint32_t *distinct, uint8_t *last_symbol)
+{
+  memset(counts, 0, 256 * sizeof(uint32_t));
+  for (size_t i = begin; i < end; i++)
+    counts[in[i]]++;
+  *distinct = 0;
+  for (int s = 0; s < 256; s++)
+    if (counts[s])
+    {
+      (*distinct)++;
+      *last_symbol = (uint8_t)s;
+    }
+}
+
+std::vector<BlockSpan> reference_blocks(int container, const uint8_t *in, size_t n, uint32_t S, uint32_t bits)
+{
+  const Policy pol = reference_policy(container, S, bits);
+  const size_t unit = (size_t)1 << pol.min_block_bits;
+  std::vector<BlockSpan> back_to_front;
+  uint32_t counts[256];
+  uint32_t distinct;
+  uint8_t symbol = 0;
+
+  size_t target = (((n - 1) & ~(size_t)(S - 1)) & ~(unit - 1));
+  if (target > unit)
+    target -= unit;
+  if (target > 0 && n - target < S) // see the note above: never leave a last block shorter than one group
+    target -= unit;
+  size_t stale_end = n; // `blockBackPoint`: the end of the PREVIOUSLY chosen block while the next one is being chosen
+  size_t block_end = n;
+  bool first = true;
+  while (true)
+  {
+    BlockSpan b{};
+    count_range(counts, in, target, block_end, &distinct, &symbol);
+    if (distinct == 1)
+    {
+      // single-symbol block: swallow the whole run, then give back what does not start on a group boundary
+      size_t run = target;
+      while (run > 0 && in[run - 1] == symbol)
+        run--;
+      target = (run + S - 1) & ~(size_t)(S - 1);
+      b.single = true;
+    }
+    else
+    {
+      size_t extra = 0;
+      for (int s = 0; s < 256; s++)
+        if (counts[s] == 0)
+        {
+          counts[s] = 1; // "safe" histogram: every symbol stays codable while the block is extended
+          extra++;
+        }
+      normalize_counts(&b.hist, counts, first ? block_end - target + extra : unit, bits);
+      while (target > 0 && stale_end - target < pol.max_block && can_extend(in, target - unit, unit, b.hist, bits, pol, S))
+        target -= unit;
+      // the histogram that is actually used: counts of [target, stale_end) — for every block but the last that range
+      // reaches into the block behind it
+      uint32_t d2;
+      uint8_t s2;
+      count_range(counts, in, target, stale_end, &d2, &s2);
+      normalize_counts(&b.hist, counts, stale_end - target, bits);
+      b.single = false;
+    }
+    b.begin = target;
+    b.end = block_end;
+    back_to_front.push_back(b);
+    if (target == 0)
+      break;
+    // next block towards the front
+    stale_end = block_end;
+    block_end = target;
+    first = false;
+    target = (target - 1) & ~(unit - 1);
+    if (target > 0 && block_end - target < unit * 2 / 3)
+      target -= unit;
+  }
+  std::reverse(back_to_front.begin(), back_to_front.end());
+  return back_to_front;
 }
 
 } // namespace
@@ -260,7 +412,10 @@ size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_
   const uint32_t interval = opts ? opts->index_interval : 0;
   if (interval != 0 && (interval % 4 != 0 || opts->plan_out == nullptr))
     return 0;
-  size_t block = opts && opts->block_size ? opts->block_size : 65536;
+  // block_/mt_: block_size == 0 selects the reference's adaptive block policy (byte-identical streams), anything else
+  // fixed blocks of that many symbols
+  const bool fixed_blocks = opts && opts->block_size != 0;
+  const size_t block = fixed_blocks ? opts->block_size : 65536;
   if (block % 64 != 0)
     return 0;
 
@@ -312,7 +467,7 @@ size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_
   }
   else
   {
-    const std::vector<BlockSpan> spans = split_blocks(in, n, block, S);
+    const std::vector<BlockSpan> spans = fixed_blocks ? split_blocks(in, n, block, S, bits) : reference_blocks(container, in, n, S, bits);
     uint64_t next_header_from_end = 0;
     for (size_t b = spans.size(); b-- > 0;)
     {
@@ -331,10 +486,7 @@ size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_
       }
       else
       {
-        uint32_t raw[256] = {};
-        for (size_t i = sp.begin; i < sp.end; i++)
-          raw[in[i]]++;
-        normalize_counts(&c.hist, raw, size, bits);
+        c.hist = sp.hist;
         const size_t g_first = sp.begin / S;
         const size_t g_last = (sp.end - 1) / S; // inclusive; may be the file's partial group
         // positions of this block's counts are only known once its words are written: checkpoints inside the
@@ -357,7 +509,9 @@ size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_
           c.push_bytes(c.x, 4 * (size_t)S);
           const uint64_t states_from_end = c.written();
           // skip: uint16 units from the state array to the next block header, minus one (mt_…decode.cpp:59)
-          const uint64_t skip = (states_from_end - next_header_from_end) / 2 - 1;
+          // (the last block's field is never read; the reference measures it from the stream's last word instead of its
+          // end, mt_…encode.cpp:149,277, hence one less there)
+          const uint64_t skip = (states_from_end - next_header_from_end) / 2 - 1 - (next_header_from_end == 0 ? 1 : 0);
           c.push_bytes(&skip, 8);
         }
         c.push_bytes(&size, 8);

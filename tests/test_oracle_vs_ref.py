@@ -58,3 +58,16 @@ def test_error_returns(oracle, ref, data):
         bad[off] ^= 1
         assert oracle.decode(container, 64, 11, bad, 5000)[0] == 0
         assert ref.decode(container, 64, 11, bad, 5000)[0] == 0
+
+
+@pytest.mark.parametrize("container", (BLOCK, MT))
+def test_product_container_encoders_match_the_real_reference(ref, data, container):
+    """The product's block_/mt_ encoders (reference block policy) against the real reference's encoders, byte for byte."""
+    import hypersonic_rans_amd as H
+
+    zipf, nonstat = data
+    for states in (32, 64):
+        for bits in (10, 11, 12, 13, 14, 15):
+            for src, n in ((zipf, 64), (zipf, 1000), (zipf, 65536), (zipf, 65600), (zipf, 262144), (zipf, 300_000), (nonstat, 1_200_000), (nonstat, 700_001)):
+                d = src[:n]
+                assert np.array_equal(H.encode(container, states, bits, d), ref.encode(container, states, bits, d)), (container, states, bits, n)
