@@ -543,9 +543,10 @@ int hsrans_dplan_launch_info(const hsrans_dplan *d, hsrans_launch_info *info)
 size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint32_t index_interval,
                           uint8_t *plan_out, size_t plan_capacity)
 {
-  // One sequential single-wavefront pass over a raw stream that records {states, read cursor} every
-  // `index_interval` groups; the checkpoints then become the chains of a parallel plan.
-  if (ctx == nullptr || in == nullptr || plan_out == nullptr || container != HSRANS_RAW || !valid_codec(container, states, bits))
+  // One pass over an existing stream that records {states, read cursor} every `index_interval` groups inside every rANS
+  // piece of the stream's own plan (raw: one sequential wavefront; mt_: one wavefront per block, in parallel); the
+  // checkpoints then become additional chains.  block_ streams are one chain with inline headers and are not indexed here.
+  if (ctx == nullptr || in == nullptr || plan_out == nullptr || (container != HSRANS_RAW && container != HSRANS_MT) || !valid_codec(container, states, bits))
     return 0;
   if (index_interval == 0 || index_interval % 4 != 0 || in_length < 16)
     return 0;
@@ -557,11 +558,13 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
     return 0;
   PlanHeader h;
   memcpy(&h, base.data(), sizeof(h));
-  const Piece *p0 = (const Piece *)(base.data() + plan_pieces_off(h.n_chains));
+  const uint32_t *cf0 = (const uint32_t *)(base.data() + plan_chain_first_off());
+  const Piece *pc0 = (const Piece *)(base.data() + plan_pieces_off(h.n_chains));
   const uint32_t *st0 = (const uint32_t *)(base.data() + plan_states_off(h.n_chains, h.n_pieces));
   const uint32_t S = (uint32_t)states;
-  const uint64_t T = p0->steps;
-  const uint64_t n_ck = T / index_interval + 1; // slot 0 unused (= stream start)
+  if (h.n_pieces != h.n_chains) // the planner only produces single-piece chains for raw and mt_
+    return 0;
+  const uint64_t n_ck = out_len / S / index_interval + 2;
 
   std::lock_guard<std::mutex> guard(ctx->lock);
   if (hipSetDevice(ctx->device) != hipSuccess)
@@ -593,7 +596,9 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
     kp.ckpt_states = d_ck_states;
     kp.ckpt_words = d_ck_words;
     kp.ckpt_interval = index_interval;
-    if (launch_decode(kp, h, s, nullptr) != hipSuccess)
+    PlanHeader hl = h;
+    hl.shared_hist = 0; // private tables: every chain of the pass builds its own (raw has one chain, mt_ one per block)
+    if (launch_decode(kp, hl, s, nullptr) != hipSuccess)
       break;
     if (hipMemcpyAsync(ck_states.data(), d_ck_states, n_ck * S * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipMemcpyAsync(ck_words.data(), d_ck_words, n_ck * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -604,19 +609,33 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
     PlanBuilder pb;
     pb.begin(container, states, bits, out_len, in_length);
     pb.hdr.interval = index_interval;
-    uint16_t counts[256];
-    memcpy(counts, in + p0->hist_off, 512);
-    pb.set_hist(counts);
-    for (uint64_t g = 0; g < T || g == 0; g += index_interval)
+    if (container == HSRANS_RAW)
     {
-      Piece p{};
-      p.hist_off = p0->hist_off;
-      p.out_off = g * S;
-      p.words_off = g == 0 ? p0->words_off : ck_words[g / index_interval];
-      const uint64_t steps = T - g < index_interval ? T - g : index_interval;
-      p.steps = (uint32_t)steps;
-      p.tail = (uint16_t)(g + steps == T ? p0->tail : 0);
-      pb.add_chain(p, g == 0 ? st0 : &ck_states[(g / index_interval) * S]);
+      uint16_t counts[256];
+      memcpy(counts, in + pc0[0].hist_off, 512);
+      pb.set_hist(counts);
+    }
+    for (uint32_t ch = 0; ch < h.n_chains; ch++)
+    {
+      const Piece &bp = pc0[cf0[ch]];
+      if (bp.flags & kPieceFill)
+      {
+        pb.add_chain(bp, nullptr);
+        continue;
+      }
+      const uint64_t T = bp.steps, g_abs0 = bp.out_off / S;
+      for (uint64_t g = 0; g < T || g == 0; g += index_interval)
+      {
+        Piece p{};
+        p.hist_off = bp.hist_off;
+        p.out_off = bp.out_off + g * S;
+        const uint64_t slot = (g_abs0 + g) / index_interval;
+        p.words_off = g == 0 ? bp.words_off : ck_words[slot];
+        const uint64_t steps = T - g < index_interval ? T - g : index_interval;
+        p.steps = (uint32_t)steps;
+        p.tail = (uint16_t)(g + steps == T ? bp.tail : 0);
+        pb.add_chain(p, g == 0 ? st0 + (size_t)bp.state_idx * S : &ck_states[slot * S]);
+      }
     }
     result = pb.serialize(plan_out, plan_capacity);
   } while (false);

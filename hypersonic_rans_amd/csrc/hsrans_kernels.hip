@@ -519,13 +519,16 @@ __device__ void run_planned_chain(const WaveCtx &c, const PlanView &pv, uint32_t
 
     if (kp.ckpt_interval != 0)
     {
-      // index-build pass (hsrans_index_build): record {states, cursor} at every `ckpt_interval`-th group boundary
+      // index-build pass (hsrans_index_build): record {states, cursor} at every `ckpt_interval`-th group boundary of the
+      // piece.  Slot = absolute group index / interval: checkpoints of one piece are an interval apart and pieces do
+      // not overlap in the output, so slots are unique across all chains of a stream.
       uint32_t g = 0;
+      const uint64_t g_abs0 = o / c.S;
       while (steps > 0)
       {
         if (g != 0)
         {
-          const uint64_t slot = g / kp.ckpt_interval;
+          const uint64_t slot = (g_abs0 + g) / kp.ckpt_interval;
           if (c.lane < c.S)
             kp.ckpt_states[slot * c.S + c.lane] = x;
           if (c.lane == 0)

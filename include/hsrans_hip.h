@@ -125,8 +125,9 @@ size_t hsrans_dplan_read_plan(hsrans_dplan *dplan, uint8_t *out, size_t capacity
 int hsrans_dplan_status(hsrans_ctx *ctx, hsrans_dplan *dplan, void *hip_stream);
 
 /* Build a plan with checkpoints every `index_interval` groups for an EXISTING stream (e.g. one written by the
- * reference's encoder) by one sequential single-wavefront pass on the GPU; the pass also decodes into d_out.
- * Returns plan bytes written to plan_out (host memory), 0 on failure. */
+ * reference's encoder) by one decode pass on the GPU that records the states at the checkpoints: HSRANS_RAW (one
+ * sequential wavefront) and HSRANS_MT (one wavefront per block).  Returns plan bytes written to plan_out (host
+ * memory), 0 on failure. */
 size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length,
                           uint32_t index_interval, uint8_t *plan_out, size_t plan_capacity);
 

@@ -212,3 +212,19 @@ def test_device_side_mt_walk_matches_host_planner(gpu_ctx, ref, zipf, nonstat, s
     d_bad = torch.from_numpy(np.concatenate([bad, np.zeros((-bad.size) % 16, np.uint8)])).cuda()
     with pytest.raises(H.HsransError):
         gpu_ctx.make_device_plan_from_stream(H.MT, states, 11, d_bad, bad.size, 2_000_003)
+
+
+@pytest.mark.parametrize("states", (32, 64))
+def test_index_build_for_reference_mt_streams(gpu_ctx, ref, nonstat, zipf, states):
+    """An mt_ stream written by the real reference gets in-block checkpoints from one GPU pass; the indexed plan decodes
+    to the same bytes through the grouped launch."""
+    for bits, src, n in ((11, nonstat, 3_000_000), (14, zipf, 1 << 20)):
+        d = src[:n]
+        s = ref.encode(MT, states, bits, d)
+        plan = gpu_ctx.index_build(H.MT, states, bits, s, 32)
+        assert H.plan_chain_count(plan) > 4 * H.plan_chain_count(H.plan_build(H.MT, states, bits, s))
+        r, got = gpu_ctx.decode_host(H.MT, states, bits, s, n, plan=plan)
+        assert r == n and np.array_equal(got, d)
+        # and it is the plan our encoder writes for the same stream (same block policy -> same bytes -> same checkpoints)
+        s2, plan2 = H.encode(H.MT, states, bits, d, index_interval=32)
+        assert np.array_equal(s, s2) and np.array_equal(plan, plan2)
