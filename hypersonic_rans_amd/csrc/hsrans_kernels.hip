@@ -35,7 +35,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t kRingSlots = 4;
 constexpr uint32_t kChunkBytes = 512; // 32 lanes x 16 B
 constexpr uint32_t kRingBytes = kRingSlots * kChunkBytes; // 2 KiB
-constexpr uint32_t kChunkWordsLog2 = 8;
 // (the mirror is 128 bytes: the first 64 words of the ring, copied behind its end)
 constexpr uint32_t kWaveRingBytes = kRingBytes + 256;     // per wave (ring + mirror, 256-byte granular)
 constexpr uint32_t kConsume = 1u << 15; // rans.h:8 DecodeConsumePoint16
@@ -109,23 +108,31 @@ struct Ring
   uint32_t k;     // chunk the cursor was in at the last ring_advance()
   uint32_t cur;   // next word to read, counted from voff0 (wave-uniform)
   uint32_t lds;   // LDS byte address of the ring (what M0 / ds_read take)
+  uint32_t clog;  // log2 of the chunk size in bytes: 9 (32 lanes x 16 B; 64-state chains) or 8 (16 lanes; paired 32-state chains)
 };
 
-__device__ __forceinline__ void ring_bind(Ring &r, const uint8_t *lds_ring) { r.lds = uni(lds_address(lds_ring)); }
+// clog = 9: 2 KiB ring + 128 B mirror (a group reads <= 64 words); clog = 8: 1 KiB ring + 64 B mirror (<= 32 words)
+__device__ __forceinline__ void ring_bind(Ring &r, const uint8_t *lds_ring, uint32_t clog = 9)
+{
+  r.lds = uni(lds_address(lds_ring));
+  r.clog = clog;
+}
+__device__ __forceinline__ uint32_t ring_bytes(const Ring &r) { return kRingSlots << r.clog; }
 
 __device__ __forceinline__ void ring_request(const StreamWin &sw, const Ring &r, const WaveCtx &c, uint32_t chunk)
 {
-  const uint32_t voff = r.voff0 + chunk * kChunkBytes + c.lane * 16;
+  const uint32_t voff = r.voff0 + (chunk << r.clog) + c.lane * 16;
   const uint32_t slot = chunk & (kRingSlots - 1);
-  const uint32_t dst = uni(r.lds + slot * kChunkBytes);
-  asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_mov_b32 exec_hi, 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds\n\ts_mov_b32 exec_hi, -1"
+  const uint32_t dst = uni(r.lds + (slot << r.clog));
+  const uint32_t lanes = r.clog == 9 ? 0xFFFFFFFFu : 0xFFFFu; // 32 or 16 lanes x 16 B
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds\n\ts_mov_b64 exec, -1"
                :
-               : "v"(voff), "s"(dst), "s"(sw.rs)
+               : "v"(voff), "s"(dst), "s"(sw.rs), "s"(lanes)
                : "memory");
-  if (slot == 0) // wave-uniform: the ring's first 128 bytes once more, behind its end (lanes 0..7)
-    asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 exec, 0xff\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds\n\ts_mov_b64 exec, -1"
+  if (slot == 0) // wave-uniform: the ring's first 128 (64) bytes once more, behind its end (lanes 0..7 / 0..3)
+    asm volatile("s_mov_b32 m0, %1\n\ts_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds\n\ts_mov_b64 exec, -1"
                  :
-                 : "v"(voff), "s"(uni(r.lds + kRingBytes)), "s"(sw.rs)
+                 : "v"(voff), "s"(uni(r.lds + ring_bytes(r))), "s"(sw.rs), "s"(r.clog == 9 ? 0xFFu : 0xFu)
                  : "memory");
 }
 
@@ -178,7 +185,7 @@ __device__ __forceinline__ void ring_init(StreamWin &sw, Ring &r, const WaveCtx 
 // call at least once per 256 consumed words
 __device__ __forceinline__ void ring_advance(const StreamWin &sw, Ring &r, const WaveCtx &c)
 {
-  if ((r.cur >> kChunkWordsLog2) > r.k)
+  if ((r.cur >> (r.clog - 1)) > r.k)
   {
     r.k++;
     ring_request(sw, r, c, r.k + 2);
@@ -338,7 +345,7 @@ __device__ __forceinline__ uint32_t group_step(uint32_t &x, Ring &r, const WaveC
   const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
   // this lane's word: ring + (cursor mod ring) + 2 * rank; the mirror behind the ring's end makes the wrap invisible
   uint32_t waddr;
-  asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(waddr) : "v"(rank), "s"(r.lds + ((r.cur << 1) & (kRingBytes - 1))));
+  asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(waddr) : "v"(rank), "s"(r.lds + ((r.cur << 1) & (ring_bytes(r) - 1))));
   uint32_t w = *(const __attribute__((address_space(3))) uint16_t *)(uintptr_t)waddr;
   // x = low ? (nx << 16 | w) : nx, as one VALU op under EXEC = renormalising lanes (EXEC is all ones here: every
   // caller is in wave-uniform control flow of a full 64-lane wave); the two EXEC writes go to the scalar unit
@@ -427,6 +434,94 @@ __device__ __forceinline__ void run_groups(uint32_t &x, const StreamWin &sw, Rin
     run_groups_impl<MODE, true>(x, sw, r, c, o, steps);
   else
     run_groups_impl<MODE, false>(x, sw, r, c, o, steps);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Paired 32-state chains (rANS32x32, persistent launches): lanes 0..31 decode chain A, lanes 32..63 chain B, each with
+// its own ring (1 KiB + 64 B mirror) and cursor, so a wave64 is fully used.  One ballot serves both: its low half is
+// A's renormalisation mask, its high half B's; v_mbcnt over the whole mask gives lanes >= 32 rank_B + popcount(A),
+// and that popcount is folded into B's scalar cursor base.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ uint32_t group_step_pair(uint32_t &x, Ring &ra, Ring &rb, const WaveCtx &c)
+{
+  const uint32_t mask = (1u << c.bits) - 1;
+  const uint32_t slot = x & mask;
+  const uint32_t q = x >> c.bits;
+  uint32_t e, nx;
+  if (MODE == kModePack64)
+  {
+    const uint2 e2 = ((const uint2 *)c.table)[slot];
+    e = e2.x;
+    nx = __umul24(q, e2.x) + e2.y;
+  }
+  else if (MODE == kModePack)
+  {
+    e = ((const uint32_t *)c.table)[slot];
+    nx = __umul24(q, (e >> 8) & 0xFFF) + (e >> 20);
+  }
+  else if (MODE == kModePackM1)
+  {
+    e = ((const uint32_t *)c.table)[slot];
+    nx = __umul24(q, (e >> 8) & 0xFFF) + q + (e >> 20);
+  }
+  else
+  {
+    e = c.table[slot];
+    const uint32_t fc = ((const uint32_t *)(c.table + mask + 1))[e];
+    nx = __umul24(q, fc & 0xFFFF) + slot - (fc >> 16);
+  }
+  const bool low = nx < kConsume;
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(low);
+  const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0));
+  const uint32_t cnt_a = (uint32_t)__popc(m_lo), cnt_b = (uint32_t)__popc(m_hi);
+  // LDS address of this half's cursor (lanes >= 32 carry A's count in their rank, so it comes off B's base): the two
+  // scalars are spread to their halves with one DPP move restricted to rows 2..3 (lanes 32..63) — no EXEC writes
+  const uint32_t base_a = ra.lds + ((ra.cur << 1) & (ring_bytes(ra) - 1));
+  const uint32_t base_b = rb.lds + ((rb.cur << 1) & (ring_bytes(rb) - 1)) - 2 * cnt_a;
+  uint32_t va, vb;
+  asm("v_mov_b32 %0, %1" : "=v"(va) : "s"(base_a));
+  asm("v_mov_b32 %0, %1" : "=v"(vb) : "s"(base_b));
+  const uint32_t vbase = (uint32_t)__builtin_amdgcn_update_dpp((int)va, (int)vb, 0xE4, 0xC, 0xF, false);
+  uint32_t waddr;
+  asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(waddr) : "v"(rank), "v"(vbase));
+  uint32_t w = *(const __attribute__((address_space(3))) uint16_t *)(uintptr_t)waddr;
+  x = nx;
+  asm volatile("s_mov_b64 exec, %2\n\tv_lshl_or_b32 %0, %0, 16, %1\n\ts_mov_b64 exec, -1" : "+v"(x) : "v"(w), "s"(m));
+  ra.cur += cnt_a;
+  rb.cur += cnt_b;
+  return e;
+}
+
+// `steps` whole 32-symbol groups of chain A (lanes 0..31, output at oa) and of chain B (lanes 32..63, output at ob)
+template <int MODE>
+__device__ __forceinline__ void run_pair_groups(uint32_t &x, const StreamWin &sw, Ring &ra, Ring &rb, const WaveCtx &c, uint64_t &oa_ref, uint64_t &ob_ref,
+                                                uint32_t steps)
+{
+  const uint64_t oa = uni64(oa_ref), ob = uni64(ob_ref);
+  constexpr uint32_t kSymByte = MODE == kModePack64 ? 3 : 0;
+  const uint32_t l32 = c.lane & 31, row = l32 & 3, quad = l32 >> 2;
+  const uint32_t dcol = ((quad & 1) << 2) | ((quad & 6) >> 1);
+  const uint32_t sel_a = (c.lane & 1) ? 0x03070105u : 0x06020400u;
+  const uint32_t sel_b = (c.lane & 2) ? 0x03020706u : 0x05040100u;
+  uint8_t *vout = c.out + (c.lane < 32 ? oa : ob) + row * 32 + dcol * 4; // per-lane: this half's output row
+  uint32_t done = 0;
+  for (; steps - done >= 4; done += 4)
+  {
+    const uint32_t e0 = group_step_pair<MODE>(x, ra, rb, c);
+    const uint32_t e1 = group_step_pair<MODE>(x, ra, rb, c);
+    const uint32_t lo = __builtin_amdgcn_perm(e1, e0, 0x0c0c0400u + kSymByte * 0x0101u);
+    const uint32_t e2 = group_step_pair<MODE>(x, ra, rb, c);
+    const uint32_t e3 = group_step_pair<MODE>(x, ra, rb, c);
+    const uint32_t hi = __builtin_amdgcn_perm(e3, e2, 0x0c0c0400u + kSymByte * 0x0101u);
+    *(uint32_t *)vout = quad_transpose(__builtin_amdgcn_perm(hi, lo, 0x05040100u), sel_a, sel_b);
+    vout += 128;
+    ring_advance(sw, ra, c);
+    ring_advance(sw, rb, c);
+  }
+  oa_ref = oa + (uint64_t)done * 32;
+  ob_ref = ob + (uint64_t)done * 32;
 }
 
 // final partial group (rANS32x64_16w.cpp:252-280): only lanes whose output byte exists take part, in lane order
@@ -664,6 +759,114 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
   }
 }
 
+// Persistent launch for 32-state streams: every wave runs TWO runs of chains side by side (group_step_pair), A = run 2u,
+// B = run 2u+1 of a numbering in which run j of the static part is chains [j*q0, (j+1)*q0) and a dynamic ticket t of
+// queue k is the pair of adjacent chains lo+2t, lo+2t+1.  Whatever the pair loop leaves (unequal lengths, < 4 groups,
+// the stream's final partial group) is finished one chain at a time on lanes 0..31.
+template <int MODE>
+__device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_t waves, uint32_t w)
+{
+  const PersistentArgs &pa = kp.pa;
+  const uint32_t W = gridDim.x * waves;
+  StreamWin sw;
+  Ring ra, rb;
+  ring_bind(ra, c.rings, 8);
+  ring_bind(rb, c.rings + 1152, 8);
+  const uint32_t q0 = pa.static_per_wave; // chains per static run; host guarantees 2 * W * q0 <= n_chains
+  const bool host_table = MODE == kModePack64 && pa.table != nullptr;
+  if (!host_table)
+    build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
+
+  // decode chains [a0, a1) on lanes 0..31 and [a1, b1) on lanes 32..63 (b1 == a1: only A)
+  auto run = [&](uint32_t a0, uint32_t a1, uint32_t b1, bool table_pending) {
+    const bool have_b = b1 > a1;
+    win_open(sw, c, uni64(pa.pieces[a0].words_off), b1 < pa.n_chains ? uni64(pa.pieces[b1].words_off) : c.stream_len);
+    ring_begin(sw, ra, c, uni64(pa.pieces[a0].words_off));
+    if (have_b)
+      ring_begin(sw, rb, c, uni64(pa.pieces[a1].words_off));
+    // lanes 0..31: state j of chain a0; lanes 32..63: state j of chain a1
+    const uint32_t src_chain = (c.lane < 32 || !have_b) ? a0 : a1;
+    uint32_t x = pa.states[(uint64_t)src_chain * 32 + (c.lane & 31)];
+    auto geom = [&](uint32_t c0, uint32_t c1, uint64_t &o, uint32_t &steps, uint32_t &tail) {
+      const uint64_t g0 = (uint64_t)c0 * pa.interval;
+      const uint64_t g1 = (uint64_t)c1 * pa.interval < pa.steps_total ? (uint64_t)c1 * pa.interval : pa.steps_total;
+      o = pa.out_base + g0 * 32;
+      steps = (uint32_t)(g1 - g0);
+      tail = c1 == pa.n_chains ? pa.tail : 0;
+    };
+    uint64_t oa, ob = 0;
+    uint32_t sa, sb = 0, ta, tb = 0;
+    geom(a0, a1, oa, sa, ta);
+    if (have_b)
+      geom(a1, b1, ob, sb, tb);
+    if (table_pending)
+    {
+      // the table was built on the host from the plan's histogram copy: one coalesced 16 B load + LDS store per thread
+      // (see run_persistent for the check of the copy against the stream)
+      const uint32_t entries = 1u << c.bits;
+      for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
+        *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
+      __syncthreads();
+    }
+    ring_ready();
+    if (have_b)
+    {
+      const uint32_t both = (sa < sb ? sa : sb) & ~3u;
+      run_pair_groups<MODE>(x, sw, ra, rb, c, oa, ob, both);
+      sa -= both;
+      sb -= both;
+      // chain B's states move down to lanes 0..31 and B is finished alone
+      uint32_t xb = __shfl(x, (c.lane & 31) + 32, 64);
+      run_groups<MODE>(xb, sw, rb, c, ob, sb);
+      run_tail<MODE>(xb, rb, c, ob, tb);
+    }
+    run_groups<MODE>(x, sw, ra, c, oa, sa);
+    run_tail<MODE>(x, ra, c, oa, ta);
+  };
+
+  if (host_table && blockIdx.x == 0 && threadIdx.x < 64)
+  {
+    bool same = pa.hist_off + 512 <= c.stream_len;
+    if (same)
+    {
+      const uint64_t mine = *(const uint64_t *)(pa.hist_copy + 4 * c.lane);
+      uint64_t theirs = 0;
+      for (int b = 3; b >= 0; b--)
+        theirs = (theirs << 16) | *(const uint16_t *)(c.stream + pa.hist_off + 8 * c.lane + 2 * b);
+      same = mine == theirs;
+    }
+    if (__builtin_amdgcn_ballot_w64(!same) != 0 && c.lane == 0)
+      atomicOr(c.status, kStatusBadHist);
+  }
+  if (q0 != 0)
+    run(2 * w * q0, 2 * w * q0 + q0, 2 * w * q0 + 2 * q0, host_table);
+  else if (host_table)
+  {
+    const uint32_t entries = 1u << c.bits;
+    for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
+      *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
+    __syncthreads();
+  }
+
+  const uint32_t dyn0 = 2 * W * q0;
+  const uint64_t D = pa.n_chains - dyn0;
+  const uint32_t k = w & (kDynQueues - 1);
+  const uint32_t lo = dyn0 + (uint32_t)(k * D / kDynQueues), hi = dyn0 + (uint32_t)((k + 1) * D / kDynQueues);
+  const uint32_t pairs = (hi - lo + 1) / 2;
+  const uint64_t H = (uint64_t)pairs + (W - k + kDynQueues - 1) / kDynQueues; // tickets per launch, see run_persistent
+  while (true)
+  {
+    unsigned long long t = 0;
+    if (c.lane == 0)
+      t = atomicAdd(pa.counters + k * kDynQueueStride, 1ull);
+    t = uni64(t) % H;
+    if (t >= pairs)
+      break;
+    const uint32_t a0 = lo + 2 * (uint32_t)t;
+    run(a0, a0 + 1, a0 + 2 <= hi ? a0 + 2 : a0 + 1, false);
+  }
+}
+
 // Grouped launch: workgroup b walks groups b, b + gridDim.x, ...; per group one table build, then every wave decodes an
 // equal contiguous share of the group's chains.
 template <int MODE>
@@ -827,7 +1030,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
     const uint64_t hist_off = pv.hdr->aux_off; // shared plans: the one histogram every chain uses
     if (kp.pa.pieces != nullptr)
     {
-      run_persistent<MODE>(c, kp, waves, chain);
+      if (c.S == 32)
+        run_persistent_pair<MODE>(c, kp, waves, chain);
+      else
+        run_persistent<MODE>(c, kp, waves, chain);
       return;
     }
     if (kp.groups != nullptr)
@@ -1058,7 +1264,8 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
   {
     // static share: a fixed fraction of the chains, split evenly; the rest goes through the queues
     const uint64_t W = (uint64_t)grid * waves;
-    kp.pa.static_per_wave = (uint32_t)((uint64_t)h.n_chains * g_static_percent / 100 / W);
+    // 32-state streams: two runs per wave (run_persistent_pair)
+    kp.pa.static_per_wave = (uint32_t)((uint64_t)h.n_chains * g_static_percent / 100 / (h.states == 32 ? 2 * W : W));
   }
   KernelFn fn = kernel_for(mode, shared);
   if (info)
