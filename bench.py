@@ -219,7 +219,7 @@ def main() -> None:
         }
 
         # the same stream WITHOUT the sidecar plan: one wavefront, one dependent chain (SURVEY.md finding 2)
-        if not args.no_single:
+        if not args.no_single and world == 1:
             plan1 = H.plan_build(H.RAW, S, bits, stream)
             dplan1 = ctx.make_device_plan(plan1)
             d_out.zero_()
@@ -233,7 +233,7 @@ def main() -> None:
             result["single_wavefront_no_plan"] = {"value": n / 2**20 / (ms1 * 1e-3), "unit": "MiB/s", "ms": ms1, "bit_exact": True,
                                                   "note": "raw format has no restart points: 1 wave64 = 1 dependent chain"}
 
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and not args.no_cpu and world == 1:  # reported baseline, N=1 only
         result["cpu_baseline"] = cpu_baseline(stream, data, S, bits)
     if distributed:
         dist.barrier()

@@ -228,3 +228,29 @@ def test_index_build_for_reference_mt_streams(gpu_ctx, ref, nonstat, zipf, state
         # and it is the plan our encoder writes for the same stream (same block policy -> same bytes -> same checkpoints)
         s2, plan2 = H.encode(H.MT, states, bits, d, index_interval=32)
         assert np.array_equal(s, s2) and np.array_equal(plan, plan2)
+
+
+def test_corrupted_streams_fail_cleanly(gpu_ctx, zipf):
+    """Memory safety: random corruption of headers / histograms / words must end in `return 0` or in (wrong) bytes of the
+    right length — never in a fault or a hang (every index in the kernel is masked, every loop bounded by the plan)."""
+    rng = np.random.default_rng(12345)
+    d = zipf[:200_000]
+    for container in (H.RAW, H.BLOCK, H.MT):
+        for states in (32, 64):
+            s = H.encode(container, states, 11, d)
+            for trial in range(12):
+                bad = s.copy()
+                hot = 16 + 4 * states + 1024  # headers, counts, states live here
+                for _ in range(1 + trial % 4):
+                    pos = int(rng.integers(16, hot)) if trial % 2 == 0 else int(rng.integers(16, bad.size))
+                    bad[pos] ^= 1 << int(rng.integers(0, 8))
+                r, got = gpu_ctx.decode_host(container, states, 11, bad, d.size)
+                assert r in (0, d.size)
+            # truncated input
+            for cut in (17, 600, s.size // 2, s.size - 2):
+                r, _ = gpu_ctx.decode_host(container, states, 11, s[:cut], d.size)
+                assert r == 0
+    # the context is still healthy afterwards
+    s = H.encode(H.RAW, 64, 11, d)
+    r, got = gpu_ctx.decode_host(H.RAW, 64, 11, s, d.size)
+    assert r == d.size and np.array_equal(got, d)
