@@ -72,6 +72,7 @@ struct WaveCtx
   uint64_t out_cap;
   uint32_t *status;
   uint32_t bits, S, lane;
+  uint32_t v_mask, v_bits; // 2^bits - 1 and bits, each held in a VGPR: a VALU op with an SGPR operand issues at half rate
   uint8_t *rings;        // LDS, kWaveRingBytes: this wave's stream ring + mirror
   uint8_t *table;        // LDS
   uint16_t *scratch_cnt; // LDS, 512 B each, only live during table builds: they alias a ring that has no request in
@@ -314,8 +315,8 @@ template <int MODE, bool FULL>
 __device__ __forceinline__ uint32_t group_step(uint32_t &x, Ring &r, const WaveCtx &c, unsigned long long act_mask)
 {
   const uint32_t mask = (1u << c.bits) - 1;
-  const uint32_t slot = x & mask;
-  const uint32_t q = x >> c.bits; // < 2^21: the 24-bit multiplier applies (x < 2^31, bits >= 10)
+  const uint32_t slot = x & c.v_mask;
+  const uint32_t q = x >> c.v_bits; // < 2^21: the 24-bit multiplier applies (x < 2^31, bits >= 10)
   uint32_t e, nx;
   if (MODE == kModePack64)
   {
@@ -446,8 +447,8 @@ template <int MODE>
 __device__ __forceinline__ uint32_t group_step_pair(uint32_t &x, Ring &ra, Ring &rb, const WaveCtx &c)
 {
   const uint32_t mask = (1u << c.bits) - 1;
-  const uint32_t slot = x & mask;
-  const uint32_t q = x >> c.bits;
+  const uint32_t slot = x & c.v_mask;
+  const uint32_t q = x >> c.v_bits;
   uint32_t e, nx;
   if (MODE == kModePack64)
   {
@@ -1018,6 +1019,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.bits = bits;
   c.S = pv.hdr->states;
   c.lane = threadIdx.x & 63;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << bits) - 1));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(bits));
 
   const uint32_t chain = blockIdx.x * waves + wave;
 
