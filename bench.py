@@ -209,6 +209,9 @@ def main() -> None:
                 "ratio": stream.size / n, "plan_bytes": int(plan.size), "index_interval_groups": args.interval, "chains": chains,
                 "launch": info, "bit_exact": True, "sha256": sha, "host_encode_s": t_enc,
             },
+            # the reference harness prints min/mean throughput per decoder (src/main.cpp:72-118): same two numbers here
+            "mib_s": {"mean_over_timed_region": world * n / 2**20 / elapsed * args.steps, "best_single_launch": n / 2**20 / (k_min * 1e-3),
+                      "launches_in_timed_region": args.steps},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": _pmc_traffic(n, S, bits, args.interval),
