@@ -29,7 +29,8 @@ class Hist(ctypes.Structure):
 
 
 class EncodeOpts(ctypes.Structure):
-    _fields_ = [("block_size", _u32), ("index_interval", _u32), ("plan_out", _vp), ("plan_capacity", _sz), ("plan_size", _sz)]
+    _fields_ = [("block_size", _u32), ("index_interval", _u32), ("plan_out", _vp), ("plan_capacity", _sz), ("plan_size", _sz), ("flags", _u32),
+                ("reserved", _u32)]
 
 
 class LaunchInfo(ctypes.Structure):
@@ -96,6 +97,8 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_dplan_create_from_device_stream.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _sz, _vp, ctypes.POINTER(_vp)]
     L.hsrans_dplan_read_plan.restype = _sz
     L.hsrans_dplan_read_plan.argtypes = [_vp, _vp, _sz]
+    L.hsrans_encode_device.restype = _sz
+    L.hsrans_encode_device.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _vp, _sz, _u32, _vp]
     L.hsrans_index_build.restype = _sz
     L.hsrans_index_build.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _u32, _vp, _sz]
     _LIB = L
@@ -135,21 +138,25 @@ def hist_from_counts(counts) -> Hist:
     return h
 
 
-def encode(container: int, states: int, bits: int, data, hist: Hist | None = None, block_size: int = 0, index_interval: int = 0):
+ENC_INDEPENDENT_BLOCKS = 1
+
+
+def encode(container: int, states: int, bits: int, data, hist: Hist | None = None, block_size: int = 0, index_interval: int = 0,
+           independent_blocks: bool = False):
     """Returns ``stream`` (np.uint8) or ``(stream, plan)`` when ``index_interval`` != 0."""
     L = load_library()
     data = _u8(data)
     cap = L.hsrans_capacity(container, states, data.size)
     out = np.zeros(cap, np.uint8)
     hp = ctypes.byref(hist) if hist is not None else None
-    if index_interval == 0 and block_size == 0:
+    if index_interval == 0 and block_size == 0 and not independent_blocks:
         m = L.hsrans_encode(container, states, bits, _p(data), data.size, _p(out), cap, hp)
         if m == 0:
             raise HsransError("encode failed")
         return out[:m].copy()
     pcap = L.hsrans_plan_capacity(container, states, data.size, index_interval, block_size) if index_interval else 0
     plan = np.zeros(max(pcap, 1), np.uint8)
-    opts = EncodeOpts(block_size, index_interval, plan.ctypes.data if index_interval else None, pcap, 0)
+    opts = EncodeOpts(block_size, index_interval, plan.ctypes.data if index_interval else None, pcap, 0, ENC_INDEPENDENT_BLOCKS if independent_blocks else 0, 0)
     m = L.hsrans_encode_ex(container, states, bits, _p(data), data.size, _p(out), cap, hp, ctypes.byref(opts))
     if m == 0:
         raise HsransError("encode failed")
@@ -333,6 +340,16 @@ class Context:
     def status(self, dplan: DevicePlan, stream: torch.cuda.Stream | None = None) -> int:
         s = stream if stream is not None else torch.cuda.current_stream()
         return self.L.hsrans_dplan_status(self.handle, dplan.handle, ctypes.c_void_p(s.cuda_stream))
+
+    def encode_device(self, container: int, states: int, bits: int, d_in: torch.Tensor, d_out: torch.Tensor, block_size: int = 1 << 16,
+                      stream: torch.cuda.Stream | None = None) -> int:
+        """GPU encoder (mt_, independent fixed-size blocks).  Returns the stream length written to d_out."""
+        s = stream if stream is not None else torch.cuda.current_stream(d_in.device)
+        n = self.L.hsrans_encode_device(self.handle, container, states, bits, d_in.data_ptr(), d_in.numel(), d_out.data_ptr(), d_out.numel(), block_size,
+                                        ctypes.c_void_p(s.cuda_stream))
+        if n == 0:
+            raise HsransError("hsrans_encode_device failed")
+        return n
 
     def index_build(self, container: int, states: int, bits: int, stream, index_interval: int) -> np.ndarray:
         stream = _u8(stream)

@@ -10,6 +10,7 @@
 
 #include "../../include/hsrans_hip.h"
 #include "hsrans_host.h"
+#include "hsrans_encode.h"
 #include "hsrans_kernels.h"
 
 using namespace hsrans;
@@ -27,6 +28,10 @@ struct hsrans_ctx
   uint8_t *d_plan = nullptr;
   size_t d_plan_cap = 0;
   uint32_t *d_status = nullptr;
+  uint8_t *d_enc_scratch = nullptr; // hsrans_encode_device: block images, then {image_bytes, image_off, result}
+  size_t d_enc_scratch_cap = 0;
+  uint8_t *d_enc_meta = nullptr;
+  size_t d_enc_meta_cap = 0;
 };
 
 struct hsrans_dplan
@@ -190,6 +195,10 @@ void hsrans_ctx_destroy(hsrans_ctx *ctx)
     (void)hipFree(ctx->d_out);
   if (ctx->d_plan)
     (void)hipFree(ctx->d_plan);
+  if (ctx->d_enc_scratch)
+    (void)hipFree(ctx->d_enc_scratch);
+  if (ctx->d_enc_meta)
+    (void)hipFree(ctx->d_enc_meta);
   if (ctx->d_status)
     (void)hipFree(ctx->d_status);
   delete ctx;
@@ -538,6 +547,46 @@ int hsrans_dplan_launch_info(const hsrans_dplan *d, hsrans_launch_info *info)
   info->walk = d->info.walk;
   info->two_level = d->info.two_level;
   return HSRANS_OK;
+}
+
+size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t bits, const void *d_in, size_t length, void *d_out, size_t out_capacity,
+                            uint32_t block_size, void *hip_stream)
+{
+  if (ctx == nullptr || container != HSRANS_MT || !valid_codec(container, states, bits) || d_in == nullptr || d_out == nullptr || length == 0)
+    return 0;
+  if (block_size == 0 || block_size % 64 != 0 || ((uintptr_t)d_in & 15) != 0 || ((uintptr_t)d_out & 15) != 0)
+    return 0;
+  if (out_capacity < capacity(container, states, length)) // same contract as the host encoders
+    return 0;
+  EncParams ep{};
+  ep.S = (uint32_t)states;
+  ep.bits = bits;
+  ep.n = length;
+  ep.block = block_size;
+  ep.n_blocks = encode_block_count(length, block_size, ep.S);
+  if (ep.n_blocks == 0)
+    return 0;
+  ep.slot_bytes = encode_slot_bytes(block_size, ep.S);
+  std::lock_guard<std::mutex> guard(ctx->lock);
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return 0;
+  const size_t meta_bytes = ((size_t)ep.n_blocks * 2 + 2) * 8;
+  if (!grow(&ctx->d_enc_scratch, &ctx->d_enc_scratch_cap, (size_t)ep.n_blocks * ep.slot_bytes) || !grow(&ctx->d_enc_meta, &ctx->d_enc_meta_cap, meta_bytes))
+    return 0;
+  ep.in = (const uint8_t *)d_in;
+  ep.out = (uint8_t *)d_out;
+  ep.out_cap = out_capacity;
+  ep.scratch = ctx->d_enc_scratch;
+  ep.image_bytes = (uint64_t *)ctx->d_enc_meta;
+  ep.image_off = ep.image_bytes + ep.n_blocks;
+  ep.result = ep.image_off + ep.n_blocks;
+  hipStream_t s = (hipStream_t)hip_stream;
+  uint64_t result[2] = {0, 0};
+  if (launch_encode(ep, s) != hipSuccess)
+    return 0;
+  if (hipMemcpyAsync(result, ep.result, sizeof(result), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    return 0;
+  return result[1] == 1 ? (size_t)result[0] : 0;
 }
 
 size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint32_t index_interval,

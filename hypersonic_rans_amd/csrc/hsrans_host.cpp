@@ -415,6 +415,9 @@ size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_
   // block_/mt_: block_size == 0 selects the reference's adaptive block policy (byte-identical streams), anything else
   // fixed blocks of that many symbols
   const bool fixed_blocks = opts && opts->block_size != 0;
+  const bool independent = opts && (opts->flags & HSRANS_ENC_INDEPENDENT_BLOCKS) != 0;
+  if (independent && (container != HSRANS_MT || !fixed_blocks))
+    return 0;
   const size_t block = fixed_blocks ? opts->block_size : 65536;
   if (block % 64 != 0)
     return 0;
@@ -487,6 +490,9 @@ size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_
       else
       {
         c.hist = sp.hist;
+        if (independent)
+          for (uint32_t j = 0; j < 64; j++)
+            c.x[j] = kConsumePoint16; // HSRANS_ENC_INDEPENDENT_BLOCKS: every block starts from fresh states
         const size_t g_first = sp.begin / S;
         const size_t g_last = (sp.end - 1) / S; // inclusive; may be the file's partial group
         // positions of this block's counts are only known once its words are written: checkpoints inside the

@@ -55,12 +55,20 @@ size_t hsrans_encode(int container, int states, uint32_t bits, const uint8_t *in
 
 typedef struct hsrans_encode_opts
 {
-  uint32_t block_size;       /* block_/mt_: symbols per block (multiple of 64; 0 = default 65536).                           */
+  uint32_t block_size;       /* block_/mt_: symbols per block (multiple of 64); 0 = the reference's adaptive block policy      */
   uint32_t index_interval;   /* 0 = no plan; else emit a checkpoint every `index_interval` groups of `states` symbols         */
   uint8_t *plan_out;         /* receives the decode plan (see hsrans_plan_*) when index_interval != 0                         */
   size_t plan_capacity;      /* bytes available at plan_out (hsrans_plan_capacity)                                            */
   size_t plan_size;          /* out: bytes written to plan_out                                                                */
+  uint32_t flags;            /* HSRANS_ENC_INDEPENDENT_BLOCKS: mt_ only, needs block_size != 0                                 */
+  uint32_t reserved;
 } hsrans_encode_opts;
+
+/* mt_: start every block from fresh states (2^15) instead of carrying the encoder's states across block boundaries as
+ * the reference's encoder does (src/mt_rANS32x64_16w_encode.cpp:220-222 initialises them once).  The stream stays a
+ * valid mt_ stream (every block header stores its start states anyway) and the blocks become encodable independently —
+ * this is the layout hsrans_encode_device produces, so that the two can be compared byte for byte. */
+#define HSRANS_ENC_INDEPENDENT_BLOCKS 1u
 
 /* same as hsrans_encode, additionally emitting the sidecar decode plan; the stream bytes are unchanged by it */
 size_t hsrans_encode_ex(int container, int states, uint32_t bits, const uint8_t *in, size_t length, uint8_t *out, size_t out_capacity,
@@ -123,6 +131,13 @@ int hsrans_dplan_create_from_device_stream(hsrans_ctx *ctx, int container, int s
 size_t hsrans_dplan_read_plan(hsrans_dplan *dplan, uint8_t *out, size_t capacity);
 /* synchronises `hip_stream` and returns HSRANS_OK or HSRANS_E_DEVICE (kernel found a bad histogram/header) */
 int hsrans_dplan_status(hsrans_ctx *ctx, hsrans_dplan *dplan, void *hip_stream);
+
+/* GPU encoder: mt_ stream with fixed blocks of `block_size` symbols (multiple of 64), each block
+ * encoded independently by one wavefront (HSRANS_ENC_INDEPENDENT_BLOCKS layout).  d_in / d_out are device pointers;
+ * d_out needs hsrans_capacity(HSRANS_MT, states, length) bytes.  Synchronises `hip_stream`; returns the stream size, 0 on
+ * failure.  Byte-identical to hsrans_encode_ex(HSRANS_MT, ..., {block_size, flags = HSRANS_ENC_INDEPENDENT_BLOCKS}). */
+size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t bits, const void *d_in, size_t length, void *d_out, size_t out_capacity,
+                            uint32_t block_size, void *hip_stream);
 
 /* Build a plan with checkpoints every `index_interval` groups for an EXISTING stream (e.g. one written by the
  * reference's encoder) by one decode pass on the GPU that records the states at the checkpoints: HSRANS_RAW (one

@@ -254,3 +254,56 @@ def test_corrupted_streams_fail_cleanly(gpu_ctx, zipf):
     s = H.encode(H.RAW, 64, 11, d)
     r, got = gpu_ctx.decode_host(H.RAW, 64, 11, s, d.size)
     assert r == d.size and np.array_equal(got, d)
+
+
+# ---- GPU encoder: byte-identical to the host encoder with the same block layout ----------------
+def _gpu_encode(ctx, states, bits, data, block):
+    import torch
+    d_in = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+    cap = H.capacity(H.MT, states, data.size)
+    d_out = torch.full((cap,), 0xA5, dtype=torch.uint8, device="cuda")
+    n = ctx.encode_device(H.MT, states, bits, d_in, d_out, block_size=block)
+    return d_out[:n].cpu().numpy(), d_out
+
+
+@pytest.mark.parametrize("states", (32, 64))
+@pytest.mark.parametrize("bits", (10, 11, 12, 13, 14, 15))
+def test_gpu_encoder_matches_host_encoder(gpu_ctx, oracle, zipf, nonstat, states, bits):
+    runs = np.concatenate([np.full(70_000, 7, np.uint8), zipf[:100_000], np.full(200_000, 200, np.uint8), zipf[:33]])
+    for src, n, block in ((zipf, 1, 64), (zipf, 63, 64), (zipf, 64, 64), (zipf, 65, 64), (zipf, 100_000, 4096), (zipf, 4096 + 17, 4096), (zipf, 65536, 65536),
+                          (zipf, 65536 + 31, 65536), (zipf, 65536 + 64, 65536), (zipf, 300_001, 32768), (nonstat, 3_000_000, 65536),
+                          (nonstat, 1_000_003, 1 << 18), (runs, runs.size, 4096), (runs, runs.size, 65536)):
+        d = src[:n]
+        want = H.encode(H.MT, states, bits, d, block_size=block, independent_blocks=True)
+        got, _ = _gpu_encode(gpu_ctx, states, bits, d, block)
+        assert got.size == want.size, (states, bits, n, block, got.size, want.size)
+        assert np.array_equal(got, want), (states, bits, n, block, int(np.argmax(got != want)))
+        if n >= states - 1:  # shorter inputs are undefined behaviour in the reference decoders
+            r, back = oracle.decode(MT, states, bits, got, n)
+            assert r == n and np.array_equal(back, d), (states, bits, n, block)
+
+
+def test_gpu_encoder_round_trip_on_device_100mb(gpu_ctx):
+    import torch
+    n = 100_000_000
+    d = synth.enwik8_shaped(n, seed=5)
+    stream, d_out = _gpu_encode(gpu_ctx, 64, 11, d, 1 << 16)
+    assert 0.5 * n < stream.size < 0.8 * n
+    dplan = gpu_ctx.make_device_plan_from_stream(H.MT, 64, 11, d_out, stream.size, n)
+    back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    gpu_ctx.decode_device(dplan, d_out, back, stream_length=stream.size)
+    assert gpu_ctx.status(dplan) == 0
+    assert torch.equal(back.cpu(), torch.from_numpy(d))
+
+
+def test_gpu_encoder_rejects_bad_arguments(gpu_ctx, zipf):
+    import torch
+    d_in = torch.from_numpy(zipf[:4096].copy()).cuda()
+    d_out = torch.empty(H.capacity(H.MT, 64, 4096), dtype=torch.uint8, device="cuda")
+    for kw in (dict(container=H.RAW), dict(block_size=100), dict(block_size=0), dict(bits=9), dict(states=16)):
+        a = dict(container=H.MT, states=64, bits=11, block_size=1024)
+        a.update(kw)
+        with pytest.raises(H.HsransError):
+            gpu_ctx.encode_device(a["container"], a["states"], a["bits"], d_in, d_out, block_size=a["block_size"])
+    with pytest.raises(H.HsransError):
+        gpu_ctx.encode_device(H.MT, 64, 11, d_in, d_out[:1000], block_size=1024)  # capacity contract
