@@ -1,6 +1,7 @@
 // C ABI of libhsrans_hip.so (declared in include/hsrans_hip.h).  Nothing here decodes on the CPU: every decode entry
 // ends in a launch of the gfx950 kernels in hsrans_kernels.hip and fails when no usable device exists.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -570,7 +571,8 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   std::lock_guard<std::mutex> guard(ctx->lock);
   if (hipSetDevice(ctx->device) != hipSuccess)
     return 0;
-  const size_t meta_bytes = ((size_t)ep.n_blocks * 2 + 2) * 8;
+  const bool stamps = getenv("HSRANS_DEBUG_STAMPS") != nullptr;
+  const size_t meta_bytes = ((size_t)ep.n_blocks * (stamps ? 6 : 2) + 2) * 8;
   if (!grow(&ctx->d_enc_scratch, &ctx->d_enc_scratch_cap, (size_t)ep.n_blocks * ep.slot_bytes) || !grow(&ctx->d_enc_meta, &ctx->d_enc_meta_cap, meta_bytes))
     return 0;
   ep.in = (const uint8_t *)d_in;
@@ -580,12 +582,31 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   ep.image_bytes = (uint64_t *)ctx->d_enc_meta;
   ep.image_off = ep.image_bytes + ep.n_blocks;
   ep.result = ep.image_off + ep.n_blocks;
+  ep.stamps = stamps ? ep.result + 2 : nullptr;
   hipStream_t s = (hipStream_t)hip_stream;
   uint64_t result[2] = {0, 0};
   if (launch_encode(ep, s) != hipSuccess)
     return 0;
   if (hipMemcpyAsync(result, ep.result, sizeof(result), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
     return 0;
+  if (stamps) // printed, not returned: a tuning aid only
+  {
+    std::vector<uint64_t> st((size_t)ep.n_blocks * 4);
+    if (hipMemcpy(st.data(), ep.stamps, st.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+    {
+      double ph[3] = {0, 0, 0};
+      uint64_t lo = ~0ull, hi = 0;
+      for (uint32_t b = 0; b < ep.n_blocks; b++)
+      {
+        for (int k = 0; k < 3; k++)
+          ph[k] += (double)(st[b * 4 + k + 1] - st[b * 4 + k]);
+        lo = st[b * 4] < lo ? st[b * 4] : lo;
+        hi = st[b * 4 + 3] > hi ? st[b * 4 + 3] : hi;
+      }
+      fprintf(stderr, "[hsrans encode stamps] blocks %u  mean us: histogram %.1f  normalise+table %.1f  rANS pass %.1f   first start -> last end %.1f us\n", ep.n_blocks,
+              ph[0] / ep.n_blocks / 100.0, ph[1] / ep.n_blocks / 100.0, ph[2] / ep.n_blocks / 100.0, (double)(hi - lo) / 100.0);
+    }
+  }
   return result[1] == 1 ? (size_t)result[0] : 0;
 }
 

@@ -22,6 +22,7 @@ struct EncParams
   uint64_t block;        // symbols per block (multiple of 64)
   uint32_t n_blocks;
   uint32_t S, bits;
+  uint64_t *stamps; // diagnostics (HSRANS_DEBUG_STAMPS=1): per block {start, histogram done, table done, words done} s_memrealtime; else null
 };
 
 uint32_t encode_block_count(uint64_t n, uint64_t block, uint32_t S); // 0: too many blocks

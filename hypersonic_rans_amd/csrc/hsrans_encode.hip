@@ -22,7 +22,9 @@ namespace
 {
 
 constexpr uint32_t kWavesPerWG = 4;
-constexpr uint32_t kChunk = 2048; // input bytes staged in LDS per step (two buffers)
+constexpr uint32_t kChunk = 4096;        // input bytes fetched per step of the rANS pass
+constexpr uint32_t kRing = 2 * kChunk;   // LDS staging ring: two chunks resident, a third on its way in registers
+constexpr uint32_t kSubHists = 8;        // histogram copies (lane & 7) that keep equal bytes of one load off one LDS address
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)); }
 __device__ __forceinline__ uint32_t enc_lane_to_byte(uint32_t j) { return (j & 0x23u) | ((j & 0x04u) << 2) | ((j & 0x18u) >> 1); }
@@ -44,88 +46,220 @@ struct __attribute__((packed, aligned(2))) U32a2
 
 struct WaveLds
 {
-  uint32_t scaled[256];  // raw counts, then the normalised counts
-  uint32_t order[256];   // count << 8 | symbol, heap-sorted by count
-  uint4 table[256];      // {x_max, bias, rcp, cmpl | shift << 16}
-  uint8_t stage[2][kChunk];
+  uint32_t scaled[256]; // normalised counts
+  uint32_t order[256];  // count << 8 | symbol in heap-sort order
+  uint4 table[256];     // {x_max, bias, rcp, cmpl | shift << 24}
+  uint8_t stage[kRing]; // (table and stage double as the kSubHists histogram copies before the table exists)
+};
+static_assert(sizeof(uint4) * 256 + kRing >= kSubHists * 256 * 4, "histogram copies must fit");
+
+// ---- hist.cpp:16-215: the heap sort ---------------------------------------------------------------------------------
+// The reference sorts the symbols by count with a textbook heap sort; the order of EQUAL counts that sort happens to
+// produce decides which symbols are adjusted, so the sort is replayed exactly (hsrans_host.cpp heap_sift) — but as
+// wave-uniform code: the heap lives in five registers by tree level (entries count << 8 | symbol),
+//   A: nodes 0..62 (levels 0-5, lane = node), B: 63..126 (level 6), C: 127..190, D: 191..254 (level 7), E: node 255,
+// read with v_readlane and written with a one-lane select, all control flow scalar.  ~4x faster than one lane walking LDS.
+struct Heap
+{
+  uint32_t A, B, C, D, E;
 };
 
-// ---- hist.cpp:16-215 on one lane ----------------------------------------------------------------------------------
-// textbook heap sort by count; the order of equal counts it happens to produce decides which symbols are adjusted,
-// so it is replayed exactly (hsrans_host.cpp heap_sift); the sifted element stays in a register
-__device__ void heap_sift(uint32_t *a, int n, int root)
+// one lane of a register takes a wave-uniform value (v_cmp + v_cndmask: as cheap as v_writelane through M0, and the
+// compiler keeps track of the hazards)
+__device__ __forceinline__ uint32_t write_lane(uint32_t value, uint32_t lane, uint32_t reg) { return lane_id() == lane ? value : reg; }
+
+template <int LEVEL>
+__device__ __forceinline__ uint32_t heap_get(const Heap &h, uint32_t i)
 {
-  const uint32_t val = a[root];
-  while (true)
+  if constexpr (LEVEL <= 5)
+    return __builtin_amdgcn_readlane(h.A, i);
+  else if constexpr (LEVEL == 6)
+    return __builtin_amdgcn_readlane(h.B, i - 63);
+  else if constexpr (LEVEL == 7)
+    return i < 191 ? __builtin_amdgcn_readlane(h.C, i - 127) : __builtin_amdgcn_readlane(h.D, i - 191);
+  else
+    return h.E;
+}
+
+template <int LEVEL>
+__device__ __forceinline__ void heap_set(Heap &h, uint32_t i, uint32_t v)
+{
+  if constexpr (LEVEL <= 5)
+    h.A = write_lane(v, i, h.A);
+  else if constexpr (LEVEL == 6)
+    h.B = write_lane(v, i - 63, h.B);
+  else if constexpr (LEVEL == 7)
   {
-    const int l = 2 * root + 1, r = l + 1;
+    if (i < 191)
+      h.C = write_lane(v, i - 127, h.C);
+    else
+      h.D = write_lane(v, i - 191, h.D);
+  }
+  else
+    h.E = v;
+}
+
+// `val` belongs at node `root` (on level LEVEL) or below it; n = heap size
+template <int LEVEL>
+__device__ __forceinline__ void heap_sift(Heap &h, uint32_t root, uint32_t n, uint32_t val)
+{
+  if constexpr (LEVEL == 8)
+    heap_set<8>(h, root, val);
+  else
+  {
+    const uint32_t l = 2 * root + 1;
     if (l >= n)
-      break;
-    const uint32_t al = a[l];
-    const uint32_t ar = r < n ? a[r] : 0;
-    int big = root;
-    uint32_t kb = val >> 8, vb = val;
-    if ((al >> 8) > kb)
     {
-      big = l;
-      kb = al >> 8;
-      vb = al;
+      heap_set<LEVEL>(h, root, val);
+      return;
     }
-    if (r < n && (ar >> 8) > kb)
+    uint32_t big = l;
+    uint32_t vb = heap_get<LEVEL + 1>(h, l);
+    if constexpr (LEVEL + 1 < 8)
+      if (l + 1 < n)
+      {
+        const uint32_t ar = heap_get<LEVEL + 1>(h, l + 1);
+        if ((ar >> 8) > (vb >> 8)) // the right child only wins when strictly larger
+        {
+          big = l + 1;
+          vb = ar;
+        }
+      }
+    if ((vb >> 8) > (val >> 8))
     {
-      big = r;
-      vb = ar;
+      heap_set<LEVEL>(h, root, vb);
+      heap_sift<LEVEL + 1>(h, big, n, val);
     }
-    if (big == root)
-      break;
-    a[root] = vb;
-    root = big;
+    else
+      heap_set<LEVEL>(h, root, val);
   }
-  a[root] = val;
 }
 
-__device__ int first_at_least_two(const uint32_t *order, const uint32_t *scaled, int from, int fallback)
+template <int LEVEL>
+__device__ __forceinline__ void heap_build_level(Heap &h, uint32_t first, uint32_t last)
 {
-  for (int i = from; i < 256; i++)
-    if (scaled[order[i] & 0xFF] >= 2)
-      return i;
-  return fallback;
+  for (uint32_t i = last + 1; i-- > first;)
+    heap_sift<LEVEL>(h, i, 256, heap_get<LEVEL>(h, i));
 }
 
-__device__ void adjust_counts_one_lane(uint32_t *scaled, uint32_t *order, uint32_t sum, uint32_t target)
+// moves the maximum to node i (on level LEVEL) and re-heapifies nodes [0, i); false = every remaining count is < 2
+template <int LEVEL>
+__device__ __forceinline__ bool heap_extract(Heap &h, uint32_t i)
 {
-  for (int i = 127; i >= 0; i--)
-    heap_sift(order, 256, i);
-  for (int i = 255; i > 0; i--)
+  const uint32_t top = __builtin_amdgcn_readlane(h.A, 0);
+  if ((top >> 8) < 2)
+    return false;
+  const uint32_t last = heap_get<LEVEL>(h, i);
+  heap_set<LEVEL>(h, i, top);
+  heap_sift<0>(h, 0, i, last);
+  return true;
+}
+
+// Sorts (as far as needed) and returns `lo`, the number of symbols with count < 2: sorted positions [lo, 256) are in
+// L.order afterwards.  Positions below lo are never looked at by the adjustment (first_at_least_two, hist.cpp), which
+// is why the extraction may stop as soon as the heap's maximum is < 2.
+__device__ __forceinline__ uint32_t heap_sort_counts(WaveLds &L, uint32_t lane)
+{
+  Heap h;
+  h.A = L.order[lane < 63 ? lane : 62];
+  h.B = L.order[63 + lane];
+  h.C = L.order[127 + lane];
+  h.D = L.order[lane < 64 ? (191 + lane > 255 ? 255 : 191 + lane) : 255];
+  h.E = __builtin_amdgcn_readlane(h.D, 63) * 0 + __builtin_amdgcn_readfirstlane(L.order[255]);
+  heap_sift<7>(h, 127, 256, heap_get<7>(h, 127)); // the only level-7 node with a child
+  heap_build_level<6>(h, 63, 126);
+  heap_build_level<5>(h, 31, 62);
+  heap_build_level<4>(h, 15, 30);
+  heap_build_level<3>(h, 7, 14);
+  heap_build_level<2>(h, 3, 6);
+  heap_build_level<1>(h, 1, 2);
+  heap_build_level<0>(h, 0, 0);
+  uint32_t lo = 0;
+  bool more = heap_extract<8>(h, 255);
+  if (!more)
+    lo = 256;
+  for (uint32_t i = 254; more && i >= 191; i--)
+    if (!(more = heap_extract<7>(h, i)))
+      lo = i + 1;
+  for (uint32_t i = 190; more && i >= 127; i--)
+    if (!(more = heap_extract<7>(h, i)))
+      lo = i + 1;
+  for (uint32_t i = 126; more && i >= 63; i--)
+    if (!(more = heap_extract<6>(h, i)))
+      lo = i + 1;
+  for (uint32_t i = 62; more && i >= 1; i--)
+    if (!(more = heap_extract<5>(h, i)))
+      lo = i + 1;
+  if (more)
+    lo = (__builtin_amdgcn_readlane(h.A, 0) >> 8) < 2 ? 1 : 0;
+  wave_sync();
+  if (lane < 63)
+    L.order[lane] = h.A;
+  L.order[63 + lane] = h.B;
+  L.order[127 + lane] = h.C;
+  L.order[191 + lane] = h.D; // lane 63 writes node 255's slot with a stale value, fixed next
+  wave_sync();
+  if (lane == 0)
+    L.order[255] = h.E;
+  wave_sync();
+  return lo;
+}
+
+__device__ __forceinline__ uint32_t ballot_count(bool pred) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pred)); }
+
+// the reference's "steal" / "charity" passes over the sorted symbols (hist.cpp; hsrans_host.cpp normalize_counts), four
+// sorted positions per lane: a pass changes every position of [lo, 256) by one, the last pass only as many as are missing
+__device__ __forceinline__ void adjust_counts(WaveLds &L, uint32_t lane, uint32_t lo, uint32_t sum, uint32_t target)
+{
+  uint32_t id[4], key[4];
+  for (uint32_t k = 0; k < 4; k++)
   {
-    const uint32_t t = order[0];
-    order[0] = order[i];
-    order[i] = t;
-    heap_sift(order, i, 0);
+    const uint32_t o = L.order[lane * 4 + k];
+    id[k] = o & 0xFF;
+    key[k] = o >> 8;
   }
-  int lo = first_at_least_two(order, scaled, 0, 0);
-  while (sum > target)
+  const uint32_t lo0 = lo;
+  auto next_lo = [&](uint32_t from) { // first position >= from whose count is >= 2, `from` when there is none
+    uint32_t small = 0;
+    for (uint32_t k = 0; k < 4; k++)
+      small += ballot_count(lane * 4 + k >= from && key[k] < 2);
+    return from + small < 256 ? from + small : from;
+  };
+  if (sum > target)
   {
-    bool done = false;
-    for (int i = lo; i < 256 && !done; i++)
+    uint32_t e = sum - target;
+    while (true)
     {
-      scaled[order[i] & 0xFF]--;
-      done = --sum == target;
+      const uint32_t m = 256 - lo;
+      const uint32_t upto = e <= m ? lo + e : 256;
+      for (uint32_t k = 0; k < 4; k++)
+        if (lane * 4 + k >= lo && lane * 4 + k < upto)
+          key[k]--;
+      if (e <= m)
+        break;
+      e -= m;
+      lo = next_lo(lo);
     }
-    if (!done)
-      lo = first_at_least_two(order, scaled, lo, lo);
   }
-  while (sum < target)
+  else
   {
-    bool done = false;
-    for (int i = 255; i >= lo && !done; i--)
+    uint32_t e = target - sum;
+    while (true)
     {
-      scaled[order[i] & 0xFF]++;
-      done = ++sum == target;
+      const uint32_t m = 256 - lo;
+      const uint32_t from = e <= m ? 256 - e : lo;
+      for (uint32_t k = 0; k < 4; k++)
+        if (lane * 4 + k >= from)
+          key[k]++;
+      if (e <= m)
+        break;
+      e -= m;
+      lo = next_lo(lo);
     }
-    if (!done)
-      lo = first_at_least_two(order, scaled, lo, lo);
   }
+  for (uint32_t k = 0; k < 4; k++)
+    if (lane * 4 + k >= lo0)
+      L.scaled[id[k]] = key[k];
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
@@ -146,13 +280,31 @@ __device__ __forceinline__ uint4 load16_guarded(const uint8_t *in, uint64_t pos,
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <uint32_t S, bool FULL>
-__device__ __forceinline__ void encode_group(uint32_t &x, const WaveLds &L, const uint8_t *stage, uint32_t group_off, uint32_t valid, uint8_t *&p, uint32_t lane,
-                                             uint32_t byte_in_group)
+struct Chunk
 {
-  // FULL: all S lanes code a symbol; else only those whose byte exists (the file's last, partial group)
-  const bool active = lane < S && (FULL || byte_in_group < valid);
-  const uint32_t sym = stage[group_off + byte_in_group];
+  uint4 q[kChunk / 1024];
+};
+__device__ __forceinline__ Chunk chunk_load(const uint8_t *in, uint64_t begin, uint64_t end, uint32_t c, uint32_t lane)
+{
+  Chunk r;
+#pragma unroll
+  for (uint32_t k = 0; k < kChunk / 1024; k++)
+    r.q[k] = load16_guarded(in, begin + (uint64_t)c * kChunk + k * 1024 + lane * 16, end);
+  return r;
+}
+__device__ __forceinline__ void chunk_to_lds(WaveLds &L, const Chunk &r, uint32_t c, uint32_t lane)
+{
+#pragma unroll
+  for (uint32_t k = 0; k < kChunk / 1024; k++)
+    *(uint4 *)(L.stage + (c & 1) * kChunk + k * 1024 + lane * 16) = r.q[k];
+}
+
+// one group, general form: lanes whose byte does not exist (the file's last, partial group) keep their state
+template <uint32_t S>
+__device__ __forceinline__ void encode_group_slow(uint32_t &x, const WaveLds &L, uint32_t group_off, uint32_t valid, uint8_t *&p, uint32_t lane, uint32_t byte_in_group)
+{
+  const bool active = lane < S && byte_in_group < valid;
+  const uint32_t sym = L.stage[(group_off + byte_in_group) & (kRing - 1)];
   const uint4 e = L.table[sym];
   const bool emit = active && x >= e.x;
   const unsigned long long mask = __builtin_amdgcn_ballot_w64(emit);
@@ -164,9 +316,27 @@ __device__ __forceinline__ void encode_group(uint32_t &x, const WaveLds &L, cons
     *(uint16_t *)(p + 2 * rank) = (uint16_t)x; // lane S-1's word goes last in memory (rANS32x64_16w.cpp:65-99)
     v = x >> 16;
   }
-  const uint32_t q = __umulhi(v, e.z) >> (e.w >> 16);
-  const uint32_t nx = v + e.y + q * (e.w & 0xFFFFu);
+  const uint32_t q = __umulhi(v, e.z) >> (e.w >> 24);
+  const uint32_t nx = __umul24(q, e.w) + v + e.y;
   x = active ? nx : x;
+}
+
+// one whole group with its table entries already in registers; lanes >= S (32-state codec) carry garbage states that
+// never emit
+template <uint32_t S>
+__device__ __forceinline__ void encode_group_fast(uint32_t &x, const uint4 &e, uint8_t *&p)
+{
+  const bool emit = S == 64 ? x >= e.x : (x >= e.x && lane_id() < 32);
+  const unsigned long long mask = __builtin_amdgcn_ballot_w64(emit);
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+  p -= 2 * (uint32_t)__builtin_popcountll(mask);
+  if (emit)
+  {
+    *(uint16_t *)(p + 2 * rank) = (uint16_t)x;
+    x >>= 16;
+  }
+  const uint32_t q = __umulhi(x, e.z) >> (e.w >> 24);
+  x = __umul24(q, e.w) + x + e.y; // x + bias + q * (2^bits - freq)
 }
 
 template <uint32_t S>
@@ -185,27 +355,49 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
   const uint8_t *in = ep.in;
   uint8_t *slot_end = ep.scratch + (uint64_t)(b + 1) * ep.slot_bytes;
 
-  // ---- byte histogram ----
-  for (uint32_t k = 0; k < 4; k++)
-    L.scaled[lane * 4 + k] = 0;
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  // ---- byte histogram: kSubHists copies, copy = lane & 7 ----
+  uint32_t *sub = (uint32_t *)L.table;
+  for (uint32_t k = 0; k < kSubHists * 4; k++)
+    sub[k * 64 + lane] = 0;
   wave_sync();
-  for (uint32_t off = lane * 16; off < size; off += 1024)
+  uint32_t *mine = sub + (lane & (kSubHists - 1)) * 256;
+  for (uint32_t off = lane * 16; off < size; off += 4096)
   {
-    const uint4 d = load16_guarded(in, begin + off, end);
-    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
-    const uint32_t have = size - off < 16 ? size - off : 16;
-    for (uint32_t k = 0; k < 16; k++)
-      if (k < have)
-        atomicAdd(&L.scaled[(w[k >> 2] >> (8 * (k & 3))) & 0xFF], 1u);
+    uint4 d[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++)
+      d[u] = off + u * 1024 < size ? load16_guarded(in, begin + off + u * 1024, end) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++)
+    {
+      const uint32_t w[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+      const uint32_t o = off + u * 1024;
+      const uint32_t have = o >= size ? 0 : size - o < 16 ? size - o : 16;
+      if (have == 16)
+      {
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++)
+          atomicAdd(&mine[(w[k >> 2] >> (8 * (k & 3))) & 0xFF], 1u);
+      }
+      else
+        for (uint32_t k = 0; k < have; k++)
+          atomicAdd(&mine[(w[k >> 2] >> (8 * (k & 3))) & 0xFF], 1u);
+    }
   }
   wave_sync();
-  uint32_t raw[4];
+  uint32_t raw[4] = {0, 0, 0, 0};
+  for (uint32_t c = 0; c < kSubHists; c++)
+  {
+    const uint4 v = *(const uint4 *)(sub + c * 256 + lane * 4);
+    raw[0] += v.x;
+    raw[1] += v.y;
+    raw[2] += v.z;
+    raw[3] += v.w;
+  }
   uint32_t present = 0;
   for (uint32_t k = 0; k < 4; k++)
-  {
-    raw[k] = L.scaled[lane * 4 + k];
     present += raw[k] != 0;
-  }
   const uint32_t distinct = wave_sum(present);
   if (distinct == 1) // single-symbol block: only the marker word (mt_rANS32x64_16w_encode.cpp:289-295)
   {
@@ -222,6 +414,7 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
     return;
   }
 
+  const uint64_t t1 = __builtin_amdgcn_s_memrealtime();
   // ---- normalisation (hist.cpp:16-215; hsrans_host.cpp normalize_counts) ----
   const uint32_t target = 1u << ep.bits;
   const float factor = (float)target / (float)(uint64_t)size;
@@ -242,8 +435,8 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
   wave_sync();
   if (sum != target)
   {
-    if (lane == 0)
-      adjust_counts_one_lane(L.scaled, L.order, sum, target);
+    const uint32_t lo = heap_sort_counts(L, lane);
+    adjust_counts(L, lane, lo, sum, target);
     wave_sync();
     part = 0;
     for (uint32_t k = 0; k < 4; k++)
@@ -263,76 +456,122 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
   uint32_t cum = incl - part;
   for (uint32_t k = 0; k < 4; k++)
   {
+    // x' = x + bias + (x / freq) * (2^bits - freq), the division as multiply-high by a rounded-up reciprocal (exact for
+    // x < 2^31, which renormalisation guarantees)
     const uint32_t freq = sc[k];
     uint4 e;
     e.x = freq << (31 - ep.bits); // emit when x >= ((2^15 >> bits) << 16) * freq
     if (freq < 2)
     {
-      e.y = cum + target - 1; // q = x - 1 for freq == 1
+      e.y = cum + target - 1; // rcp = 2^32 - 1 gives x - 1 for freq == 1
       e.z = 0xFFFFFFFFu;
-      e.w = (target - freq);
+      e.w = target - freq;
       if (freq == 0)
         e.x = 0xFFFFFFFFu;
     }
     else
     {
-      uint32_t shift = 32 - __clz(freq - 1); // smallest shift with freq <= 1 << shift
+      const uint32_t shift = 32 - __clz(freq - 1); // smallest shift with freq <= 1 << shift
       e.y = cum;
       e.z = (uint32_t)((((uint64_t)1 << (shift + 31)) + freq - 1) / freq);
-      e.w = (target - freq) | ((shift - 1) << 16);
+      e.w = (target - freq) | ((shift - 1) << 24);
     }
     L.table[lane * 4 + k] = e;
     cum += freq;
   }
 
+  const uint64_t t2 = __builtin_amdgcn_s_memrealtime();
   // ---- backward rANS pass over the block (rANS32x64_16w.cpp:34-166) ----
+  // The block's bytes pass through an LDS ring of two chunks (byte r of the block at ring offset r mod kRing) with a third
+  // chunk on its way in registers; symbols and their table entries are fetched one and two sets (of four groups) ahead of
+  // the set being coded, so that the state update is the only dependent chain.
   const uint32_t n_chunks = (size + kChunk - 1) / kChunk;
   const uint32_t byte_in_group = enc_lane_to_byte(lane) & (S - 1);
   uint32_t x = 1u << 15;
   uint8_t *p = slot_end;
-  uint4 pre0, pre1;
+  chunk_to_lds(L, chunk_load(in, begin, end, n_chunks - 1, lane), n_chunks - 1, lane);
+  if (n_chunks >= 2)
+    chunk_to_lds(L, chunk_load(in, begin, end, n_chunks - 2, lane), n_chunks - 2, lane);
+  Chunk pre{};
+  if (n_chunks >= 3)
+    pre = chunk_load(in, begin, end, n_chunks - 3, lane);
+  wave_sync();
+
+  uint32_t g = (size + S - 1) / S; // groups of the block still to code; group i covers bytes [i*S, i*S+S)
+  if (size % S != 0)               // only the file's last group can be partial
   {
-    const uint32_t c = n_chunks - 1;
-    pre0 = load16_guarded(in, begin + (uint64_t)c * kChunk + lane * 16, end);
-    pre1 = load16_guarded(in, begin + (uint64_t)c * kChunk + 1024 + lane * 16, end);
-    *(uint4 *)(L.stage[c & 1] + lane * 16) = pre0;
-    *(uint4 *)(L.stage[c & 1] + 1024 + lane * 16) = pre1;
+    g--;
+    encode_group_slow<S>(x, L, g * S, size - g * S, p, lane, byte_in_group);
   }
-  for (uint32_t c = n_chunks; c-- > 0;)
+  while (g % 4 != 0)
   {
-    if (c > 0)
-    {
-      pre0 = load16_guarded(in, begin + (uint64_t)(c - 1) * kChunk + lane * 16, end);
-      pre1 = load16_guarded(in, begin + (uint64_t)(c - 1) * kChunk + 1024 + lane * 16, end);
-    }
-    wave_sync();
-    const uint8_t *stage = L.stage[c & 1];
-    const uint32_t bytes = size - c * kChunk < kChunk ? size - c * kChunk : kChunk;
-    uint32_t g = (bytes + S - 1) / S; // groups in this chunk
-    if (bytes % S != 0)               // only the file's last group can be partial
-    {
-      g--;
-      encode_group<S, false>(x, L, stage, g * S, bytes - g * S, p, lane, byte_in_group);
-    }
-    while (g % 4 != 0)
-    {
-      g--;
-      encode_group<S, true>(x, L, stage, g * S, S, p, lane, byte_in_group);
-    }
-    while (g != 0)
-    {
-      g -= 4;
-#pragma unroll
-      for (int k = 3; k >= 0; k--)
-        encode_group<S, true>(x, L, stage, (g + k) * S, S, p, lane, byte_in_group);
-    }
-    if (c > 0)
-    {
-      *(uint4 *)(L.stage[(c - 1) & 1] + lane * 16) = pre0;
-      *(uint4 *)(L.stage[(c - 1) & 1] + 1024 + lane * 16) = pre1;
-    }
+    g--;
+    encode_group_slow<S>(x, L, g * S, S, p, lane, byte_in_group);
   }
 
+  constexpr uint32_t kSetBytes = 4 * S;
+  constexpr uint32_t kSetsPerChunk = kChunk / kSetBytes;
+  const uint8_t *my_byte = L.stage + byte_in_group;
+  auto read_syms = [&](int32_t t, uint32_t(&s)[4]) { // t < 0 wraps inside the ring: harmless, never coded
+    const uint32_t off = (uint32_t)t * kSetBytes;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+      s[k] = my_byte[(off + k * S) & (kRing - 1)];
+  };
+  auto read_entries = [&](const uint32_t(&s)[4], uint4(&e)[4]) {
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+      e[k] = L.table[s[k]];
+  };
+  auto code_set = [&](const uint4(&e)[4]) {
+#pragma unroll
+    for (int k = 3; k >= 0; k--)
+      encode_group_fast<S>(x, e[k], p);
+  };
+  auto chunk_finished = [&](uint32_t c) { // every group of chunk c is coded: its ring half takes the chunk two further down
+    if (c < 2)
+      return;
+    chunk_to_lds(L, pre, c - 2, lane);
+    if (c >= 3)
+      pre = chunk_load(in, begin, end, c - 3, lane);
+    wave_sync();
+  };
+  auto chunk_done = [&](int32_t t) {
+    if ((uint32_t)t % kSetsPerChunk == 0)
+      chunk_finished((uint32_t)t / kSetsPerChunk);
+  };
+  if ((uint64_t)g * S <= (uint64_t)(n_chunks - 1) * kChunk) // the groups coded one by one above were all of the last chunk
+    chunk_finished(n_chunks - 1);
+
+  int32_t t = (int32_t)(g / 4) - 1;
+  uint32_t sa[4], sb[4];
+  uint4 ea[4], eb[4];
+  read_syms(t, sa);
+  read_entries(sa, ea);
+  read_syms(t - 1, sb);
+  while (t >= 0)
+  {
+    read_entries(sb, eb);
+    read_syms(t - 2, sa);
+    code_set(ea);
+    chunk_done(t);
+    if (--t < 0)
+      break;
+    read_entries(sa, ea);
+    read_syms(t - 2, sb);
+    code_set(eb);
+    chunk_done(t);
+    --t;
+  }
+
+  const uint64_t t3 = __builtin_amdgcn_s_memrealtime();
+  if (ep.stamps && lane == 0)
+  {
+    ep.stamps[b * 4 + 0] = t0;
+    ep.stamps[b * 4 + 1] = t1;
+    ep.stamps[b * 4 + 2] = t2;
+    ep.stamps[b * 4 + 3] = t3;
+  }
   // ---- block header in front of the words: [size u64][skip u64][states S x u32][counts 256 x u16] ----
   const uint32_t words_bytes = (uint32_t)(slot_end - p);
   constexpr uint32_t kHeader = 16 + 4 * S + 512;
