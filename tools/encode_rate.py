@@ -16,6 +16,7 @@ from hypersonic_rans_amd import synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=100_000_000)
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--cpu-sample", type=int, default=16 << 20, help="bytes the library's own scalar host encoder is timed on (0 = skip)")
 args = ap.parse_args()
 ctx = H.Context(0)
 d = synth.enwik8_shaped(args.size, seed=1)
@@ -32,3 +33,15 @@ for states, bits, block in ((64, 11, 1 << 16), (64, 11, 1 << 15), (64, 11, 1 << 
     best, mean = min(ts), sum(ts) / len(ts)
     print(json.dumps({"codec": f"mt_ rANS32x{states} 16w {bits}", "block": block, "size": args.size, "stream": n, "ratio": round(n / args.size, 4),
                       "ms_best": round(best * 1e3, 3), "ms_mean": round(mean * 1e3, 3), "GB_s_best": round(args.size / best / 1e9, 1)}))
+
+if args.cpu_sample:
+    # the same stream from the library's scalar host encoder (hsrans_encode_ex, 1 core): the CPU side of the comparison
+    sample = d[: args.cpu_sample]
+    t0 = time.perf_counter()
+    s_host = H.encode(H.MT, 64, 11, sample, block_size=1 << 16, independent_blocks=True)
+    dt = time.perf_counter() - t0
+    d_out = torch.empty(H.capacity(H.MT, 64, sample.size), dtype=torch.uint8, device="cuda")
+    n = ctx.encode_device(H.MT, 64, 11, d_in[: sample.size], d_out, block_size=1 << 16)
+    same = n == s_host.size and bool((d_out[:n].cpu().numpy() == s_host).all())
+    print(json.dumps({"codec": "mt_ rANS32x64 16w 11 host encoder (1 core)", "block": 1 << 16, "size": int(sample.size), "ms": round(dt * 1e3, 1),
+                      "MiB_s": round(sample.size / dt / 2**20, 1), "gpu_stream_identical": same}))
