@@ -172,7 +172,8 @@ int hsrans_ctx_create(int device, hsrans_ctx **out_ctx)
   if (ctx == nullptr)
     return HSRANS_E_HIP;
   ctx->device = device;
-  strncpy(ctx->name, prop.name, sizeof(ctx->name) - 1);
+  // the marketing name needs the amdgpu.ids table, which minimal images lack: fall back to the ISA name
+  snprintf(ctx->name, sizeof(ctx->name), "%s%s%s (%d CUs)", prop.name, prop.name[0] ? " " : "", prop.gcnArchName, prop.multiProcessorCount);
   if (prepare_kernels() != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void **)&ctx->d_status, 64) != hipSuccess)
   {

@@ -19,7 +19,12 @@ struct PersistentArgs
   uint32_t n_chains, interval, S, bits;
   uint64_t out_base, steps_total, hist_off;
   uint32_t tail;            // symbols of the final partial group (after the last chain)
-  uint32_t static_per_wave; // chains every wave decodes as one merged run before it starts pulling single chains
+  uint32_t static_per_wave; // chains every wave decodes as one merged run before it starts pulling single chains (mean)
+  // 64-state launches: the static run of a wave depends on its slot, class k = (workgroup in the grid's second half) * 4
+  // + (wave in workgroup / 4): the SIMD arbiter serves its oldest wave first, so equal shares finish far apart
+  // (run_persistent).  run_len[k] chains; wave j of class k in workgroup b' of its half starts at
+  // half_base[h] + b' * wg_chains[h] + class_off[k] + (j & 3) * run_len[k].  static_total = all static chains.
+  uint32_t run_len[8], class_off[8], wg_chains[2], half_base[2], static_total;
   const uint2 *table;       // host-built MODE-3 decode table (kPlanHasHist plans, bits <= 11) or null: build it in the kernel
   const uint16_t *hist_copy; // the 256 counts that table was built from (device copy inside the plan)
   unsigned long long *counters; // [kDynQueues * kDynQueueStride] monotonic queue heads (never reset, see run_persistent)

@@ -687,12 +687,19 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
   Ring r;
   ring_bind(r, c.rings);
   RunGeom g{};
-  const uint32_t q0 = pa.static_per_wave; // host guarantees W * q0 <= n_chains
+  // static run of this wave: run_len[class] chains (host guarantees static_total <= n_chains)
+  const uint32_t wave_in_wg = w % waves, blk = w / waves;
+  const uint32_t first_half = (gridDim.x + 1) / 2;
+  const uint32_t half = blk >= first_half ? 1 : 0;
+  const uint32_t per_class = waves >= 4 ? waves / 4 : 1; // waves of one class in a workgroup
+  const uint32_t cls = half * 4 + wave_in_wg / per_class;
+  const uint32_t q0 = pa.run_len[cls];
+  const uint32_t c_first = pa.half_base[half] + (blk - half * first_half) * pa.wg_chains[half] + pa.class_off[cls] + (wave_in_wg % per_class) * q0;
   const bool host_table = MODE == kModePack64 && pa.table != nullptr;
   if (!host_table) // the in-kernel build borrows ring space: it has to come before the first stream request
     build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
   if (q0 != 0)
-    g = run_begin<MODE>(c, pa, sw, w * q0, w * q0 + q0, x, r);
+    g = run_begin<MODE>(c, pa, sw, c_first, c_first + q0, x, r);
   if (host_table)
   {
     // the table was built on the host from the plan's histogram copy: one coalesced 16 B load + LDS store per thread,
@@ -730,7 +737,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
   // Dynamic part: queue k hands out chains [lo, hi) in order.  Its 64-bit head is never reset: every launch draws
   // exactly H = (hi - lo) + (waves on this queue) tickets from it (each wave fails exactly once), and launches on one
   // plan are serialised by their stream, so ticket mod H is this launch's ticket.  No memset node, no exit protocol.
-  const uint32_t dyn0 = W * q0;
+  const uint32_t dyn0 = pa.static_total;
   const uint64_t D = pa.n_chains - dyn0;
   const uint32_t k = w & (kDynQueues - 1);
   const uint32_t lo = dyn0 + (uint32_t)(k * D / kDynQueues), hi = dyn0 + (uint32_t)((k + 1) * D / kDynQueues);
@@ -1189,6 +1196,8 @@ hipError_t launch_mt_walk(const uint8_t *d_stream, uint64_t stream_len, uint64_t
 static uint32_t g_max_lds = 160 * 1024;
 static uint32_t g_num_cus = 256;
 static uint32_t g_static_percent = 100; // HSRANS_STATIC_PERCENT (tuning): share of the chains handed out statically
+// HSRANS_SLOT_WEIGHTS (tuning): per-mille run length of the 8 wave classes, see PersistentArgs::run_len
+static uint32_t g_slot_weights[8] = {1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000};
 
 typedef void (*KernelFn)(KParams);
 static KernelFn kernel_for(int mode, bool shared)
@@ -1209,6 +1218,21 @@ hipError_t prepare_kernels()
 {
   if (const char *e = getenv("HSRANS_STATIC_PERCENT"))
     g_static_percent = (uint32_t)atoi(e) > 100 ? 100 : (uint32_t)atoi(e);
+  if (const char *e = getenv("HSRANS_SLOT_WEIGHTS")) // 8 comma-separated per-mille values, rescaled to mean 1000
+  {
+    uint32_t v[8], n = 0;
+    uint64_t sum = 0;
+    for (const char *p = e; n < 8 && *p; n++)
+    {
+      v[n] = (uint32_t)strtoul(p, (char **)&p, 10);
+      sum += v[n];
+      if (*p == ',')
+        p++;
+    }
+    if (n == 8 && sum > 0)
+      for (uint32_t k = 0; k < 8; k++)
+        g_slot_weights[k] = (uint32_t)((uint64_t)v[k] * 8000 / sum);
+  }
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
     g_num_cus = (uint32_t)cus;
@@ -1269,6 +1293,28 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
     const uint64_t W = (uint64_t)grid * waves;
     // 32-state streams: two runs per wave (run_persistent_pair)
     kp.pa.static_per_wave = (uint32_t)((uint64_t)h.n_chains * g_static_percent / 100 / (h.states == 32 ? 2 * W : W));
+    // 64-state launches: per-slot run lengths (PersistentArgs::run_len).  Weights in per mille of the mean, class =
+    // (second half of the grid) * 4 + wave / 4; uniform unless the workgroup has 16 waves.
+    const uint32_t q0 = kp.pa.static_per_wave;
+    const uint32_t first_half = (grid + 1) / 2, second_half = grid - first_half;
+    const uint32_t per_class = waves >= 4 ? waves / 4 : 1, classes = waves / per_class;
+    for (uint32_t hf = 0; hf < 2; hf++)
+    {
+      uint32_t off = 0;
+      for (uint32_t k = 0; k < 4; k++)
+      {
+        const uint32_t wt = waves == 16 ? g_slot_weights[hf * 4 + k] : 1000;
+        kp.pa.run_len[hf * 4 + k] = k < classes ? (uint32_t)((uint64_t)q0 * wt / 1000) : 0;
+        kp.pa.class_off[hf * 4 + k] = off;
+        off += kp.pa.run_len[hf * 4 + k] * per_class;
+      }
+      kp.pa.wg_chains[hf] = off;
+    }
+    kp.pa.half_base[0] = 0;
+    kp.pa.half_base[1] = first_half * kp.pa.wg_chains[0];
+    kp.pa.static_total = first_half * kp.pa.wg_chains[0] + second_half * kp.pa.wg_chains[1];
+    if (kp.pa.static_total > h.n_chains) // weights sum to <= 8000 by construction; belt and braces
+      return hipErrorInvalidValue;
   }
   KernelFn fn = kernel_for(mode, shared);
   if (info)
