@@ -1196,8 +1196,11 @@ hipError_t launch_mt_walk(const uint8_t *d_stream, uint64_t stream_len, uint64_t
 static uint32_t g_max_lds = 160 * 1024;
 static uint32_t g_num_cus = 256;
 static uint32_t g_static_percent = 100; // HSRANS_STATIC_PERCENT (tuning): share of the chains handed out statically
-// HSRANS_SLOT_WEIGHTS (tuning): per-mille run length of the 8 wave classes, see PersistentArgs::run_len
-static uint32_t g_slot_weights[8] = {1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000};
+// HSRANS_SLOT_WEIGHTS (tuning): per-mille run length of the 8 wave classes, see PersistentArgs::run_len.  Measured on
+// MI355X at 8 waves per SIMD (bits <= 12): with equal runs the four age classes of a workgroup finish at 33/36/39/42 us,
+// with these weights all at 39 us (tools/stamps.py), 3-7 % less kernel time; at 4 waves per SIMD (bits >= 13) equal
+// runs are better and are kept.
+static uint32_t g_slot_weights[8] = {1350, 1100, 870, 680, 1300, 1080, 860, 660};
 
 typedef void (*KernelFn)(KParams);
 static KernelFn kernel_for(int mode, bool shared)
@@ -1295,7 +1298,6 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
     kp.pa.static_per_wave = (uint32_t)((uint64_t)h.n_chains * g_static_percent / 100 / (h.states == 32 ? 2 * W : W));
     // 64-state launches: per-slot run lengths (PersistentArgs::run_len).  Weights in per mille of the mean, class =
     // (second half of the grid) * 4 + wave / 4; uniform unless the workgroup has 16 waves.
-    const uint32_t q0 = kp.pa.static_per_wave;
     const uint32_t first_half = (grid + 1) / 2, second_half = grid - first_half;
     const uint32_t per_class = waves >= 4 ? waves / 4 : 1, classes = waves / per_class;
     for (uint32_t hf = 0; hf < 2; hf++)
@@ -1303,8 +1305,8 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
       uint32_t off = 0;
       for (uint32_t k = 0; k < 4; k++)
       {
-        const uint32_t wt = waves == 16 ? g_slot_weights[hf * 4 + k] : 1000;
-        kp.pa.run_len[hf * 4 + k] = k < classes ? (uint32_t)((uint64_t)q0 * wt / 1000) : 0;
+        const uint32_t wt = waves == 16 && !two_level ? g_slot_weights[hf * 4 + k] : 1000;
+        kp.pa.run_len[hf * 4 + k] = k < classes ? (uint32_t)((uint64_t)h.n_chains * g_static_percent / 100 * wt / (1000 * W)) : 0;
         kp.pa.class_off[hf * 4 + k] = off;
         off += kp.pa.run_len[hf * 4 + k] * per_class;
       }
