@@ -1195,6 +1195,7 @@ hipError_t launch_mt_walk(const uint8_t *d_stream, uint64_t stream_len, uint64_t
 // ---------------------------------------------------------------------------------------------------------------
 static uint32_t g_max_lds = 160 * 1024;
 static uint32_t g_num_cus = 256;
+static uint32_t g_waves_per_wg = 16;    // HSRANS_WAVES_PER_WG (tuning): waves per workgroup of the shared-table launches
 static uint32_t g_static_percent = 100; // HSRANS_STATIC_PERCENT (tuning): share of the chains handed out statically
 // HSRANS_SLOT_WEIGHTS (tuning): per-mille run length of the 8 wave classes, see PersistentArgs::run_len.  Measured on
 // MI355X at 8 waves per SIMD (bits <= 12): with equal runs the four age classes of a workgroup finish at 33/36/39/42 us,
@@ -1221,6 +1222,9 @@ hipError_t prepare_kernels()
 {
   if (const char *e = getenv("HSRANS_STATIC_PERCENT"))
     g_static_percent = (uint32_t)atoi(e) > 100 ? 100 : (uint32_t)atoi(e);
+  if (const char *e = getenv("HSRANS_WAVES_PER_WG"))
+    if (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16)
+      g_waves_per_wg = (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_SLOT_WEIGHTS")) // 8 comma-separated per-mille values, rescaled to mean 1000
   {
     uint32_t v[8], n = 0;
@@ -1264,7 +1268,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
   uint32_t waves, lds, grid;
   if (shared)
   {
-    waves = 16;
+    waves = g_waves_per_wg;
     while (waves > 1 && waves / 2 >= h.n_chains)
       waves /= 2;
     lds = waves * kWaveRingBytes + table_bytes;
