@@ -98,7 +98,7 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_dplan_read_plan.restype = _sz
     L.hsrans_dplan_read_plan.argtypes = [_vp, _vp, _sz]
     L.hsrans_encode_device.restype = _sz
-    L.hsrans_encode_device.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _vp, _sz, _u32, _vp]
+    L.hsrans_encode_device.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _vp, _sz, _u32, _u32, _vp, ctypes.POINTER(_vp)]
     L.hsrans_index_build.restype = _sz
     L.hsrans_index_build.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _u32, _vp, _sz]
     _LIB = L
@@ -342,14 +342,16 @@ class Context:
         return self.L.hsrans_dplan_status(self.handle, dplan.handle, ctypes.c_void_p(s.cuda_stream))
 
     def encode_device(self, container: int, states: int, bits: int, d_in: torch.Tensor, d_out: torch.Tensor, block_size: int = 1 << 16,
-                      stream: torch.cuda.Stream | None = None) -> int:
-        """GPU encoder (mt_, independent fixed-size blocks).  Returns the stream length written to d_out."""
+                      index_interval: int = 0, want_plan: bool = False, stream: torch.cuda.Stream | None = None):
+        """GPU encoder (mt_, independent fixed-size blocks).  Returns the stream length written to d_out, or
+        ``(length, DevicePlan)`` with ``want_plan`` (plan with a checkpoint every ``index_interval`` groups, built on the device)."""
         s = stream if stream is not None else torch.cuda.current_stream(d_in.device)
+        h = _vp()
         n = self.L.hsrans_encode_device(self.handle, container, states, bits, d_in.data_ptr(), d_in.numel(), d_out.data_ptr(), d_out.numel(), block_size,
-                                        ctypes.c_void_p(s.cuda_stream))
+                                        index_interval, ctypes.c_void_p(s.cuda_stream), ctypes.byref(h) if want_plan else None)
         if n == 0:
             raise HsransError("hsrans_encode_device failed")
-        return n
+        return (n, DevicePlan(self, h)) if want_plan else n
 
     def index_build(self, container: int, states: int, bits: int, stream, index_interval: int) -> np.ndarray:
         stream = _u8(stream)

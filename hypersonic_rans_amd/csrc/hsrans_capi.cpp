@@ -33,6 +33,8 @@ struct hsrans_ctx
   size_t d_enc_scratch_cap = 0;
   uint8_t *d_enc_meta = nullptr;
   size_t d_enc_meta_cap = 0;
+  uint8_t *d_enc_ck = nullptr; // checkpoint states / cursors of the blocks being encoded
+  size_t d_enc_ck_cap = 0;
 };
 
 struct hsrans_dplan
@@ -201,6 +203,8 @@ void hsrans_ctx_destroy(hsrans_ctx *ctx)
     (void)hipFree(ctx->d_enc_scratch);
   if (ctx->d_enc_meta)
     (void)hipFree(ctx->d_enc_meta);
+  if (ctx->d_enc_ck)
+    (void)hipFree(ctx->d_enc_ck);
   if (ctx->d_status)
     (void)hipFree(ctx->d_status);
   delete ctx;
@@ -552,11 +556,13 @@ int hsrans_dplan_launch_info(const hsrans_dplan *d, hsrans_launch_info *info)
 }
 
 size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t bits, const void *d_in, size_t length, void *d_out, size_t out_capacity,
-                            uint32_t block_size, void *hip_stream)
+                            uint32_t block_size, uint32_t index_interval, void *hip_stream, hsrans_dplan **out_dplan)
 {
+  if (out_dplan)
+    *out_dplan = nullptr;
   if (ctx == nullptr || container != HSRANS_MT || !valid_codec(container, states, bits) || d_in == nullptr || d_out == nullptr || length == 0)
     return 0;
-  if (block_size == 0 || block_size % 64 != 0 || ((uintptr_t)d_in & 15) != 0 || ((uintptr_t)d_out & 15) != 0)
+  if (block_size == 0 || block_size % 64 != 0 || index_interval % 4 != 0 || ((uintptr_t)d_in & 15) != 0 || ((uintptr_t)d_out & 15) != 0)
     return 0;
   if (out_capacity < capacity(container, states, length)) // same contract as the host encoders
     return 0;
@@ -569,30 +575,41 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   if (ep.n_blocks == 0)
     return 0;
   ep.slot_bytes = encode_slot_bytes(block_size, ep.S);
+  ep.interval = out_dplan ? index_interval : 0; // checkpoints only serve the plan
+  ep.max_ck = ep.interval ? (block_size / ep.S - 1) / ep.interval : 0;
   std::lock_guard<std::mutex> guard(ctx->lock);
   if (hipSetDevice(ctx->device) != hipSuccess)
     return 0;
   const bool stamps = getenv("HSRANS_DEBUG_STAMPS") != nullptr;
-  const size_t meta_bytes = ((size_t)ep.n_blocks * (stamps ? 6 : 2) + 2) * 8;
-  if (!grow(&ctx->d_enc_scratch, &ctx->d_enc_scratch_cap, (size_t)ep.n_blocks * ep.slot_bytes) || !grow(&ctx->d_enc_meta, &ctx->d_enc_meta_cap, meta_bytes))
+  const size_t nb = ep.n_blocks;
+  const size_t meta_bytes = (nb * 2 + kEncResultWords) * 8 + nb * 2 * 4 + (stamps ? nb * 4 * 8 : 0) + 64;
+  const size_t ck_slots = nb * (ep.max_ck ? ep.max_ck : 1);
+  if (!grow(&ctx->d_enc_scratch, &ctx->d_enc_scratch_cap, nb * ep.slot_bytes) || !grow(&ctx->d_enc_meta, &ctx->d_enc_meta_cap, meta_bytes) ||
+      !grow(&ctx->d_enc_ck, &ctx->d_enc_ck_cap, ck_slots * ((size_t)ep.S * 4 + 4)))
     return 0;
   ep.in = (const uint8_t *)d_in;
   ep.out = (uint8_t *)d_out;
   ep.out_cap = out_capacity;
   ep.scratch = ctx->d_enc_scratch;
   ep.image_bytes = (uint64_t *)ctx->d_enc_meta;
-  ep.image_off = ep.image_bytes + ep.n_blocks;
-  ep.result = ep.image_off + ep.n_blocks;
-  ep.stamps = stamps ? ep.result + 2 : nullptr;
+  ep.image_off = ep.image_bytes + nb;
+  ep.result = ep.image_off + nb;
+  uint64_t *after = ep.result + kEncResultWords;
+  ep.stamps = stamps ? after : nullptr;
+  after += stamps ? nb * 4 : 0;
+  ep.chain_count = (uint32_t *)after;
+  ep.chain_off = ep.chain_count + nb;
+  ep.ck_states = (uint32_t *)ctx->d_enc_ck;
+  ep.ck_pos = ep.ck_states + ck_slots * ep.S;
   hipStream_t s = (hipStream_t)hip_stream;
-  uint64_t result[2] = {0, 0};
+  uint64_t result[kEncResultWords] = {};
   if (launch_encode(ep, s) != hipSuccess)
     return 0;
   if (hipMemcpyAsync(result, ep.result, sizeof(result), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
     return 0;
   if (stamps) // printed, not returned: a tuning aid only
   {
-    std::vector<uint64_t> st((size_t)ep.n_blocks * 4);
+    std::vector<uint64_t> st(nb * 4);
     if (hipMemcpy(st.data(), ep.stamps, st.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
     {
       double ph[3] = {0, 0, 0};
@@ -608,7 +625,52 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
               ph[0] / ep.n_blocks / 100.0, ph[1] / ep.n_blocks / 100.0, ph[2] / ep.n_blocks / 100.0, (double)(hi - lo) / 100.0);
     }
   }
-  return result[1] == 1 ? (size_t)result[0] : 0;
+  if (result[1] != 1)
+    return 0;
+  const size_t total = (size_t)result[0];
+  if (out_dplan == nullptr)
+    return total;
+
+  // ---- the stream's plan, written on the device (K_plan), wrapped into a device plan ready for hsrans_decode_device ----
+  if (result[2] == 0 || result[2] > 0xFFFFFFFFull)
+    return 0;
+  hsrans_dplan *d = new (std::nothrow) hsrans_dplan;
+  if (d == nullptr)
+    return 0;
+  d->ctx = ctx;
+  PlanHeader h{};
+  memcpy(h.magic, "HSRPLAN1", 8);
+  h.container = HSRANS_MT;
+  h.states = ep.S;
+  h.bits = bits;
+  h.decoded_len = length;
+  h.stream_len = total;
+  h.n_chains = h.n_pieces = (uint32_t)result[2];
+  h.shared_hist = result[3] == 1 ? 1 : 0; // exactly one block with a histogram (hsrans_host.cpp PlanBuilder::serialize)
+  h.aux_off = h.shared_hist ? result[4] : 0;
+  h.interval = ep.interval;
+  const size_t bytes = (size_t)plan_size(h.n_chains, h.n_pieces, h.states, 0);
+  const bool grouped = ep.interval != 0 && ep.n_blocks < h.n_chains;
+  bool ok = hipMalloc((void **)&d->d_plan, bytes) == hipSuccess && hipMalloc((void **)&d->d_status, 64) == hipSuccess &&
+            (!grouped || hipMalloc((void **)&d->d_groups, nb * sizeof(Group)) == hipSuccess) && hipMemsetAsync(d->d_plan, 0, bytes, s) == hipSuccess &&
+            hipMemsetAsync(d->d_status, 0, 64, s) == hipSuccess && hipMemcpyAsync(d->d_plan, &h, sizeof(h), hipMemcpyHostToDevice, s) == hipSuccess;
+  if (ok)
+  {
+    ep.plan = d->d_plan;
+    ep.groups = grouped ? d->d_groups : nullptr;
+    ep.n_chains = h.n_chains;
+    ok = launch_encode_plan(ep, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  }
+  if (!ok)
+  {
+    hsrans_dplan_destroy(d);
+    return 0;
+  }
+  d->hdr = h;
+  d->plan_bytes = bytes;
+  d->n_groups = grouped ? ep.n_blocks : 0;
+  *out_dplan = d;
+  return total;
 }
 
 size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint32_t index_interval,

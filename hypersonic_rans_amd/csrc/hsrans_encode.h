@@ -18,17 +18,31 @@ struct EncParams
   uint64_t slot_bytes;   // encode_slot_bytes()
   uint64_t *image_bytes; // [n_blocks] bytes of block b's image (header + words, or the 8-byte single-symbol marker)
   uint64_t *image_off;   // [n_blocks] position of the image in the stream
-  uint64_t *result;      // [0] stream length, [1] 1 when it fits out_cap (else nothing is written to out)
+  uint64_t *result;      // [0] stream length, [1] 1 when it fits out_cap (else nothing is written to out), [2] chains,
+                         // [3] blocks that are not single-symbol blocks, [4] position of the counts of the last such block
   uint64_t block;        // symbols per block (multiple of 64)
   uint32_t n_blocks;
   uint32_t S, bits;
+  // sidecar plan (index_interval != 0 or a device plan was asked for)
+  uint32_t interval;     // checkpoint every `interval` groups inside a block (multiple of 4; 0 = none)
+  uint32_t max_ck;       // checkpoint slots per block
+  uint32_t *ck_states;   // [n_blocks * max_ck * S] coder states at the checkpoints
+  uint32_t *ck_pos;      // [n_blocks * max_ck] bytes between the decoder's read cursor at the checkpoint and the end of the block's words
+  uint32_t *chain_count; // [n_blocks] chains of block b: 1 + its checkpoints (single-symbol block: 1)
+  uint32_t *chain_off;   // [n_blocks] first chain of block b (K_scan)
+  uint8_t *plan;         // plan blob to fill (K_plan) or null
+  void *groups;          // Group[n_blocks] for the grouped decode launch (K_plan) or null
+  uint32_t n_chains;     // total, known after K_scan (K_plan)
   uint64_t *stamps; // diagnostics (HSRANS_DEBUG_STAMPS=1): per block {start, histogram done, table done, words done} s_memrealtime; else null
 };
 
 uint32_t encode_block_count(uint64_t n, uint64_t block, uint32_t S); // 0: too many blocks
 uint64_t encode_slot_bytes(uint64_t block, uint32_t S);
+constexpr uint32_t kEncResultWords = 8;
 // asynchronous on `stream`: K_enc, K_scan, K_gather
 hipError_t launch_encode(const EncParams &ep, hipStream_t stream);
+// asynchronous on `stream`: K_plan (needs ep.plan, ep.n_chains; after launch_encode's results are known)
+hipError_t launch_encode_plan(const EncParams &ep, hipStream_t stream);
 
 } // namespace hsrans
 

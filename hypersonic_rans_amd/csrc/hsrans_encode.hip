@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "hsrans_encode.h"
+#include "hsrans_kernels.h"
 
 namespace hsrans
 {
@@ -410,6 +411,7 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
       const uint64_t marker = (uint64_t)size | ((uint64_t)1 << 63) | ((uint64_t)sym << 54);
       ((U64a2 *)(slot_end - 8))->v = marker;
       ep.image_bytes[b] = 8;
+      ep.chain_count[b] = 1;
     }
     return;
   }
@@ -497,6 +499,19 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
     pre = chunk_load(in, begin, end, n_chunks - 3, lane);
   wave_sync();
 
+  // sidecar checkpoints (hsrans_host.cpp encode(): after group gr of the block is coded, gr % interval == 0, gr != 0, the
+  // group whole): the decoder's states and read cursor when it is about to start group gr
+  const uint32_t whole_groups = size / S;
+  auto checkpoint = [&](uint32_t gr) {
+    const uint64_t slot = (uint64_t)b * ep.max_ck + (gr / ep.interval - 1);
+    if (lane < S)
+      ep.ck_states[slot * S + lane] = x;
+    if (lane == 0)
+      ep.ck_pos[slot] = (uint32_t)(slot_end - p);
+  };
+  if (lane == 0)
+    ep.chain_count[b] = 1 + (ep.interval != 0 && whole_groups >= 1 ? (whole_groups - 1) / ep.interval : 0);
+
   uint32_t g = (size + S - 1) / S; // groups of the block still to code; group i covers bytes [i*S, i*S+S)
   if (size % S != 0)               // only the file's last group can be partial
   {
@@ -508,6 +523,9 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
     g--;
     encode_group_slow<S>(x, L, g * S, S, p, lane, byte_in_group);
   }
+
+  if (ep.interval != 0 && g != 0 && g % ep.interval == 0 && g < whole_groups)
+    checkpoint(g);
 
   constexpr uint32_t kSetBytes = 4 * S;
   constexpr uint32_t kSetsPerChunk = kChunk / kSetBytes;
@@ -536,7 +554,9 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
       pre = chunk_load(in, begin, end, c - 3, lane);
     wave_sync();
   };
-  auto chunk_done = [&](int32_t t) {
+  auto chunk_done = [&](int32_t t) { // set t (groups 4t .. 4t+3) is coded
+    if (ep.interval != 0 && t != 0 && (uint32_t)(4 * t) % ep.interval == 0)
+      checkpoint((uint32_t)(4 * t));
     if ((uint32_t)t % kSetsPerChunk == 0)
       chunk_finished((uint32_t)t / kSetsPerChunk);
   };
@@ -592,48 +612,151 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
 }
 
 // ---- K_scan: one workgroup ----------------------------------------------------------------------------------------
+// exclusive prefix of `v` over the 1024 threads of the workgroup, plus the workgroup total in *total
+__device__ __forceinline__ uint64_t wg_exclusive_scan(uint64_t v, uint64_t *wave_tot, uint64_t *total)
+{
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t incl = v;
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    const uint64_t o = __shfl_up(incl, d, 64);
+    if ((int)lane >= d)
+      incl += o;
+  }
+  __syncthreads(); // wave_tot may still be read by the previous call
+  if (lane == 63)
+    wave_tot[wave] = incl;
+  __syncthreads();
+  uint64_t before = 0, all = 0;
+  for (uint32_t w = 0; w < 16; w++)
+  {
+    before += w < wave ? wave_tot[w] : 0;
+    all += wave_tot[w];
+  }
+  *total = all;
+  return before + incl - v;
+}
+
 __global__ void __launch_bounds__(1024) k_scan_images(EncParams ep)
 {
   __shared__ uint64_t wave_tot[16];
-  __shared__ uint64_t carry_s;
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0)
-    carry_s = 16; // file header
-  __syncthreads();
+  uint64_t bytes_before = 16; // file header
+  uint64_t chains_before = 0, coded_blocks = 0, last_hist = 0;
+  constexpr uint64_t kNone = ~(uint64_t)0;
+  uint64_t my_last = kNone; // highest non-single block this thread has seen
   for (uint32_t base = 0; base < ep.n_blocks; base += 1024)
   {
     const uint32_t i = base + threadIdx.x;
-    const uint64_t v = i < ep.n_blocks ? ep.image_bytes[i] : 0;
-    uint64_t incl = v;
-    for (int d = 1; d < 64; d <<= 1)
+    const bool have = i < ep.n_blocks;
+    const uint64_t bytes = have ? ep.image_bytes[i] : 0;
+    const uint64_t chains = have ? ep.chain_count[i] : 0;
+    uint64_t t_bytes, t_chains, t_coded;
+    const uint64_t off = wg_exclusive_scan(bytes, wave_tot, &t_bytes);
+    const uint64_t coff = wg_exclusive_scan(chains, wave_tot, &t_chains);
+    (void)wg_exclusive_scan(have && bytes != 8 ? 1 : 0, wave_tot, &t_coded);
+    if (have)
     {
-      const uint64_t o = __shfl_up(incl, d, 64);
-      if ((int)lane >= d)
-        incl += o;
+      ep.image_off[i] = bytes_before + off;
+      ep.chain_off[i] = (uint32_t)(chains_before + coff);
+      if (bytes != 8)
+        my_last = bytes_before + off + 16 + 4 * (uint64_t)ep.S; // where this block's counts will be
     }
-    if (lane == 63)
-      wave_tot[wave] = incl;
-    __syncthreads();
-    uint64_t before = carry_s;
-    for (uint32_t w = 0; w < wave; w++)
-      before += wave_tot[w];
-    if (i < ep.n_blocks)
-      ep.image_off[i] = before + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023)
-      carry_s = before + incl;
-    __syncthreads();
+    bytes_before += t_bytes;
+    chains_before += t_chains;
+    coded_blocks += t_coded;
   }
+  // any thread's candidate will do when there is exactly one coded block (the only case the value is used in)
+  __shared__ uint64_t hist_s;
+  if (threadIdx.x == 0)
+    hist_s = 0;
+  __syncthreads();
+  if (my_last != kNone)
+    atomicMax((unsigned long long *)&hist_s, (unsigned long long)my_last);
+  __syncthreads();
+  last_hist = hist_s;
   if (threadIdx.x == 0)
   {
-    const uint64_t total = carry_s;
+    const uint64_t total = bytes_before;
     ep.result[0] = total;
     ep.result[1] = total <= ep.out_cap ? 1 : 0;
+    ep.result[2] = chains_before;
+    ep.result[3] = coded_blocks;
+    ep.result[4] = last_hist;
     if (total <= ep.out_cap)
     {
       ((uint64_t *)ep.out)[0] = ep.n;
       ((uint64_t *)ep.out)[1] = total;
     }
+  }
+}
+
+// ---- K_plan: the sidecar plan of the stream (hsrans_plan.h), one wavefront per block --------------------------------
+// Writes exactly what the host encoder emits for the same layout (hsrans_host.cpp encode(), "sidecar plan"): single-piece
+// chains in output order — per coded block one chain from the block header's states plus one per checkpoint, per
+// single-symbol block one fill chain — and the Group records of the grouped decode launch (one group per block).
+__global__ void __launch_bounds__(64) k_plan_blocks(EncParams ep)
+{
+  const uint32_t b = blockIdx.x, lane = threadIdx.x, S = ep.S;
+  const uint32_t nc = ep.n_chains;
+  uint32_t *chain_first = (uint32_t *)(ep.plan + plan_chain_first_off());
+  Piece *pieces = (Piece *)(ep.plan + plan_pieces_off(nc));
+  uint32_t *states = (uint32_t *)(ep.plan + plan_states_off(nc, nc));
+  const uint64_t begin = (uint64_t)b * ep.block;
+  const uint64_t end = b + 1 == ep.n_blocks ? ep.n : begin + ep.block;
+  const uint64_t bytes = ep.image_bytes[b], at = ep.image_off[b];
+  const uint32_t c0 = ep.chain_off[b], count = ep.chain_count[b];
+  const bool single = bytes == 8;
+  const uint64_t header = 16 + 4 * (uint64_t)S + 512;
+  const uint64_t hist_off = at + 16 + 4 * (uint64_t)S;
+  const uint64_t whole_file = ep.n / S; // whole groups of the file (rANS32x64_16w.cpp:220)
+  const uint8_t *image = ep.scratch + (uint64_t)(b + 1) * ep.slot_bytes - bytes;
+  if (b == 0 && lane == 0)
+    chain_first[nc] = nc;
+  for (uint32_t k = lane; k < count; k += 64)
+  {
+    Piece p{};
+    p.flags = kPieceChainStart;
+    p.state_idx = c0 + k;
+    if (single)
+    {
+      p.out_off = begin;
+      p.hist_off = (image[6] >> 6) | ((uint64_t)(image[7] & 0x3F) << 2); // bits 54..61 of the marker
+      p.fill_len = end - begin;
+      p.flags |= kPieceFill;
+    }
+    else
+    {
+      const uint64_t g_first = begin / S, g_end = (end - 1) / S + 1;
+      const uint64_t g0 = g_first + (uint64_t)k * ep.interval;
+      const uint64_t g1 = k + 1 < count ? g0 + ep.interval : g_end;
+      p.words_off = k == 0 ? at + header : at + bytes - ep.ck_pos[(uint64_t)b * ep.max_ck + (k - 1)];
+      p.out_off = g0 * S;
+      p.hist_off = hist_off;
+      const uint64_t stop = g1 < whole_file ? g1 : whole_file;
+      p.steps = (uint32_t)(stop > g0 ? stop - g0 : 0);
+      p.tail = (uint16_t)(k + 1 == count && end == ep.n ? ep.n - whole_file * S : 0);
+    }
+    pieces[c0 + k] = p;
+    chain_first[c0 + k] = c0 + k;
+  }
+  // start states: chain 0 from the block header (2-byte aligned in the image), the others from the checkpoint slots
+  for (uint32_t k = 0; k < count; k++)
+    if (lane < S)
+    {
+      uint32_t v = 0;
+      if (!single)
+        v = k == 0 ? ((const U32a2 *)(image + 16 + 4 * lane))->v : ep.ck_states[((uint64_t)b * ep.max_ck + (k - 1)) * S + lane];
+      states[(uint64_t)(c0 + k) * S + lane] = v;
+    }
+  if (ep.groups != nullptr && lane == 0)
+  {
+    Group g{};
+    g.begin = c0;
+    g.count = count;
+    g.flags = single ? kGroupFill : kGroupMergeable;
+    g.hist_off = single ? 0 : hist_off;
+    g.words_end = at + bytes;
+    ((Group *)ep.groups)[b] = g;
   }
 }
 
@@ -705,6 +828,12 @@ hipError_t launch_encode(const EncParams &ep, hipStream_t stream)
     hipLaunchKernelGGL(k_encode_blocks<32>, dim3(grid), dim3(64 * kWavesPerWG), lds, stream, ep);
   hipLaunchKernelGGL(k_scan_images, dim3(1), dim3(1024), 0, stream, ep);
   hipLaunchKernelGGL(k_gather_images, dim3(ep.n_blocks), dim3(256), 0, stream, ep);
+  return hipGetLastError();
+}
+
+hipError_t launch_encode_plan(const EncParams &ep, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_plan_blocks, dim3(ep.n_blocks), dim3(64), 0, stream, ep);
   return hipGetLastError();
 }
 

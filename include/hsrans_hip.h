@@ -133,11 +133,16 @@ size_t hsrans_dplan_read_plan(hsrans_dplan *dplan, uint8_t *out, size_t capacity
 int hsrans_dplan_status(hsrans_ctx *ctx, hsrans_dplan *dplan, void *hip_stream);
 
 /* GPU encoder: mt_ stream with fixed blocks of `block_size` symbols (multiple of 64), each block
- * encoded independently by one wavefront (HSRANS_ENC_INDEPENDENT_BLOCKS layout).  d_in / d_out are device pointers;
- * d_out needs hsrans_capacity(HSRANS_MT, states, length) bytes.  Synchronises `hip_stream`; returns the stream size, 0 on
- * failure.  Byte-identical to hsrans_encode_ex(HSRANS_MT, ..., {block_size, flags = HSRANS_ENC_INDEPENDENT_BLOCKS}). */
+ * encoded independently by one wavefront (HSRANS_ENC_INDEPENDENT_BLOCKS layout).  d_in / d_out are device pointers (16-byte
+ * aligned); d_out needs hsrans_capacity(HSRANS_MT, states, length) bytes.  Synchronises `hip_stream`; returns the stream
+ * size, 0 on failure.  Byte-identical to hsrans_encode_ex(HSRANS_MT, ..., {block_size, index_interval, flags =
+ * HSRANS_ENC_INDEPENDENT_BLOCKS}), stream and plan.
+ * out_dplan != NULL: the stream's decode plan is written on the device as well — one chain per block plus one per
+ * checkpoint every `index_interval` groups inside the blocks (multiple of 4; 0 = block starts only), the encoder passes
+ * through exactly those states — and returned as a device plan for hsrans_decode_device (hsrans_dplan_read_plan fetches
+ * the blob).  Nothing leaves HBM between encode and decode. */
 size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t bits, const void *d_in, size_t length, void *d_out, size_t out_capacity,
-                            uint32_t block_size, void *hip_stream);
+                            uint32_t block_size, uint32_t index_interval, void *hip_stream, hsrans_dplan **out_dplan);
 
 /* Build a plan with checkpoints every `index_interval` groups for an EXISTING stream (e.g. one written by the
  * reference's encoder) by one decode pass on the GPU that records the states at the checkpoints: HSRANS_RAW (one

@@ -283,6 +283,53 @@ def test_gpu_encoder_matches_host_encoder(gpu_ctx, oracle, zipf, nonstat, states
             assert r == n and np.array_equal(back, d), (states, bits, n, block)
 
 
+@pytest.mark.parametrize("states", (32, 64))
+@pytest.mark.parametrize("interval", (0, 4, 32, 256))
+def test_gpu_encoder_emits_the_host_encoders_plan(gpu_ctx, zipf, nonstat, states, interval):
+    """Stream AND sidecar plan from the device == hsrans_encode_ex on the host, byte for byte; decode with the device plan."""
+    import torch
+    runs = np.concatenate([zipf[:70_000], np.full(140_000, 9, np.uint8), zipf[:50_001]])
+    for src, n, block, bits in ((zipf, 64, 64, 11), (zipf, 65536, 65536, 11), (zipf, 65536 + 63, 65536, 12), (zipf, 300_001, 32768, 11), (zipf, 8192 * 3 + 4 * 64, 8192, 14),
+                                (nonstat, 2_000_000, 1 << 18, 11), (runs, runs.size, 65536, 15), (zipf, 1 << 20, 1 << 20, 10)):
+        d = src[:n]
+        want = H.encode(H.MT, states, bits, d, block_size=block, index_interval=interval, independent_blocks=True) if interval else \
+            (H.encode(H.MT, states, bits, d, block_size=block, independent_blocks=True), None)
+        want_stream, want_plan = want
+        d_in = torch.from_numpy(np.ascontiguousarray(d)).cuda()
+        d_out = torch.full((H.capacity(H.MT, states, n),), 0x5A, dtype=torch.uint8, device="cuda")
+        m, dplan = gpu_ctx.encode_device(H.MT, states, bits, d_in, d_out, block_size=block, index_interval=interval, want_plan=True)
+        assert m == want_stream.size and np.array_equal(d_out[:m].cpu().numpy(), want_stream), (states, interval, n, block)
+        got_plan = gpu_ctx.read_device_plan(dplan)
+        if want_plan is None:
+            want_plan = H.plan_build(H.MT, states, bits, want_stream)
+        assert got_plan.size == want_plan.size and np.array_equal(got_plan, want_plan), (states, interval, n, block, int(np.argmax(got_plan[:want_plan.size] != want_plan)))
+        back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        gpu_ctx.decode_device(dplan, d_out, back, stream_length=m)
+        assert gpu_ctx.status(dplan) == 0 and torch.equal(back, d_in), (states, interval, n, block)
+
+
+def test_gpu_encode_decode_never_leaves_hbm_1gib(gpu_ctx):
+    """BASELINE config 4 shape: 2^30 bytes, 256 KiB blocks, checkpoints every 32 groups; encoder and decoder on the device."""
+    import torch
+    n = 1 << 30
+    g = torch.Generator(device="cuda").manual_seed(7)
+    # Zipf-ish bytes made on the device (the host generator would dominate the test's run time)
+    u = torch.rand(n, device="cuda", generator=g)
+    d_in = (u.pow_(6).mul_(205)).to(torch.uint8)
+    del u
+    d_out = torch.empty(H.capacity(H.MT, 64, n), dtype=torch.uint8, device="cuda")
+    m, dplan = gpu_ctx.encode_device(H.MT, 64, 11, d_in, d_out, block_size=1 << 18, index_interval=32, want_plan=True)
+    assert 0.3 * n < m < 0.9 * n
+    back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    gpu_ctx.decode_device(dplan, d_out, back, stream_length=m)
+    assert gpu_ctx.status(dplan) == 0 and torch.equal(back, d_in)
+    # the stream alone (no sidecar) decodes too: device walk of the block headers
+    dplan2 = gpu_ctx.make_device_plan_from_stream(H.MT, 64, 11, d_out, m, n)
+    back.zero_()
+    gpu_ctx.decode_device(dplan2, d_out, back, stream_length=m)
+    assert gpu_ctx.status(dplan2) == 0 and torch.equal(back, d_in)
+
+
 def test_gpu_encoder_round_trip_on_device_100mb(gpu_ctx):
     import torch
     n = 100_000_000
