@@ -31,8 +31,27 @@ for states, bits, block in ((64, 11, 1 << 16), (64, 11, 1 << 15), (64, 11, 1 << 
         ctx.encode_device(H.MT, states, bits, d_in, d_out, block_size=block)  # synchronises its stream
         ts.append(time.perf_counter() - t0)
     best, mean = min(ts), sum(ts) / len(ts)
+    # the same encode with the sidecar plan (checkpoint every 32 groups) built on the device, then the decode it enables
+    tp = []
+    for _ in range(max(2, args.reps // 2)):
+        t0 = time.perf_counter()
+        n2, dplan = ctx.encode_device(H.MT, states, bits, d_in, d_out, block_size=block, index_interval=32, want_plan=True)
+        tp.append(time.perf_counter() - t0)
+    back = torch.empty(d.size, dtype=torch.uint8, device="cuda")
+    ctx.decode_device(dplan, d_out, back, stream_length=n2)
+    torch.cuda.synchronize()
+    ok = n2 == n and ctx.status(dplan) == 0 and bool(torch.equal(back, d_in))
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(args.reps):
+        ctx.decode_device(dplan, d_out, back, stream_length=n2)
+    b.record()
+    torch.cuda.synchronize()
+    dec_ms = a.elapsed_time(b) / args.reps
     print(json.dumps({"codec": f"mt_ rANS32x{states} 16w {bits}", "block": block, "size": args.size, "stream": n, "ratio": round(n / args.size, 4),
-                      "ms_best": round(best * 1e3, 3), "ms_mean": round(mean * 1e3, 3), "GB_s_best": round(args.size / best / 1e9, 1)}))
+                      "ms_best": round(best * 1e3, 3), "ms_mean": round(mean * 1e3, 3), "GB_s_best": round(args.size / best / 1e9, 1),
+                      "with_plan_G32_ms_best": round(min(tp) * 1e3, 3), "decode_with_that_plan_ms": round(dec_ms, 4),
+                      "decode_MiB_s": round(args.size / 2**20 / (dec_ms * 1e-3)), "round_trip_bit_exact": ok}))
 
 if args.cpu_sample:
     # the same stream from the library's scalar host encoder (hsrans_encode_ex, 1 core): the CPU side of the comparison
