@@ -562,7 +562,7 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
     *out_dplan = nullptr;
   if (ctx == nullptr || container != HSRANS_MT || !valid_codec(container, states, bits) || d_in == nullptr || d_out == nullptr || length == 0)
     return 0;
-  if (block_size == 0 || block_size % 64 != 0 || index_interval % 4 != 0 || ((uintptr_t)d_in & 15) != 0 || ((uintptr_t)d_out & 15) != 0)
+  if (block_size == 0 || block_size % 64 != 0 || block_size > (1u << 30) || index_interval % 4 != 0 || ((uintptr_t)d_in & 15) != 0 || ((uintptr_t)d_out & 15) != 0)
     return 0;
   if (out_capacity < capacity(container, states, length)) // same contract as the host encoders
     return 0;

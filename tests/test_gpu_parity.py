@@ -272,7 +272,7 @@ def test_gpu_encoder_matches_host_encoder(gpu_ctx, oracle, zipf, nonstat, states
     runs = np.concatenate([np.full(70_000, 7, np.uint8), zipf[:100_000], np.full(200_000, 200, np.uint8), zipf[:33]])
     for src, n, block in ((zipf, 1, 64), (zipf, 63, 64), (zipf, 64, 64), (zipf, 65, 64), (zipf, 100_000, 4096), (zipf, 4096 + 17, 4096), (zipf, 65536, 65536),
                           (zipf, 65536 + 31, 65536), (zipf, 65536 + 64, 65536), (zipf, 300_001, 32768), (zipf, 8192 + 5, 8192), (zipf, 12288 + 64 + 3, 65536), (zipf, 3 * 4096 + 130, 1 << 20), (nonstat, 3_000_000, 65536),
-                          (nonstat, 1_000_003, 1 << 18), (runs, runs.size, 4096), (runs, runs.size, 65536)):
+                          (nonstat, 1_000_003, 1 << 18), (runs, runs.size, 4096), (runs, runs.size, 65536), (nonstat, 3_000_000, 1 << 21), (zipf, 500_000, 192 * 64)):
         d = src[:n]
         want = H.encode(H.MT, states, bits, d, block_size=block, independent_blocks=True)
         got, _ = _gpu_encode(gpu_ctx, states, bits, d, block)
