@@ -780,7 +780,14 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
   Ring ra, rb;
   ring_bind(ra, c.rings, 8);
   ring_bind(rb, c.rings + 1152, 8);
-  const uint32_t q0 = pa.static_per_wave; // chains per static run; host guarantees 2 * W * q0 <= n_chains
+  // static runs of this wave: two of run_len[class] chains each (PersistentArgs::run_len; host guarantees static_total <= n_chains)
+  const uint32_t wave_in_wg = w % waves, blk = w / waves;
+  const uint32_t first_half = (gridDim.x + 1) / 2;
+  const uint32_t half = blk >= first_half ? 1 : 0;
+  const uint32_t per_class = waves >= 4 ? waves / 4 : 1;
+  const uint32_t cls = half * 4 + wave_in_wg / per_class;
+  const uint32_t q0 = pa.run_len[cls];
+  const uint32_t c_first = pa.half_base[half] + (blk - half * first_half) * pa.wg_chains[half] + pa.class_off[cls] + (wave_in_wg % per_class) * 2 * q0;
   const bool host_table = MODE == kModePack64 && pa.table != nullptr;
   if (!host_table)
     build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
@@ -847,7 +854,7 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
       atomicOr(c.status, kStatusBadHist);
   }
   if (q0 != 0)
-    run(2 * w * q0, 2 * w * q0 + q0, 2 * w * q0 + 2 * q0, host_table);
+    run(c_first, c_first + q0, c_first + 2 * q0, host_table);
   else if (host_table)
   {
     const uint32_t entries = 1u << c.bits;
@@ -856,7 +863,7 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
     __syncthreads();
   }
 
-  const uint32_t dyn0 = 2 * W * q0;
+  const uint32_t dyn0 = pa.static_total;
   const uint64_t D = pa.n_chains - dyn0;
   const uint32_t k = w & (kDynQueues - 1);
   const uint32_t lo = dyn0 + (uint32_t)(k * D / kDynQueues), hi = dyn0 + (uint32_t)((k + 1) * D / kDynQueues);
@@ -1304,15 +1311,16 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
     // (second half of the grid) * 4 + wave / 4; uniform unless the workgroup has 16 waves.
     const uint32_t first_half = (grid + 1) / 2, second_half = grid - first_half;
     const uint32_t per_class = waves >= 4 ? waves / 4 : 1, classes = waves / per_class;
+    const uint32_t runs_per_wave = h.states == 32 ? 2 : 1; // run_persistent_pair decodes two runs side by side
     for (uint32_t hf = 0; hf < 2; hf++)
     {
       uint32_t off = 0;
       for (uint32_t k = 0; k < 4; k++)
       {
         const uint32_t wt = waves == 16 && !two_level ? g_slot_weights[hf * 4 + k] : 1000;
-        kp.pa.run_len[hf * 4 + k] = k < classes ? (uint32_t)((uint64_t)h.n_chains * g_static_percent / 100 * wt / (1000 * W)) : 0;
+        kp.pa.run_len[hf * 4 + k] = k < classes ? (uint32_t)((uint64_t)h.n_chains * g_static_percent / 100 * wt / (1000 * W * runs_per_wave)) : 0;
         kp.pa.class_off[hf * 4 + k] = off;
-        off += kp.pa.run_len[hf * 4 + k] * per_class;
+        off += kp.pa.run_len[hf * 4 + k] * per_class * runs_per_wave;
       }
       kp.pa.wg_chains[hf] = off;
     }
