@@ -354,3 +354,74 @@ def test_gpu_encoder_rejects_bad_arguments(gpu_ctx, zipf):
             gpu_ctx.encode_device(a["container"], a["states"], a["bits"], d_in, d_out, block_size=a["block_size"])
     with pytest.raises(H.HsransError):
         gpu_ctx.encode_device(H.MT, 64, 11, d_in, d_out[:1000], block_size=1024)  # capacity contract
+
+
+# ---- seeded random sweep over the whole configuration space ---------------------------------------------------------------
+def _random_case(rng, zipf, nonstat):
+    kind = rng.integers(0, 4)
+    n = int(np.exp(rng.uniform(np.log(63), np.log(400_000))))
+    if kind == 0:
+        off = int(rng.integers(0, zipf.size - n))
+        d = zipf[off:off + n]
+    elif kind == 1:
+        off = int(rng.integers(0, nonstat.size - n))
+        d = nonstat[off:off + n]
+    elif kind == 2:
+        d = synth.uniform_bytes(n, seed=int(rng.integers(1, 1 << 30)))
+    else:
+        d = synth.two_symbol(n, seed=int(rng.integers(1, 1 << 30)))
+    return np.ascontiguousarray(d)
+
+
+def test_random_sweep_decode(gpu_ctx, oracle, zipf, nonstat):
+    rng = np.random.default_rng(20241008)
+    for case in range(160):
+        container = int(rng.integers(0, 3))
+        states = int(rng.choice((32, 64)))
+        bits = int(rng.integers(10, 16))
+        d = _random_case(rng, zipf, nonstat)
+        n = d.size
+        interval = int(rng.choice((0, 4, 8, 32, 100, 1024)))
+        block = int(rng.choice((0, 32768, 65536))) if container != RAW else 0  # capacity() is sized for blocks >= 32 KiB
+        tag = (case, container, states, bits, n, interval, block)
+        if interval:
+            s, plan = H.encode(container, states, bits, d, index_interval=interval, block_size=block)
+        else:
+            s, plan = (H.encode(container, states, bits, d, block_size=block) if block else H.encode(container, states, bits, d)), None
+        r0, want = oracle.decode(container, states, bits, s, n)
+        if r0 == 0:  # the reference cannot decode its own one-symbol block_/mt_ files (tests/test_oracle_vs_ref.py): neither do we
+            assert container != RAW and np.unique(d).size == 1, tag
+            assert gpu_ctx.decode_host(container, states, bits, s, n)[0] == 0, tag
+            continue
+        assert r0 == n and np.array_equal(want, d), tag
+        r, got = gpu_ctx.decode_host(container, states, bits, s, n, plan=plan)
+        assert r == n and np.array_equal(got, want), tag + (int(np.argmax(got != want)),)
+        if container != BLOCK and n >= 4096 and case % 4 == 0:  # checkpoints recovered from the stream alone by a GPU pass
+            plan2 = gpu_ctx.index_build(container, states, bits, s, 8)
+            r, got = gpu_ctx.decode_host(container, states, bits, s, n, plan=plan2)
+            assert r == n and np.array_equal(got, want), tag
+
+
+def test_random_sweep_gpu_encoder(gpu_ctx, oracle, zipf, nonstat):
+    import torch
+    rng = np.random.default_rng(7)
+    for case in range(60):
+        states = int(rng.choice((32, 64)))
+        bits = int(rng.integers(10, 16))
+        d = _random_case(rng, zipf, nonstat)
+        n = d.size
+        block = int(rng.choice((32768, 65536, 1 << 17)))  # capacity() is sized for blocks >= 32 KiB
+        interval = int(rng.choice((0, 4, 16, 64)))
+        tag = (case, states, bits, n, block, interval)
+        d_in = torch.from_numpy(d).cuda()
+        d_out = torch.empty(H.capacity(H.MT, states, n), dtype=torch.uint8, device="cuda")
+        m, dplan = gpu_ctx.encode_device(H.MT, states, bits, d_in, d_out, block_size=block, index_interval=interval, want_plan=True)
+        stream = d_out[:m].cpu().numpy()
+        want = H.encode(H.MT, states, bits, d, block_size=block, independent_blocks=True)
+        assert np.array_equal(stream, want), tag
+        if n >= states - 1 and np.unique(d).size > 1:  # (one-symbol files: the reference rejects its own streams)
+            r, back = oracle.decode(MT, states, bits, stream, n)
+            assert r == n and np.array_equal(back, d), tag
+        back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        gpu_ctx.decode_device(dplan, d_out, back, stream_length=m)
+        assert gpu_ctx.status(dplan) == 0 and torch.equal(back, d_in), tag

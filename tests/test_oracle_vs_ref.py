@@ -45,6 +45,24 @@ def test_containers_including_quirk_lengths(oracle, ref, data, container, states
             assert r1 == r2 and np.array_equal(o1, o2), (container, states, bits, n)
 
 
+@pytest.mark.parametrize("container", (BLOCK, MT))
+def test_one_symbol_files_do_not_round_trip_in_the_reference(oracle, ref, container):
+    """Reference quirk: a file of ONE repeated byte encodes to a lone single-symbol block (280 / 24 bytes), which the
+    reference's own decoders reject because every stream must be at least 16 + 4*S + 512 bytes long
+    (block_rANS32x64_16w_decode.cpp:15-32, mt_rANS32x64_16w_decode.cpp:15-32).  The product encoder writes the same bytes,
+    the oracle returns the same 0."""
+    import hypersonic_rans_amd as H
+    for n in (1000, 65536, 67230, 200_000):
+        d = np.full(n, 77, np.uint8)
+        s = ref.encode(container, 64, 11, d)
+        mine = H.encode(container, 64, 11, d)
+        assert np.array_equal(s, mine) and s.size == (280 if container == BLOCK else 24)
+        assert ref.decode(container, 64, 11, s, n)[0] == 0
+        assert oracle.decode(container, 64, 11, s, n)[0] == 0
+        with pytest.raises(H.HsransError):
+            H.plan_build(container, 64, 11, s)
+
+
 def test_error_returns(oracle, ref, data):
     zipf, _ = data
     d = zipf[:5000]
