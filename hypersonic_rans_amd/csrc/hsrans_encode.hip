@@ -47,7 +47,6 @@ struct __attribute__((packed, aligned(2))) U32a2
 
 struct WaveLds
 {
-  uint32_t scaled[256]; // normalised counts
   uint32_t order[256];  // count << 8 | symbol in heap-sort order
   uint4 table[256];     // {x_max, bias, rcp, cmpl | shift << 24}
   uint8_t stage[kRing]; // (table and stage double as the kSubHists histogram copies before the table exists)
@@ -143,30 +142,30 @@ __device__ __forceinline__ void heap_build_level(Heap &h, uint32_t first, uint32
     heap_sift<LEVEL>(h, i, 256, heap_get<LEVEL>(h, i));
 }
 
-// moves the maximum to node i (on level LEVEL) and re-heapifies nodes [0, i); false = every remaining count is < 2
+// moves the maximum to node i (on level LEVEL), re-heapifies nodes [0, i) and returns the maximum (count << 8 | symbol)
 template <int LEVEL>
-__device__ __forceinline__ bool heap_extract(Heap &h, uint32_t i)
+__device__ __forceinline__ uint32_t heap_extract(Heap &h, uint32_t i)
 {
   const uint32_t top = __builtin_amdgcn_readlane(h.A, 0);
-  if ((top >> 8) < 2)
-    return false;
   const uint32_t last = heap_get<LEVEL>(h, i);
   heap_set<LEVEL>(h, i, top);
   heap_sift<0>(h, 0, i, last);
-  return true;
+  return top;
 }
 
-// Sorts (as far as needed) and returns `lo`, the number of symbols with count < 2: sorted positions [lo, 256) are in
-// L.order afterwards.  Positions below lo are never looked at by the adjustment (first_at_least_two, hist.cpp), which
-// is why the extraction may stop as soon as the heap's maximum is < 2.
-__device__ __forceinline__ uint32_t heap_sort_counts(WaveLds &L, uint32_t lane)
+__device__ __forceinline__ uint32_t ballot_count(bool pred) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pred)); }
+
+// Heap sort of L.order (count << 8 | symbol) as far as the adjustment needs it: the `take` largest entries in the order
+// the reference's sort puts them at the top of its array.  Returns, per lane, a 4-bit mask of its symbols (4 * lane + k)
+// that are among them.
+__device__ __forceinline__ uint32_t heap_take_largest(const WaveLds &L, uint32_t lane, uint32_t take)
 {
   Heap h;
   h.A = L.order[lane < 63 ? lane : 62];
   h.B = L.order[63 + lane];
   h.C = L.order[127 + lane];
-  h.D = L.order[lane < 64 ? (191 + lane > 255 ? 255 : 191 + lane) : 255];
-  h.E = __builtin_amdgcn_readlane(h.D, 63) * 0 + __builtin_amdgcn_readfirstlane(L.order[255]);
+  h.D = L.order[191 + lane < 255 ? 191 + lane : 254];
+  h.E = __builtin_amdgcn_readfirstlane(L.order[255]);
   heap_sift<7>(h, 127, 256, heap_get<7>(h, 127)); // the only level-7 node with a child
   heap_build_level<6>(h, 63, 126);
   heap_build_level<5>(h, 31, 62);
@@ -175,92 +174,74 @@ __device__ __forceinline__ uint32_t heap_sort_counts(WaveLds &L, uint32_t lane)
   heap_build_level<2>(h, 3, 6);
   heap_build_level<1>(h, 1, 2);
   heap_build_level<0>(h, 0, 0);
-  uint32_t lo = 0;
-  bool more = heap_extract<8>(h, 255);
-  if (!more)
-    lo = 256;
-  for (uint32_t i = 254; more && i >= 191; i--)
-    if (!(more = heap_extract<7>(h, i)))
-      lo = i + 1;
-  for (uint32_t i = 190; more && i >= 127; i--)
-    if (!(more = heap_extract<7>(h, i)))
-      lo = i + 1;
-  for (uint32_t i = 126; more && i >= 63; i--)
-    if (!(more = heap_extract<6>(h, i)))
-      lo = i + 1;
-  for (uint32_t i = 62; more && i >= 1; i--)
-    if (!(more = heap_extract<5>(h, i)))
-      lo = i + 1;
-  if (more)
-    lo = (__builtin_amdgcn_readlane(h.A, 0) >> 8) < 2 ? 1 : 0;
-  wave_sync();
-  if (lane < 63)
-    L.order[lane] = h.A;
-  L.order[63 + lane] = h.B;
-  L.order[127 + lane] = h.C;
-  L.order[191 + lane] = h.D; // lane 63 writes node 255's slot with a stale value, fixed next
-  wave_sync();
-  if (lane == 0)
-    L.order[255] = h.E;
-  wave_sync();
-  return lo;
+  uint32_t taken = 0;
+  auto mark = [&](uint32_t top) {
+    const uint32_t sym = top & 0xFF;
+    taken |= lane == (sym >> 2) ? 1u << (sym & 3) : 0;
+    take--;
+  };
+  if (take != 0)
+    mark(heap_extract<8>(h, 255));
+  for (uint32_t i = 254; take != 0 && i >= 191; i--)
+    mark(heap_extract<7>(h, i));
+  for (uint32_t i = 190; take != 0 && i >= 127; i--)
+    mark(heap_extract<7>(h, i));
+  for (uint32_t i = 126; take != 0 && i >= 63; i--)
+    mark(heap_extract<6>(h, i));
+  for (uint32_t i = 62; take != 0 && i >= 1; i--)
+    mark(heap_extract<5>(h, i));
+  if (take != 0)
+    mark(__builtin_amdgcn_readlane(h.A, 0));
+  return taken;
 }
 
-__device__ __forceinline__ uint32_t ballot_count(bool pred) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pred)); }
-
-// the reference's "steal" / "charity" passes over the sorted symbols (hist.cpp; hsrans_host.cpp normalize_counts), four
-// sorted positions per lane: a pass changes every position of [lo, 256) by one, the last pass only as many as are missing
-__device__ __forceinline__ void adjust_counts(WaveLds &L, uint32_t lane, uint32_t lo, uint32_t sum, uint32_t target)
+// The reference's fix-up of the scaled counts (hist.cpp:103-199; hsrans_host.cpp normalize_counts).  It sorts the symbols
+// by count (heap sort) and then runs "steal" passes (sum too large: every symbol with count >= 2 gives one, smallest
+// first, until the sum fits) or "charity" passes (sum too small: every symbol with count >= 2 gets one, largest first).
+// Only the LAST pass depends on the order, and only through which symbols are on which side of one cut in the sorted
+// array; everything else follows from the counts alone:
+//   steal:   pass j takes one from every symbol with original count >= j + 1 (m_j of them) while more than m_j are still
+//            missing; the final pass J takes from the e_J smallest of those m_J, i.e. from all of them except the
+//            m_J - e_J largest of the sort;
+//   charity: the symbols with count >= 2 (m of them, their number never changes) each get F = (e - 1) / m, then the
+//            e - F * m largest of the sort get one more.
+// So the heap sort only has to deliver its largest few entries (heap_take_largest), in exactly the order the reference's
+// sort would put them (ties!).  Counts stay in registers: sc[k] is symbol 4 * lane + k.
+__device__ __forceinline__ void adjust_counts(const WaveLds &L, uint32_t lane, uint32_t (&sc)[4], uint32_t sum, uint32_t target)
 {
-  uint32_t id[4], key[4];
-  for (uint32_t k = 0; k < 4; k++)
-  {
-    const uint32_t o = L.order[lane * 4 + k];
-    id[k] = o & 0xFF;
-    key[k] = o >> 8;
-  }
-  const uint32_t lo0 = lo;
-  auto next_lo = [&](uint32_t from) { // first position >= from whose count is >= 2, `from` when there is none
-    uint32_t small = 0;
+  auto count_ge = [&](uint32_t t) {
+    uint32_t n = 0;
     for (uint32_t k = 0; k < 4; k++)
-      small += ballot_count(lane * 4 + k >= from && key[k] < 2);
-    return from + small < 256 ? from + small : from;
+      n += ballot_count(sc[k] >= t);
+    return n;
   };
+  const uint32_t m = count_ge(2); // >= 1: 256 counts <= 1 cannot come from counts that scale to 2^bits >= 1024
   if (sum > target)
   {
-    uint32_t e = sum - target;
-    while (true)
+    uint32_t e = sum - target, j = 1, mj = m;
+    while (e > mj) // terminates: the symbols can give sum - 256 > e in total
     {
-      const uint32_t m = 256 - lo;
-      const uint32_t upto = e <= m ? lo + e : 256;
-      for (uint32_t k = 0; k < 4; k++)
-        if (lane * 4 + k >= lo && lane * 4 + k < upto)
-          key[k]--;
-      if (e <= m)
-        break;
-      e -= m;
-      lo = next_lo(lo);
+      e -= mj;
+      j++;
+      mj = count_ge(j + 1);
+    }
+    const uint32_t spared = heap_take_largest(L, lane, mj - e);
+    for (uint32_t k = 0; k < 4; k++)
+    {
+      const uint32_t c = sc[k];
+      uint32_t give = c >= 2 ? (c - 1 < j - 1 ? c - 1 : j - 1) : 0;
+      give += c >= j + 1 && !((spared >> k) & 1) ? 1 : 0;
+      sc[k] = c - give;
     }
   }
   else
   {
-    uint32_t e = target - sum;
-    while (true)
-    {
-      const uint32_t m = 256 - lo;
-      const uint32_t from = e <= m ? 256 - e : lo;
-      for (uint32_t k = 0; k < 4; k++)
-        if (lane * 4 + k >= from)
-          key[k]++;
-      if (e <= m)
-        break;
-      e -= m;
-      lo = next_lo(lo);
-    }
+    const uint32_t e = target - sum;
+    const uint32_t full = (e - 1) / m;
+    const uint32_t lucky = heap_take_largest(L, lane, e - full * m);
+    for (uint32_t k = 0; k < 4; k++)
+      sc[k] += (sc[k] >= 2 ? full : 0) + ((lucky >> k) & 1);
   }
-  for (uint32_t k = 0; k < 4; k++)
-    if (lane * 4 + k >= lo0)
-      L.scaled[id[k]] = key[k];
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
@@ -430,22 +411,14 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
       c = 1;
     sc[k] = c;
     part += c;
-    L.scaled[lane * 4 + k] = c;
     L.order[lane * 4 + k] = (c << 8) | (lane * 4 + k);
   }
   const uint32_t sum = wave_sum(part);
   wave_sync();
   if (sum != target)
   {
-    const uint32_t lo = heap_sort_counts(L, lane);
-    adjust_counts(L, lane, lo, sum, target);
-    wave_sync();
-    part = 0;
-    for (uint32_t k = 0; k < 4; k++)
-    {
-      sc[k] = L.scaled[lane * 4 + k];
-      part += sc[k];
-    }
+    adjust_counts(L, lane, sc, sum, target);
+    part = sc[0] + sc[1] + sc[2] + sc[3];
   }
   // exclusive prefix over the 256 counts: lane-local then across lanes
   uint32_t incl = part;
