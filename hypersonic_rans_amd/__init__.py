@@ -21,9 +21,10 @@ from .api import (  # noqa: F401
     plan_chain_range,
     plan_decoded_length,
     plan_slice,
+    plan_stream_ranges,
 )
 
 __all__ = [
     "RAW", "BLOCK", "MT", "Context", "HsransError", "capacity", "encode", "make_hist", "plan_build", "plan_chain_count",
-    "plan_chain_range", "plan_decoded_length", "plan_slice", "lib_path", "load_library",
+    "plan_chain_range", "plan_decoded_length", "plan_slice", "plan_stream_ranges", "lib_path", "load_library",
 ]

@@ -73,6 +73,8 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_plan_decoded_length.argtypes = [_vp, _sz]
     L.hsrans_plan_slice.restype = _sz
     L.hsrans_plan_slice.argtypes = [_vp, _sz, _u32, _u32, _vp, _sz]
+    L.hsrans_plan_stream_ranges.restype = _i
+    L.hsrans_plan_stream_ranges.argtypes = [_vp, _sz, _u32, _u32, ctypes.POINTER(ctypes.c_uint64)]
     L.hsrans_plan_chain_range.restype = _i
     L.hsrans_plan_chain_range.argtypes = [_vp, _sz, _u32, _u32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     L.hsrans_ctx_create.restype = _i
@@ -206,6 +208,15 @@ def plan_chain_range(plan, first: int, count: int) -> tuple[int, int]:
     if load_library().hsrans_plan_chain_range(_p(plan), plan.size, first, count, ctypes.byref(b), ctypes.byref(e)) != 0:
         raise HsransError("plan_chain_range failed")
     return b.value, e.value
+
+
+def plan_stream_ranges(plan, first: int, count: int) -> tuple[tuple[int, int], tuple[int, int]]:
+    """((head_begin, head_end), (body_begin, body_end)): the stream bytes chains [first, first+count) can read."""
+    plan = _u8(plan)
+    r = (ctypes.c_uint64 * 4)()
+    if load_library().hsrans_plan_stream_ranges(_p(plan), plan.size, first, count, r) != 0:
+        raise HsransError("plan_stream_ranges failed")
+    return (r[0], r[1]), (r[2], r[3])
 
 
 PIECE_DTYPE = np.dtype([("words_off", "<u8"), ("out_off", "<u8"), ("hist_off", "<u8"), ("fill_len", "<u8"), ("steps", "<u4"),

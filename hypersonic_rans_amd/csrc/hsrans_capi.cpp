@@ -154,6 +154,13 @@ int hsrans_plan_chain_range(const uint8_t *plan, size_t plan_size, uint32_t firs
   return plan_chain_range(plan, plan_size, first_chain, chain_count, begin, end) ? HSRANS_OK : HSRANS_E_FORMAT;
 }
 
+int hsrans_plan_stream_ranges(const uint8_t *plan, size_t plan_size, uint32_t first_chain, uint32_t chain_count, uint64_t ranges[4])
+{
+  if (ranges == nullptr)
+    return HSRANS_E_ARG;
+  return plan_stream_ranges(plan, plan_size, first_chain, chain_count, ranges) ? HSRANS_OK : HSRANS_E_FORMAT;
+}
+
 // ---- GPU side ---------------------------------------------------------------------------------------------------
 int hsrans_ctx_create(int device, hsrans_ctx **out_ctx)
 {

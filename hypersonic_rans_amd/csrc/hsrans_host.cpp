@@ -988,4 +988,49 @@ bool plan_chain_range(const uint8_t *plan, size_t size, uint32_t first, uint32_t
   return true;
 }
 
+// Stream bytes the chains [first, first + count) can touch: `head` = the histogram every chain shares (shared_hist
+// plans: raw streams), `body` = from the first of their own histograms / words to where the next chain's data starts (the
+// kernels never request stream bytes beyond the next chain's first word).  Chains are in stream order in every plan this
+// library builds.
+bool plan_stream_ranges(const uint8_t *plan, size_t size, uint32_t first, uint32_t count, uint64_t out[4])
+{
+  if (plan == nullptr || size < sizeof(PlanHeader))
+    return false;
+  PlanHeader h;
+  memcpy(&h, plan, sizeof(h));
+  if (memcmp(h.magic, "HSRPLAN1", 8) != 0 || (h.flags & kPlanWalk) || count == 0 || first >= h.n_chains || count > h.n_chains - first)
+    return false;
+  if (plan_size(h.n_chains, h.n_pieces, h.states, h.flags) != size)
+    return false;
+  const uint32_t *cf = (const uint32_t *)(plan + plan_chain_first_off());
+  const Piece *pc = (const Piece *)(plan + plan_pieces_off(h.n_chains));
+  uint64_t lo = ~(uint64_t)0, hi = 0;
+  bool any = false;
+  for (uint32_t i = cf[first]; i < cf[first + count]; i++)
+  {
+    if (pc[i].flags & kPieceFill)
+      continue;
+    any = true;
+    lo = std::min(lo, pc[i].words_off);
+    if (!h.shared_hist)
+      lo = std::min(lo, pc[i].hist_off);
+    hi = std::max(hi, pc[i].words_off);
+  }
+  // the end: the first word of the next chain that has words, or the end of the stream
+  uint64_t next = h.stream_len;
+  for (uint32_t i = cf[first + count]; i < h.n_pieces; i++)
+    if (!(pc[i].flags & kPieceFill))
+    {
+      next = pc[i].words_off;
+      break;
+    }
+  out[0] = 0;
+  out[1] = h.shared_hist && any ? h.aux_off + 512 : 0;
+  out[2] = any ? lo : 0;
+  out[3] = any ? std::max(hi, next) : 0;
+  if (out[3] > h.stream_len || out[1] > h.stream_len)
+    return false;
+  return true;
+}
+
 } // namespace hsrans

@@ -52,6 +52,7 @@ size_t plan_build(int container, int states, uint32_t bits, const uint8_t *strea
 bool plan_validate(const uint8_t *plan, size_t plan_size, uint64_t stream_len, uint64_t out_cap);
 size_t plan_slice(const uint8_t *plan, size_t plan_size, uint32_t first, uint32_t count, uint8_t *out, size_t cap);
 bool plan_chain_range(const uint8_t *plan, size_t plan_size, uint32_t first, uint32_t count, uint64_t *begin, uint64_t *end);
+bool plan_stream_ranges(const uint8_t *plan, size_t plan_size, uint32_t first, uint32_t count, uint64_t out[4]);
 size_t plan_capacity(int container, int states, size_t decoded_size, uint32_t interval, uint32_t block_size);
 
 } // namespace hsrans

@@ -72,3 +72,47 @@ def decode_sharded(ctx: "api.Context", d_stream: torch.Tensor, stream_length: in
         if ctx.status(dplan) != 0:
             raise api.HsransError("device reported a malformed histogram / block header")
     return gather_ranges(out, ranges, group) if gather else out
+
+
+def upload_slice(host_stream: np.ndarray, plan, first: int, count: int, device, side_stream: "torch.cuda.Stream | None" = None) -> torch.Tensor:
+    """Rank-local view of the compressed stream: a device buffer of the stream's full length in which only the bytes chains
+    [first, first+count) can read are filled (hsrans_plan_stream_ranges) — so a rank's host-to-device traffic is its share of
+    the stream, not the whole stream.  The copies go through `side_stream` when given (overlap with a running decode)."""
+    host_stream = np.ascontiguousarray(host_stream, dtype=np.uint8)
+    pad = (-host_stream.size) % 16
+    d = torch.empty(host_stream.size + pad, dtype=torch.uint8, device=device)
+    if count == 0:
+        return d
+    ctx = torch.cuda.stream(side_stream) if side_stream is not None else None
+    if ctx is not None:
+        ctx.__enter__()
+    try:
+        for lo, hi in api.plan_stream_ranges(plan, first, count):
+            if hi > lo:
+                d[lo:hi].copy_(torch.from_numpy(host_stream[lo:hi]), non_blocking=True)
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    return d
+
+
+def decode_sharded_from_host(ctx: "api.Context", host_stream: np.ndarray, plan, gather: bool = True, group=None) -> torch.Tensor:
+    """BASELINE config 4/5 shape: the stream lives in host memory on every rank, each rank uploads only the slice its chains
+    read (on a side stream), decodes its chains, and the decoded ranges are exchanged with one all_gather."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    runs = shard_chains(plan, world)
+    ranges = [local_range(plan, f, c) for f, c in runs]
+    total = api.plan_decoded_length(plan)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    side = torch.cuda.Stream(device=dev)
+    first, count = runs[rank]
+    d_stream = upload_slice(host_stream, plan, first, count, dev, side)
+    out = torch.zeros(total, dtype=torch.uint8, device=dev)
+    if count:
+        dplan = ctx.make_device_plan(api.plan_slice(plan, first, count))
+        torch.cuda.current_stream(dev).wait_stream(side)
+        ctx.decode_device(dplan, d_stream, out, stream_length=int(np.asarray(host_stream).size))
+        if ctx.status(dplan) != 0:
+            raise api.HsransError("device reported a malformed histogram / block header")
+    return gather_ranges(out, ranges, group) if gather else out

@@ -93,6 +93,10 @@ uint64_t hsrans_plan_decoded_length(const uint8_t *plan, size_t plan_size);
 size_t hsrans_plan_slice(const uint8_t *plan, size_t plan_size, uint32_t first_chain, uint32_t chain_count, uint8_t *out, size_t out_capacity);
 /* output byte range [*begin, *end) covered by chains [first, first+count) */
 int hsrans_plan_chain_range(const uint8_t *plan, size_t plan_size, uint32_t first_chain, uint32_t chain_count, uint64_t *begin, uint64_t *end);
+/* stream byte ranges chains [first, first+count) can read: ranges = {head_begin, head_end, body_begin, body_end}; head is the
+ * shared histogram of a raw stream (empty otherwise), body the chains' own headers and words up to the next chain's first
+ * word.  A rank that decodes only these chains needs only these bytes of the stream in its HBM (at their stream offsets). */
+int hsrans_plan_stream_ranges(const uint8_t *plan, size_t plan_size, uint32_t first_chain, uint32_t chain_count, uint64_t ranges[4]);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GPU side

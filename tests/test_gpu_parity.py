@@ -155,6 +155,26 @@ def test_full_size_100mb_round_trip(gpu_ctx, bits):
     assert r == m and np.array_equal(got1, data[:m])
 
 
+def test_slice_upload_is_enough_for_a_slice(gpu_ctx, zipf, nonstat):
+    """A rank that holds only hsrans_plan_stream_ranges of the stream (junk elsewhere) decodes its chains correctly."""
+    import torch
+    from hypersonic_rans_amd import sharded
+    for container, src in ((H.RAW, zipf), (H.MT, nonstat[:1_500_000]), (H.BLOCK, nonstat[:1_500_000])):
+        d = src
+        stream, plan = H.encode(container, 64, 11, d, index_interval=32, block_size=0 if container == H.RAW else 65536)
+        runs = sharded.shard_chains(plan, 3)
+        out = torch.zeros(d.size, dtype=torch.uint8, device="cuda")
+        for first, count in runs:
+            d_stream = sharded.upload_slice(stream, plan, first, count, torch.device("cuda"))
+            junk = torch.full_like(d_stream, 0xEE)
+            for lo, hi in H.plan_stream_ranges(plan, first, count):
+                junk[lo:hi] = d_stream[lo:hi]
+            dplan = gpu_ctx.make_device_plan(H.plan_slice(plan, first, count))
+            gpu_ctx.decode_device(dplan, junk, out, stream_length=stream.size)
+            assert gpu_ctx.status(dplan) == 0
+        assert torch.equal(out.cpu(), torch.from_numpy(d)), container
+
+
 def test_sharded_decode_single_rank(gpu_ctx, zipf):
     """decode_sharded with a world of one rank (the N>1 host logic runs on CPU under gloo in tests/test_sharded_gloo.py)."""
     import os
@@ -173,6 +193,8 @@ def test_sharded_decode_single_rank(gpu_ctx, zipf):
             pad = (-s.size) % 16
             d_in = torch.from_numpy(np.concatenate([s, np.zeros(pad, np.uint8)])).cuda()
             out = sharded.decode_sharded(gpu_ctx, d_in, s.size, plan, gather=True)
+            assert np.array_equal(out.cpu().numpy(), zipf)
+            out = sharded.decode_sharded_from_host(gpu_ctx, s, plan, gather=True)  # stream in host memory, slice upload on a side stream
             assert np.array_equal(out.cpu().numpy(), zipf)
     finally:
         dist.destroy_process_group()

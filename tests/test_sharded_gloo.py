@@ -31,13 +31,19 @@ def _worker(rank, world, port, container, q):
         ranges = [sharded.local_range(plan, f, c) for f, c in runs]
         first, count = runs[rank]
         local = torch.zeros(data.size, dtype=torch.uint8)
+        upload = 0
         if count:
-            r, part = Oracle().exec_plan(H.plan_slice(plan, first, count), stream, data.size)
+            # the rank only "uploads" the stream bytes its chains can read (hsrans_plan_stream_ranges); everything else is junk
+            masked = np.full_like(stream, 0xEE)
+            for lo, hi in H.plan_stream_ranges(plan, first, count):
+                masked[lo:hi] = stream[lo:hi]
+                upload += hi - lo
+            r, part = Oracle().exec_plan(H.plan_slice(plan, first, count), masked, data.size)
             assert r == data.size
             b, e = ranges[rank]
             local[b:e] = torch.from_numpy(part[b:e].copy())
         full = sharded.gather_ranges(local, ranges)
-        q.put((rank, bool(np.array_equal(full.numpy(), data)), ranges))
+        q.put((rank, bool(np.array_equal(full.numpy(), data)), ranges, upload, stream.size))
     finally:
         dist.destroy_process_group()
 
@@ -55,6 +61,9 @@ def test_two_ranks_gather(container):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert all(ok for _, ok, _ in results)
+    assert all(r[1] for r in results)
+    # the two uploads together are the stream once — plus the shared histogram of a raw stream on both ranks, or the part of
+    # an mt_ block between its histogram and the checkpoint the second rank starts from — not twice
+    assert sum(r[3] for r in results) < 1.1 * results[0][4]
     ranges = results[0][2]
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == 700_003
