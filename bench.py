@@ -236,6 +236,25 @@ def main() -> None:
             result["single_wavefront_no_plan"] = {"value": n / 2**20 / (ms1 * 1e-3), "unit": "MiB/s", "ms": ms1, "bit_exact": True,
                                                   "note": "raw format has no restart points: 1 wave64 = 1 dependent chain"}
 
+        # the step before the path, informational: the same input through the GPU encoder (mt_ container,
+        # 64 KiB independent blocks, sidecar plan built on the device) and the decode that plan enables
+        if not args.no_single and world == 1:
+            d_enc = torch.empty(H.capacity(H.MT, S, n), dtype=torch.uint8, device=dev)
+            m, dplan_e = ctx.encode_device(H.MT, S, bits, d_ref, d_enc, block_size=1 << 16, index_interval=32, want_plan=True)  # warm-up
+            t0 = time.perf_counter()
+            m = ctx.encode_device(H.MT, S, bits, d_ref, d_enc, block_size=1 << 16)  # synchronises its stream
+            t_gpu_enc = time.perf_counter() - t0
+            d_out.zero_()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            ctx.decode_device(dplan_e, d_enc, d_out, stream_length=m)
+            b.record()
+            torch.cuda.synchronize()
+            assert ctx.status(dplan_e) == 0 and torch.equal(d_out, d_ref)
+            result["gpu_encoder"] = {"container": "mt_", "block_size": 1 << 16, "compressed_bytes": int(m), "encode_ms": t_gpu_enc * 1e3,
+                                     "encode_GB_s": n / t_gpu_enc / 1e9, "decode_with_device_built_plan_MiB_s": n / 2**20 / (a.elapsed_time(b) * 1e-3),
+                                     "round_trip_bit_exact": True}
+
     if rank == 0 and not args.no_cpu and world == 1:  # reported baseline, N=1 only
         result["cpu_baseline"] = cpu_baseline(stream, data, S, bits)
     if distributed:
