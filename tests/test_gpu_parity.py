@@ -175,6 +175,28 @@ def test_slice_upload_is_enough_for_a_slice(gpu_ctx, zipf, nonstat):
         assert torch.equal(out.cpu(), torch.from_numpy(d)), container
 
 
+def test_pipelined_host_decode(gpu_ctx, nonstat, zipf):
+    """Upload / decode / download overlapped over slices of the plan (pinned host buffers): same bytes as one decode."""
+    import torch
+    from hypersonic_rans_amd import pipeline
+    for container, d, kw in ((H.MT, nonstat, dict(block_size=65536, index_interval=32)), (H.RAW, zipf, dict(index_interval=64)),
+                             (H.MT, nonstat[:500_000], dict(block_size=65536))):
+        out = H.encode(container, 64, 11, d, **kw)
+        stream, plan = out if isinstance(out, tuple) else (out, H.plan_build(container, 64, 11, out))
+        host_stream = torch.from_numpy(stream).pin_memory()
+        host_out = torch.full((d.size,), 0xCC, dtype=torch.uint8).pin_memory()
+        for k in (1, 3, 8):
+            dec = pipeline.PipelinedHostDecoder(gpu_ctx, plan, n_slices=k)
+            host_out.fill_(0xCC)
+            dec.decode(host_stream, host_out)
+            assert np.array_equal(host_out.numpy(), d), (container, k)
+            dec.decode(host_stream, host_out)  # reusable
+            assert np.array_equal(host_out.numpy(), d), (container, k)
+        host_out.fill_(0xCC)
+        pipeline.decode_from_host_unpipelined(gpu_ctx, plan, host_stream, host_out)
+        assert np.array_equal(host_out.numpy(), d)
+
+
 def test_sharded_decode_single_rank(gpu_ctx, zipf):
     """decode_sharded with a world of one rank (the N>1 host logic runs on CPU under gloo in tests/test_sharded_gloo.py)."""
     import os
