@@ -26,6 +26,7 @@ constexpr uint32_t kWavesPerWG = 4;
 constexpr uint32_t kChunk = 4096;        // input bytes fetched per step of the rANS pass
 constexpr uint32_t kRing = 2 * kChunk;   // LDS staging ring: two chunks resident, a third on its way in registers
 constexpr uint32_t kSubHists = 8;        // histogram copies (lane & 7) that keep equal bytes of one load off one LDS address
+constexpr uint32_t kSubStride = 257;     // dwords between copies: copy c of symbol s sits in bank (c + s) % 32, not all in bank s % 32
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)); }
 __device__ __forceinline__ uint32_t enc_lane_to_byte(uint32_t j) { return (j & 0x23u) | ((j & 0x04u) << 2) | ((j & 0x18u) >> 1); }
@@ -51,7 +52,7 @@ struct WaveLds
   uint4 table[256];     // {x_max, bias, rcp, cmpl | shift << 24}
   uint8_t stage[kRing]; // (table and stage double as the kSubHists histogram copies before the table exists)
 };
-static_assert(sizeof(uint4) * 256 + kRing >= kSubHists * 256 * 4, "histogram copies must fit");
+static_assert(sizeof(uint4) * 256 + kRing >= kSubHists * kSubStride * 4, "histogram copies must fit");
 
 // ---- hist.cpp:16-215: the heap sort ---------------------------------------------------------------------------------
 // The reference sorts the symbols by count with a textbook heap sort; the order of EQUAL counts that sort happens to
@@ -340,10 +341,10 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
   const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
   // ---- byte histogram: kSubHists copies, copy = lane & 7 ----
   uint32_t *sub = (uint32_t *)L.table;
-  for (uint32_t k = 0; k < kSubHists * 4; k++)
-    sub[k * 64 + lane] = 0;
+  for (uint32_t k = lane; k < kSubHists * kSubStride; k += 64)
+    sub[k] = 0;
   wave_sync();
-  uint32_t *mine = sub + (lane & (kSubHists - 1)) * 256;
+  uint32_t *mine = sub + (lane & (kSubHists - 1)) * kSubStride;
   for (uint32_t off = lane * 16; off < size; off += 4096)
   {
     uint4 d[4];
@@ -370,13 +371,8 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
   wave_sync();
   uint32_t raw[4] = {0, 0, 0, 0};
   for (uint32_t c = 0; c < kSubHists; c++)
-  {
-    const uint4 v = *(const uint4 *)(sub + c * 256 + lane * 4);
-    raw[0] += v.x;
-    raw[1] += v.y;
-    raw[2] += v.z;
-    raw[3] += v.w;
-  }
+    for (uint32_t k = 0; k < 4; k++)
+      raw[k] += sub[c * kSubStride + lane * 4 + k];
   uint32_t present = 0;
   for (uint32_t k = 0; k < 4; k++)
     present += raw[k] != 0;
