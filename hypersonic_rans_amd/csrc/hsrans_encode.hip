@@ -284,7 +284,8 @@ __device__ __forceinline__ void chunk_to_lds(WaveLds &L, const Chunk &r, uint32_
 
 // one group, general form: lanes whose byte does not exist (the file's last, partial group) keep their state
 template <uint32_t S>
-__device__ __forceinline__ void encode_group_slow(uint32_t &x, const WaveLds &L, uint32_t group_off, uint32_t valid, uint8_t *&p, uint32_t lane, uint32_t byte_in_group)
+__device__ __forceinline__ void encode_group_slow(uint32_t &x, const WaveLds &L, uint32_t group_off, uint32_t valid, uint8_t *slot, uint32_t &p, uint32_t lane,
+                                                  uint32_t byte_in_group)
 {
   const bool active = lane < S && byte_in_group < valid;
   const uint32_t sym = L.stage[(group_off + byte_in_group) & (kRing - 1)];
@@ -296,7 +297,7 @@ __device__ __forceinline__ void encode_group_slow(uint32_t &x, const WaveLds &L,
   uint32_t v = x;
   if (emit)
   {
-    *(uint16_t *)(p + 2 * rank) = (uint16_t)x; // lane S-1's word goes last in memory (rANS32x64_16w.cpp:65-99)
+    *(uint16_t *)(slot + (p + 2 * rank)) = (uint16_t)x; // lane S-1's word goes last in memory (rANS32x64_16w.cpp:65-99)
     v = x >> 16;
   }
   const uint32_t q = __umulhi(v, e.z) >> (e.w >> 24);
@@ -307,7 +308,7 @@ __device__ __forceinline__ void encode_group_slow(uint32_t &x, const WaveLds &L,
 // one whole group with its table entries already in registers; lanes >= S (32-state codec) carry garbage states that
 // never emit
 template <uint32_t S>
-__device__ __forceinline__ void encode_group_fast(uint32_t &x, const uint4 &e, uint8_t *&p)
+__device__ __forceinline__ void encode_group_fast(uint32_t &x, const uint4 &e, uint8_t *slot, uint32_t &p) // p: byte offset of the lowest word written, from `slot`
 {
   const bool emit = S == 64 ? x >= e.x : (x >= e.x && lane_id() < 32);
   const unsigned long long mask = __builtin_amdgcn_ballot_w64(emit);
@@ -315,7 +316,7 @@ __device__ __forceinline__ void encode_group_fast(uint32_t &x, const uint4 &e, u
   p -= 2 * (uint32_t)__builtin_popcountll(mask);
   if (emit)
   {
-    *(uint16_t *)(p + 2 * rank) = (uint16_t)x;
+    *(uint16_t *)(slot + (p + 2 * rank)) = (uint16_t)x;
     x >>= 16;
   }
   const uint32_t q = __umulhi(x, e.z) >> (e.w >> 24);
@@ -459,7 +460,8 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
   const uint32_t n_chunks = (size + kChunk - 1) / kChunk;
   const uint32_t byte_in_group = enc_lane_to_byte(lane) & (S - 1);
   uint32_t x = 1u << 15;
-  uint8_t *p = slot_end;
+  uint8_t *slot = slot_end - ep.slot_bytes; // the block's scratch slot; words are written from its end downwards
+  uint32_t p = (uint32_t)ep.slot_bytes;     // byte offset (from `slot`) of the lowest word written so far
   chunk_to_lds(L, chunk_load(in, begin, end, n_chunks - 1, lane), n_chunks - 1, lane);
   if (n_chunks >= 2)
     chunk_to_lds(L, chunk_load(in, begin, end, n_chunks - 2, lane), n_chunks - 2, lane);
@@ -472,11 +474,11 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
   // group whole): the decoder's states and read cursor when it is about to start group gr
   const uint32_t whole_groups = size / S;
   auto checkpoint = [&](uint32_t gr) {
-    const uint64_t slot = (uint64_t)b * ep.max_ck + (gr / ep.interval - 1);
+    const uint64_t ck = (uint64_t)b * ep.max_ck + (gr / ep.interval - 1);
     if (lane < S)
-      ep.ck_states[slot * S + lane] = x;
+      ep.ck_states[ck * S + lane] = x;
     if (lane == 0)
-      ep.ck_pos[slot] = (uint32_t)(slot_end - p);
+      ep.ck_pos[ck] = (uint32_t)ep.slot_bytes - p;
   };
   if (lane == 0)
     ep.chain_count[b] = 1 + (ep.interval != 0 && whole_groups >= 1 ? (whole_groups - 1) / ep.interval : 0);
@@ -485,12 +487,12 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
   if (size % S != 0)               // only the file's last group can be partial
   {
     g--;
-    encode_group_slow<S>(x, L, g * S, size - g * S, p, lane, byte_in_group);
+    encode_group_slow<S>(x, L, g * S, size - g * S, slot, p, lane, byte_in_group);
   }
   while (g % 4 != 0)
   {
     g--;
-    encode_group_slow<S>(x, L, g * S, S, p, lane, byte_in_group);
+    encode_group_slow<S>(x, L, g * S, S, slot, p, lane, byte_in_group);
   }
 
   if (ep.interval != 0 && g != 0 && g % ep.interval == 0 && g < whole_groups)
@@ -513,7 +515,7 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
   auto code_set = [&](const uint4(&e)[4]) {
 #pragma unroll
     for (int k = 3; k >= 0; k--)
-      encode_group_fast<S>(x, e[k], p);
+      encode_group_fast<S>(x, e[k], slot, p);
   };
   auto chunk_finished = [&](uint32_t c) { // every group of chunk c is coded: its ring half takes the chunk two further down
     if (c < 2)
@@ -562,9 +564,9 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
     ep.stamps[b * 4 + 3] = t3;
   }
   // ---- block header in front of the words: [size u64][skip u64][states S x u32][counts 256 x u16] ----
-  const uint32_t words_bytes = (uint32_t)(slot_end - p);
+  const uint32_t words_bytes = (uint32_t)ep.slot_bytes - p;
   constexpr uint32_t kHeader = 16 + 4 * S + 512;
-  uint8_t *h = p - kHeader;
+  uint8_t *h = slot + p - kHeader;
   // skip: uint16 units from the state array to the next block header, minus one; the last block's is one less
   // (hsrans_host.cpp encode(); mt_rANS32x64_16w_encode.cpp:149,277)
   const uint64_t skip = (uint64_t)(4 * S + 512 + words_bytes) / 2 - 1 - (b + 1 == ep.n_blocks ? 1 : 0);
