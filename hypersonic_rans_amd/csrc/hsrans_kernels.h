@@ -60,7 +60,6 @@ struct KParams
   uint32_t ckpt_interval;
   // diagnostics only (HSRANS_DEBUG_STAMPS=1): per wave {entry, table built, stream ready, done} s_memtime stamps; null otherwise
   uint64_t *stamps;
-  uint32_t exp_flags; // tuning experiments (bit 0: rotate s_setprio)
   PersistentArgs pa;
   const Group *groups; // null = not a grouped launch
   uint32_t n_groups;
