@@ -320,7 +320,7 @@ int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
       d->pa.hist_off = h.aux_off;
       d->pa.tail = last.tail;
       d->pa.counters = d->d_counters;
-      if ((h.flags & kPlanHasHist) && h.bits <= 11)
+      if ((h.flags & kPlanHasHist) && h.bits <= pack64_max_bits())
       {
         // decode table for the shared-table kernel (MODE 3): {freq | sym << 24, slot - cumul} per slot, the same
         // entries build_table<kModePack64> produces (hist.cpp:291-306 / :308-324 for the sum check)

@@ -81,6 +81,8 @@ struct WalkResult
 hipError_t launch_mt_walk(const uint8_t *d_stream, uint64_t stream_len, uint64_t out_cap, uint32_t S, uint32_t bits, uint8_t *d_plan, uint32_t n_chains,
                           WalkResult *d_result, hipStream_t stream);
 
+// widest histogram the shared 8-byte-per-slot table (MODE 3) is used for
+uint32_t pack64_max_bits();
 // one-time per process: raise the dynamic-LDS limit of every kernel variant to the gfx950 maximum (160 KiB)
 hipError_t prepare_kernels();
 // asynchronous on `stream`; no allocation, no synchronisation (graph-capturable)

@@ -43,7 +43,7 @@ constexpr uint32_t kConsume = 1u << 15; // rans.h:8 DecodeConsumePoint16
 constexpr int kModePack = 0;     // bits <= 11: uint32 per slot = sym | freq << 8 | (slot - cumul) << 20
 constexpr int kModePackM1 = 1;   // bits == 12: same with freq - 1 (freq == 4096 must fit 12 bits)
 constexpr int kModeTwoLevel = 2; // bits >= 13: uint8 sym[2^bits] + uint32 {freq | cumul << 16}[256]
-constexpr int kModePack64 = 3;   // bits <= 11, table shared by a workgroup: uint2 per slot = {freq | sym << 24, slot - cumul}:
+constexpr int kModePack64 = 3;   // bits <= 14, table shared by a workgroup: uint2 per slot = {freq | sym << 24, slot - cumul}:
                                  // v_mad_u32_u24 takes freq (low 24 bits) and the bias operand as they are, v_perm takes byte 3
 
 __host__ __device__ constexpr uint32_t table_bytes_for(int mode, uint32_t bits)
@@ -1202,6 +1202,7 @@ hipError_t launch_mt_walk(const uint8_t *d_stream, uint64_t stream_len, uint64_t
 // ---------------------------------------------------------------------------------------------------------------
 static uint32_t g_max_lds = 160 * 1024;
 static uint32_t g_num_cus = 256;
+static uint32_t g_pack64_max_bits = 14; // HSRANS_PACK64_MAX_BITS (tuning): widest histogram decoded with the 8-byte-per-slot shared table
 static uint32_t g_waves_per_wg = 16;    // HSRANS_WAVES_PER_WG (tuning): waves per workgroup of the shared-table launches
 static uint32_t g_static_percent = 100; // HSRANS_STATIC_PERCENT (tuning): share of the chains handed out statically
 // HSRANS_SLOT_WEIGHTS (tuning): per-mille run length of the 8 wave classes, see PersistentArgs::run_len.  Measured on
@@ -1225,10 +1226,15 @@ static KernelFn kernel_for(int mode, bool shared)
   }
 }
 
+uint32_t pack64_max_bits() { return g_pack64_max_bits; }
+
 hipError_t prepare_kernels()
 {
   if (const char *e = getenv("HSRANS_STATIC_PERCENT"))
     g_static_percent = (uint32_t)atoi(e) > 100 ? 100 : (uint32_t)atoi(e);
+  if (const char *e = getenv("HSRANS_PACK64_MAX_BITS"))
+    if (atoi(e) >= 9 && atoi(e) <= 14)
+      g_pack64_max_bits = (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_WAVES_PER_WG"))
     if (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16)
       g_waves_per_wg = (uint32_t)atoi(e);
@@ -1263,12 +1269,12 @@ hipError_t prepare_kernels()
 hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t stream, LaunchInfo *info)
 {
   KParams kp = kp_in;
-  const bool two_level = h.bits >= 13;
   const bool walk = (h.flags & kPlanWalk) != 0;
   const bool grouped = kp.groups != nullptr && kp.ckpt_interval == 0;
   const bool shared = !walk && (grouped || (h.shared_hist != 0 && h.n_chains > 1));
   // 64-bit entries only where one table serves a whole workgroup (LDS: 16 KiB table + 16 x 4 KiB rings, two per CU)
-  const int mode = two_level ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : shared ? kModePack64 : kModePack;
+  const int mode = shared && h.bits <= pack64_max_bits() ? kModePack64 : h.bits >= 13 ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : kModePack;
+  const bool two_level = mode == kModeTwoLevel;
   const uint32_t table_bytes = table_bytes_for(mode, h.bits);
   const uint32_t wave_bytes = kWaveRingBytes + ((table_bytes + 15) & ~15u); // private rings + table
 
@@ -1276,7 +1282,9 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
   if (shared)
   {
     waves = g_waves_per_wg;
-    while (waves > 1 && waves / 2 >= h.n_chains)
+    if (waves * kWaveRingBytes + table_bytes > g_max_lds && table_bytes + 4 * kWaveRingBytes <= g_max_lds)
+      waves = (g_max_lds - table_bytes) / kWaveRingBytes / 4 * 4; // a big table: as many waves as still fit (multiple of 4: one per SIMD)
+    while (waves > 1 && (waves / 2 >= h.n_chains || waves * kWaveRingBytes + table_bytes > g_max_lds))
       waves /= 2;
     lds = waves * kWaveRingBytes + table_bytes;
     grid = (h.n_chains + waves - 1) / waves;
