@@ -1210,6 +1210,9 @@ static uint32_t g_static_percent = 100; // HSRANS_STATIC_PERCENT (tuning): share
 // with these weights all at 39 us (tools/stamps.py), 3-7 % less kernel time; at 4 waves per SIMD (bits >= 13) equal
 // runs are better and are kept.
 static uint32_t g_slot_weights[8] = {1350, 1100, 870, 680, 1300, 1080, 860, 660};
+// HSRANS_SLOT_WEIGHTS4: the same for launches with one 16-wave workgroup per CU (4 waves per SIMD: 13-bit tables)
+static uint32_t g_slot_weights4[8] = {1150, 1050, 950, 850, 1150, 1050, 950, 850};
+static bool g_weights_two_level = false; // HSRANS_WEIGHTS_TWO_LEVEL (tuning): apply the weights to the two-level table mode as well
 
 typedef void (*KernelFn)(KParams);
 static KernelFn kernel_for(int mode, bool shared)
@@ -1238,8 +1241,10 @@ hipError_t prepare_kernels()
   if (const char *e = getenv("HSRANS_WAVES_PER_WG"))
     if (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16)
       g_waves_per_wg = (uint32_t)atoi(e);
-  if (const char *e = getenv("HSRANS_SLOT_WEIGHTS")) // 8 comma-separated per-mille values, rescaled to mean 1000
-  {
+  auto read_weights = [](const char *name, uint32_t *w) { // 8 comma-separated per-mille values, rescaled to mean 1000
+    const char *e = getenv(name);
+    if (e == nullptr)
+      return;
     uint32_t v[8], n = 0;
     uint64_t sum = 0;
     for (const char *p = e; n < 8 && *p; n++)
@@ -1251,8 +1256,11 @@ hipError_t prepare_kernels()
     }
     if (n == 8 && sum > 0)
       for (uint32_t k = 0; k < 8; k++)
-        g_slot_weights[k] = (uint32_t)((uint64_t)v[k] * 8000 / sum);
-  }
+        w[k] = (uint32_t)((uint64_t)v[k] * 8000 / sum);
+  };
+  read_weights("HSRANS_SLOT_WEIGHTS", g_slot_weights);
+  read_weights("HSRANS_SLOT_WEIGHTS4", g_slot_weights4);
+  g_weights_two_level = getenv("HSRANS_WEIGHTS_TWO_LEVEL") != nullptr;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
     g_num_cus = (uint32_t)cus;
@@ -1325,7 +1333,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
       uint32_t off = 0;
       for (uint32_t k = 0; k < 4; k++)
       {
-        const uint32_t wt = waves == 16 && !two_level ? g_slot_weights[hf * 4 + k] : 1000;
+        const uint32_t wt = (waves == 16 || waves == 12) && (!two_level || g_weights_two_level) ? (grid > g_num_cus ? g_slot_weights : g_slot_weights4)[hf * 4 + k] : 1000;
         kp.pa.run_len[hf * 4 + k] = k < classes ? (uint32_t)((uint64_t)h.n_chains * g_static_percent / 100 * wt / (1000 * W * runs_per_wave)) : 0;
         kp.pa.class_off[hf * 4 + k] = off;
         off += kp.pa.run_len[hf * 4 + k] * per_class * runs_per_wave;
