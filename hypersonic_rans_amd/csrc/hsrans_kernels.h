@@ -63,6 +63,9 @@ struct KParams
   PersistentArgs pa;
   const Group *groups; // null = not a grouped launch
   uint32_t n_groups;
+  // grouped launches: wave k of a workgroup in grid half h takes chains [count * cum[h][k] / cum[h][waves], count * cum[h][k+1] / cum[h][waves])
+  // of its group (the same age-class weights as PersistentArgs::run_len)
+  uint16_t group_cum[2][17];
 };
 
 struct LaunchInfo

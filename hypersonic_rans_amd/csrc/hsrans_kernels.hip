@@ -895,7 +895,12 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
     __syncthreads();                                    // every wave is done with the previous group's table and rings
     if (!(flags & kGroupFill))
       build_table<MODE, true>(c, uni64(G->hist_off), threadIdx.x, blockDim.x);
-    const uint32_t first = begin + (uint32_t)((uint64_t)wave * count / waves), last = begin + (uint32_t)((uint64_t)(wave + 1) * count / waves);
+    const uint32_t half = blockIdx.x >= (gridDim.x + 1) / 2 ? 1 : 0;
+    // age-class weights only where a wave gets enough chains for them to mean something (else an even split)
+    const bool weighted = count >= 8 * waves;
+    const uint32_t cum_all = weighted ? kp.group_cum[half][waves] : waves;
+    const uint32_t first = begin + (uint32_t)((uint64_t)(weighted ? kp.group_cum[half][wave] : wave) * count / cum_all);
+    const uint32_t last = begin + (uint32_t)((uint64_t)(weighted ? kp.group_cum[half][wave + 1] : wave + 1) * count / cum_all);
     if (first >= last)
       continue;
     if (flags & kGroupMergeable)
@@ -1317,6 +1322,21 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
   if (grid == 0)
     grid = 1;
 
+  if (grouped)
+  {
+    const uint32_t per_class = waves >= 4 ? waves / 4 : 1;
+    for (uint32_t hf = 0; hf < 2; hf++)
+    {
+      uint32_t cum = 0;
+      for (uint32_t k = 0; k <= 16; k++)
+      {
+        kp.group_cum[hf][k] = (uint16_t)cum;
+        const uint32_t cls = k / per_class < 4 ? k / per_class : 3;
+        const bool weighted = (waves == 16 || waves == 12) && !two_level;
+        cum += k < waves ? (weighted ? (grid > g_num_cus ? g_slot_weights : g_slot_weights4)[hf * 4 + cls] / 10 : 100) : 0;
+      }
+    }
+  }
   if (kp.pa.pieces != nullptr)
   {
     // static share: a fixed fraction of the chains, split evenly; the rest goes through the queues
