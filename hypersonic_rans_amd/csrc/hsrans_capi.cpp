@@ -685,8 +685,10 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
 {
   // One pass over an existing stream that records {states, read cursor} every `index_interval` groups inside every rANS
   // piece of the stream's own plan (raw: one sequential wavefront; mt_: one wavefront per block, in parallel); the
-  // checkpoints then become additional chains.  block_ streams are one chain with inline headers and are not indexed here.
-  if (ctx == nullptr || in == nullptr || plan_out == nullptr || (container != HSRANS_RAW && container != HSRANS_MT) || !valid_codec(container, states, bits))
+  // checkpoints then become additional chains.  A block_ stream is one chain with inline headers (the position of a block's
+  // header is only known once the block before it is decoded): the single wavefront that walks it also reports every block
+  // header it meets and the states it enters the block with, and the plan gets one chain per block plus the checkpoints.
+  if (ctx == nullptr || in == nullptr || plan_out == nullptr || !valid_codec(container, states, bits))
     return 0;
   if (index_interval == 0 || index_interval % 4 != 0 || in_length < 16)
     return 0;
@@ -702,9 +704,12 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
   const Piece *pc0 = (const Piece *)(base.data() + plan_pieces_off(h.n_chains));
   const uint32_t *st0 = (const uint32_t *)(base.data() + plan_states_off(h.n_chains, h.n_pieces));
   const uint32_t S = (uint32_t)states;
-  if (h.n_pieces != h.n_chains) // the planner only produces single-piece chains for raw and mt_
+  const bool walk = (h.flags & kPlanWalk) != 0;
+  if (!walk && h.n_pieces != h.n_chains) // the planner only produces single-piece chains for raw and mt_
     return 0;
   const uint64_t n_ck = out_len / S / index_interval + 2;
+  // block_: room for blocks of >= 4 KiB on average (the reference's smallest block is 32 KiB, block_rANS32x64_16w_encode.cpp:21-39)
+  const uint64_t max_blocks = walk ? out_len / 4096 + 16 : 0;
 
   std::lock_guard<std::mutex> guard(ctx->lock);
   if (hipSetDevice(ctx->device) != hipSuccess)
@@ -714,6 +719,8 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
     return 0;
   uint32_t *d_ck_states = nullptr;
   uint64_t *d_ck_words = nullptr;
+  uint64_t *d_walk_blocks = nullptr;
+  uint32_t *d_walk_states = nullptr, *d_walk_count = nullptr;
   size_t result = 0;
   hipStream_t s = ctx->stream;
   std::vector<uint32_t> ck_states(n_ck * S);
@@ -722,6 +729,9 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
   do
   {
     if (hipMalloc((void **)&d_ck_states, n_ck * S * 4) != hipSuccess || hipMalloc((void **)&d_ck_words, n_ck * 8) != hipSuccess)
+      break;
+    if (walk && (hipMalloc((void **)&d_walk_blocks, max_blocks * 24) != hipSuccess || hipMalloc((void **)&d_walk_states, max_blocks * S * 4) != hipSuccess ||
+                 hipMalloc((void **)&d_walk_count, 4) != hipSuccess || hipMemsetAsync(d_walk_count, 0, 4, s) != hipSuccess))
       break;
     if (hipMemcpyAsync(ctx->d_in, in, in_length, hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemcpyAsync(ctx->d_plan, base.data(), base_size, hipMemcpyHostToDevice, s) != hipSuccess || hipMemsetAsync(ctx->d_status, 0, 4, s) != hipSuccess)
@@ -736,6 +746,10 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
     kp.ckpt_states = d_ck_states;
     kp.ckpt_words = d_ck_words;
     kp.ckpt_interval = index_interval;
+    kp.walk_blocks = d_walk_blocks;
+    kp.walk_states = d_walk_states;
+    kp.walk_count = d_walk_count;
+    kp.walk_max_blocks = (uint32_t)(max_blocks > 0xFFFFFFFFull ? 0xFFFFFFFFull : max_blocks);
     PlanHeader hl = h;
     hl.shared_hist = 0; // private tables: every chain of the pass builds its own (raw has one chain, mt_ one per block)
     if (launch_decode(kp, hl, s, nullptr) != hipSuccess)
@@ -755,6 +769,54 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
       memcpy(counts, in + pc0[0].hist_off, 512);
       pb.set_hist(counts);
     }
+    if (walk)
+    {
+      uint32_t n_blocks = 0;
+      if (hipMemcpy(&n_blocks, d_walk_count, 4, hipMemcpyDeviceToHost) != hipSuccess || n_blocks == 0 || n_blocks > max_blocks)
+        break;
+      std::vector<uint64_t> blocks((size_t)n_blocks * 3);
+      std::vector<uint32_t> bstates((size_t)n_blocks * S);
+      if (hipMemcpy(blocks.data(), d_walk_blocks, blocks.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(bstates.data(), d_walk_states, bstates.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        break;
+      const uint64_t whole_file = out_len / S; // whole groups of the file (block_rANS32x64_16w_decode.cpp:82-88)
+      const uint64_t tail = out_len - whole_file * S;
+      bool ok = true;
+      for (uint32_t b = 0; b < n_blocks && ok; b++)
+      {
+        const uint64_t pos = blocks[3 * (size_t)b], at = blocks[3 * (size_t)b + 1], hdr = blocks[3 * (size_t)b + 2];
+        const bool last = b + 1 == n_blocks;
+        if (hdr >> 63)
+        {
+          Piece p{};
+          p.out_off = at;
+          p.hist_off = (hdr >> 54) & 0xFF;
+          p.fill_len = hdr & (((uint64_t)1 << 54) - 1);
+          p.flags = kPieceChainStart | kPieceFill;
+          pb.add_chain(p, nullptr);
+          ok = !(last && at + p.fill_len < out_len); // a tail behind a single-symbol block has no histogram
+          continue;
+        }
+        const uint64_t g0 = at / S;
+        const uint64_t g1 = std::min<uint64_t>((at + hdr + S - 1) / S, whole_file); // the decoder stops at the last whole group
+        const uint64_t T = g1 > g0 ? g1 - g0 : 0;
+        for (uint64_t g = 0; g < T || g == 0; g += index_interval)
+        {
+          Piece p{};
+          p.hist_off = pos + 8;
+          p.out_off = at + g * S;
+          const uint64_t slot = (g0 + g) / index_interval;
+          p.words_off = g == 0 ? pos + 8 + 512 : ck_words[slot];
+          const uint64_t steps = T - g < index_interval ? T - g : index_interval;
+          p.steps = (uint32_t)steps;
+          p.tail = (uint16_t)(last && g + steps >= T ? tail : 0);
+          pb.add_chain(p, g == 0 ? &bstates[(size_t)b * S] : &ck_states[slot * S]);
+        }
+      }
+      if (!ok)
+        break;
+    }
+    else
     for (uint32_t ch = 0; ch < h.n_chains; ch++)
     {
       const Piece &bp = pc0[cf0[ch]];
@@ -783,6 +845,12 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
     (void)hipFree(d_ck_states);
   if (d_ck_words)
     (void)hipFree(d_ck_words);
+  if (d_walk_blocks)
+    (void)hipFree(d_walk_blocks);
+  if (d_walk_states)
+    (void)hipFree(d_walk_states);
+  if (d_walk_count)
+    (void)hipFree(d_walk_count);
   return result;
 }
 

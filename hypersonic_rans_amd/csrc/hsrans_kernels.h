@@ -58,6 +58,12 @@ struct KParams
   uint32_t *ckpt_states;
   uint64_t *ckpt_words;
   uint32_t ckpt_interval;
+  // index-build pass over a block_ stream (walk plan): block b's header position, output offset and header word go to
+  // walk_blocks[3b .. 3b+2], the coder states on entry to walk_states[b * S ..]; walk_count[0] = blocks seen
+  uint64_t *walk_blocks;
+  uint32_t *walk_states;
+  uint32_t *walk_count;
+  uint32_t walk_max_blocks;
   // diagnostics only (HSRANS_DEBUG_STAMPS=1): per wave {entry, table built, stream ready, done} s_memtime stamps; null otherwise
   uint64_t *stamps;
   PersistentArgs pa;

@@ -929,7 +929,7 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
 // block_ container without checkpoints: one wave follows the inline headers exactly like
 // block_rANS32x64_16w_decode.cpp:47-123 (states carry over, histogram swapped per block).
 template <int MODE>
-__device__ void run_block_walk(const WaveCtx &c, const PlanView &pv)
+__device__ void run_block_walk(const WaveCtx &c, const PlanView &pv, const KParams &kp)
 {
   const uint32_t S = c.S;
   const uint64_t out_len = pv.hdr->decoded_len;
@@ -938,6 +938,7 @@ __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv)
   uint64_t pos = pv.hdr->aux_off;
   uint64_t i = 0;
   bool have_table = false;
+  uint32_t n_blocks = 0;
   StreamWin sw;
   Ring r;
   ring_bind(r, c.rings);
@@ -953,6 +954,25 @@ __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv)
     for (int b = 3; b >= 0; b--) // stream offsets are only 2-byte aligned
       hdr = (hdr << 16) | *(const uint16_t *)(c.stream + pos + 2 * b);
     hdr = uni64(hdr);
+    if (kp.ckpt_interval != 0) // index-build pass: where this block starts and the states the decoder enters it with
+    {
+      if (n_blocks >= kp.walk_max_blocks)
+      {
+        if (c.lane == 0)
+          atomicOr(c.status, kStatusOutOfRange);
+        return;
+      }
+      if (c.lane == 0)
+      {
+        kp.walk_blocks[3 * (uint64_t)n_blocks] = pos;
+        kp.walk_blocks[3 * (uint64_t)n_blocks + 1] = i;
+        kp.walk_blocks[3 * (uint64_t)n_blocks + 2] = hdr;
+        kp.walk_count[0] = n_blocks + 1;
+      }
+      if (c.lane < S)
+        kp.walk_states[(uint64_t)n_blocks * S + c.lane] = x;
+      n_blocks++;
+    }
     pos += 8;
     if (hdr >> 63)
     {
@@ -988,8 +1008,30 @@ __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv)
         return;
       }
       ring_init(sw, r, c, pos);
-      const uint64_t steps = end > i ? (end - i + S - 1) / S : 0;
-      run_groups<MODE>(x, sw, r, c, i, (uint32_t)steps);
+      uint64_t steps = end > i ? (end - i + S - 1) / S : 0;
+      if (kp.ckpt_interval != 0)
+      {
+        // checkpoints every ckpt_interval groups of the block, slot = absolute group / interval (unique: see run_planned_chain)
+        uint64_t g = 0;
+        const uint64_t g_abs0 = i / S;
+        while (steps > 0)
+        {
+          if (g != 0)
+          {
+            const uint64_t slot = (g_abs0 + g) / kp.ckpt_interval;
+            if (c.lane < S)
+              kp.ckpt_states[slot * S + c.lane] = x;
+            if (c.lane == 0)
+              kp.ckpt_words[slot] = ring_pos(sw, r);
+          }
+          const uint32_t n = steps < kp.ckpt_interval ? (uint32_t)steps : kp.ckpt_interval;
+          run_groups<MODE>(x, sw, r, c, i, n);
+          steps -= n;
+          g += n;
+        }
+      }
+      else
+        run_groups<MODE>(x, sw, r, c, i, (uint32_t)steps);
       pos = ring_pos(sw, r);
     }
     if (i > whole)
@@ -1076,7 +1118,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
     if (pv.hdr->flags & kPlanWalk)
     {
       if (chain == 0)
-        run_block_walk<MODE>(c, pv);
+        run_block_walk<MODE>(c, pv, kp);
     }
     else if (chain < pv.hdr->n_chains)
       run_planned_chain<MODE, false>(c, pv, chain, kp);

@@ -150,8 +150,10 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
 
 /* Build a plan with checkpoints every `index_interval` groups for an EXISTING stream (e.g. one written by the
  * reference's encoder) by one decode pass on the GPU that records the states at the checkpoints: HSRANS_RAW (one
- * sequential wavefront) and HSRANS_MT (one wavefront per block).  Returns plan bytes written to plan_out (host
- * memory), 0 on failure. */
+ * sequential wavefront), HSRANS_MT (one wavefront per block) and HSRANS_BLOCK (one sequential wavefront that also reports
+ * the inline block headers it meets: the plan then has a chain per block and per checkpoint, which is what makes a block_
+ * stream chunk-parallel; blocks must average >= 4 KiB).  Returns plan bytes written to plan_out (host memory), 0 on
+ * failure. */
 size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length,
                           uint32_t index_interval, uint8_t *plan_out, size_t plan_capacity);
 

@@ -274,6 +274,28 @@ def test_index_build_for_reference_mt_streams(gpu_ctx, ref, nonstat, zipf, state
         assert np.array_equal(s, s2) and np.array_equal(plan, plan2)
 
 
+@pytest.mark.parametrize("states", (32, 64))
+def test_index_build_for_block_streams(gpu_ctx, oracle, ref, nonstat, zipf, states):
+    """block_ streams are one chain with inline headers: the single wavefront that walks them also reports the headers it meets,
+    so one pass turns a stream (ours or the real reference's) into a plan with a chain per block and per checkpoint."""
+    for bits in (11, 13):
+        for src, n, block in ((zipf, 300_000, 65536), (nonstat, 2_000_000, 65536), (nonstat, 1_000_003, 32768)):
+            d = src[:n]
+            s, plan_enc = H.encode(H.BLOCK, states, bits, d, index_interval=32, block_size=block)
+            plan = gpu_ctx.index_build(H.BLOCK, states, bits, s, 32)
+            assert np.array_equal(plan, plan_enc), (states, bits, n, block)
+            r, got = gpu_ctx.decode_host(H.BLOCK, states, bits, s, n, plan=plan)
+            assert r == n and np.array_equal(got, d)
+        for src, n in ((nonstat, 3_000_000), (zipf, 1 << 20), (zipf, 524_300)):  # the real reference's adaptive blocks (incl. a quirk length)
+            d = src[:n]
+            s = ref.encode(BLOCK, states, bits, d)
+            r0, want = oracle.decode(BLOCK, states, bits, s, n)
+            plan = gpu_ctx.index_build(H.BLOCK, states, bits, s, 64)
+            assert H.plan_chain_count(plan) > 1
+            r, got = gpu_ctx.decode_host(H.BLOCK, states, bits, s, n, plan=plan)
+            assert r == r0 and np.array_equal(got, want), (states, bits, n)
+
+
 def test_corrupted_streams_fail_cleanly(gpu_ctx, zipf):
     """Memory safety: random corruption of headers / histograms / words must end in `return 0` or in (wrong) bytes of the
     right length — never in a fault or a hang (every index in the kernel is masked, every loop bounded by the plan)."""
