@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -412,8 +413,8 @@ int hsrans_dplan_create_from_device_stream(hsrans_ctx *ctx, int container, int s
                                            size_t out_capacity, void *hip_stream, hsrans_dplan **out_dplan)
 {
   // K2: the mt_ header chain is followed on the device, so a stream that only exists in HBM can be
-  // planned without a host copy.  Two passes of one single-wavefront kernel (count, then write); the pointer chase costs
-  // about a memory round trip per block.
+  // planned without a host copy.  Pass 1 is a pointer chase by one wavefront (one 16-byte read per block: about one memory
+  // round trip each) that lists the blocks; pass 2 writes the plan, one wavefront per block.
   if (ctx == nullptr || out_dplan == nullptr || d_stream == nullptr)
     return HSRANS_E_ARG;
   *out_dplan = nullptr;
@@ -423,6 +424,7 @@ int hsrans_dplan_create_from_device_stream(hsrans_ctx *ctx, int container, int s
     return HSRANS_E_HIP;
   hipStream_t s = (hipStream_t)hip_stream;
   WalkResult *d_res = nullptr;
+  uint64_t *d_blocks = nullptr;
   WalkResult res{};
   hsrans_dplan *d = nullptr;
   int rc = HSRANS_E_HIP;
@@ -430,8 +432,31 @@ int hsrans_dplan_create_from_device_stream(hsrans_ctx *ctx, int container, int s
   {
     if (hipMalloc((void **)&d_res, sizeof(WalkResult)) != hipSuccess)
       break;
-    if (launch_mt_walk((const uint8_t *)d_stream, stream_length, out_capacity, (uint32_t)states, bits, nullptr, 0, d_res, s) != hipSuccess ||
-        hipMemcpyAsync(&res, d_res, sizeof(res), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    // block list: sized for blocks of >= 4 KiB on average, enlarged (up to one entry per 8 stream bytes, the smallest
+    // block there is) when the chase reports that it ran out
+    uint64_t max_blocks = out_capacity / 4096 + 4096;
+    const uint64_t hard_max = std::min<uint64_t>(stream_length / 8 + 1, 0xFFFFFFFFull);
+    bool chased = false;
+    while (true)
+    {
+      max_blocks = std::min(max_blocks, hard_max);
+      if (d_blocks)
+        (void)hipFree(d_blocks);
+      d_blocks = nullptr;
+      if (hipMalloc((void **)&d_blocks, max_blocks * 16) != hipSuccess)
+        break;
+      if (launch_mt_chase((const uint8_t *)d_stream, stream_length, out_capacity, (uint32_t)states, d_blocks, (uint32_t)max_blocks, d_res, s) != hipSuccess ||
+          hipMemcpyAsync(&res, d_res, sizeof(res), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        break;
+      if (res.error == 7 && max_blocks < hard_max)
+      {
+        max_blocks *= 8;
+        continue;
+      }
+      chased = true;
+      break;
+    }
+    if (!chased)
       break;
     if (res.error != 0 || res.n_chains == 0)
     {
@@ -455,10 +480,10 @@ int hsrans_dplan_create_from_device_stream(hsrans_ctx *ctx, int container, int s
     if (hipMalloc((void **)&d->d_plan, bytes) != hipSuccess || hipMalloc((void **)&d->d_status, 64) != hipSuccess ||
         hipMemsetAsync(d->d_plan, 0, bytes, s) != hipSuccess || hipMemsetAsync(d->d_status, 0, 64, s) != hipSuccess ||
         hipMemcpyAsync(d->d_plan, &h, sizeof(h), hipMemcpyHostToDevice, s) != hipSuccess ||
-        launch_mt_walk((const uint8_t *)d_stream, stream_length, out_capacity, (uint32_t)states, bits, d->d_plan, h.n_chains, d_res, s) != hipSuccess ||
+        launch_mt_fill((const uint8_t *)d_stream, stream_length, (uint32_t)states, bits, d_blocks, d->d_plan, h.n_chains, res.decoded_len, d_res, s) != hipSuccess ||
         hipMemcpyAsync(&res2, d_res, sizeof(res2), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
       break;
-    if (res2.error != 0 || res2.n_chains != res.n_chains)
+    if (res2.error != 0)
     {
       rc = HSRANS_E_FORMAT;
       break;
@@ -469,6 +494,8 @@ int hsrans_dplan_create_from_device_stream(hsrans_ctx *ctx, int container, int s
   } while (false);
   if (d_res)
     (void)hipFree(d_res);
+  if (d_blocks)
+    (void)hipFree(d_blocks);
   if (rc != HSRANS_OK)
   {
     hsrans_dplan_destroy(d);

@@ -80,15 +80,18 @@ struct LaunchInfo
 };
 
 // K2: device-side walk of an mt_ stream's header chain (mt_rANS32x64_16w_decode.cpp:41-96), the device twin of the host
-// planner.  Two passes of the same single-wavefront kernel: count (plan == nullptr), then write the plan blob.
+// planner.  Pass 1 (k_mt_chase, one wavefront) follows the chain with one 16-byte read per block and lists the blocks;
+// pass 2 (k_mt_fill, one wavefront per block) writes the plan blob.
 struct WalkResult
 {
-  uint32_t n_chains; // chains (= pieces) the walk produces
-  uint32_t error;    // 0 ok; else the stream is malformed (the reference's "return 0" cases)
+  uint32_t n_chains; // chains (= pieces = blocks) found
+  uint32_t error;    // 0 ok; 7: the block list was too small; else the stream is malformed (the reference's "return 0" cases)
   uint64_t decoded_len;
 };
-hipError_t launch_mt_walk(const uint8_t *d_stream, uint64_t stream_len, uint64_t out_cap, uint32_t S, uint32_t bits, uint8_t *d_plan, uint32_t n_chains,
-                          WalkResult *d_result, hipStream_t stream);
+hipError_t launch_mt_chase(const uint8_t *d_stream, uint64_t stream_len, uint64_t out_cap, uint32_t S, uint64_t *d_blocks, uint32_t max_blocks, WalkResult *d_result,
+                           hipStream_t stream);
+hipError_t launch_mt_fill(const uint8_t *d_stream, uint64_t stream_len, uint32_t S, uint32_t bits, const uint64_t *d_blocks, uint8_t *d_plan, uint32_t n_chains,
+                          uint64_t out_len, WalkResult *d_result, hipStream_t stream);
 
 // widest histogram the shared 8-byte-per-slot table (MODE 3) is used for
 uint32_t pack64_max_bits();
