@@ -89,3 +89,33 @@ def test_product_container_encoders_match_the_real_reference(ref, data, containe
             for src, n in ((zipf, 64), (zipf, 1000), (zipf, 65536), (zipf, 65600), (zipf, 262144), (zipf, 300_000), (nonstat, 1_200_000), (nonstat, 700_001)):
                 d = src[:n]
                 assert np.array_equal(H.encode(container, states, bits, d), ref.encode(container, states, bits, d)), (container, states, bits, n)
+
+
+@pytest.mark.parametrize("states", (32, 64))
+def test_independent_block_streams_are_plain_mt_streams_for_the_real_reference(oracle, ref, data, states):
+    """The layout the GPU encoder writes (HSRANS_ENC_INDEPENDENT_BLOCKS: every block restarts from states 2^15) is decoded by
+    the real reference — single-threaded and through its thread pool — and by the oracle; each block's histogram is the
+    reference's make_hist of that block, byte for byte."""
+    import hypersonic_rans_amd as H
+    zipf, nonstat = data
+    for bits in (10, 11, 13, 15):
+        for src, n, block in ((zipf, 64, 64), (zipf, 65536, 65536), (zipf, 65536 + 31, 65536), (zipf, 299_999, 32768), (nonstat, 1_200_000, 65536),
+                              (nonstat, 700_001, 1 << 18)):
+            if n < states:
+                continue
+            d = src[:n]
+            assert d.size == n
+            s = H.encode(H.MT, states, bits, d, block_size=block, independent_blocks=True)
+            for variant in (0, 2):
+                r, out = ref.decode(MT, states, bits, s, n, variant=variant)
+                assert r == n and np.array_equal(out, d), (states, bits, n, block, variant)
+            r, out = oracle.decode(MT, states, bits, s, n)
+            assert r == n and np.array_equal(out, d)
+            # first block: [size][skip][states][counts]
+            first = d[: min(n, block)] if n - block >= states or n <= block else d
+            if np.unique(first).size > 1:
+                counts = s[16 + 16 + 4 * states: 16 + 16 + 4 * states + 512].view("<u2")
+                want = np.asarray(ref.make_hist(first, bits)[0], dtype=np.uint16)
+                assert np.array_equal(counts, want), (states, bits, n, block)
+                st = s[32: 32 + 4 * states].view("<u4")
+                assert st.min() >= 1 << 15  # decoder start states are normalised
