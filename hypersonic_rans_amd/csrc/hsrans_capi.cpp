@@ -391,6 +391,36 @@ int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
         groups.push_back(g);
       }
     }
+    // Few, large blocks would leave workgroup slots empty (one workgroup per group): cut mergeable groups into parts of
+    // >= 128 chains (8 per wave: below that the per-part prologue costs more than the idle slots) while there are fewer
+    // groups than resident workgroups.  A part is a group of its own: same histogram, a sub-range of the chains, and its
+    // words end where the next part's first chain starts reading.  Measured: 382 groups of 128 chains are best left alone.
+    const size_t want = (size_t)resident_workgroups_hint();
+    if (groups.size() < h.n_chains && groups.size() < want)
+    {
+      const uint32_t k_max = (uint32_t)((want + groups.size() - 1) / groups.size());
+      std::vector<Group> parts;
+      for (const Group &g : groups)
+      {
+        uint32_t k = (g.flags & kGroupMergeable) ? std::min(k_max, (g.count + 143) / 144) : 1;
+        if (k < 2)
+        {
+          parts.push_back(g);
+          continue;
+        }
+        for (uint32_t part = 0; part < k; part++)
+        {
+          Group q = g;
+          const uint32_t lo = (uint32_t)((uint64_t)g.count * part / k), hi = (uint32_t)((uint64_t)g.count * (part + 1) / k);
+          q.begin = g.begin + lo;
+          q.count = hi - lo;
+          if (part + 1 < k)
+            q.words_end = pc[cf[g.begin + hi]].words_off;
+          parts.push_back(q);
+        }
+      }
+      groups.swap(parts);
+    }
     if (groups.size() < h.n_chains && hipMalloc((void **)&d->d_groups, groups.size() * sizeof(Group)) == hipSuccess &&
         hipMemcpy(d->d_groups, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice) == hipSuccess)
       d->n_groups = (uint32_t)groups.size();
@@ -685,8 +715,14 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   h.interval = ep.interval;
   const size_t bytes = (size_t)plan_size(h.n_chains, h.n_pieces, h.states, 0);
   const bool grouped = ep.interval != 0 && ep.n_blocks < h.n_chains;
+  // few large blocks: cut every block's chains into parts so that there are about two workgroup tasks per resident workgroup
+  // (parts of >= 128 chains, only while there are fewer blocks than resident workgroups: see hsrans_dplan_create)
+  const size_t want = (size_t)resident_workgroups_hint();
+  ep.group_split = 1;
+  if (grouped && nb < want)
+    ep.group_split = (uint32_t)std::max<size_t>(1, std::min<size_t>({(want + nb - 1) / nb, (size_t)(ep.max_ck + 1) / 128, (size_t)64}));
   bool ok = hipMalloc((void **)&d->d_plan, bytes) == hipSuccess && hipMalloc((void **)&d->d_status, 64) == hipSuccess &&
-            (!grouped || hipMalloc((void **)&d->d_groups, nb * sizeof(Group)) == hipSuccess) && hipMemsetAsync(d->d_plan, 0, bytes, s) == hipSuccess &&
+            (!grouped || hipMalloc((void **)&d->d_groups, nb * ep.group_split * sizeof(Group)) == hipSuccess) && hipMemsetAsync(d->d_plan, 0, bytes, s) == hipSuccess &&
             hipMemsetAsync(d->d_status, 0, 64, s) == hipSuccess && hipMemcpyAsync(d->d_plan, &h, sizeof(h), hipMemcpyHostToDevice, s) == hipSuccess;
   if (ok)
   {
@@ -702,7 +738,7 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   }
   d->hdr = h;
   d->plan_bytes = bytes;
-  d->n_groups = grouped ? ep.n_blocks : 0;
+  d->n_groups = grouped ? ep.n_blocks * ep.group_split : 0;
   *out_dplan = d;
   return total;
 }

@@ -31,7 +31,8 @@ struct EncParams
   uint32_t *chain_count; // [n_blocks] chains of block b: 1 + its checkpoints (single-symbol block: 1)
   uint32_t *chain_off;   // [n_blocks] first chain of block b (K_scan)
   uint8_t *plan;         // plan blob to fill (K_plan) or null
-  void *groups;          // Group[n_blocks] for the grouped decode launch (K_plan) or null
+  void *groups;          // Group[n_blocks * group_split] for the grouped decode launch (K_plan) or null
+  uint32_t group_split;  // parts a block's chains are cut into (few large blocks: more workgroup tasks than blocks)
   uint32_t n_chains;     // total, known after K_scan (K_plan)
   uint64_t *stamps; // diagnostics (HSRANS_DEBUG_STAMPS=1): per block {start, histogram done, table done, words done} s_memrealtime; else null
 };

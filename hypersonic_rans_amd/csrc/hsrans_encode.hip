@@ -719,15 +719,30 @@ __global__ void __launch_bounds__(64) k_plan_blocks(EncParams ep)
         v = k == 0 ? ((const U32a2 *)(image + 16 + 4 * lane))->v : ep.ck_states[((uint64_t)b * ep.max_ck + (k - 1)) * S + lane];
       states[(uint64_t)(c0 + k) * S + lane] = v;
     }
-  if (ep.groups != nullptr && lane == 0)
+  if (ep.groups != nullptr && lane < ep.group_split)
   {
+    // one Group per part: a block is cut into up to group_split parts of >= 128 chains; the parts that are not needed
+    // (short last block, single-symbol block) stay empty
+    const uint32_t by_size = (count + 143) / 144 < ep.group_split ? (count + 143) / 144 : ep.group_split; // 128-chain parts, a remainder of > 16 gets its own
+    const uint32_t k = single || by_size < 1 ? 1 : by_size;
     Group g{};
-    g.begin = c0;
-    g.count = count;
     g.flags = single ? kGroupFill : kGroupMergeable;
     g.hist_off = single ? 0 : hist_off;
-    g.words_end = at + bytes;
-    ((Group *)ep.groups)[b] = g;
+    if (lane < k)
+    {
+      const uint32_t lo = (uint32_t)((uint64_t)count * lane / k), hi = (uint32_t)((uint64_t)count * (lane + 1) / k);
+      g.begin = c0 + lo;
+      g.count = hi - lo;
+      g.words_end = hi < count ? at + bytes - ep.ck_pos[(uint64_t)b * ep.max_ck + (hi - 1)] : at + bytes;
+    }
+    else
+    {
+      g.begin = c0;
+      g.count = 0;
+      g.flags = kGroupFill;
+      g.words_end = at + bytes;
+    }
+    ((Group *)ep.groups)[(uint64_t)b * ep.group_split + lane] = g;
   }
 }
 

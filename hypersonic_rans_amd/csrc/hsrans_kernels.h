@@ -93,6 +93,8 @@ hipError_t launch_mt_chase(const uint8_t *d_stream, uint64_t stream_len, uint64_
 hipError_t launch_mt_fill(const uint8_t *d_stream, uint64_t stream_len, uint32_t S, uint32_t bits, const uint64_t *d_blocks, uint8_t *d_plan, uint32_t n_chains,
                           uint64_t out_len, WalkResult *d_result, hipStream_t stream);
 
+// workgroups of 16 waves the device holds at once when two fit a CU (what launches size their task lists for)
+uint32_t resident_workgroups_hint();
 // widest histogram the shared 8-byte-per-slot table (MODE 3) is used for
 uint32_t pack64_max_bits();
 // one-time per process: raise the dynamic-LDS limit of every kernel variant to the gfx950 maximum (160 KiB)

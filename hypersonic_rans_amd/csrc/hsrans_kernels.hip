@@ -1320,6 +1320,7 @@ static KernelFn kernel_for(int mode, bool shared)
 }
 
 uint32_t pack64_max_bits() { return g_pack64_max_bits; }
+uint32_t resident_workgroups_hint() { return 2 * g_num_cus; }
 
 hipError_t prepare_kernels()
 {
