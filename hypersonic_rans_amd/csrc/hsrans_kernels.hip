@@ -903,7 +903,45 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
     const uint32_t last = begin + (uint32_t)((uint64_t)(weighted ? kp.group_cum[half][wave + 1] : wave + 1) * count / cum_all);
     if (first >= last)
       continue;
-    if (flags & kGroupMergeable)
+    if ((flags & kGroupMergeable) && c.S == 32)
+    {
+      // 32-state chains: the wave's share is cut in two runs that are decoded side by side, A on lanes 0..31 and B on
+      // lanes 32..63 (group_step_pair), like run_persistent_pair; whatever the pair loop leaves is finished one run at a time
+      const uint32_t mid = first + (last - first + 1) / 2;
+      const bool have_b = mid < last;
+      const Piece *a0 = pv.pieces + uni(pv.chain_first[first]);
+      const Piece *a1 = pv.pieces + uni(pv.chain_first[mid - 1]);
+      const Piece *b0 = pv.pieces + uni(pv.chain_first[have_b ? mid : first]);
+      const Piece *b1 = pv.pieces + uni(pv.chain_first[last - 1]);
+      const uint64_t limit = last < begin + count ? uni64(pv.pieces[uni(pv.chain_first[last])].words_off) : uni64(G->words_end);
+      StreamWin sw;
+      Ring ra, rb;
+      ring_bind(ra, c.rings, 8);
+      ring_bind(rb, c.rings + 1152, 8);
+      win_open(sw, c, uni64(a0->words_off), limit);
+      ring_begin(sw, ra, c, uni64(a0->words_off));
+      if (have_b)
+        ring_begin(sw, rb, c, uni64(b0->words_off));
+      const uint32_t src = (c.lane < 32 || !have_b) ? uni(a0->state_idx) : uni(b0->state_idx);
+      uint32_t x = pv.states[(uint64_t)src * 32 + (c.lane & 31)];
+      uint64_t oa = uni64(a0->out_off), ob = have_b ? uni64(b0->out_off) : 0;
+      uint32_t sa = (uint32_t)((uni64(a1->out_off) - oa) / 32) + uni(a1->steps);
+      uint32_t sb = have_b ? (uint32_t)((uni64(b1->out_off) - ob) / 32) + uni(b1->steps) : 0;
+      ring_ready();
+      if (have_b)
+      {
+        const uint32_t both = (sa < sb ? sa : sb) & ~3u;
+        run_pair_groups<MODE>(x, sw, ra, rb, c, oa, ob, both);
+        sa -= both;
+        sb -= both;
+        uint32_t xb = __shfl(x, (c.lane & 31) + 32, 64); // B's states move down to lanes 0..31 and B is finished alone
+        run_groups<MODE>(xb, sw, rb, c, ob, sb);
+        run_tail<MODE>(xb, rb, c, ob, uni(b1->tail));
+      }
+      run_groups<MODE>(x, sw, ra, c, oa, sa);
+      run_tail<MODE>(x, ra, c, oa, uni(a1->tail));
+    }
+    else if (flags & kGroupMergeable)
     {
       const Piece *p0 = pv.pieces + uni(pv.chain_first[first]);
       const Piece *p1 = pv.pieces + uni(pv.chain_first[last - 1]);
