@@ -110,18 +110,21 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    # one process per GPU; if the launcher narrowed each rank's view to its own GPU (HIP_VISIBLE_DEVICES), index 0 is that GPU
+    n_visible = torch.cuda.device_count()
+    dev_index = local_rank % n_visible if n_visible else 0
     if distributed:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     if args.gpus != world and rank == 0 and distributed:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU decode path")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
-    ctx = H.Context(local_rank)
+    ctx = H.Context(dev_index)
 
     # ---- synthetic workload (BASELINE.json configs[1]): enwik8-shaped, one stream per rank -------------------------
     n, S, bits = args.size, args.states, args.bits
@@ -139,16 +142,18 @@ def main() -> None:
     def step():
         ctx.decode_device(dplan, d_in, d_out, stream_length=stream.size)
 
-    for _ in range(args.warmup):
-        step()
+    step()  # validation decode (not one of the W warm-up steps): the checks below idle the GPU, so they come before the warm-up
     torch.cuda.synchronize()
     assert ctx.status(dplan) == 0
     assert torch.equal(d_out, d_ref), "GPU output is not bit-exact"
+    d_out.zero_()
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides ------------------------------------------
     # One HIP event pair brackets the K launches ON THE LAUNCH STREAM (hsrans_decode_device launches on torch's current
     # stream, which is where torch.cuda.Event records): span / K = the kernel's average launch duration for the roofline.
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(args.warmup):  # W untimed warm-up steps, immediately in front of the timed region
+        step()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
