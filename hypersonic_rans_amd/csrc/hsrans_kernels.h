@@ -72,6 +72,9 @@ struct KParams
   // grouped launches: wave k of a workgroup in grid half h takes chains [count * cum[h][k] / cum[h][waves], count * cum[h][k+1] / cum[h][waves])
   // of its group (the same age-class weights as PersistentArgs::run_len)
   uint16_t group_cum[2][17];
+  // private-table launches of 32-state plans: every wave takes TWO chains (2w, 2w+1), one per wave half, each with its own
+  // table (run_private_pair); the LDS layout then holds two tables per wave
+  uint32_t private_pair;
 };
 
 struct LaunchInfo

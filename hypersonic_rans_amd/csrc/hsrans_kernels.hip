@@ -75,6 +75,7 @@ struct WaveCtx
   uint32_t v_mask, v_bits; // 2^bits - 1 and bits, each held in a VGPR: a VALU op with an SGPR operand issues at half rate
   uint8_t *rings;        // LDS, kWaveRingBytes: this wave's stream ring + mirror
   uint8_t *table;        // LDS
+  uint8_t *table_b;      // LDS: the table lanes 32..63 use in the paired 32-state modes (== table unless the halves decode different blocks)
   uint16_t *scratch_cnt; // LDS, 512 B each, only live during table builds: they alias a ring that has no request in
   uint16_t *scratch_cum; // flight (build_table is always called before the ring is begun)
 };
@@ -449,27 +450,28 @@ __device__ __forceinline__ uint32_t group_step_pair(uint32_t &x, Ring &ra, Ring 
   const uint32_t mask = (1u << c.bits) - 1;
   const uint32_t slot = x & c.v_mask;
   const uint32_t q = x >> c.v_bits;
+  const uint8_t *tab = c.lane < 32 ? c.table : c.table_b; // per half (loop-invariant)
   uint32_t e, nx;
   if (MODE == kModePack64)
   {
-    const uint2 e2 = ((const uint2 *)c.table)[slot];
+    const uint2 e2 = ((const uint2 *)tab)[slot];
     e = e2.x;
     nx = __umul24(q, e2.x) + e2.y;
   }
   else if (MODE == kModePack)
   {
-    e = ((const uint32_t *)c.table)[slot];
+    e = ((const uint32_t *)tab)[slot];
     nx = __umul24(q, (e >> 8) & 0xFFF) + (e >> 20);
   }
   else if (MODE == kModePackM1)
   {
-    e = ((const uint32_t *)c.table)[slot];
+    e = ((const uint32_t *)tab)[slot];
     nx = __umul24(q, (e >> 8) & 0xFFF) + q + (e >> 20);
   }
   else
   {
-    e = c.table[slot];
-    const uint32_t fc = ((const uint32_t *)(c.table + mask + 1))[e];
+    e = tab[slot];
+    const uint32_t fc = ((const uint32_t *)(tab + mask + 1))[e];
     nx = __umul24(q, fc & 0xFFFF) + slot - (fc >> 16);
   }
   const bool low = nx < kConsume;
@@ -964,6 +966,58 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
   }
 }
 
+// Private-table launch of a 32-state plan: the wave decodes chains `ca` and `ca + 1` side by side, lanes 0..31 with the
+// first chain's table, lanes 32..63 with the second's (mt_ blocks without a sidecar: every block has its own histogram).
+// Anything but two plain single-piece rANS chains is done one chain after the other.
+template <int MODE>
+__device__ void run_private_pair(WaveCtx &c, const PlanView &pv, uint32_t ca, const KParams &kp)
+{
+  const uint32_t cb = ca + 1;
+  const bool have_b = cb < pv.hdr->n_chains;
+  const uint32_t fa = uni(pv.chain_first[ca]);
+  const Piece *pa = pv.pieces + fa;
+  const Piece *pb = pv.pieces + (have_b ? uni(pv.chain_first[cb]) : fa);
+  bool plain = have_b && uni(pv.chain_first[ca + 1]) - fa == 1 && uni(pv.chain_first[cb + 1]) - uni(pv.chain_first[cb]) == 1;
+  plain = plain && uni(pa->flags) == kPieceChainStart && uni(pb->flags) == kPieceChainStart;
+  if (plain)
+  {
+    // both tables first (the builds borrow ring space), A's in c.table, B's in c.table_b
+    WaveCtx cb_ctx = c;
+    cb_ctx.table = c.table_b;
+    plain = build_table<MODE, false>(c, uni64(pa->hist_off), c.lane, 64);
+    plain = build_table<MODE, false>(cb_ctx, uni64(pb->hist_off), c.lane, 64) && plain;
+    if (plain)
+    {
+      StreamWin sw;
+      Ring ra, rb;
+      ring_bind(ra, c.rings, 8);
+      ring_bind(rb, c.rings + 1152, 8);
+      const uint64_t wa = uni64(pa->words_off), wb = uni64(pb->words_off);
+      win_open(sw, c, wa < wb ? wa : wb, c.stream_len);
+      ring_begin(sw, ra, c, wa);
+      ring_begin(sw, rb, c, wb);
+      uint32_t x = pv.states[(uint64_t)(c.lane < 32 ? uni(pa->state_idx) : uni(pb->state_idx)) * 32 + (c.lane & 31)];
+      uint64_t oa = uni64(pa->out_off), ob = uni64(pb->out_off);
+      uint32_t sa = uni(pa->steps), sb = uni(pb->steps);
+      ring_ready();
+      const uint32_t both = (sa < sb ? sa : sb) & ~3u;
+      run_pair_groups<MODE>(x, sw, ra, rb, c, oa, ob, both);
+      sa -= both;
+      sb -= both;
+      uint32_t xb = __shfl(x, (c.lane & 31) + 32, 64); // B's states move down to lanes 0..31; B is finished alone with its table
+      run_groups<MODE>(xb, sw, rb, cb_ctx, ob, sb);
+      run_tail<MODE>(xb, rb, cb_ctx, ob, uni(pb->tail));
+      run_groups<MODE>(x, sw, ra, c, oa, sa);
+      run_tail<MODE>(x, ra, c, oa, uni(pa->tail));
+      return;
+    }
+    // a histogram did not sum up: the status bit is set; decode what can be decoded the ordinary way
+  }
+  run_planned_chain<MODE, false>(c, pv, ca, kp);
+  if (have_b)
+    run_planned_chain<MODE, false>(c, pv, cb, kp);
+}
+
 // block_ container without checkpoints: one wave follows the inline headers exactly like
 // block_rANS32x64_16w_decode.cpp:47-123 (states carry over, histogram swapped per block).
 template <int MODE>
@@ -1127,6 +1181,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   {
     c.rings = smem + wave * kWaveRingBytes;
     c.table = smem + waves * kWaveRingBytes;
+    c.table_b = c.table;
     c.scratch_cnt = (uint16_t *)smem;         // wave 0's ring (no request in flight while a table is built)
     c.scratch_cum = (uint16_t *)(smem + 512);
     const uint64_t hist_off = pv.hdr->aux_off; // shared plans: the one histogram every chain uses
@@ -1149,14 +1204,21 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   }
   else
   {
+    const uint32_t table_stride = (table_bytes + 15) & ~15u;
     c.rings = smem + wave * kWaveRingBytes; // all rings first: they stay kRingBytes-aligned
-    c.table = smem + waves * kWaveRingBytes + wave * ((table_bytes + 15) & ~15u);
+    c.table = smem + waves * kWaveRingBytes + wave * table_stride * (kp.private_pair ? 2 : 1);
+    c.table_b = kp.private_pair ? c.table + table_stride : c.table;
     c.scratch_cnt = (uint16_t *)c.rings;
     c.scratch_cum = (uint16_t *)(c.rings + 512);
     if (pv.hdr->flags & kPlanWalk)
     {
       if (chain == 0)
         run_block_walk<MODE>(c, pv, kp);
+    }
+    else if (kp.private_pair)
+    {
+      if (2 * chain < pv.hdr->n_chains)
+        run_private_pair<MODE>(c, pv, 2 * chain, kp);
     }
     else if (chain < pv.hdr->n_chains)
       run_planned_chain<MODE, false>(c, pv, chain, kp);
@@ -1340,6 +1402,10 @@ static uint32_t g_static_percent = 100; // HSRANS_STATIC_PERCENT (tuning): share
 static uint32_t g_slot_weights[8] = {1350, 1100, 870, 680, 1300, 1080, 860, 660};
 // HSRANS_SLOT_WEIGHTS4: the same for launches with one 16-wave workgroup per CU (4 waves per SIMD: 13-bit tables)
 static uint32_t g_slot_weights4[8] = {1150, 1050, 950, 850, 1150, 1050, 950, 850};
+// HSRANS_PRIVATE_PAIR (tuning): 0 = never, 1 = when there are more chains than wave slots (default), 2 = always pair the
+// chains of 32-state plans in private-table launches.  Measured: 2^30 B in 16,384 blocks 1.40 -> 1.33 ms, but 100 MB in 1,526
+// blocks 0.25 -> 0.30 ms (everything is latency-bound there and half as many waves are in flight)
+static uint32_t g_private_pair = 1;
 static bool g_weights_two_level = false; // HSRANS_WEIGHTS_TWO_LEVEL (tuning): apply the weights to the two-level table mode as well
 
 typedef void (*KernelFn)(KParams);
@@ -1390,6 +1456,8 @@ hipError_t prepare_kernels()
   read_weights("HSRANS_SLOT_WEIGHTS", g_slot_weights);
   read_weights("HSRANS_SLOT_WEIGHTS4", g_slot_weights4);
   g_weights_two_level = getenv("HSRANS_WEIGHTS_TWO_LEVEL") != nullptr;
+  if (const char *e = getenv("HSRANS_PRIVATE_PAIR"))
+    g_private_pair = (uint32_t)atoi(e);
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
     g_num_cus = (uint32_t)cus;
@@ -1437,11 +1505,17 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
   }
   else
   {
+    // 32-state plans: two chains per wave, one per half, when two tables fit (run_private_pair); not for the index-build pass
+    const bool pair = (g_private_pair == 2 || (g_private_pair == 1 && h.n_chains >= 32 * g_num_cus)) && !walk && h.states == 32 && h.n_chains > 1 &&
+                      table_bytes <= 16384 && kp.ckpt_interval == 0;
+    kp.private_pair = pair ? 1 : 0;
+    const uint32_t wave_lds = pair ? wave_bytes + ((table_bytes + 15) & ~15u) : wave_bytes;
+    const uint32_t work = pair ? (h.n_chains + 1) / 2 : h.n_chains;
     waves = walk ? 1 : 4;
-    while (waves > 1 && (waves * wave_bytes > g_max_lds / 2 || waves / 2 >= h.n_chains))
+    while (waves > 1 && (waves * wave_lds > g_max_lds / 2 || waves / 2 >= work))
       waves /= 2;
-    lds = waves * wave_bytes;
-    grid = walk ? 1 : (h.n_chains + waves - 1) / waves;
+    lds = waves * wave_lds;
+    grid = walk ? 1 : (work + waves - 1) / waves;
   }
   if (grid == 0)
     grid = 1;

@@ -491,3 +491,36 @@ def test_random_sweep_gpu_encoder(gpu_ctx, oracle, zipf, nonstat):
         back = torch.zeros(n, dtype=torch.uint8, device="cuda")
         gpu_ctx.decode_device(dplan, d_out, back, stream_length=m)
         assert gpu_ctx.status(dplan) == 0 and torch.equal(back, d_in), tag
+
+
+def test_private_pair_mode_in_a_subprocess(tmp_path):
+    """32-state mt_ plans without a sidecar: two blocks per wavefront, one per wave half, each with its own table
+    (run_private_pair).  By default only used when there are more blocks than wave slots, so it is forced here
+    (HSRANS_PRIVATE_PAIR=2 is read when the library initialises: separate process)."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "pair.py"
+    script.write_text("""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import hypersonic_rans_amd as H
+from hypersonic_rans_amd import synth
+from oracle_lib import MT, Oracle
+ctx = H.Context(0)
+oracle = Oracle()
+zipf = synth.enwik8_shaped(1 << 20, seed=11)
+nonstat = synth.nonstationary(3_000_000)
+for bits in (10, 11, 12, 13):
+    for src, n, block in ((zipf, 65536, 0), (zipf, 300_001, 32768), (nonstat, 3_000_000, 0), (nonstat, 1_000_003, 65536), (zipf, 131072 + 65, 65536)):
+        d = src[:n]
+        s = H.encode(H.MT, 32, bits, d, block_size=block) if block else H.encode(H.MT, 32, bits, d)
+        r0, want = oracle.decode(MT, 32, bits, s, n)
+        r, got = ctx.decode_host(H.MT, 32, bits, s, n)
+        assert r == r0 == n and np.array_equal(got, want), (bits, n, block)
+print("pair ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, HSRANS_PRIVATE_PAIR="2")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "pair ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
