@@ -440,8 +440,9 @@ def _random_case(rng, zipf, nonstat):
 
 
 def test_random_sweep_decode(gpu_ctx, oracle, zipf, nonstat):
-    rng = np.random.default_rng(20241008)
-    for case in range(160):
+    import os
+    rng = np.random.default_rng(int(os.environ.get("HSRANS_SWEEP_SEED", "20241008")))
+    for case in range(int(os.environ.get("HSRANS_SWEEP_CASES", "160"))):  # a one-off soak run scales these up
         container = int(rng.integers(0, 3))
         states = int(rng.choice((32, 64)))
         bits = int(rng.integers(10, 16))
@@ -470,8 +471,9 @@ def test_random_sweep_decode(gpu_ctx, oracle, zipf, nonstat):
 
 def test_random_sweep_gpu_encoder(gpu_ctx, oracle, zipf, nonstat):
     import torch
-    rng = np.random.default_rng(7)
-    for case in range(60):
+    import os
+    rng = np.random.default_rng(int(os.environ.get("HSRANS_SWEEP_SEED", "7")))
+    for case in range(int(os.environ.get("HSRANS_SWEEP_CASES", "160")) * 3 // 8):
         states = int(rng.choice((32, 64)))
         bits = int(rng.integers(10, 16))
         d = _random_case(rng, zipf, nonstat)
