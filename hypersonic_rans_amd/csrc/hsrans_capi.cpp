@@ -344,6 +344,25 @@ int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
             hipMemcpy(d->d_table, tab.data(), total * sizeof(uint2), hipMemcpyHostToDevice) == hipSuccess)
         {
           d->pa.table = d->d_table;
+          d->pa.table_mode = 3;
+          d->pa.hist_copy = (const uint16_t *)(d->d_plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
+        }
+      }
+      else if ((h.flags & kPlanHasHist) && h.bits >= 13 && h.states == 64 && getenv("HSRANS_NO_COARSE_TABLE") == nullptr)
+      {
+        // wider histograms: the coarse + fine table pair (kModeCoarse), 36 / 40 / 48 KiB instead of 64 / 128 / 256 KiB
+        const uint16_t *counts = (const uint16_t *)(plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
+        std::vector<uint2> tab(coarse_table_entries(h.bits));
+        if (build_coarse_table(counts, h.bits, tab.data(), tab.size()) == 0)
+        {
+          hsrans_dplan_destroy(d);
+          return HSRANS_E_FORMAT;
+        }
+        if (hipMalloc((void **)&d->d_table, tab.size() * sizeof(uint2)) == hipSuccess &&
+            hipMemcpy(d->d_table, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice) == hipSuccess)
+        {
+          d->pa.table = d->d_table;
+          d->pa.table_mode = 4;
           d->pa.hist_copy = (const uint16_t *)(d->d_plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
         }
       }

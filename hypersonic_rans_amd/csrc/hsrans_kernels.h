@@ -25,7 +25,8 @@ struct PersistentArgs
   // (run_persistent).  run_len[k] chains; wave j of class k in workgroup b' of its half starts at
   // half_base[h] + b' * wg_chains[h] + class_off[k] + (j & 3) * run_len[k].  static_total = all static chains.
   uint32_t run_len[8], class_off[8], wg_chains[2], half_base[2], static_total;
-  const uint2 *table;       // host-built MODE-3 decode table (kPlanHasHist plans, bits <= 11) or null: build it in the kernel
+  const uint2 *table;       // host-built decode table (kPlanHasHist plans) or null: build it in the kernel
+  uint32_t table_mode;      // 3: one uint2 per slot (bits <= 12); 4: coarse + fine tables (bits 13..15), see hsrans_kernels.hip
   const uint16_t *hist_copy; // the 256 counts that table was built from (device copy inside the plan)
   unsigned long long *counters; // [kDynQueues * kDynQueueStride] monotonic queue heads (never reset, see run_persistent)
 };
@@ -98,6 +99,9 @@ hipError_t launch_mt_fill(const uint8_t *d_stream, uint64_t stream_len, uint32_t
 
 // workgroups of 16 waves the device holds at once when two fit a CU (what launches size their task lists for)
 uint32_t resident_workgroups_hint();
+// host-side builder of the bits >= 13 coarse/fine decode table (layout: kModeCoarse in hsrans_kernels.hip); returns entries written
+size_t build_coarse_table(const uint16_t counts[256], uint32_t bits, uint2 *out, size_t capacity_entries);
+size_t coarse_table_entries(uint32_t bits);
 // widest histogram the shared 8-byte-per-slot table (MODE 3) is used for
 uint32_t pack64_max_bits();
 // one-time per process: raise the dynamic-LDS limit of every kernel variant to the gfx950 maximum (160 KiB)

@@ -46,9 +46,20 @@ constexpr int kModeTwoLevel = 2; // bits >= 13: uint8 sym[2^bits] + uint32 {freq
 constexpr int kModePack64 = 3;   // bits <= 14, table shared by a workgroup: uint2 per slot = {freq | sym << 24, slot - cumul}:
                                  // v_mad_u32_u24 takes freq (low 24 bits) and the bias operand as they are, v_perm takes byte 3
 
+// bits >= 13 with a host-built table (persistent 64-state launches): a COARSE table of 4096 granules of g = 2^(bits-12) slots,
+// uint2 {freq | sym << 24, bias of the granule's first slot} when all g slots decode to one symbol (bias = that + slot % g),
+// else {0, 1 << 31 | index} into a FINE table of ordinary per-slot entries; at most 255 granules straddle a symbol boundary,
+// so the fine table has 255 * g entries.  32 KiB + 4/8/16 KiB instead of 64/128/256 KiB: two workgroups per CU at every
+// width, one 8-byte gather per group plus a second one on the few lanes that hit a boundary granule.
+constexpr int kModeCoarse = 4;
+constexpr uint32_t kCoarseEntries = 4096;
+
 __host__ __device__ constexpr uint32_t table_bytes_for(int mode, uint32_t bits)
 {
-  return mode == kModeTwoLevel ? (1u << bits) + 1024 : mode == kModePack64 ? 8u << bits : 4u << bits;
+  return mode == kModeTwoLevel ? (1u << bits) + 1024
+         : mode == kModePack64 ? 8u << bits
+         : mode == kModeCoarse ? 8u * kCoarseEntries + 8u * 255u * (1u << (bits - 12))
+                               : 4u << bits;
 }
 
 __device__ __forceinline__ uint32_t lds_address(const void *p)
@@ -73,6 +84,7 @@ struct WaveCtx
   uint32_t *status;
   uint32_t bits, S, lane;
   uint32_t v_mask, v_bits; // 2^bits - 1 and bits, each held in a VGPR: a VALU op with an SGPR operand issues at half rate
+  uint32_t v_gshift, v_gmask; // kModeCoarse: log2 of the granule and granule - 1, in VGPRs for the same reason
   uint8_t *rings;        // LDS, kWaveRingBytes: this wave's stream ring + mirror
   uint8_t *table;        // LDS
   uint8_t *table_b;      // LDS: the table lanes 32..63 use in the paired 32-state modes (== table unless the halves decode different blocks)
@@ -325,6 +337,23 @@ __device__ __forceinline__ uint32_t group_step(uint32_t &x, Ring &r, const WaveC
     e = e2.x;                      // symbol in byte 3: the output v_perm selects it from there
     nx = __umul24(q, e2.x) + e2.y; // the 24-bit multiplier ignores the symbol in bits 24..31
   }
+  else if (MODE == kModeCoarse)
+  {
+    uint2 e2 = ((const uint2 *)c.table)[slot >> c.v_gshift];
+    const uint32_t in_granule = slot & c.v_gmask;
+    uint32_t bias = e2.y + in_granule;
+    const bool mixed = (int32_t)e2.y < 0; // the granule straddles a symbol boundary: per-slot entry from the fine table
+    if (__builtin_amdgcn_ballot_w64(mixed) != 0)
+    {
+      if (mixed)
+      {
+        e2 = ((const uint2 *)(c.table + 8 * kCoarseEntries))[(e2.y & 0x7FFFFFFFu) + in_granule];
+        bias = e2.y;
+      }
+    }
+    e = e2.x;
+    nx = __umul24(q, e2.x) + bias;
+  }
   else if (MODE == kModePack)
   {
     e = ((const uint32_t *)c.table)[slot]; // sym | freq << 8 | (slot - cumul) << 20, freq <= 2048
@@ -401,7 +430,7 @@ __device__ __forceinline__ void run_groups_impl(uint32_t &x, const StreamWin &sw
   const uint32_t S = FULL ? 64 : c.S;
   const bool act = FULL || c.lane < S;
   const unsigned long long act_mask = FULL ? ~0ull : __builtin_amdgcn_ballot_w64(act);
-  constexpr uint32_t kSymByte = MODE == kModePack64 ? 3 : 0; // where group_step's return value holds the symbol
+  constexpr uint32_t kSymByte = (MODE == kModePack64 || MODE == kModeCoarse) ? 3 : 0; // where group_step's return value holds the symbol
   const OutLanes ol = out_lanes(c.lane, S);
 
   for (; steps >= 4; steps -= 4)
@@ -537,7 +566,7 @@ __device__ __forceinline__ void run_tail(uint32_t &x, Ring &r, const WaveCtx &c,
   const bool act = c.lane < c.S && p < tail;
   const uint32_t e = group_step<MODE, false>(x, r, c, __builtin_amdgcn_ballot_w64(act));
   if (act)
-    c.out[o + p] = (uint8_t)(e >> (MODE == kModePack64 ? 24 : 0));
+    c.out[o + p] = (uint8_t)(e >> ((MODE == kModePack64 || MODE == kModeCoarse) ? 24 : 0));
 }
 
 // single-symbol block (block_rANS32x64_16w_decode.cpp:52-60): wave-wide fill
@@ -697,7 +726,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
   const uint32_t cls = half * 4 + wave_in_wg / per_class;
   const uint32_t q0 = pa.run_len[cls];
   const uint32_t c_first = pa.half_base[half] + (blk - half * first_half) * pa.wg_chains[half] + pa.class_off[cls] + (wave_in_wg % per_class) * q0;
-  const bool host_table = MODE == kModePack64 && pa.table != nullptr;
+  const bool host_table = (MODE == kModePack64 || MODE == kModeCoarse) && pa.table != nullptr; // kModeCoarse is host-built only
   if (!host_table) // the in-kernel build borrows ring space: it has to come before the first stream request
     build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
   if (q0 != 0)
@@ -706,7 +735,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
   {
     // the table was built on the host from the plan's histogram copy: one coalesced 16 B load + LDS store per thread,
     // while the first wave checks that the stream really carries that histogram (else: status, as a failed sum check)
-    const uint32_t entries = 1u << c.bits;
+    const uint32_t entries = table_bytes_for(MODE, c.bits) / 8;
     for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
       *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
     if (blockIdx.x == 0 && threadIdx.x < 64)
@@ -1174,6 +1203,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.lane = threadIdx.x & 63;
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << bits) - 1));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(bits));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gshift) : "s"(bits > 12 ? bits - 12 : 0));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gmask) : "s"(bits > 12 ? (1u << (bits - 12)) - 1 : 0));
 
   const uint32_t chain = blockIdx.x * waves + wave;
 
@@ -1419,11 +1450,54 @@ static KernelFn kernel_for(int mode, bool shared)
   case 3: return k_decode<kModePackM1, true>;
   case 4: return k_decode<kModeTwoLevel, false>;
   case 5: return k_decode<kModeTwoLevel, true>;
+  case 8: case 9: return k_decode<kModeCoarse, true>;
   default: return k_decode<kModePack64, true>;
   }
 }
 
 uint32_t pack64_max_bits() { return g_pack64_max_bits; }
+
+size_t coarse_table_entries(uint32_t bits) { return table_bytes_for(kModeCoarse, bits) / 8; }
+
+size_t build_coarse_table(const uint16_t counts[256], uint32_t bits, uint2 *out, size_t capacity_entries)
+{
+  if (bits < 13 || bits > 15 || capacity_entries < coarse_table_entries(bits))
+    return 0;
+  const uint32_t total = 1u << bits, g = 1u << (bits - 12);
+  // slot -> symbol by a running cursor over the cumulative counts (hist.cpp:343-351: zero-count symbols are skipped)
+  uint32_t cum[257];
+  cum[0] = 0;
+  for (uint32_t s = 0; s < 256; s++)
+    cum[s + 1] = cum[s] + counts[s];
+  if (cum[256] != total)
+    return 0;
+  uint2 *fine = out + kCoarseEntries;
+  uint32_t n_fine = 0, s = 0;
+  for (uint32_t gi = 0; gi < kCoarseEntries; gi++)
+  {
+    const uint32_t first = gi * g, last = first + g - 1;
+    while (cum[s + 1] <= first)
+      s++;
+    if (cum[s + 1] > last) // the whole granule decodes to symbol s
+    {
+      out[gi] = make_uint2((uint32_t)counts[s] | (s << 24), first - cum[s]);
+      continue;
+    }
+    if (n_fine + g > 255 * g)
+      return 0; // cannot happen: at most 255 symbol boundaries
+    out[gi] = make_uint2(0, 0x80000000u | n_fine);
+    uint32_t t = s;
+    for (uint32_t slot = first; slot <= last; slot++)
+    {
+      while (cum[t + 1] <= slot)
+        t++;
+      fine[n_fine++] = make_uint2((uint32_t)counts[t] | (t << 24), slot - cum[t]);
+    }
+  }
+  for (uint32_t k = n_fine; k < 255 * g; k++)
+    fine[k] = make_uint2(0, 0);
+  return coarse_table_entries(bits);
+}
 uint32_t resident_workgroups_hint() { return 2 * g_num_cus; }
 
 hipError_t prepare_kernels()
@@ -1461,7 +1535,7 @@ hipError_t prepare_kernels()
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
     g_num_cus = (uint32_t)cus;
-  for (int mode = 0; mode < 4; mode++)
+  for (int mode = 0; mode < 5; mode++)
     for (int shared = 0; shared < 2; shared++)
     {
       const hipError_t e = hipFuncSetAttribute((const void *)kernel_for(mode, shared != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_max_lds);
@@ -1478,7 +1552,8 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
   const bool grouped = kp.groups != nullptr && kp.ckpt_interval == 0;
   const bool shared = !walk && (grouped || (h.shared_hist != 0 && h.n_chains > 1));
   // 64-bit entries only where one table serves a whole workgroup (LDS: 16 KiB table + 16 x 4 KiB rings, two per CU)
-  const int mode = shared && h.bits <= pack64_max_bits() ? kModePack64 : h.bits >= 13 ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : kModePack;
+  const bool coarse = shared && kp.pa.pieces != nullptr && kp.pa.table != nullptr && kp.pa.table_mode == kModeCoarse && h.states == 64;
+  const int mode = coarse ? kModeCoarse : shared && h.bits <= pack64_max_bits() ? kModePack64 : h.bits >= 13 ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : kModePack;
   const bool two_level = mode == kModeTwoLevel;
   const uint32_t table_bytes = table_bytes_for(mode, h.bits);
   const uint32_t wave_bytes = kWaveRingBytes + ((table_bytes + 15) & ~15u); // private rings + table
@@ -1487,6 +1562,8 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
   if (shared)
   {
     waves = g_waves_per_wg;
+    if (mode == kModeCoarse && waves * kWaveRingBytes + table_bytes > g_max_lds / 2)
+      waves = 12; // 15 bits: 48 KiB of tables + 12 rings = 75 KiB, two workgroups per CU
     if (waves * kWaveRingBytes + table_bytes > g_max_lds && table_bytes + 4 * kWaveRingBytes <= g_max_lds)
       waves = (g_max_lds - table_bytes) / kWaveRingBytes / 4 * 4; // a big table: as many waves as still fit (multiple of 4: one per SIMD)
     while (waves > 1 && (waves / 2 >= h.n_chains || waves * kWaveRingBytes + table_bytes > g_max_lds))

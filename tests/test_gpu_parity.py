@@ -495,6 +495,18 @@ def test_random_sweep_gpu_encoder(gpu_ctx, oracle, zipf, nonstat):
         assert gpu_ctx.status(dplan) == 0 and torch.equal(back, d_in), tag
 
 
+def test_15_bit_coarse_table_on_awkward_histograms(gpu_ctx, oracle):
+    """15-bit persistent launches use a coarse table (one entry per 8 slots) plus a fine table for the granules that straddle a
+    symbol boundary: all 256 symbols present (255 boundary granules), two symbols, non-stationary and text-shaped data."""
+    for name, d in (("uniform", synth.uniform_bytes(1_000_003, seed=4)), ("two", synth.two_symbol(500_000, seed=2)),
+                    ("nonstat", synth.nonstationary(2_000_000)), ("zipf", synth.enwik8_shaped(300_000, seed=1))):
+        for interval in (4, 32):
+            s, plan = H.encode(H.RAW, 64, 15, d, index_interval=interval)
+            r0, want = oracle.decode(RAW, 64, 15, s, d.size)
+            r, got = gpu_ctx.decode_host(H.RAW, 64, 15, s, d.size, plan=plan)
+            assert r == r0 == d.size and np.array_equal(got, want), (name, interval)
+
+
 def test_private_pair_mode_in_a_subprocess(tmp_path):
     """32-state mt_ plans without a sidecar: two blocks per wavefront, one per wave half, each with its own table
     (run_private_pair).  By default only used when there are more blocks than wave slots, so it is forced here
