@@ -3,7 +3,8 @@
 // :949) around THIS library's functions, called through include/hsrans_dropin.hpp exactly as main.cpp would call them
 // from its _Codecs[] table (src/main.cpp:172-236).  Encoders are the library's scalar host encoders, decoders are the
 // gfx950 kernels: "host buffers" is the drop-in decodeFunc signature (PCIe both ways inside the timed call), "device
-// resident" is the C-ABI device entry with a sidecar plan, timed with HIP events (what bench.py reports).
+// resident" is the C-ABI device entry with a sidecar plan, timed with HIP events (what bench.py reports).  For the mt_
+// codecs the GPU encoder is timed as well (wall clock around hsrans_encode_device, which synchronises).
 //
 //   hsrans_harness <file> [--runs N] [--decode-runs N] [--only <substring>] [--bits B] [--interval G] [--test]
 #include <hip/hip_runtime.h>
@@ -257,6 +258,46 @@ int main(int argc, char **argv)
     if (dp)
       hsrans_dplan_destroy(dp);
     all_ok = all_ok && ok_dev;
+
+    // ---- the GPU encoder (mt_ container only): input and stream device-resident, plan built on the device; validated by
+    //      decoding its stream with the plan it returned ----
+    if (codec.container == HSRANS_MT)
+    {
+      uint8_t *d_src = d_out; // the decoded bytes of the leg above are the input again
+      bool ok_enc = hipMemcpy(d_src, input.data(), n, hipMemcpyHostToDevice) == hipSuccess;
+      Stats gs;
+      size_t stream_bytes = 0;
+      hsrans_dplan *dpe = nullptr;
+      for (int run = -1; ok_enc && run < decode_runs; run++)
+      {
+        if (dpe)
+          hsrans_dplan_destroy(dpe);
+        dpe = nullptr;
+        const double t0 = now_s();
+        stream_bytes = hsrans_encode_device(ctx, HSRANS_MT, codec.states, codec.bits, d_src, n, d_in, cap, 65536, interval, stream, &dpe); // synchronises
+        const double t1 = now_s();
+        ok_enc = stream_bytes != 0;
+        if (run >= 0)
+          gs.add(t1 - t0);
+      }
+      uint8_t *d_back = nullptr;
+      ok_enc = ok_enc && hipMalloc((void **)&d_back, n + 16) == hipSuccess && hsrans_decode_device(ctx, dpe, d_in, stream_bytes, d_back, n, stream) == HSRANS_OK &&
+               hsrans_dplan_status(ctx, dpe, stream) == HSRANS_OK && hipMemcpy(decoded.data(), d_back, n, hipMemcpyDeviceToHost) == hipSuccess;
+      if (ok_enc)
+      {
+        printf("  %-44s | %6.2f %% ", "enc MI355X (hip), 64 KiB blocks + plan", 100.0 * (double)stream_bytes / (double)n);
+        gs.print(n);
+        ok_enc = validate(decoded.data(), input.data(), n);
+        puts(ok_enc ? " | valid" : " | FAILED TO VALIDATE");
+      }
+      else
+        puts("  GPU encode failed.");
+      if (dpe)
+        hsrans_dplan_destroy(dpe);
+      if (d_back)
+        (void)hipFree(d_back);
+      all_ok = all_ok && ok_enc;
+    }
     if (test && !all_ok)
       break;
   }
