@@ -199,3 +199,20 @@ def test_container_encoders_fix_the_short_last_block(oracle):
         s = H.encode(container, S, bits, d[:n])
         r, got = oracle.decode(container, S, bits, s, n)
         assert r == n and np.array_equal(got, d[:n]), (container, S, bits, n)
+
+
+def test_empty_input_is_a_clean_failure():
+    """length 0: the reference's encoders run off their buffers (a segmentation fault in the compiled reference, so it is not
+    called here); the product returns 0 / raises, for every container, and no stream claims decodedLength 0."""
+    e = np.zeros(0, np.uint8)
+    for container in (H.RAW, H.BLOCK, H.MT):
+        for states in (32, 64):
+            with pytest.raises(H.HsransError):
+                H.encode(container, states, 11, e)
+            with pytest.raises(H.HsransError):
+                H.encode(container, states, 11, e, index_interval=32)
+    s = H.encode(H.RAW, 64, 11, np.arange(200, dtype=np.uint8))
+    zero_len = s.copy()
+    zero_len[:8] = 0  # a stream that says it decodes to nothing
+    with pytest.raises(H.HsransError):
+        H.plan_build(H.RAW, 64, 11, zero_len)
