@@ -580,3 +580,26 @@ def test_golden_vectors_from_the_real_reference(gpu_ctx):
         assert r == data.size and hashlib.sha256(got.tobytes()).hexdigest() == e["decoded_sha256"], e
         checked += 1
     assert checked >= 36
+
+
+def test_offsets_beyond_4_gib(gpu_ctx):
+    """Maximum sizes: 7 GiB of input, so that output offsets AND stream offsets cross 2^32 — encoded, planned (by the encoder and
+    by the device-side header walk) and decoded without leaving HBM."""
+    import torch
+    n = (7 << 30) + 12345
+    d = torch.empty(n, dtype=torch.uint8, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    step = 1 << 28
+    for o in range(0, n, step):
+        m = min(step, n - o)
+        d[o:o + m] = torch.rand(m, device="cuda", generator=g).pow_(6).mul_(205).to(torch.uint8)
+    out = torch.empty(H.capacity(H.MT, 64, n), dtype=torch.uint8, device="cuda")
+    m, dplan = gpu_ctx.encode_device(H.MT, 64, 11, d, out, block_size=1 << 18, index_interval=32, want_plan=True)
+    assert m > 1 << 32
+    back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    gpu_ctx.decode_device(dplan, out, back, stream_length=m)
+    assert gpu_ctx.status(dplan) == 0 and torch.equal(back, d)
+    dplan2 = gpu_ctx.make_device_plan_from_stream(H.MT, 64, 11, out, m, n)
+    back.zero_()
+    gpu_ctx.decode_device(dplan2, out, back, stream_length=m)
+    assert gpu_ctx.status(dplan2) == 0 and torch.equal(back, d)
