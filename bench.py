@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
 """Headline benchmark: bit-exact rANS32x64 16w 11-bit (raw) decode of a 100 MB enwik8-shaped stream on MI355X.
 
-A "step" = one decode of the whole stream (compressed input and decoded output resident in HBM).  With --gpus N
-(launched by torch.distributed.run, one rank per GPU) every rank decodes its own 100 MB stream (weak scaling, no
-data-path collective: the streams are independent objects); the timed region is bracketed by barrier + synchronize and
-the max over ranks is reported.  Rank 0 prints ONE JSON line.
+A "step" = one decode of one whole stream (compressed input and decoded output resident in HBM).  The timed loop rotates
+over `--pairs` (default 4) DISTINCT (stream, output) buffer pairs, 657 MB in all: more than the 256 MiB Infinity Cache, so
+every step reads its stream from and writes its output to HBM (the same pair replayed back to back — what round 1 timed —
+is reported beside it as `roofline.warm`).  With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank
+decodes its own streams (weak scaling, no data-path collective: the streams are independent objects); the timed region is
+bracketed by barrier + synchronize and the max over ranks is reported.  Rank 0 prints ONE JSON line.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--interval G] [--size BYTES] [--bits B] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--index wave|G] [--size BYTES] [--bits B] [--pairs P] [--no-cpu]
+
+`--workload sharded` is the strong-scaling form (BASELINE config 4): ONE 2^30-byte mt_ stream in 256 KiB blocks, its
+chains sharded over the ranks with hsrans_plan_slice (device plans made once, outside the timed region), every rank
+decodes its share from its window of the stream and the decoded ranges are exchanged over RCCL inside the timed region.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import hashlib
 import json
 import os
@@ -28,58 +35,8 @@ import hypersonic_rans_amd as H
 from hypersonic_rans_amd import synth
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable by a copy kernel
-
-
-def cpu_baseline(stream: np.ndarray, data: np.ndarray, states: int, bits: int, budget_s: float = 12.0) -> dict:
-    """Times the CPU decoder on this host, rank 0 only.  Prefers the REAL reference's fastest AVX2 decoder
-    (oracle/_ref, kind "reference"); otherwise the scalar oracle restatement (kind "port").  Checker code only."""
-    from oracle_lib import RAW, Oracle, Ref
-
-    n = data.size
-    if Ref.available():
-        ref = Ref()
-        variant = 1 if ref.L.hsref_has_avx2() else 0
-        best, runs, t_total = None, 0, 0.0
-        while runs < 3 or (t_total < min(budget_s, 4.0) and runs < 40):
-            t0 = time.perf_counter()
-            r, out = ref.decode(RAW, states, bits, stream, n, variant=variant)
-            dt = time.perf_counter() - t0
-            assert r == n
-            if runs == 0:
-                assert np.array_equal(out, data), "reference CPU decoder output differs from the original data"
-            best = dt if best is None else min(best, dt)
-            t_total += dt
-            runs += 1
-        name = ("rANS32x64_xmmShfl2_16w_decode_avx2_varC_%d" if bits <= 12 else "rANS32x64_xmmShfl2_16w_decode_avx2_varA_%d") % bits if variant else "rANS32x64_16w_decode_scalar_%d" % bits
-        return {"value": n / 2**20 / best, "unit": "MiB/s", "cores": 1, "kind": "reference",
-                "sample": f"whole {n}-byte stream, best of {runs} runs, {name} from oracle/_ref (real reference, clang -O3)",
-                "cpu": _cpu_model(), "host_cores": os.cpu_count()}
-    orc = Oracle()
-    t0 = time.perf_counter()
-    r, out = orc.decode(RAW, states, bits, stream, n)
-    dt = time.perf_counter() - t0
-    assert r == n and np.array_equal(out, data)
-    return {"value": n / 2**20 / dt, "unit": "MiB/s", "cores": 1, "kind": "port",
-            "sample": f"whole {n}-byte stream, 1 run, scalar oracle restatement (oracle/hsrans_oracle.c)", "cpu": _cpu_model(),
-            "host_cores": os.cpu_count()}
-
-
-def _pmc_traffic(n: int, states: int, bits: int, interval: int):
-    """HBM bytes per launch from the committed rocprofv3 PMC run of this very workload (profiles/*_pmc.json, written by
-    tools/pmc_summary.py: FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).
-    PMC counters cannot be collected from inside this process, so this is null unless such a run matches the workload."""
-    import glob
-
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
-        try:
-            j = json.load(open(f))
-            cfg = j["bench_line_under_trace"]["config"]
-            if (cfg["decoded_bytes"], cfg["states"], cfg["bits"], cfg["index_interval_groups"]) == (n, states, bits, interval):
-                best = float(j["hbm_traffic_bytes_per_launch"]["total"])
-        except (KeyError, ValueError, OSError):
-            continue
-    return best
+VALU_SLOT_NS = 1.9     # one wave64 VALU instruction of the loop's dominant (VOP3 / SGPR-operand) class per SIMD, measured
+SIMDS = 1024           # 256 CUs x 4
 
 
 def _cpu_model() -> str:
@@ -93,176 +50,400 @@ def _cpu_model() -> str:
     return "unknown"
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", type=int, default=100_000_000)
-    ap.add_argument("--bits", type=int, default=11)
-    ap.add_argument("--states", type=int, default=64)
-    ap.add_argument("--interval", type=int, default=32, help="checkpoint interval of the sidecar plan, in groups of `states` symbols")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-single", action="store_true", help="skip the un-indexed single-wavefront measurement")
-    args = ap.parse_args()
+def cpu_baseline(stream: np.ndarray, data: np.ndarray, states: int, bits: int, budget_s: float = 4.0) -> dict:
+    """Times the CPU decoders on this host, rank 0 only: the REAL reference's AVX2 decoder named by the north star and its
+    AVX-512 sibling where the host has AVX-512 (oracle/_ref, kind "reference"); else the scalar oracle restatement (kind
+    "port").  Checker code only — nothing here is on the product path."""
+    from oracle_lib import RAW, Oracle, Ref
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
-    # one process per GPU; if the launcher narrowed each rank's view to its own GPU (HIP_VISIBLE_DEVICES), index 0 is that GPU
-    n_visible = torch.cuda.device_count()
-    dev_index = local_rank % n_visible if n_visible else 0
-    if distributed:
-        import torch.distributed as dist
-
-        torch.cuda.set_device(dev_index)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-    if args.gpus != world and rank == 0 and distributed:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product has no CPU decode path")
-    dev = torch.device("cuda", dev_index)
-    torch.cuda.set_device(dev)
-    ctx = H.Context(dev_index)
-
-    # ---- synthetic workload (BASELINE.json configs[1]): enwik8-shaped, one stream per rank -------------------------
-    n, S, bits = args.size, args.states, args.bits
-    data = synth.enwik8_shaped(n, seed=20241008 + rank)
+    n = data.size
+    if Ref.available():
+        ref = Ref()
+        variants = []
+        if ref.L.hsref_has_avx2():
+            variants.append((1, ("rANS32x64_xmmShfl2_16w_decode_avx2_varC_%d" if bits <= 12 else "rANS32x64_xmmShfl2_16w_decode_avx2_varA_%d") % bits))
+        if ref.has_avx512():
+            variants.append((3, ("rANS32x64_ymmShfl2_16w_decode_avx512_varC_%d" if bits <= 12 else "rANS32x64_ymmShfl2_16w_decode_avx512_varA_%d") % bits))
+        if not variants:
+            variants.append((0, "rANS32x64_16w_decode_scalar_%d" % bits))
+        results = {}
+        for variant, name in variants:
+            best, runs, t_total = None, 0, 0.0
+            while runs < 3 or (t_total < budget_s and runs < 40):
+                t0 = time.perf_counter()
+                r, out = ref.decode(RAW, states, bits, stream, n, variant=variant)
+                dt = time.perf_counter() - t0
+                assert r == n
+                if runs == 0:
+                    assert np.array_equal(out, data), "reference CPU decoder output differs from the original data"
+                best = dt if best is None else min(best, dt)
+                t_total += dt
+                runs += 1
+            results[name] = {"MiB_s": n / 2**20 / best, "runs": runs}
+        fastest = max(results, key=lambda k: results[k]["MiB_s"])
+        return {"value": results[fastest]["MiB_s"], "unit": "MiB/s", "cores": 1, "kind": "reference",
+                "sample": f"whole {n}-byte stream, best of {results[fastest]['runs']} runs, {fastest} from oracle/_ref (real reference, clang -O3)",
+                "decoders": results, "cpu": _cpu_model(), "host_cores": os.cpu_count()}
+    orc = Oracle()
     t0 = time.perf_counter()
-    stream, plan = H.encode(H.RAW, S, bits, data, index_interval=args.interval)
-    t_enc = time.perf_counter() - t0
-    chains = H.plan_chain_count(plan)
-    pad = (-stream.size) % 16
-    d_in = torch.from_numpy(np.concatenate([stream, np.zeros(pad, np.uint8)])).to(dev)
-    d_out = torch.zeros(n, dtype=torch.uint8, device=dev)
-    d_ref = torch.from_numpy(data).to(dev)
-    dplan = ctx.make_device_plan(plan)
+    r, out = orc.decode(RAW, states, bits, stream, n)
+    dt = time.perf_counter() - t0
+    assert r == n and np.array_equal(out, data)
+    return {"value": n / 2**20 / dt, "unit": "MiB/s", "cores": 1, "kind": "port",
+            "sample": f"whole {n}-byte stream, 1 run, scalar oracle restatement (oracle/hsrans_oracle.c)", "cpu": _cpu_model(),
+            "host_cores": os.cpu_count()}
 
-    def step():
-        ctx.decode_device(dplan, d_in, d_out, stream_length=stream.size)
 
-    step()  # validation decode (not one of the W warm-up steps): the checks below idle the GPU, so they come before the warm-up
-    torch.cuda.synchronize()
-    assert ctx.status(dplan) == 0
-    assert torch.equal(d_out, d_ref), "GPU output is not bit-exact"
-    d_out.zero_()
+def _pmc_profile(n: int, states: int, bits: int, index: str):
+    """The committed rocprofv3 PMC run of this very workload (profiles/*_pmc.json, written by tools/pmc_summary.py: FETCH_SIZE /
+    WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  PMC counters cannot be collected
+    from inside this process, so traffic is null unless such a run matches the workload; the source file is named."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            j = json.load(open(f))
+            cfg = j["bench_line_under_trace"]["config"]
+            if (cfg["decoded_bytes"], cfg["states"], cfg["bits"], str(cfg.get("index", cfg.get("index_interval_groups")))) == (n, states, bits, index):
+                best = (os.path.relpath(f, ROOT), j)
+        except (KeyError, ValueError, OSError):
+            continue
+    return best
+
+
+def _permuted(data: np.ndarray, k: int) -> np.ndarray:
+    """Another stream of the same shape: the bytes of `data` under a fixed byte permutation (same order-0 statistics, other content)."""
+    if k == 0:
+        return data
+    return synth._permutation(1000 + k)[data]
+
+
+def headline(args, world, rank, dev, dev_index, ctx, dist):
+    n, S, bits = args.size, args.states, args.bits
+    base = synth.enwik8_shaped(n, seed=20241008 + rank)
+    pairs = []
+    t_enc = 0.0
+    groups = None if args.index != "wave" else H.index_boundaries(S, bits, n, ctx)
+    for k in range(max(1, args.pairs)):
+        data = _permuted(base, k)
+        t0 = time.perf_counter()
+        if args.index == "wave":
+            stream, plan = H.encode(H.RAW, S, bits, data, index_groups=groups)
+        else:
+            stream, plan = H.encode(H.RAW, S, bits, data, index_interval=int(args.index))
+        t_enc += time.perf_counter() - t0
+        pad = (-stream.size) % 16
+        p = {"data": data, "stream": stream, "plan": plan,
+             "d_in": torch.from_numpy(np.concatenate([stream, np.zeros(pad, np.uint8)])).to(dev),
+             "d_out": torch.zeros(n, dtype=torch.uint8, device=dev), "dplan": ctx.make_device_plan(plan)}
+        pairs.append(p)
+    P = len(pairs)
+    chains = H.plan_chain_count(pairs[0]["plan"])
+
+    def step(i):
+        p = pairs[i % P]
+        ctx.decode_device(p["dplan"], p["d_in"], p["d_out"], stream_length=p["stream"].size)
+
+    # validation decode of every pair (not one of the W warm-up steps): the checks idle the GPU, so they come before the warm-up
+    for i, p in enumerate(pairs):
+        step(i)
+        torch.cuda.synchronize()
+        assert ctx.status(p["dplan"]) == 0
+        assert torch.equal(p["d_out"].cpu(), torch.from_numpy(p["data"])), "GPU output is not bit-exact"
+        p["d_out"].zero_()
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides ------------------------------------------
     # One HIP event pair brackets the K launches ON THE LAUNCH STREAM (hsrans_decode_device launches on torch's current
     # stream, which is where torch.cuda.Event records): span / K = the kernel's average launch duration for the roofline.
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(args.warmup):  # W untimed warm-up steps, immediately in front of the timed region
-        step()
-    if distributed:
+    for i in range(args.warmup):  # W untimed warm-up steps, immediately in front of the timed region
+        step(i)
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev_a.record()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(args.warmup + i)
     ev_b.record()
     torch.cuda.synchronize()
-    if distributed:
+    if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms_span = ev_a.elapsed_time(ev_b) / args.steps
 
-    # per-launch spread (outside the timed region; each pair adds event/launch latency, so only min/max are reported)
+    # warm: ONE pair replayed back to back (stream + output + index stay in the Infinity Cache); outside the timed region
+    wa, wb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        step(0)
+    wa.record()
+    for _ in range(args.steps):
+        step(0)
+    wb.record()
+    torch.cuda.synchronize()
+    warm_ms = wa.elapsed_time(wb) / args.steps
+    # per-launch spread over the rotation (each event pair adds launch latency, so only min/max are reported)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 20))]
-    for a, b in ev:
+    for i, (a, b) in enumerate(ev):
         a.record()
-        step()
+        step(i)
         b.record()
     torch.cuda.synchronize()
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    assert ctx.status(dplan) == 0
-    assert torch.equal(d_out, d_ref), "GPU output is not bit-exact after the timed region"
-    sha = hashlib.sha256(d_out.cpu().numpy().tobytes()).hexdigest()
-    assert sha == hashlib.sha256(data.tobytes()).hexdigest()
+    shas = []
+    for p in pairs:
+        assert ctx.status(p["dplan"]) == 0
+        got = p["d_out"].cpu().numpy()
+        assert np.array_equal(got, p["data"]), "GPU output is not bit-exact after the timed region"
+        shas.append(hashlib.sha256(got.tobytes()).hexdigest())
+        assert shas[-1] == hashlib.sha256(p["data"].tobytes()).hexdigest()
 
-    if distributed:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if rank != 0:
+        return None
 
-    result = None
-    if rank == 0:
-        info = dplan.launch_info()
-        ms_per_step = elapsed * 1e3 / args.steps
-        k_avg = float(kernel_ms_span)
-        k_min = float(np.min(kernel_ms))
-        alg_bytes = stream.size + n  # compressed bytes read once + decoded bytes written once
-        achieved = alg_bytes / (k_avg * 1e-3) / 1e9
-        result = {
-            "metric": "decode MiB/s (bit-exact) on 100 MB stream",
-            "value": world * n / 2**20 / elapsed * args.steps,
-            "unit": "MiB/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32 state / u16 word / u8 symbol (integer)",
-            "data": "synthetic",
-            "config": {
-                "workload": f"rANS32x{S} 16w {bits}-bit (raw) decode, {n} B enwik8-shaped synthetic (Zipf1.2/205 symbols, seed 20241008+rank), "
-                            f"one stream per GPU, sidecar plan with a checkpoint every {args.interval} groups ({chains} chains)",
-                "container": "raw", "states": S, "bits": bits, "decoded_bytes": n, "compressed_bytes": int(stream.size),
-                "ratio": stream.size / n, "plan_bytes": int(plan.size), "index_interval_groups": args.interval, "chains": chains,
-                "launch": info, "bit_exact": True, "sha256": sha, "host_encode_s": t_enc,
-            },
-            # the reference harness prints min/mean throughput per decoder (src/main.cpp:72-118): same two numbers here
-            "mib_s": {"mean_over_timed_region": world * n / 2**20 / elapsed * args.steps, "best_single_launch": n / 2**20 / (k_min * 1e-3),
-                      "launches_in_timed_region": args.steps},
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": _pmc_traffic(n, S, bits, args.interval),
-                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": k_avg, "kernel_ms_single_launch_min": k_min,
-                "kernel": "hsrans::k_decode<%d, %s>" % (3 if info["shared_table"] and bits <= 11 else (2 if bits >= 13 else (1 if bits == 12 else 0)),
-                                                        "true" if info["shared_table"] else "false"),
-            },
-        }
+    info = pairs[0]["dplan"].launch_info()
+    stream, plan = pairs[0]["stream"], pairs[0]["plan"]
+    ms_per_step = elapsed * 1e3 / args.steps
+    k_avg = float(kernel_ms_span)
+    alg_bytes = int(np.mean([p["stream"].size for p in pairs])) + n  # SURVEY.md §8(d): compressed bytes read once + decoded bytes written once
+    achieved = alg_bytes / (k_avg * 1e-3) / 1e9
+    groups_per_launch = n // S
+    prof = _pmc_profile(n, S, bits, args.index)
+    traffic, traffic_source, issue = None, None, None
+    if prof is not None:
+        traffic_source, j = prof
+        traffic = float(j["hbm_traffic_bytes_per_launch"]["total"])
+        valu = j["counters"].get("SQ_INSTS_VALU", {}).get("mean")
+        if valu:
+            per_group = valu / groups_per_launch
+            issue = {"valu_per_group": per_group, "slot_ns": VALU_SLOT_NS, "simds": SIMDS, "us": per_group * VALU_SLOT_NS * groups_per_launch / SIMDS * 1e-3,
+                     "note": "VALU instructions per 64-symbol group (SQ_INSTS_VALU / groups) x 1.9 ns per issue slot x groups / 1,024 SIMDs: the time the "
+                             "vector issue alone needs; counters from " + traffic_source}
+    result = {
+        "metric": "decode MiB/s (bit-exact) on 100 MB stream",
+        "value": world * n / 2**20 / elapsed * args.steps,
+        "unit": "MiB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32 state / u16 word / u8 symbol (integer)",
+        "data": "synthetic",
+        "config": {
+            "workload": f"rANS32x{S} 16w {bits}-bit (raw + sidecar index) decode, {n} B enwik8-shaped synthetic (Zipf1.2/205 symbols, seed 20241008+rank), "
+                        f"{P} distinct streams per GPU rotated through the timed loop ({P * (alg_bytes) / 2**20:.0f} MiB of stream + output: beyond the Infinity Cache), "
+                        + ("index with one chain per resident wavefront + a dynamic tail" if args.index == "wave" else f"index with a checkpoint every {args.index} groups")
+                        + f" ({chains} chains)",
+            "container": "raw", "states": S, "bits": bits, "decoded_bytes": n, "compressed_bytes": int(stream.size),
+            "ratio": stream.size / n, "index": args.index, "plan_bytes": int(plan.size), "plan_over_compressed": plan.size / stream.size,
+            "effective_ratio_with_index": (stream.size + plan.size) / n, "chains": chains, "pairs": P,
+            "launch": info, "bit_exact": True, "sha256": shas[0], "host_encode_s": t_enc / P,
+        },
+        # the reference harness prints min/mean throughput per decoder (src/main.cpp:72-118): same two numbers here
+        "mib_s": {"mean_over_timed_region": world * n / 2**20 / elapsed * args.steps, "best_single_launch": n / 2**20 / (float(np.min(kernel_ms)) * 1e-3),
+                  "warm_one_pair_replayed": n / 2**20 / (warm_ms * 1e-3), "launches_in_timed_region": args.steps},
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": (traffic_source + " (rocprofv3 --pmc run of this workload, not this process)") if traffic_source else None,
+            "algorithmic_bytes_per_launch": alg_bytes, "index_bytes_read_per_launch": int(plan.size),
+            "kernel_ms_avg": k_avg, "kernel_ms_single_launch_min": float(np.min(kernel_ms)),
+            "cache_state": f"cold: {P} (stream, output) pairs rotated, working set {P * alg_bytes / 2**20:.0f} MiB > 256 MiB Infinity Cache",
+            "warm": {"kernel_ms_avg": float(warm_ms), "frac": alg_bytes / (warm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "cache_state": "one pair replayed back to back (Infinity-Cache resident, as BENCH_r01 measured)"},
+            "issue_bound": issue,
+            "kernel": "hsrans::k_decode<%d, %s>" % (info["table_mode"], "true" if info["shared_table"] else "false"),
+        },
+    }
 
-        # the same stream WITHOUT the sidecar plan: one wavefront, one dependent chain (SURVEY.md finding 2)
-        if not args.no_single and world == 1:
-            plan1 = H.plan_build(H.RAW, S, bits, stream)
-            dplan1 = ctx.make_device_plan(plan1)
-            d_out.zero_()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            ctx.decode_device(dplan1, d_in, d_out, stream_length=stream.size)
-            b.record()
-            torch.cuda.synchronize()
-            assert ctx.status(dplan1) == 0 and torch.equal(d_out, d_ref)
-            ms1 = a.elapsed_time(b)
-            result["single_wavefront_no_plan"] = {"value": n / 2**20 / (ms1 * 1e-3), "unit": "MiB/s", "ms": ms1, "bit_exact": True,
-                                                  "note": "raw format has no restart points: 1 wave64 = 1 dependent chain"}
+    # the same stream WITHOUT the sidecar index: one wavefront, one dependent chain (SURVEY.md finding 2)
+    d_in, d_out, d_ref = pairs[0]["d_in"], pairs[0]["d_out"], torch.from_numpy(pairs[0]["data"]).to(dev)
+    if not args.no_single and world == 1:
+        plan1 = H.plan_build(H.RAW, S, bits, stream)
+        dplan1 = ctx.make_device_plan(plan1)
+        d_out.zero_()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ctx.decode_device(dplan1, d_in, d_out, stream_length=stream.size)
+        b.record()
+        torch.cuda.synchronize()
+        assert ctx.status(dplan1) == 0 and torch.equal(d_out, d_ref)
+        ms1 = a.elapsed_time(b)
+        result["single_wavefront_no_plan"] = {"value": n / 2**20 / (ms1 * 1e-3), "unit": "MiB/s", "ms": ms1, "bit_exact": True,
+                                              "note": "raw format has no restart points: 1 wave64 = 1 dependent chain"}
 
-        # the step before the path, informational: the same input through the GPU encoder (mt_ container,
-        # 64 KiB independent blocks, sidecar plan built on the device) and the decode that plan enables
-        if not args.no_single and world == 1:
-            d_enc = torch.empty(H.capacity(H.MT, S, n), dtype=torch.uint8, device=dev)
-            m, dplan_e = ctx.encode_device(H.MT, S, bits, d_ref, d_enc, block_size=1 << 16, index_interval=32, want_plan=True)  # warm-up
-            t0 = time.perf_counter()
-            m = ctx.encode_device(H.MT, S, bits, d_ref, d_enc, block_size=1 << 16)  # synchronises its stream
-            t_gpu_enc = time.perf_counter() - t0
-            d_out.zero_()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            ctx.decode_device(dplan_e, d_enc, d_out, stream_length=m)
-            b.record()
-            torch.cuda.synchronize()
-            assert ctx.status(dplan_e) == 0 and torch.equal(d_out, d_ref)
-            result["gpu_encoder"] = {"container": "mt_", "block_size": 1 << 16, "compressed_bytes": int(m), "encode_ms": t_gpu_enc * 1e3,
-                                     "encode_GB_s": n / t_gpu_enc / 1e9, "decode_with_device_built_plan_MiB_s": n / 2**20 / (a.elapsed_time(b) * 1e-3),
-                                     "round_trip_bit_exact": True}
+    # the step before the path (SURVEY.md §8(f) row 2), informational: the same input through the GPU encoder (mt_ container,
+    # 64 KiB independent blocks, sidecar plan built on the device) and the decode that plan enables
+    if not args.no_single and world == 1:
+        d_enc = torch.empty(H.capacity(H.MT, S, n), dtype=torch.uint8, device=dev)
+        m, dplan_e = ctx.encode_device(H.MT, S, bits, d_ref, d_enc, block_size=1 << 16, index_interval=32, want_plan=True)  # warm-up
+        t0 = time.perf_counter()
+        m = ctx.encode_device(H.MT, S, bits, d_ref, d_enc, block_size=1 << 16)  # synchronises its stream
+        t_gpu_enc = time.perf_counter() - t0
+        d_out.zero_()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ctx.decode_device(dplan_e, d_enc, d_out, stream_length=m)
+        b.record()
+        torch.cuda.synchronize()
+        assert ctx.status(dplan_e) == 0 and torch.equal(d_out, d_ref)
+        result["gpu_encoder"] = {"container": "mt_", "block_size": 1 << 16, "compressed_bytes": int(m), "encode_ms": t_gpu_enc * 1e3,
+                                 "encode_GB_s": n / t_gpu_enc / 1e9, "decode_with_device_built_plan_MiB_s": n / 2**20 / (a.elapsed_time(b) * 1e-3),
+                                 "round_trip_bit_exact": True}
 
-    if rank == 0 and not args.no_cpu and world == 1:  # reported baseline, N=1 only
-        result["cpu_baseline"] = cpu_baseline(stream, data, S, bits)
+    if not args.no_cpu and world == 1:  # reported baseline, N=1 only
+        result["cpu_baseline"] = cpu_baseline(stream, pairs[0]["data"], S, bits)
+    return result
+
+
+def _tiled(n: int, seed: int) -> np.ndarray:
+    """n bytes of enwik8-shaped data, generated as 2^24-byte tiles of one base block under per-tile byte permutations (the
+    integer generator makes ~7 MB/s per core: a GiB of it would take minutes; the tiles keep its order-0 statistics)."""
+    tile = 1 << 24
+    base = synth.enwik8_shaped(min(tile, n), seed=seed)
+    out = np.empty(n, np.uint8)
+    for k, s in enumerate(range(0, n, tile)):
+        c = min(tile, n - s)
+        out[s:s + c] = _permuted(base, k % 7)[:c]
+    return out
+
+
+def sharded_workload(args, world, rank, dev, dev_index, ctx, dist):
+    """ONE stream over all ranks (strong scaling): decode of this rank's chains + the exchange of the decoded ranges, both inside
+    the timed region; device plans, window uploads and buffers outside it."""
+    from hypersonic_rans_amd import sharded
+
+    n, S, bits = args.size, args.states, args.bits
+    data = _tiled(n, seed=20241008)
+    t0 = time.perf_counter()
+    stream, plan = H.encode(H.MT, S, bits, data, block_size=args.block, index_interval=args.interval)
+    t_enc = time.perf_counter() - t0
+    dec = sharded.ShardedDecoder(ctx, plan)
+    d_window = dec.upload_window(stream, dev)
+    out = torch.zeros(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    root = None if args.gather == "all" else 0
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+
+    def step(timed=False):
+        if timed:
+            ev[0].record()
+        dec.decode_window(d_window, out, gather=False)
+        if timed:
+            ev[1].record()
+        sharded.gather_ranges(out, dec.ranges, root=root)
+        if timed:
+            ev[2].record()
+
+    step()
+    torch.cuda.synchronize()
+    assert dec.global_status() == 0
+    if root is None or rank == 0:
+        assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == hashlib.sha256(data.tobytes()).hexdigest(), "sharded decode is not bit-exact"
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dec_ms = gat_ms = 0.0
+    for _ in range(args.steps):
+        step(timed=True)
+        # the per-leg times need the events resolved; the synchronisation is part of a step (a consumer would wait for the output too)
+        torch.cuda.synchronize()
+        dec_ms += ev[0].elapsed_time(ev[1])
+        gat_ms += ev[1].elapsed_time(ev[2])
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ok = dec.global_status() == 0
+    if root is None or rank == 0:
+        ok = ok and hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == hashlib.sha256(data.tobytes()).hexdigest()
+    assert ok, "sharded decode is not bit-exact after the timed region"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    seen = torch.ones(1, dtype=torch.int32, device=dev)
+    dist.all_reduce(seen)
+    legs = [None] * world
+    dist.all_gather_object(legs, {"rank": rank, "decode_ms": dec_ms / args.steps, "gather_ms": gat_ms / args.steps, "chains": dec.count,
+                                  "range": list(dec.ranges[rank]), "window_bytes": dec.window[1] - dec.window[0]})
+    if rank != 0:
+        return None
+    ms = elapsed * 1e3 / args.steps
+    worst_dec = max(l["decode_ms"] for l in legs)
+    alg = stream.size + n
+    return {
+        "metric": "decode MiB/s (bit-exact), one stream sharded over the GPUs, exchange of the decoded ranges included",
+        "value": n / 2**20 / (elapsed / args.steps), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 state / u16 word / u8 symbol (integer)", "data": "synthetic",
+        "config": {"workload": f"mt_rANS32x{S} 16w {bits}-bit, ONE {n}-byte stream in {args.block}-byte blocks + index every {args.interval} groups, chains sharded "
+                               f"over {world} rank(s) by hsrans_plan_slice, decoded ranges exchanged point-to-point over RCCL ({args.gather})",
+                   "container": "mt_", "states": S, "bits": bits, "decoded_bytes": n, "compressed_bytes": int(stream.size), "ratio": stream.size / n,
+                   "plan_bytes": int(plan.size), "plan_over_compressed": plan.size / stream.size, "chains": H.plan_chain_count(plan), "block": args.block,
+                   "index_interval_groups": args.interval, "gather": args.gather, "backend": dist.get_backend(), "n_ranks_seen": int(seen.item()),
+                   "host_encode_s": t_enc, "bit_exact": True},
+        "per_rank": legs,
+        "decode_only_MiB_s": n / 2**20 / (worst_dec * 1e-3),
+        "roofline": {"bound": "hbm", "achieved": alg / (worst_dec * 1e-3) / 1e9 / 1.0, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                     "frac": alg / (worst_dec * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                     "note": "decode kernels only (slowest rank), against the HBM peak of all ranks; the exchange is xGMI-bound, see per_rank.gather_ms"},
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=("headline", "sharded"), default="headline")
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--bits", type=int, default=11)
+    ap.add_argument("--states", type=int, default=64)
+    ap.add_argument("--index", default="wave", help="'wave' = one chain per resident wavefront (hsrans_index_boundaries); or G = a checkpoint every G groups")
+    ap.add_argument("--pairs", type=int, default=4, help="distinct (stream, output) pairs rotated through the timed loop")
+    ap.add_argument("--block", type=int, default=1 << 18, help="sharded: mt_ block size in bytes")
+    ap.add_argument("--interval", type=int, default=256, help="sharded: checkpoint interval inside the blocks, in groups")
+    ap.add_argument("--gather", choices=("all", "root"), default="all", help="sharded: every rank gets the whole output, or rank 0 only")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-single", action="store_true", help="skip the un-indexed single-wavefront and GPU-encoder legs")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 50 if args.workload == "headline" else 20
+    if args.size is None:
+        args.size = 100_000_000 if args.workload == "headline" else 1 << 30
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1 or args.workload == "sharded"
+    # one process per GPU; if the launcher narrowed each rank's view to its own GPU (HIP_VISIBLE_DEVICES), index 0 is that GPU
+    n_visible = torch.cuda.device_count()
+    dev_index = local_rank % n_visible if n_visible else 0
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU decode path")
+    dist = None
     if distributed:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(dev_index)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+    if args.gpus != world and rank == 0 and distributed:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
+    ctx = H.Context(dev_index)
+
+    fn = headline if args.workload == "headline" else sharded_workload
+    result = fn(args, world, rank, dev, dev_index, ctx, dist)
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

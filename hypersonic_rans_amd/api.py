@@ -30,11 +30,11 @@ class Hist(ctypes.Structure):
 
 class EncodeOpts(ctypes.Structure):
     _fields_ = [("block_size", _u32), ("index_interval", _u32), ("plan_out", _vp), ("plan_capacity", _sz), ("plan_size", _sz), ("flags", _u32),
-                ("reserved", _u32)]
+                ("reserved", _u32), ("index_groups", _vp), ("n_index_groups", _sz)]
 
 
 class LaunchInfo(ctypes.Structure):
-    _fields_ = [(n, _u32) for n in ("grid", "block", "lds_bytes", "waves_per_block", "chains", "shared_table", "walk", "two_level")]
+    _fields_ = [(n, _u32) for n in ("grid", "block", "lds_bytes", "waves_per_block", "chains", "shared_table", "walk", "two_level", "table_mode")]
 
 
 def lib_path() -> str:
@@ -77,6 +77,11 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_plan_stream_ranges.argtypes = [_vp, _sz, _u32, _u32, ctypes.POINTER(ctypes.c_uint64)]
     L.hsrans_plan_chain_range.restype = _i
     L.hsrans_plan_chain_range.argtypes = [_vp, _sz, _u32, _u32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    L.hsrans_cpu_level.restype = _i
+    L.hsrans_decode_cpu.restype = _sz
+    L.hsrans_decode_cpu.argtypes = [_i, _u32, _i, _i, _u32, _vp, _sz, _vp, _sz, _vp, _sz]
+    L.hsrans_index_build_host.restype = _sz
+    L.hsrans_index_build_host.argtypes = [_i, _u32, _i, _i, _u32, _vp, _sz, _vp, _sz, _vp, _sz]
     L.hsrans_ctx_create.restype = _i
     L.hsrans_ctx_create.argtypes = [_i, ctypes.POINTER(_vp)]
     L.hsrans_ctx_destroy.restype = None
@@ -91,6 +96,8 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_dplan_destroy.argtypes = [_vp]
     L.hsrans_decode_device.restype = _i
     L.hsrans_decode_device.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp]
+    L.hsrans_decode_device_window.restype = _i
+    L.hsrans_decode_device_window.argtypes = [_vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp]
     L.hsrans_dplan_status.restype = _i
     L.hsrans_dplan_status.argtypes = [_vp, _vp, _vp]
     L.hsrans_dplan_launch_info.restype = _i
@@ -103,6 +110,26 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_encode_device.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _vp, _sz, _u32, _u32, _vp, ctypes.POINTER(_vp)]
     L.hsrans_index_build.restype = _sz
     L.hsrans_index_build.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _u32, _vp, _sz]
+    L.hsrans_index_build_at.restype = _sz
+    L.hsrans_index_build_at.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _vp, _sz, _vp, _sz]
+    L.hsrans_index_boundaries.restype = _sz
+    L.hsrans_index_boundaries.argtypes = [_vp, _i, _u32, _sz, _vp, _sz]
+    L.hsrans_plan_thin.restype = _sz
+    L.hsrans_plan_thin.argtypes = [_vp, _sz, _vp, _sz, _vp, _sz]
+    L.hsrans_plan_capacity_chains.restype = _sz
+    L.hsrans_plan_capacity_chains.argtypes = [_i, _i, _sz, _sz, _u32]
+    L.hsrans_hpipe_create.restype = _i
+    L.hsrans_hpipe_create.argtypes = [_vp, _vp, _sz, _u32, ctypes.POINTER(_vp)]
+    L.hsrans_hpipe_decode.restype = _sz
+    L.hsrans_hpipe_decode.argtypes = [_vp, _vp, _sz, _vp, _sz]
+    L.hsrans_hpipe_destroy.restype = None
+    L.hsrans_hpipe_destroy.argtypes = [_vp]
+    L.hsrans_decode_host_pipelined.restype = _sz
+    L.hsrans_decode_host_pipelined.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _vp, _sz, _vp, _sz, _u32]
+    L.hsrans_host_register.restype = _i
+    L.hsrans_host_register.argtypes = [_vp, _vp, _sz]
+    L.hsrans_host_unregister.restype = _i
+    L.hsrans_host_unregister.argtypes = [_vp, _vp]
     _LIB = L
     return L
 
@@ -143,28 +170,55 @@ def hist_from_counts(counts) -> Hist:
 ENC_INDEPENDENT_BLOCKS = 1
 
 
+def index_boundaries(states: int, bits: int, decoded_size: int, ctx: "Context | None" = None) -> np.ndarray:
+    """Checkpoint positions (group indices) for ONE chain per resident wavefront (hsrans_index_boundaries); ctx None = MI355X defaults."""
+    out = np.zeros(1 << 16, np.uint64)
+    n = load_library().hsrans_index_boundaries(ctx.handle if ctx is not None else None, states, bits, decoded_size, _p(out), out.size)
+    return out[:n].copy()
+
+
 def encode(container: int, states: int, bits: int, data, hist: Hist | None = None, block_size: int = 0, index_interval: int = 0,
-           independent_blocks: bool = False):
-    """Returns ``stream`` (np.uint8) or ``(stream, plan)`` when ``index_interval`` != 0."""
+           independent_blocks: bool = False, index_groups=None):
+    """Returns ``stream`` (np.uint8) or ``(stream, plan)`` when ``index_interval`` != 0 or ``index_groups`` (explicit checkpoints) is given."""
     L = load_library()
     data = _u8(data)
     cap = L.hsrans_capacity(container, states, data.size)
     out = np.zeros(cap, np.uint8)
     hp = ctypes.byref(hist) if hist is not None else None
-    if index_interval == 0 and block_size == 0 and not independent_blocks:
+    if index_groups is not None:
+        index_groups = np.ascontiguousarray(index_groups, dtype=np.uint64)
+        if index_groups.size == 0:  # a stream too short for more than one chain
+            index_groups, index_interval = None, 4
+    want_plan = index_interval != 0 or index_groups is not None
+    if not want_plan and block_size == 0 and not independent_blocks:
         m = L.hsrans_encode(container, states, bits, _p(data), data.size, _p(out), cap, hp)
         if m == 0:
             raise HsransError("encode failed")
         return out[:m].copy()
-    pcap = L.hsrans_plan_capacity(container, states, data.size, index_interval, block_size) if index_interval else 0
+    if index_groups is not None:
+        pcap = L.hsrans_plan_capacity_chains(container, states, data.size, index_groups.size, block_size)
+    else:
+        pcap = L.hsrans_plan_capacity(container, states, data.size, index_interval, block_size) if index_interval else 0
     plan = np.zeros(max(pcap, 1), np.uint8)
-    opts = EncodeOpts(block_size, index_interval, plan.ctypes.data if index_interval else None, pcap, 0, ENC_INDEPENDENT_BLOCKS if independent_blocks else 0, 0)
+    opts = EncodeOpts(block_size, 0 if index_groups is not None else index_interval, plan.ctypes.data if want_plan else None, pcap, 0,
+                      ENC_INDEPENDENT_BLOCKS if independent_blocks else 0, 0, index_groups.ctypes.data if index_groups is not None else None,
+                      index_groups.size if index_groups is not None else 0)
     m = L.hsrans_encode_ex(container, states, bits, _p(data), data.size, _p(out), cap, hp, ctypes.byref(opts))
     if m == 0:
         raise HsransError("encode failed")
-    if index_interval == 0:
+    if not want_plan:
         return out[:m].copy()
     return out[:m].copy(), plan[:opts.plan_size].copy()
+
+
+def plan_thin(plan, groups) -> np.ndarray:
+    plan = _u8(plan)
+    groups = np.ascontiguousarray(groups, dtype=np.uint64)
+    out = np.zeros(plan.size, np.uint8)
+    n = load_library().hsrans_plan_thin(_p(plan), plan.size, _p(groups), groups.size, _p(out), out.size)
+    if n == 0:
+        raise HsransError("plan_thin failed")
+    return out[:n].copy()
 
 
 def plan_build(container: int, states: int, bits: int, stream, out_capacity: int | None = None) -> np.ndarray:
@@ -217,6 +271,45 @@ def plan_stream_ranges(plan, first: int, count: int) -> tuple[tuple[int, int], t
     if load_library().hsrans_plan_stream_ranges(_p(plan), plan.size, first, count, r) != 0:
         raise HsransError("plan_stream_ranges failed")
     return (r[0], r[1]), (r[2], r[3])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# host SIMD decoders (csrc/hsrans_cpu.cpp): the CPU comparator / single-chain path; never used by Context (the GPU entries)
+# ---------------------------------------------------------------------------------------------------------------------
+CPU_LEVELS = {0: "scalar", 1: "avx2", 2: "avx512"}
+
+
+def cpu_level() -> int:
+    return load_library().hsrans_cpu_level()
+
+
+def decode_cpu(container: int, states: int, bits: int, stream, out_capacity: int | None = None, plan=None, level: int = -1, threads: int = 1,
+               in_length: int | None = None):
+    """Returns (returned_length, out) like the reference's decoders (0 = failure).  hsrans_decode_cpu."""
+    stream = _u8(stream)
+    if out_capacity is None:
+        out_capacity = int(stream[:8].view(np.uint64)[0]) if stream.size >= 8 else 0
+    out = np.full(max(out_capacity, 1) + 64, 0xCC, np.uint8)
+    pp, pn = (None, 0)
+    if plan is not None:
+        plan = _u8(plan)
+        pp, pn = _p(plan), plan.size
+    r = load_library().hsrans_decode_cpu(level, threads, container, states, bits, _p(stream), stream.size if in_length is None else in_length, _p(out),
+                                         out_capacity, pp, pn)
+    return r, out[:out_capacity]
+
+
+def index_build_host(container: int, states: int, bits: int, stream, groups, level: int = -1, threads: int = 1) -> np.ndarray:
+    stream = _u8(stream)
+    groups = np.ascontiguousarray(groups, dtype=np.uint64)
+    out_len = int(stream[:8].view(np.uint64)[0])
+    L = load_library()
+    pcap = L.hsrans_plan_capacity_chains(container, states, out_len, groups.size, 0)
+    plan = np.zeros(pcap, np.uint8)
+    n = L.hsrans_index_build_host(level, threads, container, states, bits, _p(stream), stream.size, _p(groups), groups.size, _p(plan), pcap)
+    if n == 0:
+        raise HsransError("hsrans_index_build_host failed")
+    return plan[:n].copy()
 
 
 PIECE_DTYPE = np.dtype([("words_off", "<u8"), ("out_off", "<u8"), ("hist_off", "<u8"), ("fill_len", "<u8"), ("steps", "<u4"),
@@ -348,6 +441,15 @@ class Context:
         if rc != 0:
             raise HsransError(f"hsrans_decode_device failed with code {rc}")
 
+    def decode_device_window(self, dplan: DevicePlan, d_window: torch.Tensor, window_offset: int, window_length: int, d_out: torch.Tensor,
+                             stream: torch.cuda.Stream | None = None):
+        """As decode_device for a caller that holds only stream bytes [window_offset, window_offset + window_length) (hsrans_decode_device_window)."""
+        s = stream if stream is not None else torch.cuda.current_stream(d_window.device)
+        rc = self.L.hsrans_decode_device_window(self.handle, dplan.handle, d_window.data_ptr(), window_offset, window_length, d_out.data_ptr(), d_out.numel(),
+                                                ctypes.c_void_p(s.cuda_stream))
+        if rc != 0:
+            raise HsransError(f"hsrans_decode_device_window failed with code {rc}")
+
     def status(self, dplan: DevicePlan, stream: torch.cuda.Stream | None = None) -> int:
         s = stream if stream is not None else torch.cuda.current_stream()
         return self.L.hsrans_dplan_status(self.handle, dplan.handle, ctypes.c_void_p(s.cuda_stream))
@@ -363,6 +465,23 @@ class Context:
         if n == 0:
             raise HsransError("hsrans_encode_device failed")
         return (n, DevicePlan(self, h)) if want_plan else n
+
+    def index_build_at(self, container: int, states: int, bits: int, stream, groups) -> np.ndarray:
+        stream = _u8(stream)
+        groups = np.ascontiguousarray(groups, dtype=np.uint64)
+        out_len = int(stream[:8].view(np.uint64)[0])
+        pcap = self.L.hsrans_plan_capacity_chains(container, states, out_len, groups.size, 0)
+        plan = np.zeros(pcap, np.uint8)
+        n = self.L.hsrans_index_build_at(self.handle, container, states, bits, _p(stream), stream.size, _p(groups), groups.size, _p(plan), pcap)
+        if n == 0:
+            raise HsransError("hsrans_index_build_at failed")
+        return plan[:n].copy()
+
+    def decode_host_pipelined(self, container: int, states: int, bits: int, stream: torch.Tensor, out: torch.Tensor, plan, n_slices: int = 8) -> int:
+        """Host tensors (ideally pinned); returns the decoded length (0 = failure).  hsrans_decode_host_pipelined."""
+        plan = _u8(plan)
+        return self.L.hsrans_decode_host_pipelined(self.handle, container, states, bits, stream.data_ptr(), stream.numel(), out.data_ptr(), out.numel(),
+                                                   _p(plan), plan.size, n_slices)
 
     def index_build(self, container: int, states: int, bits: int, stream, index_interval: int) -> np.ndarray:
         stream = _u8(stream)

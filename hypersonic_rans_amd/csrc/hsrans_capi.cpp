@@ -6,23 +6,33 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
 
 #include "../../include/hsrans_hip.h"
 #include "hsrans_host.h"
+#include "hsrans_cpu.h"
 #include "hsrans_encode.h"
 #include "hsrans_kernels.h"
 
 using namespace hsrans;
 
+struct hsrans_dplan;
+struct hsrans_hpipe;
+
 struct hsrans_ctx
 {
   int device = 0;
   char name[256] = {};
-  std::mutex lock; // guards the staging buffers of the host-pointer entry
+  DeviceGeom geom{};     // CU count / LDS of THIS context's device (nothing about a device is process-global)
+  bool enc_prepared = false;
+  std::mutex lock; // guards the staging buffers of the host-pointer entries
   hipStream_t stream = nullptr;
+  hsrans_dplan *host_dplan = nullptr; // device plan of the host-pointer entries, refilled per call (buffers are kept)
+  hsrans_hpipe *cached_pipe = nullptr; // hsrans_decode_host_pipelined: the pipeline of the plan used last
+  uint64_t cached_pipe_key[3] = {};
   uint8_t *d_in = nullptr;
   size_t d_in_cap = 0;
   uint8_t *d_out = nullptr;
@@ -43,12 +53,16 @@ struct hsrans_dplan
   hsrans_ctx *ctx = nullptr;
   PlanHeader hdr{};
   uint8_t *d_plan = nullptr;
+  size_t d_plan_cap = 0;
   uint32_t *d_status = nullptr;
   size_t plan_bytes = 0;
   uint64_t *d_stamps = nullptr; // diagnostics (HSRANS_DEBUG_STAMPS=1)
-  unsigned long long *d_counters = nullptr; // persistent launches: monotonic queue heads
-  uint2 *d_table = nullptr;                 // host-built decode table (plans that carry their histogram)
-  Group *d_groups = nullptr;                // grouped launches (block_/mt_ plans with checkpoints)
+  unsigned long long *d_counters = nullptr; // uniform persistent launches: kCounterSets sets of monotonic queue heads
+  std::atomic<uint32_t> epoch{0};           // launches so far: launch k uses counter set k % kCounterSets
+  uint8_t *d_table = nullptr;               // host-built decode table (plans that carry their histogram)
+  size_t d_table_cap = 0;
+  uint8_t *d_groups = nullptr;              // grouped launches (block_/mt_ plans with checkpoints)
+  size_t d_groups_cap = 0;
   uint32_t n_groups = 0;
   PersistentArgs pa{};
   LaunchInfo info{};
@@ -162,6 +176,34 @@ int hsrans_plan_stream_ranges(const uint8_t *plan, size_t plan_size, uint32_t fi
   return plan_stream_ranges(plan, plan_size, first_chain, chain_count, ranges) ? HSRANS_OK : HSRANS_E_FORMAT;
 }
 
+// ---- host SIMD decoders (hsrans_cpu.cpp): never reached from the GPU entries below --------------------------------------
+int hsrans_cpu_level(void) { return cpu::best_level(); }
+
+size_t hsrans_decode_cpu(int level, uint32_t threads, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out,
+                         size_t out_capacity, const uint8_t *plan, size_t plan_size)
+{
+  if (in == nullptr || out == nullptr || !valid_codec(container, states, bits))
+    return 0;
+  if (level < 0)
+    level = cpu::best_level();
+  if (threads == 0)
+    threads = 1;
+  if (plan == nullptr)
+    return cpu::decode(level, threads, container, states, bits, in, in_length, out, out_capacity);
+  PlanHeader h;
+  if (!read_header(plan, plan_size, &h) || (int)h.container != container || (int)h.states != states || h.bits != bits)
+    return 0;
+  return cpu::exec_plan(level, threads, plan, plan_size, in, in_length, out, out_capacity);
+}
+
+size_t hsrans_index_build_host(int level, uint32_t threads, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length,
+                               const uint64_t *groups, size_t n_groups, uint8_t *plan_out, size_t plan_capacity)
+{
+  if (level < 0)
+    level = cpu::best_level();
+  return cpu::index_build(level, threads ? threads : 1, container, states, bits, in, in_length, groups, n_groups, plan_out, plan_capacity);
+}
+
 // ---- GPU side ---------------------------------------------------------------------------------------------------
 int hsrans_ctx_create(int device, hsrans_ctx **out_ctx)
 {
@@ -184,7 +226,7 @@ int hsrans_ctx_create(int device, hsrans_ctx **out_ctx)
   ctx->device = device;
   // the marketing name needs the amdgpu.ids table, which minimal images lack: fall back to the ISA name
   snprintf(ctx->name, sizeof(ctx->name), "%s%s%s (%d CUs)", prop.name, prop.name[0] ? " " : "", prop.gcnArchName, prop.multiProcessorCount);
-  if (prepare_kernels() != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+  if (prepare_kernels(&ctx->geom) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void **)&ctx->d_status, 64) != hipSuccess)
   {
     hsrans_ctx_destroy(ctx);
@@ -199,6 +241,10 @@ void hsrans_ctx_destroy(hsrans_ctx *ctx)
   if (ctx == nullptr)
     return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->cached_pipe)
+    hsrans_hpipe_destroy(ctx->cached_pipe);
+  if (ctx->host_dplan)
+    hsrans_dplan_destroy(ctx->host_dplan);
   if (ctx->stream)
     (void)hipStreamDestroy(ctx->stream);
   if (ctx->d_in)
@@ -220,151 +266,89 @@ void hsrans_ctx_destroy(hsrans_ctx *ctx)
 
 const char *hsrans_ctx_device_name(const hsrans_ctx *ctx) { return ctx ? ctx->name : ""; }
 
-size_t hsrans_decode_host(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out, size_t out_capacity,
-                          const uint8_t *plan, size_t plan_size)
+// (Re)fills a device plan from a validated host plan blob: uploads it and prepares whatever the launch of this plan's
+// kind needs (persistent arguments + host-built table, or the group list).  Device buffers are kept and grown, so a plan
+// object can be refilled per call without allocations (the host-pointer entries do that).  The device must be current.
+static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, const PlanHeader &h, hipStream_t s)
 {
-  if (ctx == nullptr || in == nullptr || out == nullptr || !valid_codec(container, states, bits))
-    return 0;
-
-  std::vector<uint8_t> own_plan;
-  if (plan == nullptr)
-  {
-    // header-only peek to size the plan, then the real planner (which repeats the reference's entry checks)
-    if (in_length < 16)
-      return 0;
-    uint64_t out_len;
-    memcpy(&out_len, in, 8);
-    if (out_len > out_capacity)
-      return 0;
-    own_plan.resize(plan_capacity(container, states, (size_t)out_len, 0, 0));
-    const size_t n = plan_build(container, states, bits, in, in_length, out_capacity, own_plan.data(), own_plan.size());
-    if (n == 0)
-      return 0;
-    plan = own_plan.data();
-    plan_size = n;
-  }
-  PlanHeader h;
-  if (!read_header(plan, plan_size, &h) || (int)h.container != container || (int)h.states != states || h.bits != bits)
-    return 0;
-  if (!plan_validate(plan, plan_size, in_length, out_capacity))
-    return 0;
-
-  std::lock_guard<std::mutex> guard(ctx->lock);
-  if (hipSetDevice(ctx->device) != hipSuccess)
-    return 0;
-  const size_t in_pad = (in_length + 15) / 16 * 16;
-  if (!grow(&ctx->d_in, &ctx->d_in_cap, in_pad) || !grow(&ctx->d_out, &ctx->d_out_cap, (size_t)h.decoded_len + 16) ||
-      !grow(&ctx->d_plan, &ctx->d_plan_cap, plan_size))
-    return 0;
-  hipStream_t s = ctx->stream;
-  if (hipMemcpyAsync(ctx->d_in, in, in_length, hipMemcpyHostToDevice, s) != hipSuccess ||
-      hipMemcpyAsync(ctx->d_plan, plan, plan_size, hipMemcpyHostToDevice, s) != hipSuccess || hipMemsetAsync(ctx->d_status, 0, 4, s) != hipSuccess)
-    return 0;
-  KParams kp{};
-  kp.stream = ctx->d_in;
-  kp.stream_len = in_length;
-  kp.out = ctx->d_out;
-  kp.out_cap = h.decoded_len;
-  kp.plan = ctx->d_plan;
-  kp.status = ctx->d_status;
-  if (launch_decode(kp, h, s, nullptr) != hipSuccess)
-    return 0;
-  uint32_t status = 0xFFFFFFFF;
-  if (hipMemcpyAsync(out, ctx->d_out, (size_t)h.decoded_len, hipMemcpyDeviceToHost, s) != hipSuccess ||
-      hipMemcpyAsync(&status, ctx->d_status, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-    return 0;
-  return status == 0 ? (size_t)h.decoded_len : 0;
-}
-
-int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, hsrans_dplan **out_dplan)
-{
-  if (ctx == nullptr || out_dplan == nullptr)
-    return HSRANS_E_ARG;
-  *out_dplan = nullptr;
-  PlanHeader h;
-  if (!read_header(plan, plan_size, &h) || !plan_validate(plan, plan_size, h.stream_len, h.decoded_len))
-    return HSRANS_E_FORMAT;
-  if (hipSetDevice(ctx->device) != hipSuccess)
-    return HSRANS_E_HIP;
-  hsrans_dplan *d = new (std::nothrow) hsrans_dplan;
-  if (d == nullptr)
-    return HSRANS_E_HIP;
-  d->ctx = ctx;
+  hsrans_ctx *ctx = d->ctx;
   d->hdr = h;
   d->plan_bytes = plan_size;
-  if (hipMalloc((void **)&d->d_plan, plan_size) != hipSuccess || hipMalloc((void **)&d->d_status, 64) != hipSuccess ||
-      hipMemcpy(d->d_plan, plan, plan_size, hipMemcpyHostToDevice) != hipSuccess || hipMemset(d->d_status, 0, 64) != hipSuccess)
-  {
-    hsrans_dplan_destroy(d);
+  d->pa = PersistentArgs{};
+  d->n_groups = 0;
+  if (!grow(&d->d_plan, &d->d_plan_cap, plan_size) || hipMemcpyAsync(d->d_plan, plan, plan_size, hipMemcpyHostToDevice, s) != hipSuccess)
     return HSRANS_E_HIP;
-  }
-  if ((h.flags & kPlanMergeable) && h.container == HSRANS_RAW && h.interval != 0)
+  if (d->d_status == nullptr && (hipMalloc((void **)&d->d_status, 64) != hipSuccess || hipMemsetAsync(d->d_status, 0, 64, s) != hipSuccess))
+    return HSRANS_E_HIP;
+  if ((h.flags & kPlanMergeable) && h.container == HSRANS_RAW)
   {
-    // persistent launch arguments, taken from the plan once (hsrans_kernels.h PersistentArgs)
+    // persistent launch arguments, taken from the plan once (hsrans_kernels.h PersistentArgs).  plan_validate has
+    // re-derived what the flag promises: single-piece chains, back to back in output and stream, tail on the last only,
+    // uniform `interval` (or interval == 0: chains of any length, decoded one per wave by the direct launch)
     const Piece *pc = (const Piece *)(plan + plan_pieces_off(h.n_chains));
     const Piece &first = pc[0], &last = pc[h.n_pieces - 1];
-    bool uniform = h.n_pieces == h.n_chains;
-    for (uint32_t i = 0; uniform && i + 1 < h.n_pieces; i++)
-      uniform = pc[i].steps == h.interval && pc[i].state_idx == i;
-    uniform = uniform && last.steps >= 1 && last.steps <= h.interval && last.state_idx == h.n_pieces - 1;
-    if (uniform && hipMalloc((void **)&d->d_counters, kDynQueues * kDynQueueStride * 8) == hipSuccess &&
-        hipMemset(d->d_counters, 0, kDynQueues * kDynQueueStride * 8) == hipSuccess)
+    const uint64_t steps_total = (last.out_off - first.out_off) / h.states + last.steps;
+    if (first.out_off > h.decoded_len || steps_total * h.states + last.tail > h.decoded_len - first.out_off)
+      return HSRANS_E_FORMAT;
     {
-      d->pa.pieces = (const Piece *)(d->d_plan + plan_pieces_off(h.n_chains));
-      d->pa.states = (const uint32_t *)(d->d_plan + plan_states_off(h.n_chains, h.n_pieces));
-      d->pa.n_chains = h.n_chains;
-      d->pa.interval = h.interval;
-      d->pa.S = h.states;
-      d->pa.bits = h.bits;
-      d->pa.out_base = first.out_off;
-      d->pa.steps_total = (uint64_t)(h.n_chains - 1) * h.interval + last.steps;
-      d->pa.hist_off = h.aux_off;
-      d->pa.tail = last.tail;
-      d->pa.counters = d->d_counters;
-      if ((h.flags & kPlanHasHist) && h.bits <= pack64_max_bits())
+      // queue heads: zeroed on every (re)fill — "ticket mod draws-per-launch" only works while every launch on a set of
+      // heads draws the same number of tickets, i.e. for ONE plan; a refilled plan object starts from zero again
+      const size_t bytes = (size_t)kCounterSets * kDynQueues * kDynQueueStride * 8;
+      if (d->d_counters == nullptr && hipMalloc((void **)&d->d_counters, bytes) != hipSuccess)
+        return HSRANS_E_HIP;
+      if (hipMemsetAsync(d->d_counters, 0, bytes, s) != hipSuccess)
+        return HSRANS_E_HIP;
+      d->epoch.store(0, std::memory_order_relaxed);
+    }
+    d->pa.pieces = (const Piece *)(d->d_plan + plan_pieces_off(h.n_chains));
+    d->pa.states = (const uint32_t *)(d->d_plan + plan_states_off(h.n_chains, h.n_pieces));
+    d->pa.n_chains = h.n_chains;
+    d->pa.interval = h.interval;
+    d->pa.S = h.states;
+    d->pa.bits = h.bits;
+    d->pa.out_base = first.out_off;
+    d->pa.steps_total = steps_total;
+    d->pa.hist_off = h.aux_off;
+    d->pa.tail = last.tail;
+    d->pa.counters = d->d_counters;
+    if (h.flags & kPlanHasHist)
+    {
+      const uint16_t *counts = (const uint16_t *)(plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
+      std::vector<uint2> tab;
+      uint32_t mode = 0;
+      if (h.bits <= pack64_max_bits() || table_spill())
       {
         // decode table for the shared-table kernel (MODE 3): {freq | sym << 24, slot - cumul} per slot, the same
         // entries build_table<kModePack64> produces (hist.cpp:291-306 / :308-324 for the sum check)
-        const uint16_t *counts = (const uint16_t *)(plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
         const uint32_t total = 1u << h.bits;
-        std::vector<uint2> tab(total);
+        tab.resize(total);
         uint32_t cum = 0;
-        for (uint32_t s = 0; s < 256; s++)
+        for (uint32_t sy = 0; sy < 256; sy++)
         {
-          for (uint32_t k = 0; k < counts[s] && cum + k < total; k++)
-            tab[cum + k] = make_uint2((uint32_t)counts[s] | (s << 24), k);
-          cum += counts[s];
+          for (uint32_t k = 0; k < counts[sy] && cum + k < total; k++)
+            tab[cum + k] = make_uint2((uint32_t)counts[sy] | (sy << 24), k);
+          cum += counts[sy];
         }
         if (cum != total)
-        {
-          hsrans_dplan_destroy(d);
           return HSRANS_E_FORMAT;
-        }
-        if (hipMalloc((void **)&d->d_table, total * sizeof(uint2)) == hipSuccess &&
-            hipMemcpy(d->d_table, tab.data(), total * sizeof(uint2), hipMemcpyHostToDevice) == hipSuccess)
-        {
-          d->pa.table = d->d_table;
-          d->pa.table_mode = 3;
-          d->pa.hist_copy = (const uint16_t *)(d->d_plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
-        }
+        mode = table_spill() ? 5 : 3;
       }
-      else if ((h.flags & kPlanHasHist) && h.bits >= 13 && h.states == 64 && getenv("HSRANS_NO_COARSE_TABLE") == nullptr)
+      else if (h.bits >= 13 && h.states == 64 && getenv("HSRANS_NO_COARSE_TABLE") == nullptr)
       {
         // wider histograms: the coarse + fine table pair (kModeCoarse), 36 / 40 / 48 KiB instead of 64 / 128 / 256 KiB
-        const uint16_t *counts = (const uint16_t *)(plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
-        std::vector<uint2> tab(coarse_table_entries(h.bits));
+        tab.resize(coarse_table_entries(h.bits));
         if (build_coarse_table(counts, h.bits, tab.data(), tab.size()) == 0)
-        {
-          hsrans_dplan_destroy(d);
           return HSRANS_E_FORMAT;
-        }
-        if (hipMalloc((void **)&d->d_table, tab.size() * sizeof(uint2)) == hipSuccess &&
-            hipMemcpy(d->d_table, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice) == hipSuccess)
-        {
-          d->pa.table = d->d_table;
-          d->pa.table_mode = 4;
-          d->pa.hist_copy = (const uint16_t *)(d->d_plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
-        }
+        mode = 4;
+      }
+      if (mode != 0)
+      {
+        if (!grow(&d->d_table, &d->d_table_cap, tab.size() * sizeof(uint2)) ||
+            hipMemcpyAsync(d->d_table, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+          return HSRANS_E_HIP; // (synchronised: `tab` is about to go away)
+        d->pa.table = (const uint2 *)d->d_table;
+        d->pa.table_mode = mode;
+        d->pa.hist_copy = (const uint16_t *)(d->d_plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
       }
     }
   }
@@ -414,7 +398,7 @@ int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
     // >= 128 chains (8 per wave: below that the per-part prologue costs more than the idle slots) while there are fewer
     // groups than resident workgroups.  A part is a group of its own: same histogram, a sub-range of the chains, and its
     // words end where the next part's first chain starts reading.  Measured: 382 groups of 128 chains are best left alone.
-    const size_t want = (size_t)resident_workgroups_hint();
+    const size_t want = (size_t)2 * ctx->geom.num_cus;
     if (groups.size() < h.n_chains && groups.size() < want)
     {
       const uint32_t k_max = (uint32_t)((want + groups.size() - 1) / groups.size());
@@ -440,12 +424,121 @@ int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
       }
       groups.swap(parts);
     }
-    if (groups.size() < h.n_chains && hipMalloc((void **)&d->d_groups, groups.size() * sizeof(Group)) == hipSuccess &&
-        hipMemcpy(d->d_groups, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice) == hipSuccess)
+    if (groups.size() < h.n_chains)
+    {
+      if (!grow(&d->d_groups, &d->d_groups_cap, groups.size() * sizeof(Group)) ||
+          hipMemcpyAsync(d->d_groups, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return HSRANS_E_HIP;
       d->n_groups = (uint32_t)groups.size();
+    }
   }
-  if (getenv("HSRANS_DEBUG_STAMPS") && hipMalloc((void **)&d->d_stamps, kStampWaves * 4 * 8) == hipSuccess)
-    (void)hipMemset(d->d_stamps, 0, kStampWaves * 4 * 8);
+  return HSRANS_OK;
+}
+
+// one launch of a filled device plan (asynchronous on s; the device must be current)
+static int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity, hipStream_t s, uint64_t stream_lo = 0)
+{
+  KParams kp{};
+  kp.stream = (const uint8_t *)d_stream;
+  kp.stream_len = stream_length;
+  kp.stream_lo = stream_lo;
+  kp.out = (uint8_t *)d_out;
+  kp.out_cap = out_capacity;
+  kp.plan = d->d_plan;
+  kp.status = d->d_status;
+  kp.stamps = d->d_stamps;
+  kp.pa = d->pa;
+  if (kp.pa.counters != nullptr) // uniform persistent launch: its own set of queue heads
+    kp.pa.counters += (size_t)(d->epoch.fetch_add(1, std::memory_order_relaxed) % kCounterSets) * kDynQueues * kDynQueueStride;
+  if (d->n_groups)
+  {
+    kp.groups = (const Group *)d->d_groups;
+    kp.n_groups = d->n_groups;
+  }
+  return launch_decode(kp, d->hdr, d->ctx->geom, s, &d->info) == hipSuccess ? HSRANS_OK : HSRANS_E_HIP;
+}
+
+size_t hsrans_decode_host(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out, size_t out_capacity,
+                          const uint8_t *plan, size_t plan_size)
+{
+  if (ctx == nullptr || in == nullptr || out == nullptr || !valid_codec(container, states, bits))
+    return 0;
+
+  std::vector<uint8_t> own_plan;
+  if (plan == nullptr)
+  {
+    // header-only peek to size the plan, then the real planner (which repeats the reference's entry checks)
+    if (in_length < 16)
+      return 0;
+    uint64_t out_len;
+    memcpy(&out_len, in, 8);
+    if (out_len > out_capacity)
+      return 0;
+    own_plan.resize(plan_capacity(container, states, (size_t)out_len, 0, 0));
+    const size_t n = plan_build(container, states, bits, in, in_length, out_capacity, own_plan.data(), own_plan.size());
+    if (n == 0)
+      return 0;
+    plan = own_plan.data();
+    plan_size = n;
+  }
+  PlanHeader h;
+  if (!read_header(plan, plan_size, &h) || (int)h.container != container || (int)h.states != states || h.bits != bits)
+    return 0;
+  if (!plan_validate(plan, plan_size, in_length, out_capacity))
+    return 0;
+
+  std::lock_guard<std::mutex> guard(ctx->lock);
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return 0;
+  const size_t in_pad = (in_length + 15) / 16 * 16;
+  if (!grow(&ctx->d_in, &ctx->d_in_cap, in_pad) || !grow(&ctx->d_out, &ctx->d_out_cap, (size_t)h.decoded_len + 16))
+    return 0;
+  hipStream_t s = ctx->stream;
+  if (ctx->host_dplan == nullptr)
+  {
+    ctx->host_dplan = new (std::nothrow) hsrans_dplan;
+    if (ctx->host_dplan == nullptr)
+      return 0;
+    ctx->host_dplan->ctx = ctx;
+  }
+  hsrans_dplan *d = ctx->host_dplan;
+  // the same launch the device entry gets for this plan (persistent / direct / grouped), on the context's staging buffers
+  if (hipMemcpyAsync(ctx->d_in, in, in_length, hipMemcpyHostToDevice, s) != hipSuccess || dplan_fill(d, plan, plan_size, h, s) != HSRANS_OK ||
+      hipMemsetAsync(d->d_status, 0, 4, s) != hipSuccess)
+    return 0;
+  if (dplan_launch(d, ctx->d_in, in_length, ctx->d_out, (size_t)h.decoded_len, s) != HSRANS_OK)
+    return 0;
+  uint32_t status = 0xFFFFFFFF;
+  if (hipMemcpyAsync(out, ctx->d_out, (size_t)h.decoded_len, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipMemcpyAsync(&status, d->d_status, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    return 0;
+  return status == 0 ? (size_t)h.decoded_len : 0;
+}
+
+int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, hsrans_dplan **out_dplan)
+{
+  if (ctx == nullptr || out_dplan == nullptr)
+    return HSRANS_E_ARG;
+  *out_dplan = nullptr;
+  PlanHeader h;
+  if (!read_header(plan, plan_size, &h) || !plan_validate(plan, plan_size, h.stream_len, h.decoded_len))
+    return HSRANS_E_FORMAT;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return HSRANS_E_HIP;
+  hsrans_dplan *d = new (std::nothrow) hsrans_dplan;
+  if (d == nullptr)
+    return HSRANS_E_HIP;
+  d->ctx = ctx;
+  int rc = dplan_fill(d, plan, plan_size, h, nullptr);
+  if (rc == HSRANS_OK && hipStreamSynchronize(nullptr) != hipSuccess)
+    rc = HSRANS_E_HIP;
+  if (rc != HSRANS_OK)
+  {
+    hsrans_dplan_destroy(d);
+    return rc;
+  }
+  if (getenv("HSRANS_DEBUG_STAMPS") && hipMalloc((void **)&d->d_stamps, kStampWaves * 8 * 8) == hipSuccess)
+    (void)hipMemset(d->d_stamps, 0, kStampWaves * 8 * 8);
   *out_dplan = d;
   return HSRANS_OK;
 }
@@ -454,7 +547,7 @@ size_t hsrans_debug_read_stamps(hsrans_dplan *d, uint64_t *out, size_t capacity_
 {
   if (d == nullptr || d->d_stamps == nullptr || out == nullptr)
     return 0;
-  const size_t n = capacity_u64 < kStampWaves * 4 ? capacity_u64 : kStampWaves * 4;
+  const size_t n = capacity_u64 < kStampWaves * 8 ? capacity_u64 : kStampWaves * 8;
   return hipMemcpy(out, d->d_stamps, n * 8, hipMemcpyDeviceToHost) == hipSuccess ? n : 0;
 }
 
@@ -582,30 +675,34 @@ void hsrans_dplan_destroy(hsrans_dplan *d)
 
 int hsrans_decode_device(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity, void *hip_stream)
 {
-  if (ctx == nullptr || d == nullptr || d_stream == nullptr || d_out == nullptr)
+  if (ctx == nullptr || d == nullptr || d_stream == nullptr || d_out == nullptr || d->ctx != ctx)
     return HSRANS_E_ARG;
   if (((uintptr_t)d_stream & 15) != 0 || ((uintptr_t)d_out & 3) != 0)
     return HSRANS_E_ARG;
   if (stream_length < d->hdr.stream_len || out_capacity < d->hdr.decoded_len)
     return HSRANS_E_FORMAT;
-  hipStream_t s = (hipStream_t)hip_stream;
+  if (hipSetDevice(ctx->device) != hipSuccess) // the launch goes to the context's device whatever the caller's current device is
+    return HSRANS_E_HIP;
   // the status word is sticky: kernels only ever OR error bits into it and hsrans_dplan_status() clears it after
   // reporting, so the launch path is exactly one kernel node (no memset node in front of it)
-  KParams kp{};
-  kp.stream = (const uint8_t *)d_stream;
-  kp.stream_len = stream_length;
-  kp.out = (uint8_t *)d_out;
-  kp.out_cap = out_capacity;
-  kp.plan = d->d_plan;
-  kp.status = d->d_status;
-  kp.stamps = d->d_stamps;
-  kp.pa = d->pa;
-  if (d->n_groups)
-  {
-    kp.groups = d->d_groups;
-    kp.n_groups = d->n_groups;
-  }
-  return launch_decode(kp, d->hdr, s, &d->info) == hipSuccess ? HSRANS_OK : HSRANS_E_HIP;
+  return dplan_launch(d, d_stream, stream_length, d_out, out_capacity, (hipStream_t)hip_stream);
+}
+
+int hsrans_decode_device_window(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_window, size_t window_offset, size_t window_length, void *d_out,
+                                size_t out_capacity, void *hip_stream)
+{
+  if (ctx == nullptr || d == nullptr || d_window == nullptr || d_out == nullptr || d->ctx != ctx)
+    return HSRANS_E_ARG;
+  if (((uintptr_t)d_window & 15) != 0 || (window_offset & 15) != 0 || ((uintptr_t)d_out & 3) != 0 || (uintptr_t)d_window < window_offset)
+    return HSRANS_E_ARG;
+  if (out_capacity < d->hdr.decoded_len || window_offset > d->hdr.stream_len)
+    return HSRANS_E_FORMAT;
+  // every stream byte the plan's chains can read must be inside the window: [body_begin, body_end) of hsrans_plan_stream_ranges
+  // (checked here from the device plan's header only for the end; the begin is the caller's contract, documented in the header)
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return HSRANS_E_HIP;
+  const uint64_t end = std::min<uint64_t>(window_offset + window_length, d->hdr.stream_len);
+  return dplan_launch(d, (const uint8_t *)d_window - window_offset, (size_t)end, d_out, out_capacity, (hipStream_t)hip_stream, window_offset);
 }
 
 int hsrans_dplan_status(hsrans_ctx *ctx, hsrans_dplan *d, void *hip_stream)
@@ -635,6 +732,7 @@ int hsrans_dplan_launch_info(const hsrans_dplan *d, hsrans_launch_info *info)
   info->shared_table = d->info.shared_table;
   info->walk = d->info.walk;
   info->two_level = d->info.two_level;
+  info->table_mode = d->info.table_mode;
   return HSRANS_OK;
 }
 
@@ -686,7 +784,7 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   ep.ck_pos = ep.ck_states + ck_slots * ep.S;
   hipStream_t s = (hipStream_t)hip_stream;
   uint64_t result[kEncResultWords] = {};
-  if (launch_encode(ep, s) != hipSuccess)
+  if (launch_encode(ep, s, &ctx->enc_prepared) != hipSuccess)
     return 0;
   if (hipMemcpyAsync(result, ep.result, sizeof(result), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
     return 0;
@@ -736,12 +834,12 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   const bool grouped = ep.interval != 0 && ep.n_blocks < h.n_chains;
   // few large blocks: cut every block's chains into parts so that there are about two workgroup tasks per resident workgroup
   // (parts of >= 128 chains, only while there are fewer blocks than resident workgroups: see hsrans_dplan_create)
-  const size_t want = (size_t)resident_workgroups_hint();
+  const size_t want = (size_t)2 * ctx->geom.num_cus;
   ep.group_split = 1;
   if (grouped && nb < want)
     ep.group_split = (uint32_t)std::max<size_t>(1, std::min<size_t>({(want + nb - 1) / nb, (size_t)(ep.max_ck + 1) / 128, (size_t)64}));
   bool ok = hipMalloc((void **)&d->d_plan, bytes) == hipSuccess && hipMalloc((void **)&d->d_status, 64) == hipSuccess &&
-            (!grouped || hipMalloc((void **)&d->d_groups, nb * ep.group_split * sizeof(Group)) == hipSuccess) && hipMemsetAsync(d->d_plan, 0, bytes, s) == hipSuccess &&
+            (!grouped || grow(&d->d_groups, &d->d_groups_cap, nb * ep.group_split * sizeof(Group))) && hipMemsetAsync(d->d_plan, 0, bytes, s) == hipSuccess &&
             hipMemsetAsync(d->d_status, 0, 64, s) == hipSuccess && hipMemcpyAsync(d->d_plan, &h, sizeof(h), hipMemcpyHostToDevice, s) == hipSuccess;
   if (ok)
   {
@@ -762,8 +860,8 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   return total;
 }
 
-size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint32_t index_interval,
-                          uint8_t *plan_out, size_t plan_capacity)
+static size_t index_build_impl(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint32_t index_interval,
+                               const uint64_t *groups, size_t n_groups, uint8_t *plan_out, size_t plan_capacity)
 {
   // One pass over an existing stream that records {states, read cursor} every `index_interval` groups inside every rANS
   // piece of the stream's own plan (raw: one sequential wavefront; mt_: one wavefront per block, in parallel); the
@@ -772,8 +870,20 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
   // header it meets and the states it enters the block with, and the plan gets one chain per block plus the checkpoints.
   if (ctx == nullptr || in == nullptr || plan_out == nullptr || !valid_codec(container, states, bits))
     return 0;
-  if (index_interval == 0 || index_interval % 4 != 0 || in_length < 16)
+  // checkpoints every index_interval groups, or (groups != nullptr) at explicit ascending group indices
+  if (groups == nullptr && (index_interval == 0 || index_interval % 4 != 0))
     return 0;
+  if (in_length < 16)
+    return 0;
+  if (groups != nullptr)
+  {
+    index_interval = 0;
+    if (n_groups == 0 || n_groups > 0xFFFFFFFFull || container == HSRANS_BLOCK)
+      return 0;
+    for (size_t k = 0; k < n_groups; k++)
+      if (groups[k] == 0 || (groups[k] % 4) != 0 || (k > 0 && groups[k] <= groups[k - 1]))
+        return 0;
+  }
   uint64_t out_len;
   memcpy(&out_len, in, 8);
   std::vector<uint8_t> base(hsrans::plan_capacity(container, states, (size_t)out_len, 0, 0));
@@ -789,7 +899,7 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
   const bool walk = (h.flags & kPlanWalk) != 0;
   if (!walk && h.n_pieces != h.n_chains) // the planner only produces single-piece chains for raw and mt_
     return 0;
-  const uint64_t n_ck = out_len / S / index_interval + 2;
+  const uint64_t n_ck = groups ? n_groups : out_len / S / index_interval + 2;
   // block_: room for blocks of >= 4 KiB on average (the reference's smallest block is 32 KiB, block_rANS32x64_16w_encode.cpp:21-39)
   const uint64_t max_blocks = walk ? out_len / 4096 + 16 : 0;
 
@@ -800,7 +910,7 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
   if (!grow(&ctx->d_in, &ctx->d_in_cap, in_pad) || !grow(&ctx->d_out, &ctx->d_out_cap, (size_t)out_len + 16) || !grow(&ctx->d_plan, &ctx->d_plan_cap, base_size))
     return 0;
   uint32_t *d_ck_states = nullptr;
-  uint64_t *d_ck_words = nullptr;
+  uint64_t *d_ck_words = nullptr, *d_groups = nullptr;
   uint64_t *d_walk_blocks = nullptr;
   uint32_t *d_walk_states = nullptr, *d_walk_count = nullptr;
   size_t result = 0;
@@ -811,6 +921,8 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
   do
   {
     if (hipMalloc((void **)&d_ck_states, n_ck * S * 4) != hipSuccess || hipMalloc((void **)&d_ck_words, n_ck * 8) != hipSuccess)
+      break;
+    if (groups && (hipMalloc((void **)&d_groups, n_groups * 8) != hipSuccess || hipMemcpyAsync(d_groups, groups, n_groups * 8, hipMemcpyHostToDevice, s) != hipSuccess))
       break;
     if (walk && (hipMalloc((void **)&d_walk_blocks, max_blocks * 24) != hipSuccess || hipMalloc((void **)&d_walk_states, max_blocks * S * 4) != hipSuccess ||
                  hipMalloc((void **)&d_walk_count, 4) != hipSuccess || hipMemsetAsync(d_walk_count, 0, 4, s) != hipSuccess))
@@ -828,13 +940,15 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
     kp.ckpt_states = d_ck_states;
     kp.ckpt_words = d_ck_words;
     kp.ckpt_interval = index_interval;
+    kp.ckpt_groups = d_groups;
+    kp.n_ckpt_groups = (uint32_t)(groups ? n_groups : 0);
     kp.walk_blocks = d_walk_blocks;
     kp.walk_states = d_walk_states;
     kp.walk_count = d_walk_count;
     kp.walk_max_blocks = (uint32_t)(max_blocks > 0xFFFFFFFFull ? 0xFFFFFFFFull : max_blocks);
     PlanHeader hl = h;
     hl.shared_hist = 0; // private tables: every chain of the pass builds its own (raw has one chain, mt_ one per block)
-    if (launch_decode(kp, hl, s, nullptr) != hipSuccess)
+    if (launch_decode(kp, hl, ctx->geom, s, nullptr) != hipSuccess)
       break;
     if (hipMemcpyAsync(ck_states.data(), d_ck_states, n_ck * S * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipMemcpyAsync(ck_words.data(), d_ck_words, n_ck * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -898,6 +1012,43 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
       if (!ok)
         break;
     }
+    else if (groups != nullptr)
+    {
+      size_t k = 0; // next boundary
+      for (uint32_t ch = 0; ch < h.n_chains; ch++)
+      {
+        const Piece &bp = pc0[cf0[ch]];
+        if (bp.flags & kPieceFill)
+        {
+          pb.add_chain(bp, nullptr);
+          continue;
+        }
+        const uint64_t T = bp.steps, g0 = bp.out_off / S;
+        while (k < n_groups && groups[k] <= g0)
+          k++;
+        uint64_t g = 0; // groups of this piece already assigned to chains
+        const uint32_t *st = st0 + (size_t)bp.state_idx * S;
+        uint64_t words = bp.words_off;
+        while (true)
+        {
+          const bool more = k < n_groups && groups[k] < g0 + T;
+          const uint64_t g_next = more ? groups[k] - g0 : T;
+          Piece p{};
+          p.hist_off = bp.hist_off;
+          p.out_off = bp.out_off + g * S;
+          p.words_off = words;
+          p.steps = (uint32_t)(g_next - g);
+          p.tail = (uint16_t)(more ? 0 : bp.tail);
+          pb.add_chain(p, st);
+          if (!more)
+            break;
+          st = &ck_states[k * S];
+          words = ck_words[k];
+          g = g_next;
+          k++;
+        }
+      }
+    }
     else
     for (uint32_t ch = 0; ch < h.n_chains; ch++)
     {
@@ -927,6 +1078,8 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
     (void)hipFree(d_ck_states);
   if (d_ck_words)
     (void)hipFree(d_ck_words);
+  if (d_groups)
+    (void)hipFree(d_groups);
   if (d_walk_blocks)
     (void)hipFree(d_walk_blocks);
   if (d_walk_states)
@@ -934,6 +1087,275 @@ size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t b
   if (d_walk_count)
     (void)hipFree(d_walk_count);
   return result;
+}
+
+size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint32_t index_interval,
+                          uint8_t *plan_out, size_t plan_capacity)
+{
+  return index_build_impl(ctx, container, states, bits, in, in_length, index_interval, nullptr, 0, plan_out, plan_capacity);
+}
+
+size_t hsrans_index_build_at(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, const uint64_t *groups,
+                             size_t n_groups, uint8_t *plan_out, size_t plan_capacity)
+{
+  if (groups == nullptr)
+    return 0;
+  return index_build_impl(ctx, container, states, bits, in, in_length, 0, groups, n_groups, plan_out, plan_capacity);
+}
+
+// ---- host buffers, PCIe legs overlapped ---------------------------------------------------------------------------
+struct hsrans_hpipe
+{
+  hsrans_ctx *ctx = nullptr;
+  PlanHeader hdr{};
+  struct Slice
+  {
+    hsrans_dplan *dplan = nullptr;
+    uint64_t in_ranges[4] = {}; // {head_begin, head_end, body_begin, body_end} of the stream (hsrans_plan_stream_ranges)
+    uint64_t out_begin = 0, out_end = 0;
+    hipEvent_t up_done = nullptr, dec_done = nullptr;
+  };
+  std::vector<Slice> slices;
+  uint8_t *d_stream = nullptr, *d_out = nullptr;
+  hipStream_t up = nullptr, dec = nullptr, down = nullptr;
+  uint32_t *h_status = nullptr; // pinned, one word per slice
+};
+
+void hsrans_hpipe_destroy(hsrans_hpipe *p)
+{
+  if (p == nullptr)
+    return;
+  if (p->ctx)
+    (void)hipSetDevice(p->ctx->device);
+  for (auto &sl : p->slices)
+  {
+    if (sl.dplan)
+      hsrans_dplan_destroy(sl.dplan);
+    if (sl.up_done)
+      (void)hipEventDestroy(sl.up_done);
+    if (sl.dec_done)
+      (void)hipEventDestroy(sl.dec_done);
+  }
+  if (p->d_stream)
+    (void)hipFree(p->d_stream);
+  if (p->d_out)
+    (void)hipFree(p->d_out);
+  if (p->up)
+    (void)hipStreamDestroy(p->up);
+  if (p->dec)
+    (void)hipStreamDestroy(p->dec);
+  if (p->down)
+    (void)hipStreamDestroy(p->down);
+  if (p->h_status)
+    (void)hipHostFree(p->h_status);
+  delete p;
+}
+
+int hsrans_hpipe_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, uint32_t n_slices, hsrans_hpipe **out_pipe)
+{
+  if (ctx == nullptr || out_pipe == nullptr)
+    return HSRANS_E_ARG;
+  *out_pipe = nullptr;
+  PlanHeader h;
+  if (!read_header(plan, plan_size, &h) || !plan_validate(plan, plan_size, h.stream_len, h.decoded_len) || (h.flags & kPlanWalk))
+    return HSRANS_E_FORMAT;
+  if (n_slices == 0)
+    n_slices = 8;
+  if (n_slices > h.n_chains)
+    n_slices = h.n_chains;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return HSRANS_E_HIP;
+  hsrans_hpipe *p = new (std::nothrow) hsrans_hpipe;
+  if (p == nullptr)
+    return HSRANS_E_HIP;
+  p->ctx = ctx;
+  p->hdr = h;
+  int rc = HSRANS_E_HIP;
+  do
+  {
+    if (hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p->dec, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking) != hipSuccess)
+      break;
+    if (hipMalloc((void **)&p->d_stream, (h.stream_len + 15) / 16 * 16 + 16) != hipSuccess || hipMalloc((void **)&p->d_out, h.decoded_len + 16) != hipSuccess ||
+        hipHostMalloc((void **)&p->h_status, n_slices * 4, hipHostMallocDefault) != hipSuccess)
+      break;
+    // chains -> n_slices contiguous runs of (nearly) equal decoded bytes (chains are in output order)
+    const uint32_t *cf = (const uint32_t *)(plan + plan_chain_first_off());
+    const Piece *pc = (const Piece *)(plan + plan_pieces_off(h.n_chains));
+    std::vector<uint64_t> chain_end(h.n_chains);
+    uint64_t run = 0;
+    for (uint32_t c = 0; c < h.n_chains; c++)
+    {
+      for (uint32_t i = cf[c]; i < cf[c + 1]; i++)
+        run += (pc[i].flags & kPieceFill) ? pc[i].fill_len : (uint64_t)pc[i].steps * h.states + pc[i].tail;
+      chain_end[c] = run;
+    }
+    std::vector<uint8_t> blob(plan_size);
+    uint32_t first = 0;
+    bool ok = true;
+    for (uint32_t k = 0; k < n_slices && ok; k++)
+    {
+      uint32_t last = k + 1 == n_slices ? h.n_chains : (uint32_t)(std::upper_bound(chain_end.begin(), chain_end.end(), run * (k + 1) / n_slices) - chain_end.begin());
+      if (last <= first)
+        last = first + 1;
+      if (last > h.n_chains)
+        last = h.n_chains;
+      if (first >= h.n_chains)
+        break;
+      hsrans_hpipe::Slice sl;
+      const size_t bytes = plan_slice(plan, plan_size, first, last - first, blob.data(), blob.size());
+      PlanHeader hs;
+      ok = bytes != 0 && read_header(blob.data(), bytes, &hs) && plan_stream_ranges(plan, plan_size, first, last - first, sl.in_ranges) &&
+           plan_chain_range(plan, plan_size, first, last - first, &sl.out_begin, &sl.out_end);
+      if (ok)
+      {
+        sl.dplan = new (std::nothrow) hsrans_dplan;
+        ok = sl.dplan != nullptr;
+      }
+      if (ok)
+      {
+        sl.dplan->ctx = ctx;
+        ok = dplan_fill(sl.dplan, blob.data(), bytes, hs, nullptr) == HSRANS_OK && hipStreamSynchronize(nullptr) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.up_done, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&sl.dec_done, hipEventDisableTiming) == hipSuccess;
+      }
+      p->slices.push_back(sl); // (pushed even on failure so that destroy releases what exists)
+      first = last;
+    }
+    if (!ok)
+      break;
+    rc = HSRANS_OK;
+  } while (false);
+  if (rc != HSRANS_OK)
+  {
+    hsrans_hpipe_destroy(p);
+    return rc;
+  }
+  *out_pipe = p;
+  return HSRANS_OK;
+}
+
+size_t hsrans_hpipe_decode(hsrans_hpipe *p, const uint8_t *in, size_t in_length, uint8_t *out, size_t out_capacity)
+{
+  if (p == nullptr || in == nullptr || out == nullptr || in_length < p->hdr.stream_len || out_capacity < p->hdr.decoded_len)
+    return 0;
+  if (hipSetDevice(p->ctx->device) != hipSuccess)
+    return 0;
+  // leg 1: every slice's stream bytes, in order, on the upload stream (a raw stream's shared histogram goes up once)
+  bool head_done = false;
+  for (auto &sl : p->slices)
+  {
+    const uint64_t *r = sl.in_ranges;
+    if (r[1] > r[0] && !head_done)
+    {
+      if (hipMemcpyAsync(p->d_stream + r[0], in + r[0], r[1] - r[0], hipMemcpyHostToDevice, p->up) != hipSuccess)
+        return 0;
+      head_done = true;
+    }
+    if (r[3] > r[2] && hipMemcpyAsync(p->d_stream + r[2], in + r[2], r[3] - r[2], hipMemcpyHostToDevice, p->up) != hipSuccess)
+      return 0;
+    if (hipEventRecord(sl.up_done, p->up) != hipSuccess)
+      return 0;
+  }
+  // legs 2 and 3: slice k decodes as soon as its bytes are up; its output comes down as soon as it is decoded
+  for (size_t k = 0; k < p->slices.size(); k++)
+  {
+    auto &sl = p->slices[k];
+    if (hipStreamWaitEvent(p->dec, sl.up_done, 0) != hipSuccess ||
+        dplan_launch(sl.dplan, p->d_stream, (size_t)p->hdr.stream_len, p->d_out, (size_t)p->hdr.decoded_len, p->dec) != HSRANS_OK ||
+        hipEventRecord(sl.dec_done, p->dec) != hipSuccess || hipStreamWaitEvent(p->down, sl.dec_done, 0) != hipSuccess)
+      return 0;
+    if (sl.out_end > sl.out_begin &&
+        hipMemcpyAsync(out + sl.out_begin, p->d_out + sl.out_begin, sl.out_end - sl.out_begin, hipMemcpyDeviceToHost, p->down) != hipSuccess)
+      return 0;
+    if (hipMemcpyAsync(p->h_status + k, sl.dplan->d_status, 4, hipMemcpyDeviceToHost, p->down) != hipSuccess)
+      return 0;
+  }
+  if (hipStreamSynchronize(p->down) != hipSuccess)
+    return 0;
+  bool good = true;
+  for (size_t k = 0; k < p->slices.size(); k++)
+    if (p->h_status[k] != 0)
+    {
+      good = false;
+      (void)hipMemsetAsync(p->slices[k].dplan->d_status, 0, 4, p->down);
+    }
+  if (!good)
+    (void)hipStreamSynchronize(p->down);
+  return good ? (size_t)p->hdr.decoded_len : 0;
+}
+
+size_t hsrans_decode_host_pipelined(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out,
+                                    size_t out_capacity, const uint8_t *plan, size_t plan_size, uint32_t n_slices)
+{
+  if (ctx == nullptr || in == nullptr || out == nullptr || plan == nullptr || !valid_codec(container, states, bits))
+    return 0;
+  PlanHeader h;
+  if (!read_header(plan, plan_size, &h) || (int)h.container != container || (int)h.states != states || h.bits != bits || h.stream_len > in_length ||
+      h.decoded_len > out_capacity)
+    return 0;
+  // the pipeline (slice plans on the device, streams, buffers) is kept for the plan seen last
+  uint64_t sum = 0x9E3779B97F4A7C15ull ^ n_slices;
+  for (size_t i = 0; i + 8 <= plan_size; i += 8)
+  {
+    uint64_t v;
+    memcpy(&v, plan + i, 8);
+    sum = (sum ^ v) * 0x100000001B3ull + (sum >> 29);
+  }
+  std::lock_guard<std::mutex> guard(ctx->lock);
+  const uint64_t key[3] = {(uint64_t)(uintptr_t)plan, (uint64_t)plan_size, sum};
+  if (ctx->cached_pipe == nullptr || memcmp(key, ctx->cached_pipe_key, sizeof(key)) != 0)
+  {
+    if (ctx->cached_pipe)
+      hsrans_hpipe_destroy(ctx->cached_pipe);
+    ctx->cached_pipe = nullptr;
+    if (hsrans_hpipe_create(ctx, plan, plan_size, n_slices, &ctx->cached_pipe) != HSRANS_OK)
+      return 0;
+    memcpy(ctx->cached_pipe_key, key, sizeof(key));
+  }
+  return hsrans_hpipe_decode(ctx->cached_pipe, in, in_length, out, out_capacity);
+}
+
+int hsrans_host_register(hsrans_ctx *ctx, void *ptr, size_t bytes)
+{
+  if (ctx == nullptr || ptr == nullptr || bytes == 0)
+    return HSRANS_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return HSRANS_E_HIP;
+  return hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess ? HSRANS_OK : HSRANS_E_HIP;
+}
+
+int hsrans_host_unregister(hsrans_ctx *ctx, void *ptr)
+{
+  if (ctx == nullptr || ptr == nullptr)
+    return HSRANS_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return HSRANS_E_HIP;
+  return hipHostUnregister(ptr) == hipSuccess ? HSRANS_OK : HSRANS_E_HIP;
+}
+
+size_t hsrans_index_boundaries(const hsrans_ctx *ctx, int states, uint32_t bits, size_t decoded_size, uint64_t *groups_out, size_t capacity)
+{
+  if ((states != 32 && states != 64) || bits < 10 || bits > 15 || groups_out == nullptr)
+    return 0;
+  const DeviceGeom dg = ctx ? ctx->geom : default_geom();
+  const uint64_t S = (uint64_t)states;
+  const uint64_t T = decoded_size + 1 >= S ? (decoded_size - S + 1 + S - 1) / S : 0; // whole groups (rANS32x64_16w.cpp:223)
+  // the table layout the launch will pick for a plan that carries its histogram (hsrans_dplan_create)
+  const uint32_t table_mode = bits <= pack64_max_bits() ? 3 : (states == 64 && getenv("HSRANS_NO_COARSE_TABLE") == nullptr ? 4 : 0);
+  const size_t chains = direct_boundaries(dg, (uint32_t)states, bits, T, table_mode, groups_out, capacity);
+  return chains > 1 ? chains - 1 : 0;
+}
+
+size_t hsrans_plan_thin(const uint8_t *plan, size_t plan_size, const uint64_t *groups, size_t n_groups, uint8_t *out, size_t out_capacity)
+{
+  return plan_thin(plan, plan_size, groups, n_groups, out, out_capacity);
+}
+
+size_t hsrans_plan_capacity_chains(int container, int states, size_t decoded_size, size_t extra_chains, uint32_t block_size)
+{
+  if (!valid_codec(container, states, 10))
+    return 0;
+  return plan_capacity_chains(container, states, decoded_size, extra_chains, block_size);
 }
 
 } // extern "C"

@@ -1,0 +1,567 @@
+// Host SIMD decoders for the hypersonic-rANS 32-bit-state / 16-bit-word formats, with runtime dispatch.
+//
+// The GPU is the product's decode path for everything that has parallelism to offer; what it cannot speed up is a stream
+// that is ONE dependent chain (a raw or block_ stream without a sidecar index): one wavefront decodes that at ~0.65 GB/s,
+// a third of what one CPU core does.  This file is the counterpart of the reference's host decoders and of its runtime
+// dispatcher (block_rANS32x64_16w_decode.cpp:130-152: `_DetectCPUFeatures()` then AVX-512 / AVX2 / scalar): written from
+// the format (SURVEY.md §8 "Wire formats"), not from the reference's SIMD code, and used for
+//   (1) the `*_decode_auto_N` drop-in entries: single-chain streams without an index go to the host, everything else to the GPU;
+//   (2) hsrans_index_build_host: the pass that records checkpoints of a foreign raw stream (3x faster than one wavefront);
+//   (3) hsrans_decode_cpu: an in-run CPU comparator (bench.py's cpu_baseline kind "port"), single- or multi-threaded.
+// The GPU entries (hsrans_decode_host / hsrans_decode_device, `*_decode_hip_N`) never come here: they fail without a GPU.
+// Nothing under oracle/ is used.  Tests: tests/test_cpu_decoder.py (all dispatch levels against the oracle and the golden
+// vectors of the real reference).
+//
+// The decode step (rANS32x64_16w.cpp:17-30,223-250), per group of S symbols, for state j = 0..S-1 in order:
+//     slot = x & (2^b - 1);  sym = cumulInv[slot];  x = (x >> b) * freq[sym] + slot - cumul[sym];
+//     if (x < 2^15) x = x << 16 | *readHead++;            out[i + idx2idx[j]] = sym
+// SIMD mapping: 8 (AVX2) / 16 (AVX-512) consecutive states per vector.  The renormalisation is a "compress/expand":
+// the lanes whose x fell below 2^15 take the next words of the stream in lane order = an expand of a contiguous load
+// (AVX-512: vpexpandd under the compare mask; AVX2: vpermd by a 256-entry table indexed with the movemask).
+// idx2idx is the bit permutation j -> (j&0x23)|((j&4)<<2)|((j&0x18)>>1): two saturating packs (dword -> word -> byte) of
+// the vectors' symbols put them in output order (AVX-512: plus one dword permute).
+#include "hsrans_cpu.h"
+
+#include <immintrin.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "hsrans_host.h"
+
+namespace hsrans
+{
+namespace cpu
+{
+
+namespace
+{
+inline uint64_t rd64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+inline uint16_t rd16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+inline uint32_t lane_to_byte(uint32_t j) { return (j & 0x23u) | ((j & 0x04u) << 2) | ((j & 0x18u) >> 1); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// decode table: one uint32 per slot.
+//   bits <= 12:  sym | (freq - 1) << 8 | (slot - cumul) << 20     (freq - 1 so that freq == 4096 fits; one gather per vector)
+//   bits >= 13:  sym | (slot - cumul) << 8, and freq[256] gathered by symbol (two gathers, like the reference's dec2 layout)
+// ---------------------------------------------------------------------------------------------------------------
+struct Table
+{
+  uint32_t bits = 0;
+  std::vector<uint32_t> slot;
+  alignas(64) uint32_t freq[256];
+  bool build(const uint8_t *counts_le16, uint32_t b)
+  {
+    bits = b;
+    const uint32_t total = 1u << b;
+    slot.resize(total + 16); // (+16: gathers never leave the allocation even with junk indices in dead lanes)
+    uint32_t cum = 0;
+    for (uint32_t s = 0; s < 256; s++)
+    {
+      const uint32_t f = rd16(counts_le16 + 2 * s);
+      freq[s] = f;
+      if (cum + f > total)
+        return false;
+      for (uint32_t k = 0; k < f; k++)
+        slot[cum + k] = b <= 12 ? (s | ((f - 1) << 8) | (k << 20)) : (s | (k << 8));
+      cum += f;
+    }
+    return cum == total; // inplace_complete_hist (hist.cpp:308-324): the decoder returns 0 otherwise
+  }
+};
+
+struct Cursor
+{
+  const uint8_t *p;   // next word
+  const uint8_t *end; // first byte that must not be read
+  inline uint32_t next()
+  {
+    uint32_t w = 0;
+    if (p + 2 <= end) // a truncated stream decodes zeros (as the GPU's bounds-checked stream window does), never reads outside
+      w = rd16(p);
+    p += 2;
+    return w;
+  }
+};
+
+// scalar: one group (lanes whose byte exists: `limit` = symbols of this group, S for a whole group)
+inline void group_scalar(uint32_t *x, const Table &t, Cursor &c, uint8_t *out, uint32_t S, uint32_t limit)
+{
+  const uint32_t mask = (1u << t.bits) - 1;
+  for (uint32_t j = 0; j < S; j++)
+  {
+    const uint32_t p = lane_to_byte(j);
+    if (p >= limit)
+      continue;
+    const uint32_t v = x[j], e = t.slot[v & mask];
+    uint32_t nx;
+    if (t.bits <= 12)
+      nx = (v >> t.bits) * (((e >> 8) & 0xFFF) + 1) + (e >> 20);
+    else
+      nx = (v >> t.bits) * t.freq[e & 0xFF] + (e >> 8);
+    out[p] = (uint8_t)e;
+    if (nx < kConsumePoint16)
+      nx = (nx << 16) | c.next();
+    x[j] = nx;
+  }
+}
+
+void groups_scalar(uint32_t *x, const Table &t, Cursor &c, uint8_t *out, uint64_t steps, uint32_t S)
+{
+  for (uint64_t g = 0; g < steps; g++, out += S)
+    group_scalar(x, t, c, out, S, S);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// AVX2
+// ---------------------------------------------------------------------------------------------------------------
+alignas(32) uint32_t g_expand8[256][8]; // [mask][lane] = index of the word lane takes (rank of the lane among the set bits)
+alignas(64) uint32_t g_out_perm16[16];  // AVX-512: dword order after the two packs -> output order
+std::once_flag g_luts_once;
+
+void init_luts()
+{
+  for (uint32_t m = 0; m < 256; m++)
+  {
+    uint32_t r = 0;
+    for (uint32_t l = 0; l < 8; l++)
+    {
+      g_expand8[m][l] = r;
+      r += (m >> l) & 1;
+    }
+  }
+  // packed dword d = 4q + v holds the symbols of vector v, lanes 4q..4q+3 -> output dword 4*(q&1) + (q>>1) + 2*(v&1) + 8*(v>>1)
+  for (uint32_t q = 0; q < 4; q++)
+    for (uint32_t v = 0; v < 4; v++)
+      g_out_perm16[4 * (q & 1) + (q >> 1) + 2 * (v & 1) + 8 * (v >> 1)] = 4 * q + v;
+}
+
+template <bool PACKED>
+__attribute__((target("avx2,bmi2,popcnt"))) void groups_avx2(uint32_t *xs, const Table &t, Cursor &c, uint8_t *out, uint64_t steps, uint32_t S)
+{
+  const uint32_t V = S / 8;
+  __m256i x[8];
+  for (uint32_t v = 0; v < V; v++)
+    x[v] = _mm256_loadu_si256((const __m256i *)(xs + 8 * v));
+  const __m256i vmask = _mm256_set1_epi32((int)((1u << t.bits) - 1));
+  const __m128i vbits = _mm_cvtsi32_si128((int)t.bits);
+  const __m256i lim = _mm256_set1_epi32((int)kConsumePoint16);
+  const __m256i m12 = _mm256_set1_epi32(0xFFF), mff = _mm256_set1_epi32(0xFF), one = _mm256_set1_epi32(1);
+  const int *tab = (const int *)t.slot.data();
+  uint64_t g = 0;
+  // a group reads at most S words + one 16-byte load at the last position: stay that far from the end, the rest goes scalar
+  while (g < steps && c.p + 2 * S + 16 <= c.end)
+  {
+    __m256i sym[8];
+    for (uint32_t v = 0; v < V; v++)
+    {
+      const __m256i slot = _mm256_and_si256(x[v], vmask);
+      const __m256i e = _mm256_i32gather_epi32(tab, slot, 4);
+      const __m256i q = _mm256_srl_epi32(x[v], vbits);
+      __m256i nx;
+      if (PACKED)
+      {
+        const __m256i f = _mm256_add_epi32(_mm256_and_si256(_mm256_srli_epi32(e, 8), m12), one);
+        nx = _mm256_add_epi32(_mm256_mullo_epi32(q, f), _mm256_srli_epi32(e, 20));
+      }
+      else
+      {
+        const __m256i f = _mm256_i32gather_epi32((const int *)t.freq, _mm256_and_si256(e, mff), 4);
+        nx = _mm256_add_epi32(_mm256_mullo_epi32(q, f), _mm256_srli_epi32(e, 8));
+      }
+      sym[v] = _mm256_and_si256(e, mff);
+      const __m256i low = _mm256_cmpgt_epi32(lim, nx); // nx < 2^15 (both < 2^31: signed compare is fine)
+      const uint32_t m = (uint32_t)_mm256_movemask_ps(_mm256_castsi256_ps(low));
+      const __m256i words = _mm256_cvtepu16_epi32(_mm_loadu_si128((const __m128i *)c.p));
+      const __m256i mine = _mm256_permutevar8x32_epi32(words, _mm256_load_si256((const __m256i *)g_expand8[m]));
+      const __m256i renorm = _mm256_or_si256(_mm256_slli_epi32(nx, 16), mine);
+      x[v] = _mm256_blendv_epi8(nx, renorm, low);
+      c.p += 2 * (uint32_t)_mm_popcnt_u32(m);
+    }
+    // symbols -> output order: packus(v0,v1) etc. put lanes 0..3 of consecutive vectors side by side, which is exactly idx2idx
+    if (V == 8)
+    {
+      const __m256i a = _mm256_packus_epi16(_mm256_packus_epi32(sym[0], sym[1]), _mm256_packus_epi32(sym[2], sym[3]));
+      const __m256i b = _mm256_packus_epi16(_mm256_packus_epi32(sym[4], sym[5]), _mm256_packus_epi32(sym[6], sym[7]));
+      _mm256_storeu_si256((__m256i *)out, a);
+      _mm256_storeu_si256((__m256i *)(out + 32), b);
+    }
+    else
+    {
+      const __m256i a = _mm256_packus_epi16(_mm256_packus_epi32(sym[0], sym[1]), _mm256_packus_epi32(sym[2], sym[3]));
+      _mm256_storeu_si256((__m256i *)out, a);
+    }
+    out += S;
+    g++;
+  }
+  for (uint32_t v = 0; v < V; v++)
+    _mm256_storeu_si256((__m256i *)(xs + 8 * v), x[v]);
+  groups_scalar(xs, t, c, out, steps - g, S);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// AVX-512 (F + BW + DQ + VL), 64 states = 4 vectors of 16
+// ---------------------------------------------------------------------------------------------------------------
+template <bool PACKED>
+__attribute__((target("avx512f,avx512bw,avx512dq,avx512vl,popcnt"))) void groups_avx512(uint32_t *xs, const Table &t, Cursor &c, uint8_t *out, uint64_t steps)
+{
+  __m512i x[4];
+  for (uint32_t v = 0; v < 4; v++)
+    x[v] = _mm512_loadu_si512(xs + 16 * v);
+  const __m512i vmask = _mm512_set1_epi32((int)((1u << t.bits) - 1));
+  const __m128i vbits = _mm_cvtsi32_si128((int)t.bits);
+  const __m512i lim = _mm512_set1_epi32((int)kConsumePoint16);
+  const __m512i m12 = _mm512_set1_epi32(0xFFF), mff = _mm512_set1_epi32(0xFF), one = _mm512_set1_epi32(1);
+  const __m512i order = _mm512_load_si512(g_out_perm16);
+  const int *tab = (const int *)t.slot.data();
+  uint64_t g = 0;
+  while (g < steps && c.p + 2 * 64 + 32 <= c.end)
+  {
+    __m512i sym[4];
+    for (uint32_t v = 0; v < 4; v++)
+    {
+      const __m512i slot = _mm512_and_si512(x[v], vmask);
+      const __m512i e = _mm512_i32gather_epi32(slot, tab, 4);
+      const __m512i q = _mm512_srl_epi32(x[v], vbits);
+      __m512i nx;
+      if (PACKED)
+      {
+        const __m512i f = _mm512_add_epi32(_mm512_and_si512(_mm512_srli_epi32(e, 8), m12), one);
+        nx = _mm512_add_epi32(_mm512_mullo_epi32(q, f), _mm512_srli_epi32(e, 20));
+      }
+      else
+      {
+        const __m512i f = _mm512_i32gather_epi32(_mm512_and_si512(e, mff), (const int *)t.freq, 4);
+        nx = _mm512_add_epi32(_mm512_mullo_epi32(q, f), _mm512_srli_epi32(e, 8));
+      }
+      sym[v] = _mm512_and_si512(e, mff);
+      const __mmask16 low = _mm512_cmplt_epu32_mask(nx, lim);
+      const __m512i words = _mm512_cvtepu16_epi32(_mm256_loadu_si256((const __m256i *)c.p));
+      const __m512i mine = _mm512_maskz_expand_epi32(low, words); // lane with the k-th set bit takes word k
+      x[v] = _mm512_mask_or_epi32(nx, low, _mm512_slli_epi32(nx, 16), mine);
+      c.p += 2 * (uint32_t)_mm_popcnt_u32((uint32_t)low);
+    }
+    const __m512i packed = _mm512_packus_epi16(_mm512_packus_epi32(sym[0], sym[1]), _mm512_packus_epi32(sym[2], sym[3]));
+    _mm512_storeu_si512(out, _mm512_permutexvar_epi32(order, packed));
+    out += 64;
+    g++;
+  }
+  for (uint32_t v = 0; v < 4; v++)
+    _mm512_storeu_si512(xs + 16 * v, x[v]);
+  groups_scalar(xs, t, c, out, steps - g, 64);
+}
+
+int detect_level()
+{
+  __builtin_cpu_init();
+  if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl"))
+    return kLevelAvx512;
+  if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt"))
+    return kLevelAvx2;
+  return kLevelScalar;
+}
+
+} // namespace
+
+int best_level()
+{
+  static const int level = detect_level();
+  return level;
+}
+
+const char *level_name(int level) { return level == kLevelAvx512 ? "avx512" : level == kLevelAvx2 ? "avx2" : "scalar"; }
+
+// `steps` whole groups from `x` (S states), advancing the cursor; level = the instruction set to use (clamped to the host's)
+static void decode_groups(int level, uint32_t *x, const Table &t, Cursor &c, uint8_t *out, uint64_t steps, uint32_t S)
+{
+  std::call_once(g_luts_once, init_luts);
+  if (level > best_level())
+    level = best_level();
+  const bool packed = t.bits <= 12;
+  if (level == kLevelAvx512 && S == 64)
+    packed ? groups_avx512<true>(x, t, c, out, steps) : groups_avx512<false>(x, t, c, out, steps);
+  else if (level >= kLevelAvx2)
+    packed ? groups_avx2<true>(x, t, c, out, steps, S) : groups_avx2<false>(x, t, c, out, steps, S);
+  else
+    groups_scalar(x, t, c, out, steps, S);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// plan execution: the chains of a decode plan (hsrans_plan.h), on the host.  Chains are independent, so they are spread
+// over `threads` std::threads (the reference's thread-pool fan-out, mt_rANS32x64_16w_decode.cpp:217-220).
+// ---------------------------------------------------------------------------------------------------------------
+namespace
+{
+struct CheckpointSink
+{
+  const uint64_t *groups = nullptr; // ascending absolute group indices to record at (index build), or null
+  size_t n = 0;
+  uint32_t *states = nullptr; // [n * S]
+  uint64_t *words = nullptr;  // [n] absolute stream offset of the read cursor
+};
+
+bool run_chain(int level, const PlanHeader &h, const uint32_t *cf, const Piece *pc, const uint32_t *st, uint32_t chain, const uint8_t *stream, uint64_t stream_len,
+               uint8_t *out, const CheckpointSink *sink)
+{
+  const uint32_t S = h.states;
+  uint32_t x[64] = {};
+  Table t;
+  uint64_t have_hist = ~(uint64_t)0;
+  for (uint32_t pi = cf[chain]; pi < cf[chain + 1]; pi++)
+  {
+    const Piece &p = pc[pi];
+    if (p.flags & kPieceChainStart)
+      memcpy(x, st + (size_t)p.state_idx * S, 4 * (size_t)S);
+    if (p.flags & kPieceFill)
+    {
+      memset(out + p.out_off, (int)(p.hist_off & 0xFF), (size_t)p.fill_len);
+      continue;
+    }
+    if (p.hist_off != have_hist)
+    {
+      if (!t.build(stream + p.hist_off, h.bits))
+        return false;
+      have_hist = p.hist_off;
+    }
+    Cursor c{stream + p.words_off, stream + stream_len};
+    uint8_t *o = out + p.out_off;
+    uint64_t steps = p.steps;
+    if (sink != nullptr && sink->n != 0)
+    {
+      uint64_t g_abs = p.out_off / S;
+      size_t k = (size_t)(std::upper_bound(sink->groups, sink->groups + sink->n, g_abs) - sink->groups);
+      while (steps > 0)
+      {
+        const uint64_t next = k < sink->n ? sink->groups[k] : ~(uint64_t)0;
+        const uint64_t n = std::min<uint64_t>(steps, next - g_abs);
+        decode_groups(level, x, t, c, o, n, S);
+        o += n * S;
+        steps -= n;
+        g_abs += n;
+        if (steps > 0)
+        {
+          memcpy(sink->states + k * S, x, 4 * (size_t)S);
+          sink->words[k] = (uint64_t)(c.p - stream);
+          k++;
+        }
+      }
+    }
+    else
+    {
+      decode_groups(level, x, t, c, o, steps, S);
+      o += steps * S;
+    }
+    if (p.tail)
+      group_scalar(x, t, c, o, S, p.tail);
+  }
+  return true;
+}
+
+// block_ container without an index: follow the inline headers (block_rANS32x64_16w_decode.cpp:47-123) — the host twin of
+// run_block_walk in hsrans_kernels.hip, same checks, same order
+bool run_block_walk(int level, const PlanHeader &h, const uint32_t *st, const uint8_t *stream, uint64_t stream_len, uint8_t *out, uint64_t out_cap)
+{
+  const uint32_t S = h.states;
+  const uint64_t out_len = h.decoded_len;
+  const uint64_t whole = out_len - S + 1;
+  uint32_t x[64] = {};
+  memcpy(x, st, 4 * (size_t)S);
+  uint64_t pos = h.aux_off, i = 0;
+  Table t;
+  bool have_table = false;
+  do
+  {
+    if (pos + 8 > stream_len)
+      return false;
+    const uint64_t hdr = rd64(stream + pos);
+    pos += 8;
+    if (hdr >> 63)
+    {
+      const uint64_t len = hdr & (((uint64_t)1 << 54) - 1);
+      if (len == 0 || len > out_cap - i)
+        return false;
+      memset(out + i, (int)((hdr >> 54) & 0xFF), (size_t)len);
+      i += len;
+    }
+    else
+    {
+      if (hdr == 0 || pos + 512 > stream_len || !t.build(stream + pos, h.bits))
+        return false;
+      have_table = true;
+      pos += 512;
+      uint64_t end = i + hdr;
+      if (end > whole)
+        end = whole;
+      else if (end & (S - 1))
+        return false;
+      const uint64_t steps = end > i ? (end - i + S - 1) / S : 0;
+      Cursor c{stream + pos, stream + stream_len};
+      decode_groups(level, x, t, c, out + i, steps, S);
+      i += steps * S;
+      pos = (uint64_t)(c.p - stream);
+    }
+    if (i > whole)
+    {
+      if (i >= out_len)
+        return true;
+      break;
+    }
+  } while (i < whole);
+  if (i < out_len)
+  {
+    if (!have_table)
+      return false;
+    Cursor c{stream + pos, stream + stream_len};
+    group_scalar(x, t, c, out + i, S, (uint32_t)(out_len - i));
+  }
+  return true;
+}
+
+size_t exec_plan_impl(int level, uint32_t threads, const uint8_t *plan, size_t plan_size, const uint8_t *stream, size_t stream_len, uint8_t *out, size_t out_cap,
+                      const CheckpointSink *sink)
+{
+  if (!plan_validate(plan, plan_size, stream_len, out_cap))
+    return 0;
+  PlanHeader h;
+  memcpy(&h, plan, sizeof(h));
+  const uint32_t *cf = (const uint32_t *)(plan + plan_chain_first_off());
+  const Piece *pc = (const Piece *)(plan + plan_pieces_off(h.n_chains));
+  const uint32_t *st = (const uint32_t *)(plan + plan_states_off(h.n_chains, h.n_pieces));
+  if (h.flags & kPlanWalk)
+    return run_block_walk(level, h, st, stream, stream_len, out, out_cap) ? (size_t)h.decoded_len : 0;
+  if (threads <= 1 || h.n_chains == 1)
+  {
+    for (uint32_t ch = 0; ch < h.n_chains; ch++)
+      if (!run_chain(level, h, cf, pc, st, ch, stream, stream_len, out, sink))
+        return 0;
+    return (size_t)h.decoded_len;
+  }
+  std::atomic<uint32_t> next{0};
+  std::atomic<bool> good{true};
+  auto worker = [&]() {
+    // chains in batches (neighbouring chains share cache lines of the output and, in mt_ plans with checkpoints, a table)
+    const uint32_t batch = std::max<uint32_t>(1, std::min<uint32_t>(64, h.n_chains / (8 * threads)));
+    while (good.load(std::memory_order_relaxed))
+    {
+      const uint32_t first = next.fetch_add(batch, std::memory_order_relaxed);
+      if (first >= h.n_chains)
+        break;
+      for (uint32_t ch = first; ch < std::min(h.n_chains, first + batch); ch++)
+        if (!run_chain(level, h, cf, pc, st, ch, stream, stream_len, out, sink))
+          good = false;
+    }
+  };
+  std::vector<std::thread> pool;
+  for (uint32_t k = 1; k < threads; k++)
+    pool.emplace_back(worker);
+  worker();
+  for (auto &th : pool)
+    th.join();
+  return good ? (size_t)h.decoded_len : 0;
+}
+} // namespace
+
+size_t exec_plan(int level, uint32_t threads, const uint8_t *plan, size_t plan_size, const uint8_t *stream, size_t stream_len, uint8_t *out, size_t out_cap)
+{
+  return exec_plan_impl(level, threads, plan, plan_size, stream, stream_len, out, out_cap, nullptr);
+}
+
+size_t decode(int level, uint32_t threads, int container, int states, uint32_t bits, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap)
+{
+  if (in == nullptr || out == nullptr || in_len < 16 || !valid_codec(container, states, bits))
+    return 0;
+  const uint64_t out_len = rd64(in);
+  if (out_len > out_cap)
+    return 0;
+  std::vector<uint8_t> plan(plan_capacity(container, states, (size_t)out_len, 0, 0));
+  const size_t n = plan_build(container, states, bits, in, in_len, out_cap, plan.data(), plan.size());
+  if (n == 0)
+    return 0;
+  return exec_plan(level, threads, plan.data(), n, in, in_len, out, out_cap);
+}
+
+// Index of an existing raw / mt_ stream with checkpoints at the given groups: one sequential host decode that records
+// {states, cursor} there — what hsrans_index_build_at does with one wavefront on the GPU
+size_t index_build(int level, uint32_t threads, int container, int states, uint32_t bits, const uint8_t *in, size_t in_len, const uint64_t *groups, size_t n_groups,
+                   uint8_t *plan_out, size_t plan_cap)
+{
+  if (in == nullptr || plan_out == nullptr || in_len < 16 || !valid_codec(container, states, bits) || container == HSRANS_BLOCK || groups == nullptr || n_groups == 0)
+    return 0;
+  for (size_t k = 0; k < n_groups; k++)
+    if (groups[k] == 0 || (groups[k] % 4) != 0 || (k > 0 && groups[k] <= groups[k - 1]))
+      return 0;
+  const uint64_t out_len = rd64(in);
+  const uint32_t S = (uint32_t)states;
+  std::vector<uint8_t> base(plan_capacity(container, states, (size_t)out_len, 0, 0));
+  const size_t base_size = plan_build(container, states, bits, in, in_len, (size_t)out_len, base.data(), base.size());
+  if (base_size == 0)
+    return 0;
+  PlanHeader h;
+  memcpy(&h, base.data(), sizeof(h));
+  if (h.n_pieces != h.n_chains)
+    return 0;
+  std::vector<uint8_t> scratch((size_t)out_len + 64);
+  std::vector<uint32_t> ck_states(n_groups * S);
+  std::vector<uint64_t> ck_words(n_groups, 0);
+  CheckpointSink sink;
+  sink.groups = groups;
+  sink.n = n_groups;
+  sink.states = ck_states.data();
+  sink.words = ck_words.data();
+  if (exec_plan_impl(level, threads, base.data(), base_size, in, in_len, scratch.data(), (size_t)out_len, &sink) == 0)
+    return 0;
+  const uint32_t *cf0 = (const uint32_t *)(base.data() + plan_chain_first_off());
+  const Piece *pc0 = (const Piece *)(base.data() + plan_pieces_off(h.n_chains));
+  const uint32_t *st0 = (const uint32_t *)(base.data() + plan_states_off(h.n_chains, h.n_pieces));
+  PlanBuilder pb;
+  pb.begin(container, states, bits, out_len, in_len);
+  pb.hdr.interval = 0;
+  if (container == HSRANS_RAW)
+  {
+    uint16_t counts[256];
+    memcpy(counts, in + pc0[0].hist_off, 512);
+    pb.set_hist(counts);
+  }
+  size_t k = 0;
+  for (uint32_t ch = 0; ch < h.n_chains; ch++)
+  {
+    const Piece &bp = pc0[cf0[ch]];
+    if (bp.flags & kPieceFill)
+    {
+      pb.add_chain(bp, nullptr);
+      continue;
+    }
+    const uint64_t T = bp.steps, g0 = bp.out_off / S;
+    while (k < n_groups && groups[k] <= g0)
+      k++;
+    uint64_t g = 0;
+    const uint32_t *st = st0 + (size_t)bp.state_idx * S;
+    uint64_t words = bp.words_off;
+    while (true)
+    {
+      const bool more = k < n_groups && groups[k] < g0 + T;
+      const uint64_t g_next = more ? groups[k] - g0 : T;
+      Piece p{};
+      p.hist_off = bp.hist_off;
+      p.out_off = bp.out_off + g * S;
+      p.words_off = words;
+      p.steps = (uint32_t)(g_next - g);
+      p.tail = (uint16_t)(more ? 0 : bp.tail);
+      pb.add_chain(p, st);
+      if (!more)
+        break;
+      st = &ck_states[k * S];
+      words = ck_words[k];
+      g = g_next;
+      k++;
+    }
+  }
+  return pb.serialize(plan_out, plan_cap);
+}
+
+} // namespace cpu
+} // namespace hsrans

@@ -40,8 +40,9 @@ struct EncParams
 uint32_t encode_block_count(uint64_t n, uint64_t block, uint32_t S); // 0: too many blocks
 uint64_t encode_slot_bytes(uint64_t block, uint32_t S);
 constexpr uint32_t kEncResultWords = 8;
-// asynchronous on `stream`: K_enc, K_scan, K_gather
-hipError_t launch_encode(const EncParams &ep, hipStream_t stream);
+// asynchronous on `stream`: K_enc, K_scan, K_gather.  `prepared` is the calling context's flag: the dynamic-LDS attribute
+// is per device, so it is raised once per context, not once per process
+hipError_t launch_encode(const EncParams &ep, hipStream_t stream, bool *prepared);
 // asynchronous on `stream`: K_plan (needs ep.plan, ep.n_chains; after launch_encode's results are known)
 hipError_t launch_encode_plan(const EncParams &ep, hipStream_t stream);
 

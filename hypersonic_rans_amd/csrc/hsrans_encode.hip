@@ -794,9 +794,10 @@ uint64_t encode_slot_bytes(uint64_t block, uint32_t S)
   return (need + 255) / 256 * 256;
 }
 
-hipError_t launch_encode(const EncParams &ep, hipStream_t stream)
+hipError_t launch_encode(const EncParams &ep, hipStream_t stream, bool *prepared_flag)
 {
-  static bool prepared = false;
+  bool local = false;
+  bool &prepared = prepared_flag ? *prepared_flag : local;
   const size_t lds = sizeof(WaveLds) * kWavesPerWG;
   if (!prepared)
   {

@@ -409,9 +409,23 @@ size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_
   if (cap < capacity(container, states, n))
     return 0;
   const uint32_t S = (uint32_t)states;
-  const uint32_t interval = opts ? opts->index_interval : 0;
-  if (interval != 0 && (interval % 4 != 0 || opts->plan_out == nullptr))
+  // checkpoints of the sidecar plan: every `interval` groups, or at the explicit group indices of opts->index_groups
+  const uint64_t *ig = opts && opts->n_index_groups ? opts->index_groups : nullptr;
+  size_t ig_left = ig ? opts->n_index_groups : 0; // entries not yet passed (the encoder walks the groups back to front)
+  const uint32_t interval = ig ? 0 : (opts ? opts->index_interval : 0);
+  const bool want_plan = interval != 0 || ig != nullptr;
+  if (want_plan && ((interval % 4) != 0 || opts->plan_out == nullptr))
     return 0;
+  for (size_t k = 0; k < ig_left; k++)
+    if (ig[k] == 0 || (ig[k] % 4) != 0 || (k > 0 && ig[k] <= ig[k - 1]))
+      return 0;
+  auto wanted = [&](uint64_t g) { // is group g a checkpoint?  (called with descending g)
+    if (interval != 0)
+      return g % interval == 0;
+    while (ig_left > 0 && ig[ig_left - 1] > g)
+      ig_left--;
+    return ig_left > 0 && ig[ig_left - 1] == g;
+  };
   // block_/mt_: block_size == 0 selects the reference's adaptive block policy (byte-identical streams), anything else
   // fixed blocks of that many symbols
   const bool fixed_blocks = opts && opts->block_size != 0;
@@ -464,7 +478,7 @@ size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_
     for (size_t g = last_group_start / S + 1; g-- > 0;)
     {
       c.put_group(in, g * S, n);
-      if (interval != 0 && g != 0 && g % interval == 0 && g < T)
+      if (want_plan && g != 0 && g < T && wanted(g))
         checkpoint(g, 0);
     }
   }
@@ -501,7 +515,7 @@ size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_
         for (size_t g = g_last + 1; g-- > g_first;)
         {
           c.put_group(in, g * S, n);
-          if (interval != 0 && g != g_first && (g - g_first) % interval == 0 && g < T)
+          if (want_plan && g != g_first && g < T && (interval != 0 ? (g - g_first) % interval == 0 : wanted(g)))
             checkpoint(g, 0);
         }
         m.words_from_end = c.written();
@@ -549,7 +563,7 @@ size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_
   }
   memmove(w, c.p, payload);
 
-  if (interval == 0)
+  if (!want_plan)
     return total;
 
   // ---- sidecar plan: chains in output order ----
@@ -736,6 +750,17 @@ size_t PlanBuilder::serialize(uint8_t *out, size_t cap)
   return need;
 }
 
+size_t plan_capacity_chains(int container, int states, size_t decoded_size, size_t extra_chains, uint32_t block_size)
+{
+  size_t chains = 2 + extra_chains;
+  if (container != HSRANS_RAW)
+  {
+    const size_t b = block_size ? block_size : 32768;
+    chains += decoded_size / b + 2;
+  }
+  return (size_t)plan_size((uint32_t)chains, (uint32_t)chains + 2, (uint32_t)states, kPlanHasHist);
+}
+
 size_t plan_capacity(int container, int states, size_t decoded_size, uint32_t interval, uint32_t block_size)
 {
   const size_t S = (size_t)states;
@@ -887,6 +912,8 @@ size_t plan_build(int container, int states, uint32_t bits, const uint8_t *in, s
   return pb.serialize(plan_out, plan_cap);
 }
 
+// Plans can come from anywhere (files, other processes): nothing a kernel derives an address from is taken on trust.
+// Every bound is written in subtraction form (off > len || len - off < need) so that offsets near 2^64 cannot wrap.
 bool plan_validate(const uint8_t *plan, size_t size, uint64_t stream_len, uint64_t out_cap)
 {
   if (plan == nullptr || size < sizeof(PlanHeader))
@@ -895,42 +922,76 @@ bool plan_validate(const uint8_t *plan, size_t size, uint64_t stream_len, uint64
   memcpy(&h, plan, sizeof(h));
   if (memcmp(h.magic, "HSRPLAN1", 8) != 0 || !valid_codec((int)h.container, (int)h.states, h.bits))
     return false;
+  if (h.flags & ~(kPlanWalk | kPlanMergeable | kPlanHasHist))
+    return false;
   if (h.n_chains == 0 || h.n_pieces < h.n_chains || plan_size(h.n_chains, h.n_pieces, h.states, h.flags) != size)
     return false;
   if (h.decoded_len > out_cap || h.stream_len > stream_len)
     return false;
+  auto fits = [](uint64_t off, uint64_t need, uint64_t len) { return off <= len && len - off >= need; };
   const uint32_t *cf = (const uint32_t *)(plan + plan_chain_first_off());
   const Piece *pc = (const Piece *)(plan + plan_pieces_off(h.n_chains));
   if (cf[0] != 0 || cf[h.n_chains] != h.n_pieces)
     return false;
   for (uint32_t c = 0; c < h.n_chains; c++)
   {
-    if (cf[c] >= cf[c + 1])
+    if (cf[c] >= cf[c + 1] || cf[c + 1] > h.n_pieces)
       return false;
     if (!(pc[cf[c]].flags & kPieceChainStart) || pc[cf[c]].state_idx >= h.n_chains)
       return false;
   }
   if (h.flags & kPlanWalk)
-    return h.container == HSRANS_BLOCK && h.n_chains == 1 && h.aux_off + 8 <= stream_len && h.decoded_len + 1 >= h.states;
+    return h.container == HSRANS_BLOCK && h.n_chains == 1 && !(h.flags & (kPlanMergeable | kPlanHasHist)) && fits(h.aux_off, 8, stream_len) &&
+           h.decoded_len + 1 >= h.states;
+  bool any_rans = false;
   for (uint32_t i = 0; i < h.n_pieces; i++)
   {
     const Piece &p = pc[i];
     if (p.flags & kPieceFill)
     {
-      if (p.out_off > h.decoded_len || p.fill_len > h.decoded_len - p.out_off)
+      if (!fits(p.out_off, p.fill_len, h.decoded_len))
         return false;
       continue;
     }
+    any_rans = true;
     const uint64_t syms = (uint64_t)p.steps * h.states + p.tail;
-    if (p.tail >= h.states || p.out_off > h.decoded_len || syms > h.decoded_len - p.out_off)
+    if (p.tail >= h.states || !fits(p.out_off, syms, h.decoded_len))
       return false;
-    if ((p.words_off & 1) || p.words_off > stream_len || p.hist_off + 512 > stream_len)
+    if ((p.words_off & 1) || p.words_off > stream_len || !fits(p.hist_off, 512, stream_len))
       return false;
     if ((p.out_off % 4) != 0)
       return false;
+    // the kernels address a chain's words with 32-bit offsets from its first word: a piece whose words could span 4 GiB
+    // (it consumes at most one word per symbol) is refused instead of decoded wrongly
+    const uint64_t span = std::min<uint64_t>(syms * 2, stream_len - p.words_off);
+    if (span >= 0xFFFF0000ull)
+      return false;
+    if (h.shared_hist && p.hist_off != h.aux_off) // one table per workgroup is built from aux_off
+      return false;
   }
-  if (h.shared_hist && h.aux_off + 512 > stream_len)
+  if (h.shared_hist && (!any_rans || !fits(h.aux_off, 512, stream_len)))
     return false;
+  if ((h.flags & kPlanHasHist) && !h.shared_hist)
+    return false;
+  if (h.flags & kPlanMergeable)
+  {
+    // what PlanBuilder::serialize checks before it sets the flag, re-derived: the persistent launches compute output and
+    // stream positions of whole runs of chains from the first chain of the run, so the chains must really be back to back
+    if (!h.shared_hist || h.container != HSRANS_RAW || h.n_pieces != h.n_chains || h.n_chains < 2)
+      return false;
+    for (uint32_t i = 0; i < h.n_pieces; i++)
+    {
+      const Piece &p = pc[i];
+      if ((p.flags & kPieceFill) || p.state_idx != i || p.steps == 0)
+        return false;
+      if (i + 1 < h.n_pieces && (p.tail != 0 || p.out_off + (uint64_t)p.steps * h.states != pc[i + 1].out_off || p.words_off > pc[i + 1].words_off))
+        return false;
+      if (h.interval != 0 && i + 1 < h.n_pieces && p.steps != h.interval) // interval 0: chains of any length (hsrans_plan_thin)
+        return false;
+    }
+    if (h.interval != 0 && pc[h.n_pieces - 1].steps > h.interval)
+      return false;
+  }
   return true;
 }
 
@@ -960,6 +1021,57 @@ size_t plan_slice(const uint8_t *plan, size_t size, uint32_t first, uint32_t cou
       else
         pb.add_piece(pc[i]);
     }
+  }
+  return pb.serialize(out, cap);
+}
+
+// Thin a mergeable (raw) plan to the chains that start at the given group indices (see hsrans_plan_thin in the C header):
+// a boundary that is not a chain start snaps to the last chain start before it; kept chains swallow the chains behind them.
+size_t plan_thin(const uint8_t *plan, size_t size, const uint64_t *groups, size_t n_groups, uint8_t *out, size_t cap)
+{
+  if (plan == nullptr || size < sizeof(PlanHeader) || out == nullptr || (n_groups != 0 && groups == nullptr))
+    return 0;
+  PlanHeader h;
+  memcpy(&h, plan, sizeof(h));
+  if (!plan_validate(plan, size, h.stream_len, h.decoded_len) || !(h.flags & kPlanMergeable))
+    return 0;
+  const Piece *pc = (const Piece *)(plan + plan_pieces_off(h.n_chains));
+  const uint32_t *st = (const uint32_t *)(plan + plan_states_off(h.n_chains, h.n_pieces));
+  const uint64_t S = h.states;
+  std::vector<uint32_t> keep;
+  keep.push_back(0);
+  for (size_t k = 0; k < n_groups; k++)
+  {
+    // last chain whose first group is <= groups[k]
+    uint32_t lo = 0, hi = h.n_chains; // invariant: start(lo) <= g < start(hi)
+    while (hi - lo > 1)
+    {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (pc[mid].out_off / S <= groups[k])
+        lo = mid;
+      else
+        hi = mid;
+    }
+    if (lo > keep.back())
+      keep.push_back(lo);
+  }
+  PlanBuilder pb;
+  pb.hdr = h;
+  pb.hdr.interval = 0;
+  pb.hdr.flags &= ~(kPlanMergeable | kPlanHasHist); // re-derived by serialize()
+  if (h.flags & kPlanHasHist)
+    pb.set_hist((const uint16_t *)(plan + plan_hist_off(h.n_chains, h.n_pieces, h.states)));
+  for (size_t j = 0; j < keep.size(); j++)
+  {
+    const uint32_t a = keep[j], b = j + 1 < keep.size() ? keep[j + 1] : h.n_chains;
+    Piece p = pc[a];
+    const Piece &last = pc[b - 1];
+    const uint64_t steps = (last.out_off - p.out_off) / S + last.steps;
+    if (steps > 0xFFFFFFFFull)
+      return 0;
+    p.steps = (uint32_t)steps;
+    p.tail = last.tail;
+    pb.add_chain(p, st + (size_t)pc[a].state_idx * h.states);
   }
   return pb.serialize(out, cap);
 }

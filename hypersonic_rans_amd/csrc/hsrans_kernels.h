@@ -16,7 +16,8 @@ struct PersistentArgs
 {
   const Piece *pieces;   // null = not a persistent launch
   const uint32_t *states;
-  uint32_t n_chains, interval, S, bits;
+  uint32_t n_chains, interval, S, bits; // interval == 0: chains of any length, one per wave (run_direct); else uniform chains
+
   uint64_t out_base, steps_total, hist_off;
   uint32_t tail;            // symbols of the final partial group (after the last chain)
   uint32_t static_per_wave; // chains every wave decodes as one merged run before it starts pulling single chains (mean)
@@ -28,10 +29,13 @@ struct PersistentArgs
   const uint2 *table;       // host-built decode table (kPlanHasHist plans) or null: build it in the kernel
   uint32_t table_mode;      // 3: one uint2 per slot (bits <= 12); 4: coarse + fine tables (bits 13..15), see hsrans_kernels.hip
   const uint16_t *hist_copy; // the 256 counts that table was built from (device copy inside the plan)
-  unsigned long long *counters; // [kDynQueues * kDynQueueStride] monotonic queue heads (never reset, see run_persistent)
+  unsigned long long *counters; // [kDynQueues * kDynQueueStride] monotonic queue heads of THIS launch's counter set (never reset, see run_persistent)
 };
 constexpr uint32_t kDynQueues = 64;
 constexpr uint32_t kDynQueueStride = 32; // in uint64: one head per 256 B, so that heads never share a line / atomic unit
+// A device plan owns kCounterSets sets of queue heads and every launch takes the next one (round robin): launches of one
+// plan may overlap (several streams, double-buffered outputs) as long as fewer than kCounterSets are in flight at once.
+constexpr uint32_t kCounterSets = 32;
 
 // Grouped launch (block_/mt_ plans with checkpoints): chains [begin, begin+count) share one histogram = one LDS table
 // per workgroup; its waves split the chains evenly (merged into one run per wave when the chains are back to back).
@@ -48,8 +52,9 @@ constexpr uint32_t kGroupFill = 2;
 
 struct KParams
 {
-  const uint8_t *stream; // device, 16-byte aligned
+  const uint8_t *stream; // device, 16-byte aligned: where stream byte 0 is (or would be: see stream_lo)
   uint64_t stream_len;
+  uint64_t stream_lo;    // first stream byte that really exists at stream + offset (window launches; else 0)
   uint8_t *out; // device, 4-byte aligned
   uint64_t out_cap;
   const uint8_t *plan; // device copy of the plan blob
@@ -59,6 +64,9 @@ struct KParams
   uint32_t *ckpt_states;
   uint64_t *ckpt_words;
   uint32_t ckpt_interval;
+  // the same pass with explicit checkpoint positions: ascending absolute group indices; boundary k -> slot k
+  const uint64_t *ckpt_groups;
+  uint32_t n_ckpt_groups;
   // index-build pass over a block_ stream (walk plan): block b's header position, output offset and header word go to
   // walk_blocks[3b .. 3b+2], the coder states on entry to walk_states[b * S ..]; walk_count[0] = blocks seen
   uint64_t *walk_blocks;
@@ -80,7 +88,22 @@ struct KParams
 
 struct LaunchInfo
 {
-  uint32_t grid, block, lds_bytes, waves_per_block, chains, shared_table, walk, two_level;
+  uint32_t grid, block, lds_bytes, waves_per_block, chains, shared_table, walk, two_level, table_mode;
+};
+
+// what the launcher needs to know about the device a context lives on
+struct DeviceGeom
+{
+  uint32_t num_cus, max_lds;
+};
+
+// a launch's shape as it follows from plan header + device (launch_shape)
+struct LaunchShape
+{
+  int mode;         // decode-table layout (kMode* in hsrans_kernels.hip)
+  bool shared, walk;
+  uint32_t waves, lds, grid, resident, private_pair;
+  uint32_t weights[8]; // per-mille run length of the 8 wave classes
 };
 
 // K2: device-side walk of an mt_ stream's header chain (mt_rANS32x64_16w_decode.cpp:41-96), the device twin of the host
@@ -97,17 +120,21 @@ hipError_t launch_mt_chase(const uint8_t *d_stream, uint64_t stream_len, uint64_
 hipError_t launch_mt_fill(const uint8_t *d_stream, uint64_t stream_len, uint32_t S, uint32_t bits, const uint64_t *d_blocks, uint8_t *d_plan, uint32_t n_chains,
                           uint64_t out_len, WalkResult *d_result, hipStream_t stream);
 
-// workgroups of 16 waves the device holds at once when two fit a CU (what launches size their task lists for)
-uint32_t resident_workgroups_hint();
+DeviceGeom default_geom(); // MI355X: 256 CUs, 160 KiB LDS (used where no device is at hand: host-side index sizing)
+LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persistent, uint32_t table_mode, uint32_t n_groups, bool index_pass, bool direct);
+// chain boundaries (in groups) of the direct launch: one chain per resident wave, sized by class weight; see hsrans_kernels.hip
+size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, uint64_t total_groups, uint32_t table_mode, uint64_t *out, size_t cap);
+bool table_spill(); // HSRANS_TABLE_SPILL: leave host-built tables in global memory (comparison only)
 // host-side builder of the bits >= 13 coarse/fine decode table (layout: kModeCoarse in hsrans_kernels.hip); returns entries written
 size_t build_coarse_table(const uint16_t counts[256], uint32_t bits, uint2 *out, size_t capacity_entries);
 size_t coarse_table_entries(uint32_t bits);
 // widest histogram the shared 8-byte-per-slot table (MODE 3) is used for
 uint32_t pack64_max_bits();
-// one-time per process: raise the dynamic-LDS limit of every kernel variant to the gfx950 maximum (160 KiB)
-hipError_t prepare_kernels();
-// asynchronous on `stream`; no allocation, no synchronisation (graph-capturable)
-hipError_t launch_decode(const KParams &kp, const PlanHeader &h, hipStream_t stream, LaunchInfo *info);
+// per device (call with the device current): raise the dynamic-LDS limit of every kernel variant to the gfx950 maximum
+// (160 KiB) and report the device's geometry
+hipError_t prepare_kernels(DeviceGeom *geom);
+// asynchronous on `stream` of the current device; no allocation, no synchronisation (graph-capturable)
+hipError_t launch_decode(const KParams &kp, const PlanHeader &h, const DeviceGeom &dg, hipStream_t stream, LaunchInfo *info);
 
 } // namespace hsrans
 

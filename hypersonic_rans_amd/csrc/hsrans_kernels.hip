@@ -53,10 +53,14 @@ constexpr int kModePack64 = 3;   // bits <= 14, table shared by a workgroup: uin
 // width, one 8-byte gather per group plus a second one on the few lanes that hit a boundary granule.
 constexpr int kModeCoarse = 4;
 constexpr uint32_t kCoarseEntries = 4096;
+// The MODE 3 entries left in global memory ("spilled" table: L1/L2-resident, gathered with global_load_dwordx2): the
+// comparison point BASELINE config 3 asks for next to the LDS-resident tables (HSRANS_TABLE_SPILL=1, host-built tables only)
+constexpr int kModeSpill = 5;
 
 __host__ __device__ constexpr uint32_t table_bytes_for(int mode, uint32_t bits)
 {
-  return mode == kModeTwoLevel ? (1u << bits) + 1024
+  return mode == kModeSpill ? 0u
+         : mode == kModeTwoLevel ? (1u << bits) + 1024
          : mode == kModePack64 ? 8u << bits
          : mode == kModeCoarse ? 8u * kCoarseEntries + 8u * 255u * (1u << (bits - 12))
                                : 4u << bits;
@@ -72,6 +76,9 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v)
   return (uint64_t)uni((uint32_t)v) | ((uint64_t)uni((uint32_t)(v >> 32)) << 32);
 }
 
+// are the 512 bytes of a histogram at stream offset `off` there to be read?
+#define HSRANS_HIST_IN_RANGE(c, off) ((off) >= (c).stream_lo && (off) <= (c).stream_len && (c).stream_len - (off) >= 512)
+
 // idx2idx as arithmetic (rANS32x64_16w.cpp:210-216; the 32-state table rANS32x32_16w.cpp:203 is its first half)
 __device__ __forceinline__ uint32_t lane_to_byte(uint32_t j) { return (j & 0x23u) | ((j & 0x04u) << 2) | ((j & 0x18u) >> 1); }
 
@@ -79,6 +86,7 @@ struct WaveCtx
 {
   const uint8_t *stream;
   uint64_t stream_len;
+  uint64_t stream_lo; // first stream byte that exists behind `stream` (0 unless the caller holds only a window of the stream, hsrans_decode_device_window)
   uint8_t *out;
   uint64_t out_cap;
   uint32_t *status;
@@ -88,6 +96,7 @@ struct WaveCtx
   uint8_t *rings;        // LDS, kWaveRingBytes: this wave's stream ring + mirror
   uint8_t *table;        // LDS
   uint8_t *table_b;      // LDS: the table lanes 32..63 use in the paired 32-state modes (== table unless the halves decode different blocks)
+  const uint2 *gtable;   // kModeSpill: the table in global memory
   uint16_t *scratch_cnt; // LDS, 512 B each, only live during table builds: they alias a ring that has no request in
   uint16_t *scratch_cum; // flight (build_table is always called before the ring is begun)
 };
@@ -226,6 +235,12 @@ __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, u
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   };
+  if (MODE == kModeSpill) // the spilled table only exists host-built; the launcher never pairs this mode with a plan that needs a build
+  {
+    if (tid == 0)
+      atomicOr(c.status, kStatusBadHist);
+    return false;
+  }
   uint16_t *cnt = c.scratch_cnt; // [256]
   uint16_t *cum = c.scratch_cum; // [256] exclusive prefix sums
   const uint32_t total = 1u << c.bits;
@@ -234,7 +249,7 @@ __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, u
   if (!BLOCK_SYNC)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // a stream request of the previous piece may still be landing in the scratch slot
   sync(); // scratch aliases a ring slot: everyone must be done with it
-  const bool in_range = hist_off + 512 <= c.stream_len;
+  const bool in_range = HSRANS_HIST_IN_RANGE(c, hist_off);
   for (uint32_t s = tid; s < 256; s += nthreads)
     cnt[s] = in_range ? *(const uint16_t *)(c.stream + hist_off + 2 * s) : (uint16_t)0;
   sync();
@@ -337,6 +352,12 @@ __device__ __forceinline__ uint32_t group_step(uint32_t &x, Ring &r, const WaveC
     e = e2.x;                      // symbol in byte 3: the output v_perm selects it from there
     nx = __umul24(q, e2.x) + e2.y; // the 24-bit multiplier ignores the symbol in bits 24..31
   }
+  else if (MODE == kModeSpill)
+  {
+    const uint2 e2 = c.gtable[slot]; // per-lane gather through L1 / L2
+    e = e2.x;
+    nx = __umul24(q, e2.x) + e2.y;
+  }
   else if (MODE == kModeCoarse)
   {
     uint2 e2 = ((const uint2 *)c.table)[slot >> c.v_gshift];
@@ -430,7 +451,7 @@ __device__ __forceinline__ void run_groups_impl(uint32_t &x, const StreamWin &sw
   const uint32_t S = FULL ? 64 : c.S;
   const bool act = FULL || c.lane < S;
   const unsigned long long act_mask = FULL ? ~0ull : __builtin_amdgcn_ballot_w64(act);
-  constexpr uint32_t kSymByte = (MODE == kModePack64 || MODE == kModeCoarse) ? 3 : 0; // where group_step's return value holds the symbol
+  constexpr uint32_t kSymByte = (MODE == kModePack64 || MODE == kModeCoarse || MODE == kModeSpill) ? 3 : 0; // where group_step's return value holds the symbol
   const OutLanes ol = out_lanes(c.lane, S);
 
   for (; steps >= 4; steps -= 4)
@@ -487,6 +508,12 @@ __device__ __forceinline__ uint32_t group_step_pair(uint32_t &x, Ring &ra, Ring 
     e = e2.x;
     nx = __umul24(q, e2.x) + e2.y;
   }
+  else if (MODE == kModeSpill)
+  {
+    const uint2 e2 = c.gtable[slot];
+    e = e2.x;
+    nx = __umul24(q, e2.x) + e2.y;
+  }
   else if (MODE == kModePack)
   {
     e = ((const uint32_t *)tab)[slot];
@@ -532,7 +559,7 @@ __device__ __forceinline__ void run_pair_groups(uint32_t &x, const StreamWin &sw
                                                 uint32_t steps)
 {
   const uint64_t oa = uni64(oa_ref), ob = uni64(ob_ref);
-  constexpr uint32_t kSymByte = MODE == kModePack64 ? 3 : 0;
+  constexpr uint32_t kSymByte = (MODE == kModePack64 || MODE == kModeSpill) ? 3 : 0;
   const uint32_t l32 = c.lane & 31, row = l32 & 3, quad = l32 >> 2;
   const uint32_t dcol = ((quad & 1) << 2) | ((quad & 6) >> 1);
   const uint32_t sel_a = (c.lane & 1) ? 0x03070105u : 0x06020400u;
@@ -566,7 +593,7 @@ __device__ __forceinline__ void run_tail(uint32_t &x, Ring &r, const WaveCtx &c,
   const bool act = c.lane < c.S && p < tail;
   const uint32_t e = group_step<MODE, false>(x, r, c, __builtin_amdgcn_ballot_w64(act));
   if (act)
-    c.out[o + p] = (uint8_t)(e >> ((MODE == kModePack64 || MODE == kModeCoarse) ? 24 : 0));
+    c.out[o + p] = (uint8_t)(e >> ((MODE == kModePack64 || MODE == kModeCoarse || MODE == kModeSpill) ? 24 : 0));
 }
 
 // single-symbol block (block_rANS32x64_16w_decode.cpp:52-60): wave-wide fill
@@ -644,7 +671,39 @@ __device__ void run_planned_chain(const WaveCtx &c, const PlanView &pv, uint32_t
     uint64_t o = uni64(pc->out_off);
     uint32_t steps = uni(pc->steps);
 
-    if (kp.ckpt_interval != 0)
+    if (kp.ckpt_groups != nullptr)
+    {
+      // index-build pass with explicit checkpoints (hsrans_index_build_at): `ckpt_groups` is an ascending list of absolute
+      // group indices; boundary k that falls strictly inside this piece gets {states, cursor} recorded in slot k
+      uint64_t g_abs = o / c.S;
+      uint32_t lo = 0, hi = kp.n_ckpt_groups; // first boundary > g_abs
+      while (lo < hi)
+      {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (uni64(kp.ckpt_groups[mid]) <= g_abs)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      uint32_t bi = lo;
+      while (steps > 0)
+      {
+        const uint64_t next = bi < kp.n_ckpt_groups ? uni64(kp.ckpt_groups[bi]) : ~(uint64_t)0;
+        const uint32_t n = next - g_abs < steps ? (uint32_t)(next - g_abs) : steps;
+        run_groups<MODE>(x, sw, r, c, o, n);
+        steps -= n;
+        g_abs += n;
+        if (steps > 0)
+        {
+          if (c.lane < c.S)
+            kp.ckpt_states[(uint64_t)bi * c.S + c.lane] = x;
+          if (c.lane == 0)
+            kp.ckpt_words[bi] = ring_pos(sw, r);
+          bi++;
+        }
+      }
+    }
+    else if (kp.ckpt_interval != 0)
     {
       // index-build pass (hsrans_index_build): record {states, cursor} at every `ckpt_interval`-th group boundary of the
       // piece.  Slot = absolute group index / interval: checkpoints of one piece are an interval apart and pieces do
@@ -740,8 +799,8 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
       *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
     if (blockIdx.x == 0 && threadIdx.x < 64)
     {
-      bool same = pa.hist_off + 512 <= c.stream_len;
-      if (same)
+      bool same = HSRANS_HIST_IN_RANGE(c, pa.hist_off) || pa.hist_off + 512 <= c.stream_lo; // (a window launch may lack the histogram: nothing to compare)
+      if (same && pa.hist_off >= c.stream_lo)
       {
         const uint64_t mine = *(const uint64_t *)(pa.hist_copy + 4 * c.lane);
         uint64_t theirs = 0;
@@ -764,15 +823,17 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
     run_groups<MODE>(x, sw, r, c, g.o, g.steps);
     run_tail<MODE>(x, r, c, g.o, g.tail);
   }
+  const uint64_t t_static = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
 
   // Dynamic part: queue k hands out chains [lo, hi) in order.  Its 64-bit head is never reset: every launch draws
   // exactly H = (hi - lo) + (waves on this queue) tickets from it (each wave fails exactly once), and launches on one
   // plan are serialised by their stream, so ticket mod H is this launch's ticket.  No memset node, no exit protocol.
   const uint32_t dyn0 = pa.static_total;
   const uint64_t D = pa.n_chains - dyn0;
-  const uint32_t k = w & (kDynQueues - 1);
-  const uint32_t lo = dyn0 + (uint32_t)(k * D / kDynQueues), hi = dyn0 + (uint32_t)((k + 1) * D / kDynQueues);
-  const uint64_t H = (uint64_t)(hi - lo) + (W - k + kDynQueues - 1) / kDynQueues;
+  const uint32_t nq = W < kDynQueues ? W : kDynQueues; // queues in use: every one of them needs a wave
+  const uint32_t k = w % nq;
+  const uint32_t lo = dyn0 + (uint32_t)(k * D / nq), hi = dyn0 + (uint32_t)((k + 1) * D / nq);
+  const uint64_t H = (uint64_t)(hi - lo) + (W - k + nq - 1) / nq;
   while (true)
   {
     unsigned long long t = 0;
@@ -790,12 +851,233 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
 
   if (kp.stamps && c.lane == 0)
   {
-    uint64_t *st = kp.stamps + (uint64_t)w * 4;
+    uint64_t *st = kp.stamps + (uint64_t)w * 8;
     st[0] = t_entry;
     st[1] = t_table;
     st[2] = t_ready;
     st[3] = __builtin_amdgcn_s_memrealtime();
+    st[4] = t_static;
   }
+}
+
+// Direct launch (kPlanMergeable plans with chains of any length, PlanHeader::interval == 0: hsrans_index_boundaries /
+// hsrans_plan_thin make exactly one chain per resident wavefront, sized by the wave's scheduling class): wave w decodes
+// chain w (then w + W, ... if the plan has more chains than the launch has waves).  Everything a wave needs is in its own
+// Piece record, fetched with scalar loads; no queues, no atomics, so launches of one plan may overlap freely.
+typedef const __attribute__((address_space(4))) uint64_t *kptr64; // constant address space: s_load through the scalar cache
+typedef const __attribute__((address_space(4))) uint32_t *kptr32;
+
+struct DirectPiece
+{
+  uint64_t words, out, limit;
+  uint32_t steps, tail;
+};
+
+__device__ __forceinline__ DirectPiece direct_piece(const WaveCtx &c, const PersistentArgs &pa, uint32_t ch)
+{
+  const kptr64 p = (kptr64)(uintptr_t)(pa.pieces + ch);
+  DirectPiece d;
+  d.words = p[0];
+  d.out = p[1];
+  const uint32_t st = ((kptr32)p)[8]; // steps
+  const uint32_t tf = ((kptr32)p)[9]; // tail | flags << 16
+  d.steps = st;
+  d.tail = tf & 0xFFFFu;
+  d.limit = ch + 1 < pa.n_chains ? p[6] : c.stream_len; // the next piece's words_off (Piece is 48 bytes)
+  return d;
+}
+
+template <int MODE>
+__device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, uint32_t w)
+{
+  const PersistentArgs &pa = kp.pa;
+  const uint32_t W = gridDim.x * waves;
+  const uint64_t t_entry = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  uint64_t t_table = 0, t_ready = 0, t_static = 0;
+  const bool host_table = (MODE == kModePack64 || MODE == kModeCoarse || MODE == kModeSpill) && pa.table != nullptr;
+  if (!host_table) // the in-kernel build borrows ring space: it has to come before the first stream request
+    build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
+  bool table_pending = host_table;
+  // the host-built table: one coalesced 16 B load + LDS store per thread (while the wave's first stream chunks and its
+  // states are in flight); the first wave also checks that the stream really carries the histogram the table was built
+  // from (else: status, as a failed sum check)
+  auto fetch_table = [&]() {
+    if (MODE != kModeSpill)
+    {
+      const uint32_t entries = table_bytes_for(MODE, c.bits) / 8;
+      for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
+        *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64)
+    {
+      bool same = HSRANS_HIST_IN_RANGE(c, pa.hist_off) || pa.hist_off + 512 <= c.stream_lo; // (a window launch may lack the histogram: nothing to compare)
+      if (same && pa.hist_off >= c.stream_lo)
+      {
+        const uint64_t mine = *(const uint64_t *)(pa.hist_copy + 4 * c.lane);
+        uint64_t theirs = 0;
+        for (int b = 3; b >= 0; b--) // stream offsets are only 2-byte aligned
+          theirs = (theirs << 16) | *(const uint16_t *)(c.stream + pa.hist_off + 8 * c.lane + 2 * b);
+        same = mine == theirs;
+      }
+      if (__builtin_amdgcn_ballot_w64(!same) != 0 && c.lane == 0)
+        atomicOr(c.status, kStatusBadHist);
+    }
+    if (MODE != kModeSpill)
+      __syncthreads();
+    if (kp.stamps)
+      t_table = __builtin_amdgcn_s_memrealtime();
+  };
+  // static part: chain w belongs to wave w (hsrans_index_boundaries sized it for this wave's scheduling class); dynamic
+  // part: the chains behind the first W (short ones at the end of the stream, there to even out the finish) go to whoever
+  // is done, through the same never-reset ticket queues as run_persistent (this launch's own set of heads).
+  // (One loop, one call site of the decode body: a second copy of it pushes the kernel over the inliner's budget.)
+  const bool have_dynamic = pa.n_chains > W && pa.counters != nullptr;
+  const uint64_t D = have_dynamic ? pa.n_chains - W : 0;
+  const uint32_t nq = W < kDynQueues ? W : kDynQueues; // queues in use: every one of them needs a wave
+  const uint32_t k = w % nq;
+  const uint32_t lo = W + (uint32_t)(k * D / nq), hi = W + (uint32_t)((k + 1) * D / nq);
+  const uint64_t H = (uint64_t)(hi - lo) + (W - k + nq - 1) / nq;
+  uint32_t ch = w;
+  bool have = w < pa.n_chains;
+  while (true)
+  {
+    if (have)
+    {
+      StreamWin sw;
+      Ring r;
+      ring_bind(r, c.rings);
+      uint32_t x = c.lane < c.S ? pa.states[(uint64_t)ch * c.S + c.lane] : 0; // address known up front: in flight beside the piece record
+      const DirectPiece d = direct_piece(c, pa, ch);
+      win_open(sw, c, d.words, d.limit);
+      ring_begin(sw, r, c, d.words);
+      if (table_pending)
+      {
+        fetch_table();
+        table_pending = false;
+      }
+      ring_ready();
+      if (kp.stamps && t_ready == 0)
+        t_ready = __builtin_amdgcn_s_memrealtime();
+      uint64_t o = d.out;
+      run_groups<MODE>(x, sw, r, c, o, d.steps);
+      run_tail<MODE>(x, r, c, o, d.tail);
+    }
+    if (kp.stamps && t_static == 0)
+      t_static = __builtin_amdgcn_s_memrealtime();
+    if (!have_dynamic)
+      break;
+    unsigned long long t = 0;
+    if (c.lane == 0)
+      t = atomicAdd(pa.counters + k * kDynQueueStride, 1ull);
+    t = uni64(t) % H;
+    if (t >= hi - lo)
+      break;
+    ch = lo + (uint32_t)t;
+    have = true;
+  }
+  if (table_pending) // a wave without a chain still takes part in the workgroup's table copy
+    fetch_table();
+  if (kp.stamps && c.lane == 0)
+  {
+    uint64_t *st = kp.stamps + (uint64_t)w * 8;
+    st[0] = t_entry;
+    st[1] = t_table;
+    st[2] = t_ready;
+    st[3] = __builtin_amdgcn_s_memrealtime();
+    st[4] = t_static;
+  }
+}
+
+// Direct launch of a 32-state plan: wave w decodes chains 2w and 2w + 1 side by side (lanes 0..31 / 32..63, group_step_pair);
+// what the pair loop leaves (unequal lengths, < 4 groups, the stream's final partial group) is finished one chain at a time.
+template <int MODE>
+__device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t waves, uint32_t w)
+{
+  const PersistentArgs &pa = kp.pa;
+  const uint32_t W = gridDim.x * waves;
+  StreamWin sw;
+  Ring ra, rb;
+  ring_bind(ra, c.rings, 8);
+  ring_bind(rb, c.rings + 1152, 8);
+  const bool host_table = (MODE == kModePack64 || MODE == kModeSpill) && pa.table != nullptr;
+  if (!host_table)
+    build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
+  bool table_pending = host_table && MODE != kModeSpill;
+  if (host_table && blockIdx.x == 0 && threadIdx.x < 64)
+  {
+    bool same = HSRANS_HIST_IN_RANGE(c, pa.hist_off) || pa.hist_off + 512 <= c.stream_lo; // (a window launch may lack the histogram: nothing to compare)
+    if (same && pa.hist_off >= c.stream_lo)
+    {
+      const uint64_t mine = *(const uint64_t *)(pa.hist_copy + 4 * c.lane);
+      uint64_t theirs = 0;
+      for (int b = 3; b >= 0; b--)
+        theirs = (theirs << 16) | *(const uint16_t *)(c.stream + pa.hist_off + 8 * c.lane + 2 * b);
+      same = mine == theirs;
+    }
+    if (__builtin_amdgcn_ballot_w64(!same) != 0 && c.lane == 0)
+      atomicOr(c.status, kStatusBadHist);
+  }
+  auto copy_table = [&]() {
+    const uint32_t entries = 1u << c.bits;
+    for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
+      *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
+    __syncthreads();
+  };
+  // static pair (2w, 2w + 1), then dynamic pairs of adjacent chains behind the first 2W (see run_direct); one loop, one
+  // call site of the decode body
+  const bool have_dynamic = pa.n_chains > 2 * W && pa.counters != nullptr;
+  const uint64_t D = have_dynamic ? pa.n_chains - 2 * W : 0;
+  const uint32_t nq = W < kDynQueues ? W : kDynQueues;
+  const uint32_t k = w % nq;
+  const uint32_t lo = 2 * W + (uint32_t)(k * D / nq), hi = 2 * W + (uint32_t)((k + 1) * D / nq);
+  const uint32_t pairs = (hi - lo + 1) / 2;
+  const uint64_t H = (uint64_t)pairs + (W - k + nq - 1) / nq;
+  uint32_t a = 2 * w, end = pa.n_chains; // chains [a, min(a + 2, end)) are this round's
+  bool have = a < pa.n_chains;
+  while (true)
+  {
+    if (have)
+    {
+      const bool have_b = a + 1 < end;
+      const DirectPiece da = direct_piece(c, pa, a);
+      const DirectPiece db = have_b ? direct_piece(c, pa, a + 1) : da;
+      win_open(sw, c, da.words, have_b ? db.limit : da.limit);
+      ring_begin(sw, ra, c, da.words);
+      if (have_b)
+        ring_begin(sw, rb, c, db.words);
+      uint32_t x = pa.states[(uint64_t)((c.lane < 32 || !have_b) ? a : a + 1) * 32 + (c.lane & 31)];
+      if (table_pending)
+      {
+        copy_table();
+        table_pending = false;
+      }
+      ring_ready();
+      uint64_t oa = da.out, ob = db.out;
+      uint32_t sa = da.steps, sb = have_b ? db.steps : 0;
+      const uint32_t both = have_b ? (sa < sb ? sa : sb) & ~3u : 0;
+      run_pair_groups<MODE>(x, sw, ra, rb, c, oa, ob, both);
+      sa -= both;
+      sb -= both;
+      uint32_t xb = __shfl(x, (c.lane & 31) + 32, 64); // B's states move down to lanes 0..31 and B is finished alone
+      run_groups<MODE>(xb, sw, rb, c, ob, sb);
+      run_tail<MODE>(xb, rb, c, ob, have_b ? db.tail : 0);
+      run_groups<MODE>(x, sw, ra, c, oa, sa);
+      run_tail<MODE>(x, ra, c, oa, da.tail);
+    }
+    if (!have_dynamic)
+      break;
+    unsigned long long t = 0;
+    if (c.lane == 0)
+      t = atomicAdd(pa.counters + k * kDynQueueStride, 1ull);
+    t = uni64(t) % H;
+    if (t >= pairs)
+      break;
+    a = lo + 2 * (uint32_t)t;
+    end = hi; // the odd chain at the end of this queue's range goes alone: its neighbour belongs to the next queue
+    have = true;
+  }
+  if (table_pending) // a wave without chains still takes part in the workgroup's table copy
+    copy_table();
 }
 
 // Persistent launch for 32-state streams: every wave runs TWO runs of chains side by side (group_step_pair), A = run 2u,
@@ -872,8 +1154,8 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
 
   if (host_table && blockIdx.x == 0 && threadIdx.x < 64)
   {
-    bool same = pa.hist_off + 512 <= c.stream_len;
-    if (same)
+    bool same = HSRANS_HIST_IN_RANGE(c, pa.hist_off) || pa.hist_off + 512 <= c.stream_lo; // (a window launch may lack the histogram: nothing to compare)
+    if (same && pa.hist_off >= c.stream_lo)
     {
       const uint64_t mine = *(const uint64_t *)(pa.hist_copy + 4 * c.lane);
       uint64_t theirs = 0;
@@ -896,10 +1178,11 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
 
   const uint32_t dyn0 = pa.static_total;
   const uint64_t D = pa.n_chains - dyn0;
-  const uint32_t k = w & (kDynQueues - 1);
-  const uint32_t lo = dyn0 + (uint32_t)(k * D / kDynQueues), hi = dyn0 + (uint32_t)((k + 1) * D / kDynQueues);
+  const uint32_t nq = W < kDynQueues ? W : kDynQueues; // queues in use: every one of them needs a wave
+  const uint32_t k = w % nq;
+  const uint32_t lo = dyn0 + (uint32_t)(k * D / nq), hi = dyn0 + (uint32_t)((k + 1) * D / nq);
   const uint32_t pairs = (hi - lo + 1) / 2;
-  const uint64_t H = (uint64_t)pairs + (W - k + kDynQueues - 1) / kDynQueues; // tickets per launch, see run_persistent
+  const uint64_t H = (uint64_t)pairs + (W - k + nq - 1) / nq; // tickets per launch, see run_persistent
   while (true)
   {
     unsigned long long t = 0;
@@ -1195,6 +1478,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   WaveCtx c;
   c.stream = kp.stream;
   c.stream_len = kp.stream_len;
+  c.stream_lo = kp.stream_lo;
   c.out = kp.out;
   c.out_cap = kp.out_cap;
   c.status = kp.status;
@@ -1216,9 +1500,18 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
     c.scratch_cnt = (uint16_t *)smem;         // wave 0's ring (no request in flight while a table is built)
     c.scratch_cum = (uint16_t *)(smem + 512);
     const uint64_t hist_off = pv.hdr->aux_off; // shared plans: the one histogram every chain uses
+    c.gtable = kp.pa.table;
     if (kp.pa.pieces != nullptr)
     {
-      if (c.S == 32)
+      // (the coarse + fine tables are only ever used for 64-state plans: no pair variants of that mode)
+      if (kp.pa.interval == 0)
+      {
+        if (MODE != kModeCoarse && c.S == 32)
+          run_direct_pair<MODE>(c, kp, waves, chain);
+        else
+          run_direct<MODE>(c, kp, waves, chain);
+      }
+      else if (MODE != kModeCoarse && c.S == 32)
         run_persistent_pair<MODE>(c, kp, waves, chain);
       else
         run_persistent<MODE>(c, kp, waves, chain);
@@ -1239,6 +1532,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
     c.rings = smem + wave * kWaveRingBytes; // all rings first: they stay kRingBytes-aligned
     c.table = smem + waves * kWaveRingBytes + wave * table_stride * (kp.private_pair ? 2 : 1);
     c.table_b = kp.private_pair ? c.table + table_stride : c.table;
+    c.gtable = nullptr;
     c.scratch_cnt = (uint16_t *)c.rings;
     c.scratch_cum = (uint16_t *)(c.rings + 512);
     if (pv.hdr->flags & kPlanWalk)
@@ -1421,23 +1715,34 @@ hipError_t launch_mt_fill(const uint8_t *d_stream, uint64_t stream_len, uint32_t
 // ---------------------------------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------------------------------
-static uint32_t g_max_lds = 160 * 1024;
-static uint32_t g_num_cus = 256;
-static uint32_t g_pack64_max_bits = 14; // HSRANS_PACK64_MAX_BITS (tuning): widest histogram decoded with the 8-byte-per-slot shared table
-static uint32_t g_waves_per_wg = 16;    // HSRANS_WAVES_PER_WG (tuning): waves per workgroup of the shared-table launches
-static uint32_t g_static_percent = 100; // HSRANS_STATIC_PERCENT (tuning): share of the chains handed out statically
-// HSRANS_SLOT_WEIGHTS (tuning): per-mille run length of the 8 wave classes, see PersistentArgs::run_len.  Measured on
+// tuning knobs (environment, read once per process; the defaults are the measured best)
+static uint32_t g_pack64_max_bits = 14; // HSRANS_PACK64_MAX_BITS: widest histogram decoded with the 8-byte-per-slot shared table
+static uint32_t g_waves_per_wg = 16;    // HSRANS_WAVES_PER_WG: waves per workgroup of the shared-table launches
+static uint32_t g_static_percent = 100; // HSRANS_STATIC_PERCENT: share of the chains handed out statically (uniform persistent launches)
+// HSRANS_SLOT_WEIGHTS: per-mille run length of the 8 wave classes, see PersistentArgs::run_len.  Measured on
 // MI355X at 8 waves per SIMD (bits <= 12): with equal runs the four age classes of a workgroup finish at 33/36/39/42 us,
 // with these weights all at 39 us (tools/stamps.py), 3-7 % less kernel time; at 4 waves per SIMD (bits >= 13) equal
 // runs are better and are kept.
 static uint32_t g_slot_weights[8] = {1350, 1100, 870, 680, 1300, 1080, 860, 660};
 // HSRANS_SLOT_WEIGHTS4: the same for launches with one 16-wave workgroup per CU (4 waves per SIMD: 13-bit tables)
 static uint32_t g_slot_weights4[8] = {1150, 1050, 950, 850, 1150, 1050, 950, 850};
-// HSRANS_PRIVATE_PAIR (tuning): 0 = never, 1 = when there are more chains than wave slots (default), 2 = always pair the
+// HSRANS_DIRECT_WEIGHTS / HSRANS_DIRECT_WEIGHTS4: the chain lengths of the one-chain-per-wave index (hsrans_index_boundaries),
+// per mille of the mean, by the same 8 classes.  Here nothing evens out a wrong weight afterwards (the queues above only hold the
+// short tail chains), so these are fitted until all classes finish together (tools/tune_weights.py: the spread of the classes'
+// mean finish times goes from 19.8 us with the weights above to 0.1 us): the waves of a CU's first workgroup run ahead of
+// the second one's on every SIMD, and inside a workgroup the older waves a little ahead of the younger.
+static uint32_t g_direct_weights[8] = {1244, 1207, 1163, 1101, 973, 883, 771, 658};
+static uint32_t g_direct_weights4[8] = {1150, 1050, 950, 850, 1150, 1050, 950, 850};
+// HSRANS_PRIVATE_PAIR: 0 = never, 1 = when there are more chains than wave slots (default), 2 = always pair the
 // chains of 32-state plans in private-table launches.  Measured: 2^30 B in 16,384 blocks 1.40 -> 1.33 ms, but 100 MB in 1,526
 // blocks 0.25 -> 0.30 ms (everything is latency-bound there and half as many waves are in flight)
 static uint32_t g_private_pair = 1;
-static bool g_weights_two_level = false; // HSRANS_WEIGHTS_TWO_LEVEL (tuning): apply the weights to the two-level table mode as well
+static bool g_weights_two_level = false; // HSRANS_WEIGHTS_TWO_LEVEL: apply the weights to the two-level table mode as well
+static bool g_table_spill = false;       // HSRANS_TABLE_SPILL: host-built tables stay in global memory (kModeSpill; comparison only)
+// one-chain-per-wave plans (hsrans_index_boundaries): share of the stream (per mille) left to short chains that the ticket
+// queues hand to waves that are done early, and the length of those chains in groups
+static uint32_t g_direct_dyn_permille = 70; // HSRANS_DIRECT_DYN_PERMILLE
+static uint32_t g_direct_dyn_groups = 32;   // HSRANS_DIRECT_DYN_GROUPS (multiple of 4)
 
 typedef void (*KernelFn)(KParams);
 static KernelFn kernel_for(int mode, bool shared)
@@ -1451,11 +1756,13 @@ static KernelFn kernel_for(int mode, bool shared)
   case 4: return k_decode<kModeTwoLevel, false>;
   case 5: return k_decode<kModeTwoLevel, true>;
   case 8: case 9: return k_decode<kModeCoarse, true>;
+  case 10: case 11: return k_decode<kModeSpill, true>;
   default: return k_decode<kModePack64, true>;
   }
 }
 
 uint32_t pack64_max_bits() { return g_pack64_max_bits; }
+bool table_spill() { return g_table_spill; }
 
 size_t coarse_table_entries(uint32_t bits) { return table_bytes_for(kModeCoarse, bits) / 8; }
 
@@ -1498,10 +1805,13 @@ size_t build_coarse_table(const uint16_t counts[256], uint32_t bits, uint2 *out,
     fine[k] = make_uint2(0, 0);
   return coarse_table_entries(bits);
 }
-uint32_t resident_workgroups_hint() { return 2 * g_num_cus; }
 
-hipError_t prepare_kernels()
+static void read_tuning_once()
 {
+  static bool done = false;
+  if (done)
+    return;
+  done = true;
   if (const char *e = getenv("HSRANS_STATIC_PERCENT"))
     g_static_percent = (uint32_t)atoi(e) > 100 ? 100 : (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_PACK64_MAX_BITS"))
@@ -1529,73 +1839,180 @@ hipError_t prepare_kernels()
   };
   read_weights("HSRANS_SLOT_WEIGHTS", g_slot_weights);
   read_weights("HSRANS_SLOT_WEIGHTS4", g_slot_weights4);
+  read_weights("HSRANS_DIRECT_WEIGHTS", g_direct_weights);
+  read_weights("HSRANS_DIRECT_WEIGHTS4", g_direct_weights4);
   g_weights_two_level = getenv("HSRANS_WEIGHTS_TWO_LEVEL") != nullptr;
+  g_table_spill = getenv("HSRANS_TABLE_SPILL") != nullptr;
   if (const char *e = getenv("HSRANS_PRIVATE_PAIR"))
     g_private_pair = (uint32_t)atoi(e);
+  if (const char *e = getenv("HSRANS_DIRECT_DYN_PERMILLE"))
+    g_direct_dyn_permille = (uint32_t)atoi(e) > 500 ? 500 : (uint32_t)atoi(e);
+  if (const char *e = getenv("HSRANS_DIRECT_DYN_GROUPS"))
+    if (atoi(e) >= 4 && atoi(e) % 4 == 0)
+      g_direct_dyn_groups = (uint32_t)atoi(e);
+}
+
+// per device (the CURRENT device): dynamic-LDS limit of every kernel variant, CU count
+hipError_t prepare_kernels(DeviceGeom *geom)
+{
+  read_tuning_once();
+  geom->max_lds = 160 * 1024;
+  geom->num_cus = 256;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-    g_num_cus = (uint32_t)cus;
-  for (int mode = 0; mode < 5; mode++)
+    geom->num_cus = (uint32_t)cus;
+  for (int mode = 0; mode < 6; mode++)
     for (int shared = 0; shared < 2; shared++)
     {
-      const hipError_t e = hipFuncSetAttribute((const void *)kernel_for(mode, shared != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_max_lds);
+      const hipError_t e = hipFuncSetAttribute((const void *)kernel_for(mode, shared != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
       if (e != hipSuccess)
         return e;
     }
   return hipSuccess;
 }
 
-hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t stream, LaunchInfo *info)
+DeviceGeom default_geom()
 {
-  KParams kp = kp_in;
-  const bool walk = (h.flags & kPlanWalk) != 0;
-  const bool grouped = kp.groups != nullptr && kp.ckpt_interval == 0;
-  const bool shared = !walk && (grouped || (h.shared_hist != 0 && h.n_chains > 1));
-  // 64-bit entries only where one table serves a whole workgroup (LDS: 16 KiB table + 16 x 4 KiB rings, two per CU)
-  const bool coarse = shared && kp.pa.pieces != nullptr && kp.pa.table != nullptr && kp.pa.table_mode == kModeCoarse && h.states == 64;
-  const int mode = coarse ? kModeCoarse : shared && h.bits <= pack64_max_bits() ? kModePack64 : h.bits >= 13 ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : kModePack;
-  const bool two_level = mode == kModeTwoLevel;
-  const uint32_t table_bytes = table_bytes_for(mode, h.bits);
-  const uint32_t wave_bytes = kWaveRingBytes + ((table_bytes + 15) & ~15u); // private rings + table
+  read_tuning_once();
+  DeviceGeom g;
+  g.max_lds = 160 * 1024;
+  g.num_cus = 256; // MI355X
+  return g;
+}
 
+// Everything about a launch that follows from the plan header and the device alone (no pointers): the table layout, the
+// workgroup shape and the grid.  launch_decode uses it; direct_boundaries uses it to size one chain per resident wave.
+LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persistent, uint32_t table_mode, uint32_t n_groups, bool index_pass, bool direct)
+{
+  read_tuning_once();
+  LaunchShape L{};
+  const bool walk = (h.flags & kPlanWalk) != 0;
+  const bool grouped = n_groups != 0 && !index_pass;
+  L.walk = walk;
+  L.shared = !walk && (grouped || (h.shared_hist != 0 && h.n_chains > 1));
+  // 64-bit entries only where one table serves a whole workgroup (LDS: 16 KiB table + 16 x 2.25 KiB rings, two per CU)
+  const bool coarse = L.shared && persistent && table_mode == kModeCoarse && h.states == 64;
+  const bool spill = L.shared && persistent && table_mode == kModeSpill;
+  L.mode = spill ? kModeSpill : coarse ? kModeCoarse : L.shared && h.bits <= pack64_max_bits() ? kModePack64 : h.bits >= 13 ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : kModePack;
+  const bool two_level = L.mode == kModeTwoLevel;
+  const uint32_t table_bytes = table_bytes_for(L.mode, h.bits);
+  const uint32_t wave_bytes = kWaveRingBytes + ((table_bytes + 15) & ~15u); // private rings + table
   uint32_t waves, lds, grid;
-  if (shared)
+  if (L.shared)
   {
     waves = g_waves_per_wg;
-    if (mode == kModeCoarse && waves * kWaveRingBytes + table_bytes > g_max_lds / 2)
+    if (L.mode == kModeCoarse && waves * kWaveRingBytes + table_bytes > dg.max_lds / 2)
       waves = 12; // 15 bits: 48 KiB of tables + 12 rings = 75 KiB, two workgroups per CU
-    if (waves * kWaveRingBytes + table_bytes > g_max_lds && table_bytes + 4 * kWaveRingBytes <= g_max_lds)
-      waves = (g_max_lds - table_bytes) / kWaveRingBytes / 4 * 4; // a big table: as many waves as still fit (multiple of 4: one per SIMD)
-    while (waves > 1 && (waves / 2 >= h.n_chains || waves * kWaveRingBytes + table_bytes > g_max_lds))
+    if (waves * kWaveRingBytes + table_bytes > dg.max_lds && table_bytes + 4 * kWaveRingBytes <= dg.max_lds)
+      waves = (dg.max_lds - table_bytes) / kWaveRingBytes / 4 * 4; // a big table: as many waves as still fit (multiple of 4: one per SIMD)
+    while (waves > 1 && (waves / 2 >= h.n_chains || waves * kWaveRingBytes + table_bytes > dg.max_lds))
       waves /= 2;
     lds = waves * kWaveRingBytes + table_bytes;
     grid = (h.n_chains + waves - 1) / waves;
     if (grouped)
-      grid = kp.n_groups;
-    if (kp.pa.pieces != nullptr || grouped)
-    {
-      const uint32_t per_cu = g_max_lds / lds ? g_max_lds / lds : 1; // workgroups one CU can hold (LDS-limited; 32 waves max)
-      const uint32_t resident = g_num_cus * (per_cu * waves > 32 ? 32 / waves : per_cu);
-      if (grid > resident)
-        grid = resident;
-    }
+      grid = n_groups;
+    const uint32_t per_cu = dg.max_lds / lds ? dg.max_lds / lds : 1; // workgroups one CU can hold (LDS-limited; 32 waves max)
+    L.resident = dg.num_cus * (per_cu * waves > 32 ? 32 / waves : per_cu);
+    if ((persistent || grouped) && grid > L.resident)
+      grid = L.resident;
   }
   else
   {
     // 32-state plans: two chains per wave, one per half, when two tables fit (run_private_pair); not for the index-build pass
-    const bool pair = (g_private_pair == 2 || (g_private_pair == 1 && h.n_chains >= 32 * g_num_cus)) && !walk && h.states == 32 && h.n_chains > 1 &&
-                      table_bytes <= 16384 && kp.ckpt_interval == 0;
-    kp.private_pair = pair ? 1 : 0;
+    const bool pair = (g_private_pair == 2 || (g_private_pair == 1 && h.n_chains >= 32 * dg.num_cus)) && !walk && h.states == 32 && h.n_chains > 1 &&
+                      table_bytes <= 16384 && !index_pass;
+    L.private_pair = pair ? 1 : 0;
     const uint32_t wave_lds = pair ? wave_bytes + ((table_bytes + 15) & ~15u) : wave_bytes;
     const uint32_t work = pair ? (h.n_chains + 1) / 2 : h.n_chains;
     waves = walk ? 1 : 4;
-    while (waves > 1 && (waves * wave_lds > g_max_lds / 2 || waves / 2 >= work))
+    while (waves > 1 && (waves * wave_lds > dg.max_lds / 2 || waves / 2 >= work))
       waves /= 2;
     lds = waves * wave_lds;
     grid = walk ? 1 : (work + waves - 1) / waves;
+    L.resident = dg.num_cus * (dg.max_lds / (lds ? lds : 1));
   }
-  if (grid == 0)
-    grid = 1;
+  L.waves = waves;
+  L.lds = lds;
+  L.grid = grid ? grid : 1;
+  // run-length weights of the 8 wave classes (per mille of the mean): class = (workgroup in the grid's second half) * 4 + wave / (waves / 4)
+  const bool weighted = (waves == 16 || waves == 12) && (!two_level || g_weights_two_level);
+  for (uint32_t k = 0; k < 8; k++)
+    L.weights[k] = !weighted ? 1000 : direct ? (L.grid > dg.num_cus ? g_direct_weights : g_direct_weights4)[k] : (L.grid > dg.num_cus ? g_slot_weights : g_slot_weights4)[k];
+  return L;
+}
+
+// Group boundaries that cut `total_groups` whole groups into one chain per wave of the direct launch this device would use
+// for a mergeable plan of (states, bits): chain w belongs to wave w, its length follows the wave's class weight.
+// Boundaries are multiples of 4 groups (the decode loop stores 4 groups at a time).  Returns the number of chains;
+// out[k] = first group of chain k + 1 (k < chains - 1).
+size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, uint64_t total_groups, uint32_t table_mode, uint64_t *out, size_t cap)
+{
+  PlanHeader h{};
+  h.states = states;
+  h.bits = bits;
+  h.shared_hist = 1;
+  h.n_chains = 1u << 30; // "many": the full machine
+  const LaunchShape L = launch_shape(h, dg, true, table_mode, 0, false, true);
+  const uint32_t runs_per_wave = states == 32 ? 2 : 1;
+  const uint64_t W = (uint64_t)L.grid * L.waves;
+  uint64_t chains = W * runs_per_wave;
+  const uint64_t all_units = total_groups / 4; // boundaries in units of 4 groups
+  if (chains > all_units / 8) // a chain is worth its 308 bytes of index and its prologue from about 32 groups on
+    chains = all_units / 8 ? all_units / 8 : 1;
+  if (chains <= 1)
+    return 1;
+  // dynamic tail: the last g_direct_dyn_permille of the stream in short chains of g_direct_dyn_groups groups, handed out by
+  // the ticket queues to whichever wave is done with its own chain (only when the static part fills the machine)
+  // (at most W / 2 of them: on big streams they get longer instead of more numerous, the index stays <= 1.5 chains per wave)
+  uint64_t dyn_unit = g_direct_dyn_groups / 4 ? g_direct_dyn_groups / 4 : 1;
+  const uint64_t dyn_units_total = all_units * g_direct_dyn_permille / 1000;
+  if (dyn_units_total / dyn_unit > W / 2)
+    dyn_unit = (dyn_units_total + W / 2 - 1) / (W / 2);
+  uint64_t n_dyn = chains == W * runs_per_wave ? dyn_units_total / dyn_unit : 0;
+  if (n_dyn * dyn_unit + chains * 8 > all_units)
+    n_dyn = 0;
+  const uint64_t units = all_units - n_dyn * dyn_unit; // what the static chains share
+  if (chains - 1 + n_dyn > cap)
+    return 0;
+  // cumulative weight up to chain k, then boundaries at units * cum / all
+  const uint32_t first_half = (L.grid + 1) / 2;
+  const uint32_t per_class = L.waves >= 4 ? L.waves / 4 : 1;
+  auto weight_of = [&](uint64_t chain) {
+    const uint64_t w = chain / runs_per_wave;
+    const uint32_t blk = (uint32_t)(w / L.waves), wave_in_wg = (uint32_t)(w % L.waves);
+    const uint32_t cls = (blk >= first_half ? 4 : 0) + (wave_in_wg / per_class < 4 ? wave_in_wg / per_class : 3);
+    return (uint64_t)L.weights[cls];
+  };
+  uint64_t all = 0;
+  for (uint64_t k = 0; k < chains; k++)
+    all += weight_of(k);
+  uint64_t cum = 0, prev = 0;
+  size_t n = 0;
+  for (uint64_t k = 0; k + 1 < chains; k++)
+  {
+    cum += weight_of(k);
+    uint64_t b = (uint64_t)((unsigned __int128)units * cum / all);
+    if (b <= prev)
+      b = prev + 1; // every chain gets at least one unit
+    if (b >= units)
+      break;
+    out[n++] = b * 4;
+    prev = b;
+  }
+  for (uint64_t k = 0; k < n_dyn; k++)
+    out[n++] = (units + k * dyn_unit) * 4;
+  return n + 1;
+}
+
+hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const DeviceGeom &dg, hipStream_t stream, LaunchInfo *info)
+{
+  KParams kp = kp_in;
+  const bool persistent = kp.pa.pieces != nullptr;
+  const bool index_pass = kp.ckpt_interval != 0 || kp.ckpt_groups != nullptr;
+  const LaunchShape L = launch_shape(h, dg, persistent, persistent && kp.pa.table != nullptr ? kp.pa.table_mode : 0, kp.groups != nullptr ? kp.n_groups : 0, index_pass, false);
+  const bool grouped = kp.groups != nullptr && !index_pass;
+  const uint32_t waves = L.waves, grid = L.grid;
+  kp.private_pair = L.private_pair;
 
   if (grouped)
   {
@@ -1607,31 +2024,29 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
       {
         kp.group_cum[hf][k] = (uint16_t)cum;
         const uint32_t cls = k / per_class < 4 ? k / per_class : 3;
-        const bool weighted = (waves == 16 || waves == 12) && !two_level;
-        cum += k < waves ? (weighted ? (grid > g_num_cus ? g_slot_weights : g_slot_weights4)[hf * 4 + cls] / 10 : 100) : 0;
+        cum += k < waves ? L.weights[hf * 4 + cls] / 10 : 0;
       }
     }
   }
-  if (kp.pa.pieces != nullptr)
+  if (persistent && kp.pa.interval != 0)
   {
-    // static share: a fixed fraction of the chains, split evenly; the rest goes through the queues
+    // static share: a fixed fraction of the chains, split over the waves by class weight; the rest goes through the queues
     const uint64_t W = (uint64_t)grid * waves;
     // 32-state streams: two runs per wave (run_persistent_pair)
     kp.pa.static_per_wave = (uint32_t)((uint64_t)h.n_chains * g_static_percent / 100 / (h.states == 32 ? 2 * W : W));
-    // 64-state launches: per-slot run lengths (PersistentArgs::run_len).  Weights in per mille of the mean, class =
-    // (second half of the grid) * 4 + wave / 4; uniform unless the workgroup has 16 waves.
     const uint32_t first_half = (grid + 1) / 2, second_half = grid - first_half;
     const uint32_t per_class = waves >= 4 ? waves / 4 : 1, classes = waves / per_class;
     const uint32_t runs_per_wave = h.states == 32 ? 2 : 1; // run_persistent_pair decodes two runs side by side
+    uint32_t longest = 0;
     for (uint32_t hf = 0; hf < 2; hf++)
     {
       uint32_t off = 0;
       for (uint32_t k = 0; k < 4; k++)
       {
-        const uint32_t wt = (waves == 16 || waves == 12) && (!two_level || g_weights_two_level) ? (grid > g_num_cus ? g_slot_weights : g_slot_weights4)[hf * 4 + k] : 1000;
-        kp.pa.run_len[hf * 4 + k] = k < classes ? (uint32_t)((uint64_t)h.n_chains * g_static_percent / 100 * wt / (1000 * W * runs_per_wave)) : 0;
+        kp.pa.run_len[hf * 4 + k] = k < classes ? (uint32_t)((uint64_t)h.n_chains * g_static_percent / 100 * L.weights[hf * 4 + k] / (1000 * W * runs_per_wave)) : 0;
         kp.pa.class_off[hf * 4 + k] = off;
         off += kp.pa.run_len[hf * 4 + k] * per_class * runs_per_wave;
+        longest = kp.pa.run_len[hf * 4 + k] > longest ? kp.pa.run_len[hf * 4 + k] : longest;
       }
       kp.pa.wg_chains[hf] = off;
     }
@@ -1640,20 +2055,24 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, hipStream_t 
     kp.pa.static_total = first_half * kp.pa.wg_chains[0] + second_half * kp.pa.wg_chains[1];
     if (kp.pa.static_total > h.n_chains) // weights sum to <= 8000 by construction; belt and braces
       return hipErrorInvalidValue;
+    // a merged run is read through one 32-bit window of the stream (at most one 16-bit word per symbol)
+    if ((uint64_t)(longest ? longest : 1) * kp.pa.interval * h.states * 2 >= 0xFFFF0000ull)
+      return hipErrorInvalidValue;
   }
-  KernelFn fn = kernel_for(mode, shared);
+  KernelFn fn = kernel_for(L.mode, L.shared);
   if (info)
   {
     info->grid = grid;
     info->block = waves * 64;
-    info->lds_bytes = lds;
+    info->lds_bytes = L.lds;
     info->waves_per_block = waves;
     info->chains = h.n_chains;
-    info->shared_table = shared;
-    info->walk = walk;
-    info->two_level = two_level;
+    info->shared_table = L.shared;
+    info->walk = L.walk;
+    info->two_level = L.mode == kModeTwoLevel;
+    info->table_mode = (uint32_t)L.mode;
   }
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), lds, stream, kp);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), L.lds, stream, kp);
   return hipGetLastError();
 }
 

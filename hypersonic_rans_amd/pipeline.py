@@ -4,68 +4,54 @@ The reference decodes host buffers in place (mt_rANS32x64_16w_decode.cpp:137-265
 stream and the output in (pinned) host memory the GPU version is PCIe-bound, so the three legs are pipelined over slices of
 the plan's chains: slice k's compressed bytes go up on one stream while slice k-1 decodes on another and slice k-2's decoded
 bytes come down on a third — the two DMA directions of the link run concurrently and the kernels hide behind them.
+
+The pipeline itself lives behind the C ABI (hsrans_hpipe_* in include/hsrans_hip.h, csrc/hsrans_capi.cpp: three HIP streams,
+slice plans resident on the device, events between the legs) so that any host language gets it; this module is the thin
+Python caller.
 """
 from __future__ import annotations
 
-import numpy as np
+import ctypes
+
 import torch
 
 from . import api
-from .sharded import local_range, shard_chains
 
 
 class PipelinedHostDecoder:
-    """Prepared once per (plan, slicing); `decode` can then be called repeatedly for streams that share the plan's layout
-    (in practice: the same stream).  `host_stream` and `host_out` should be pinned (torch `pin_memory()`): with pageable
-    memory the runtime stages the copies itself and the legs no longer overlap."""
+    """hsrans_hpipe: prepared once per (plan, slicing); `decode` can then be called repeatedly for streams that share the
+    plan's layout (in practice: the same stream).  `host_stream` and `host_out` should be pinned (torch `pin_memory()`,
+    or hsrans_host_register): with pageable memory the runtime stages the copies itself and the legs no longer overlap."""
 
     def __init__(self, ctx: "api.Context", plan, n_slices: int = 8, device: "torch.device | None" = None):
         self.ctx = ctx
-        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.L = api.load_library()
+        plan = api._u8(plan)
         self.total = api.plan_decoded_length(plan)
-        hdr, _, _ = api.plan_tables(plan)
-        self.stream_len = int(hdr["stream_len"])
-        runs = [(f, c) for f, c in shard_chains(plan, max(1, n_slices)) if c]
-        self.slices = []
-        for f, c in runs:
-            self.slices.append({
-                "in": [(lo, hi) for lo, hi in api.plan_stream_ranges(plan, f, c) if hi > lo],
-                "out": local_range(plan, f, c),
-                "dplan": ctx.make_device_plan(api.plan_slice(plan, f, c)),
-            })
-        self.d_stream = torch.empty(self.stream_len + (-self.stream_len) % 16, dtype=torch.uint8, device=self.device)
-        self.d_out = torch.empty(self.total, dtype=torch.uint8, device=self.device)
-        self.up = torch.cuda.Stream(device=self.device)
-        self.down = torch.cuda.Stream(device=self.device)
-        self.uploaded_bytes = sum(hi - lo for s in self.slices for lo, hi in s["in"])
+        h = ctypes.c_void_p()
+        rc = self.L.hsrans_hpipe_create(ctx.handle, api._p(plan), plan.size, n_slices, ctypes.byref(h))
+        if rc != 0:
+            raise api.HsransError(f"hsrans_hpipe_create failed with code {rc}")
+        self.handle = h
 
     def decode(self, host_stream: torch.Tensor, host_out: torch.Tensor) -> None:
-        """Asynchronous until the final synchronisation of the download stream; `host_out[:total]` holds the decoded bytes on return."""
+        """Synchronous: `host_out[:total]` holds the decoded bytes on return."""
         assert host_stream.dtype == torch.uint8 and host_out.dtype == torch.uint8 and host_out.numel() >= self.total
-        main = torch.cuda.current_stream(self.device)
-        self.up.wait_stream(main)      # previous use of d_stream / d_out is finished
-        self.down.wait_stream(main)
-        ups = []
-        with torch.cuda.stream(self.up):
-            for s in self.slices:
-                for lo, hi in s["in"]:
-                    self.d_stream[lo:hi].copy_(host_stream[lo:hi], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self.up)
-                ups.append(ev)
-        for s, ev in zip(self.slices, ups):
-            main.wait_event(ev)
-            self.ctx.decode_device(s["dplan"], self.d_stream, self.d_out, stream=main, stream_length=self.stream_len)
-            done = torch.cuda.Event()
-            done.record(main)
-            b, e = s["out"]
-            with torch.cuda.stream(self.down):
-                self.down.wait_event(done)
-                host_out[b:e].copy_(self.d_out[b:e], non_blocking=True)
-        self.down.synchronize()
-        for s in self.slices:
-            if self.ctx.status(s["dplan"]) != 0:
-                raise api.HsransError("device reported a malformed histogram / block header")
+        assert not host_stream.is_cuda and not host_out.is_cuda
+        r = self.L.hsrans_hpipe_decode(self.handle, host_stream.data_ptr(), host_stream.numel(), host_out.data_ptr(), host_out.numel())
+        if r != self.total:
+            raise api.HsransError("hsrans_hpipe_decode failed (malformed stream / plan mismatch)")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.hsrans_hpipe_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def decode_from_host_unpipelined(ctx: "api.Context", plan, host_stream: torch.Tensor, host_out: torch.Tensor, device=None) -> None:

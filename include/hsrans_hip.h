@@ -62,6 +62,8 @@ typedef struct hsrans_encode_opts
   size_t plan_size;          /* out: bytes written to plan_out                                                                */
   uint32_t flags;            /* HSRANS_ENC_INDEPENDENT_BLOCKS: mt_ only, needs block_size != 0                                 */
   uint32_t reserved;
+  const uint64_t *index_groups; /* optional explicit checkpoints: ascending absolute group indices (multiples of 4), e.g. from    */
+  size_t n_index_groups;        /* hsrans_index_boundaries; used instead of index_interval when n_index_groups != 0                */
 } hsrans_encode_opts;
 
 /* mt_: start every block from fresh states (2^15) instead of carrying the encoder's states across block boundaries as
@@ -69,6 +71,15 @@ typedef struct hsrans_encode_opts
  * valid mt_ stream (every block header stores its start states anyway) and the blocks become encodable independently —
  * this is the layout hsrans_encode_device produces, so that the two can be compared byte for byte. */
 #define HSRANS_ENC_INDEPENDENT_BLOCKS 1u
+
+/* Checkpoint positions that give the decode kernel exactly ONE chain per resident wavefront, each sized by the wave's
+ * scheduling class (what the uniform-interval launch otherwise works out per launch): the smallest sidecar that still
+ * fills the GPU — 8,192 checkpoints (2.5 MB) for any stream size on an MI355X, against one per `index_interval` groups
+ * (15 MB per 100 MB at 32).  `ctx` NULL = the MI355X defaults (256 CUs), so streams can be indexed where they are
+ * encoded.  Writes ascending group indices (multiples of 4) to groups_out and returns their count (0 = one chain is all
+ * the stream is good for, or capacity too small); pass them as hsrans_encode_opts::index_groups, to hsrans_index_build_at,
+ * or to hsrans_plan_thin.  A plan built for another geometry still decodes correctly, only less evenly. */
+size_t hsrans_index_boundaries(const struct hsrans_ctx *ctx, int states, uint32_t bits, size_t decoded_size, uint64_t *groups_out, size_t capacity);
 
 /* same as hsrans_encode, additionally emitting the sidecar decode plan; the stream bytes are unchanged by it */
 size_t hsrans_encode_ex(int container, int states, uint32_t bits, const uint8_t *in, size_t length, uint8_t *out, size_t out_capacity,
@@ -84,6 +95,8 @@ size_t hsrans_encode_ex(int container, int states, uint32_t bits, const uint8_t 
  * groups, which is what lets one stream fill the GPU.  Plans are position-independent byte blobs.
  * ---------------------------------------------------------------------------------------------------------- */
 size_t hsrans_plan_capacity(int container, int states, size_t decoded_size, uint32_t index_interval, uint32_t block_size);
+/* the same for a plan with `extra_chains` checkpoints (explicit index_groups) */
+size_t hsrans_plan_capacity_chains(int container, int states, size_t decoded_size, size_t extra_chains, uint32_t block_size);
 size_t hsrans_plan_build(int container, int states, uint32_t bits, const uint8_t *stream, size_t stream_length, size_t out_capacity,
                          uint8_t *plan_out, size_t plan_capacity);
 uint32_t hsrans_plan_chain_count(const uint8_t *plan, size_t plan_size);
@@ -93,10 +106,32 @@ uint64_t hsrans_plan_decoded_length(const uint8_t *plan, size_t plan_size);
 size_t hsrans_plan_slice(const uint8_t *plan, size_t plan_size, uint32_t first_chain, uint32_t chain_count, uint8_t *out, size_t out_capacity);
 /* output byte range [*begin, *end) covered by chains [first, first+count) */
 int hsrans_plan_chain_range(const uint8_t *plan, size_t plan_size, uint32_t first_chain, uint32_t chain_count, uint64_t *begin, uint64_t *end);
+/* Thin a raw-stream plan: keep only the chains that start at (or, when a boundary is not a chain start of `plan`, at the
+ * last chain start before) the given ascending group indices, merging everything in between — a finer plan (e.g. one
+ * checkpoint per 32 groups, good for any split over GPUs) becomes the one-chain-per-wave plan of one GPU.  Returns bytes
+ * written, 0 on error (not a mergeable raw plan, capacity). */
+size_t hsrans_plan_thin(const uint8_t *plan, size_t plan_size, const uint64_t *groups, size_t n_groups, uint8_t *out, size_t out_capacity);
 /* stream byte ranges chains [first, first+count) can read: ranges = {head_begin, head_end, body_begin, body_end}; head is the
  * shared histogram of a raw stream (empty otherwise), body the chains' own headers and words up to the next chain's first
  * word.  A rank that decodes only these chains needs only these bytes of the stream in its HBM (at their stream offsets). */
 int hsrans_plan_stream_ranges(const uint8_t *plan, size_t plan_size, uint32_t first_chain, uint32_t chain_count, uint64_t ranges[4]);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Host SIMD decoders with runtime dispatch (scalar / AVX2 / AVX-512) — the counterpart of the reference's CPU decoders and
+ * of its dispatcher block_rANS32x64_decode_wrapper (src/block_rANS32x64_16w_decode.cpp:130-152), written from the format.
+ * The GPU cannot speed up a stream that is one dependent chain (raw / block_ without an index: one wavefront, a third of a
+ * CPU core); these serve that case in the `*_decode_auto_N` drop-in entries, build indexes of foreign streams faster than
+ * one wavefront can, and are the in-run CPU comparator.  The GPU entries below never fall back to them.
+ * `level`: 0 scalar, 1 AVX2, 2 AVX-512, -1 = the best this host supports.  `threads` >= 1 (independent chains / mt_ blocks
+ * are spread over std::threads like the reference's thread pool, src/mt_rANS32x64_16w_decode.cpp:217-220).
+ * ---------------------------------------------------------------------------------------------------------- */
+int hsrans_cpu_level(void); /* 0 / 1 / 2: what hsrans_decode_cpu(level = -1) uses here */
+/* replaces rANS32x{32,64}_16w_decode_{scalar,avx2_*,avx512_*}_N, block_…_decode_N, mt_…_decode[_mt]_N on the host */
+size_t hsrans_decode_cpu(int level, uint32_t threads, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out,
+                         size_t out_capacity, const uint8_t *plan, size_t plan_size);
+/* hsrans_index_build_at without a GPU: one (per mt_ block: parallel) host decode pass that records the checkpoints */
+size_t hsrans_index_build_host(int level, uint32_t threads, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length,
+                               const uint64_t *groups, size_t n_groups, uint8_t *plan_out, size_t plan_capacity);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GPU side
@@ -121,12 +156,25 @@ const char *hsrans_ctx_device_name(const hsrans_ctx *ctx);
 size_t hsrans_decode_host(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out,
                           size_t out_capacity, const uint8_t *plan, size_t plan_size);
 
-/* Device-resident entry: everything asynchronous on `hip_stream` (a hipStream_t; NULL = default stream), graph-capturable
- * (no allocation, no synchronisation).  `d_stream` must be 16-byte aligned, `d_out` 4-byte aligned. */
+/* Device-resident entry: everything asynchronous on `hip_stream` (a hipStream_t of the context's device; NULL = default
+ * stream), graph-capturable (no allocation, no synchronisation).  `d_stream` must be 16-byte aligned, `d_out` 4-byte aligned.
+ * Overlapping launches of ONE device plan (several streams, double-buffered outputs) are fine: plans with one chain per
+ * wave (hsrans_index_boundaries) and block_/mt_ plans keep no per-launch state on the device; uniform-interval raw plans
+ * draw work from atomic queues and own 32 sets of queue heads, used round robin, so up to 32 of their launches may be in
+ * flight at once — a captured graph node keeps the set it was captured with, so replays of one captured graph must not
+ * overlap each other (HIP does not allow a hipGraphExec to run concurrently with itself anyway).  The status word of a
+ * plan is shared by all its launches (error bits are only ever OR-ed in; hsrans_dplan_status clears them). */
 int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, hsrans_dplan **out_dplan);
 void hsrans_dplan_destroy(hsrans_dplan *dplan);
 int hsrans_decode_device(hsrans_ctx *ctx, hsrans_dplan *dplan, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity,
                          void *hip_stream);
+/* The same launch for a caller that holds only a WINDOW of the stream in device memory — the bytes
+ * [window_offset, window_offset + window_length) at d_window — e.g. one GPU's share of a stream sharded with
+ * hsrans_plan_slice: the window must cover the body range hsrans_plan_stream_ranges reports for the plan's chains
+ * (window_offset a multiple of 16, at or below body_begin); a raw stream's shared histogram need not be in it when the plan
+ * carries its copy.  Requests outside the window are dropped by the kernel's bounds check, never issued. */
+int hsrans_decode_device_window(hsrans_ctx *ctx, hsrans_dplan *dplan, const void *d_window, size_t window_offset, size_t window_length, void *d_out,
+                                size_t out_capacity, void *hip_stream);
 /* Plan an mt_ stream that only exists in device memory: the header chain (src/mt_rANS32x64_16w_decode.cpp:166-227) is
  * followed by a device kernel; synchronises `hip_stream` twice (chain count, then the finished plan). HSRANS_MT only. */
 int hsrans_dplan_create_from_device_stream(hsrans_ctx *ctx, int container, int states, uint32_t bits, const void *d_stream, size_t stream_length,
@@ -157,15 +205,40 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
 size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length,
                           uint32_t index_interval, uint8_t *plan_out, size_t plan_capacity);
 
+/* as hsrans_index_build, with checkpoints at the given ascending group indices (raw streams; hsrans_index_boundaries) */
+size_t hsrans_index_build_at(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length,
+                             const uint64_t *groups, size_t n_groups, uint8_t *plan_out, size_t plan_capacity);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Host buffers, PCIe legs overlapped (BASELINE config 5 shape; the GPU counterpart of the reference's thread-pool fan-out,
+ * src/mt_rANS32x64_16w_decode.cpp:137-265): the plan's chains are cut into `n_slices` runs; slice k's compressed bytes go
+ * up on one HIP stream while slice k-1 decodes on a second and slice k-2's output comes down on a third.  The slice
+ * plans live on the device for the lifetime of the pipeline object.  Host buffers should be page-locked
+ * (hipHostMalloc / hipHostRegister / hsrans_host_register) — with pageable memory the runtime stages every copy and the
+ * legs serialise.  hsrans_decode_host_pipelined is the one-call form: it keeps the pipeline of the plan it saw last
+ * inside the context (keyed by the plan's address, size and checksum).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct hsrans_hpipe hsrans_hpipe;
+int hsrans_hpipe_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, uint32_t n_slices, hsrans_hpipe **out_pipe);
+size_t hsrans_hpipe_decode(hsrans_hpipe *pipe, const uint8_t *in, size_t in_length, uint8_t *out, size_t out_capacity);
+void hsrans_hpipe_destroy(hsrans_hpipe *pipe);
+size_t hsrans_decode_host_pipelined(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out,
+                                    size_t out_capacity, const uint8_t *plan, size_t plan_size, uint32_t n_slices);
+/* page-lock / release a caller-owned host buffer (hipHostRegister on the context's device); 0 on success */
+int hsrans_host_register(hsrans_ctx *ctx, void *ptr, size_t bytes);
+int hsrans_host_unregister(hsrans_ctx *ctx, void *ptr);
+
 /* kernel launch geometry of the last hsrans_decode_device call on this plan (for benchmarks / DESIGN.md tables) */
 typedef struct hsrans_launch_info
 {
   uint32_t grid, block, lds_bytes, waves_per_block, chains, shared_table, walk, two_level;
+  uint32_t table_mode; /* decode-table layout: 0/1 packed u32, 2 two-level, 3 8-byte per slot, 4 coarse + fine, 5 8-byte in global memory */
 } hsrans_launch_info;
 int hsrans_dplan_launch_info(const hsrans_dplan *dplan, hsrans_launch_info *info);
 
-/* diagnostics: with HSRANS_DEBUG_STAMPS=1 in the environment every wavefront of a persistent launch records four
- * s_memtime stamps {entry, table built, stream ready, done}; copies up to capacity_u64 values to `out`, returns the count */
+/* diagnostics: with HSRANS_DEBUG_STAMPS=1 in the environment every wavefront of a persistent / direct launch records
+ * s_memtime stamps {entry, table built, stream ready, done, static share done} in 8 slots; copies up to capacity_u64 values to
+ * `out`, returns the count */
 size_t hsrans_debug_read_stamps(hsrans_dplan *dplan, uint64_t *out, size_t capacity_u64);
 
 const char *hsrans_version(void);

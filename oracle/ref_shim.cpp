@@ -10,6 +10,7 @@
 // Reference entry points wrapped (file:line in /root/reference/src):
 //   rANS32x{32,64}_16w_{capacity,encode_scalar_N,decode_scalar_N}       rANS32x64_16w.h:6-177, rANS32x32_16w.h
 //   rANS32x{32,64}_xmmShfl2_16w_decode_avx2_var{A,C}_N                  (candidateForFastest, main.cpp:202-236)
+//   rANS32x{32,64}_ymmShfl2_16w_decode_avx512_var{A,C}_N                (the AVX-512 family)
 //   block_rANS32x{32,64}_16w_{capacity,encode_N,decode_N}               block_rANS32x64_16w.h:6-20
 //   mt_rANS32x{32,64}_16w_{capacity,encode_N,decode_N,decode_mt_N}      mt_rANS32x64_16w.h:7-28
 //   make_hist                                                           hist.h:68
@@ -38,6 +39,12 @@ static const codec_fn raw_dec_avx2[2][6] = {
     rANS32x32_xmmShfl2_16w_decode_avx2_varA_13, rANS32x32_xmmShfl2_16w_decode_avx2_varA_14, rANS32x32_xmmShfl2_16w_decode_avx2_varA_15 },
   { rANS32x64_xmmShfl2_16w_decode_avx2_varC_10, rANS32x64_xmmShfl2_16w_decode_avx2_varC_11, rANS32x64_xmmShfl2_16w_decode_avx2_varC_12,
     rANS32x64_xmmShfl2_16w_decode_avx2_varA_13, rANS32x64_xmmShfl2_16w_decode_avx2_varA_14, rANS32x64_xmmShfl2_16w_decode_avx2_varA_15 } };
+// fastest AVX-512 entries per main.cpp's registry (:209-214, the `true` flags): ymmShfl2 varC for bits <= 12, ymmShfl2 varA for
+// bits >= 13 (rANS32x64_16w.cpp:2108,3666); the 32-state codec has AVX-512 decoders for bits <= 12 only
+static const codec_fn raw_dec_avx512[2][6] = {
+  { rANS32x32_ymmShfl2_16w_decode_avx512_varC_10, rANS32x32_ymmShfl2_16w_decode_avx512_varC_11, rANS32x32_ymmShfl2_16w_decode_avx512_varC_12, nullptr, nullptr, nullptr },
+  { rANS32x64_ymmShfl2_16w_decode_avx512_varC_10, rANS32x64_ymmShfl2_16w_decode_avx512_varC_11, rANS32x64_ymmShfl2_16w_decode_avx512_varC_12,
+    rANS32x64_ymmShfl2_16w_decode_avx512_varA_13, rANS32x64_ymmShfl2_16w_decode_avx512_varA_14, rANS32x64_ymmShfl2_16w_decode_avx512_varA_15 } };
 static const codec_fn blk_enc[2][6] = { PER_BITS(block_rANS32x32_16w_encode_), PER_BITS(block_rANS32x64_16w_encode_) };
 static const codec_fn blk_dec[2][6] = { PER_BITS(block_rANS32x32_16w_decode_), PER_BITS(block_rANS32x64_16w_decode_) };
 static const codec_fn mt_enc[2][6] = { PER_BITS(mt_rANS32x32_16w_encode_), PER_BITS(mt_rANS32x64_16w_encode_) };
@@ -99,14 +106,18 @@ extern "C"
     return (container == 1 ? blk_enc : mt_enc)[si][bi](in, n, out, cap);
   }
 
-  // variant: 0 scalar (raw) / runtime-dispatched (block_, mt_ single thread); 1 fastest AVX2 (raw only); 2 mt_ on a thread pool
+  // variant: 0 scalar (raw) / runtime-dispatched (block_, mt_ single thread); 1 fastest AVX2 (raw only); 2 mt_ on a thread pool;
+  // 3 fastest AVX-512 (raw only; the caller checks hsref_has_avx512 first)
   size_t hsref_decode(int container, int states, int bits, int variant, const uint8_t *in, size_t in_len, uint8_t *out, size_t cap, int threads)
   {
     int si, bi;
     if (!sel(states, bits, &si, &bi))
       return 0;
     if (container == 0)
-      return (variant == 1 ? raw_dec_avx2 : raw_dec_scalar)[si][bi](in, in_len, out, cap);
+    {
+      const codec_fn f = variant == 3 ? raw_dec_avx512[si][bi] : (variant == 1 ? raw_dec_avx2 : raw_dec_scalar)[si][bi];
+      return f ? f(in, in_len, out, cap) : 0;
+    }
     if (container == 1)
       return blk_dec[si][bi](in, in_len, out, cap);
     if (variant == 2)
@@ -121,4 +132,9 @@ extern "C"
   size_t hsref_pool_threads(void) { return g_pool ? thread_pool_thread_count(g_pool) : 0; }
 
   int hsref_has_avx2(void) { return __builtin_cpu_supports("avx2") ? 1 : 0; }
+
+  int hsref_has_avx512(void)
+  {
+    return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl") ? 1 : 0;
+  }
 }

@@ -123,7 +123,11 @@ class Ref:
         L.hsref_decode.argtypes = [_i, _i, _i, _i, _vp, _sz, _vp, _sz, _i]
         L.hsref_pool_threads.restype = _sz
         L.hsref_has_avx2.restype = _i
+        L.hsref_has_avx512.restype = _i
         self.L = L
+
+    def has_avx512(self) -> bool:
+        return bool(self.L.hsref_has_avx512())
 
     def capacity(self, container, states, n):
         return self.L.hsref_capacity(container, states, n)
@@ -146,7 +150,7 @@ class Ref:
         return out[:m].copy()
 
     def decode(self, container, states, bits, stream: np.ndarray, out_cap: int, variant: int = 0, threads: int = 0, pad: int = 64):
-        """variant 0: scalar (raw) / runtime dispatch (block_, mt_); 1: fastest AVX2 raw; 2: mt_ thread pool."""
+        """variant 0: scalar (raw) / runtime dispatch (block_, mt_); 1: fastest AVX2 raw; 2: mt_ thread pool; 3: fastest AVX-512 raw."""
         buf = np.zeros(stream.size + pad, np.uint8)  # SIMD variants over-read up to 32 B (SURVEY §8 quirks)
         buf[:stream.size] = stream
         out = np.full(max(out_cap, 1) + 64, 0xCC, np.uint8)

@@ -1,0 +1,125 @@
+"""BASELINE.json configs 2-5 at their stated shape, on one GPU (the N>1 legs of configs 4/5 are `bench.py --workload sharded`
+under the driver's multi-GPU run; their host logic runs under gloo in tests/test_sharded_gloo.py).
+
+Full-size checks compare SHA-256 of the GPU output with the scalar CPU oracle's output for the same stream (not with the input:
+the oracle is the contract), plus the size-independent property decode(encode(x)) == x."""
+import hashlib
+import time
+
+import numpy as np
+import pytest
+
+import hypersonic_rans_amd as H
+from hypersonic_rans_amd import synth
+from oracle_lib import BLOCK, MT, RAW
+
+pytestmark = pytest.mark.gpu
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _tiled(n, seed=20241008):
+    tile = 1 << 24
+    base = synth.enwik8_shaped(min(tile, n), seed=seed)
+    out = np.empty(n, np.uint8)
+    for k, s in enumerate(range(0, n, tile)):
+        c = min(tile, n - s)
+        out[s:s + c] = (base if k % 7 == 0 else synth._permutation(1000 + k % 7)[base])[:c]
+    return out
+
+
+@pytest.fixture(scope="module")
+def data100():
+    return synth.enwik8_shaped(100_000_000, seed=20241008)
+
+
+def _device_decode(ctx, stream, plan, n):
+    import torch
+    d_in = torch.from_numpy(np.concatenate([stream, np.zeros((-stream.size) % 16, np.uint8)])).cuda()
+    d_out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    dplan = ctx.make_device_plan(plan)
+    ctx.decode_device(dplan, d_in, d_out, stream_length=stream.size)
+    torch.cuda.synchronize()
+    assert ctx.status(dplan) == 0
+    return d_out.cpu().numpy(), dplan.launch_info()
+
+
+@pytest.mark.parametrize("states,bits,index", ((64, 11, "wave"), (64, 11, 32), (32, 11, "wave"), (32, 10, 32), (64, 10, "wave"), (64, 13, "wave"), (32, 13, 32),
+                                               (64, 12, "wave"), (64, 14, "wave"), (64, 15, "wave"), (32, 15, "wave")))
+def test_config2_and_3_raw_100mb_against_the_oracle(gpu_ctx, oracle, data100, states, bits, index):
+    """BASELINE configs 2/3: raw, 100 MB, 10..15 bits, both state counts, both index kinds; SHA-256 against the scalar oracle."""
+    n = data100.size
+    if index == "wave":
+        stream, plan = H.encode(RAW, states, bits, data100, index_groups=H.index_boundaries(states, bits, n, gpu_ctx))
+    else:
+        stream, plan = H.encode(RAW, states, bits, data100, index_interval=index)
+    r, want = oracle.decode(RAW, states, bits, stream, n)
+    assert r == n
+    got, info = _device_decode(gpu_ctx, stream, plan, n)
+    assert _sha(got) == _sha(want) == _sha(data100), (states, bits, index, info)
+    assert info["shared_table"] == 1 and info["grid"] >= 256
+
+
+@pytest.mark.parametrize("container,states,bits,block,interval", ((MT, 64, 11, 0, 0), (MT, 64, 11, 1 << 18, 256), (BLOCK, 64, 11, 0, 32), (BLOCK, 32, 12, 1 << 16, 64),
+                                                                  (MT, 32, 13, 0, 0)))
+def test_containers_100mb_against_the_oracle(gpu_ctx, oracle, data100, container, states, bits, block, interval):
+    n = data100.size
+    if interval:
+        stream, plan = H.encode(container, states, bits, data100, block_size=block, index_interval=interval)
+    else:
+        stream = H.encode(container, states, bits, data100, block_size=block) if block else H.encode(container, states, bits, data100)
+        plan = H.plan_build(container, states, bits, stream)
+    r, want = oracle.decode(container, states, bits, stream, n)
+    assert r == n
+    got, info = _device_decode(gpu_ctx, stream, plan, n)
+    assert _sha(got) == _sha(want), (container, states, bits, block, interval, info)
+
+
+def test_config4_block_1gib_in_256k_blocks_on_one_gpu(gpu_ctx, oracle):
+    """BASELINE config 4 at its stated size: block_rANS32x64 16w 11-bit, 2^30 B in 256 KiB blocks + an index every 32 groups
+    (what makes a block_ stream chunk-parallel), decoded by one launch; SHA-256 against the scalar oracle."""
+    n = 1 << 30
+    data = _tiled(n)
+    stream, plan = H.encode(BLOCK, 64, 11, data, block_size=1 << 18, index_interval=32)
+    assert H.plan_chain_count(plan) >= 4096 * 127
+    r, want = oracle.decode(BLOCK, 64, 11, stream, n)
+    assert r == n
+    want_sha = _sha(want)
+    assert want_sha == _sha(data)
+    del want
+    got, info = _device_decode(gpu_ctx, stream, plan, n)
+    assert _sha(got) == want_sha, info
+
+
+def test_config5_eight_gib_of_mt_streams_through_the_pipelined_host_path(gpu_ctx):
+    """BASELINE config 5 shape on one GPU: 8 x 2^30 B mt_ streams in pinned host memory, upload / decode / download overlapped
+    over slices of the plan (hsrans_hpipe through the C ABI); every stream's output compared with its source.  The streams are
+    written by the GPU encoder (8 GiB through the scalar host encoder would take minutes) — its streams are checked against the
+    oracle and the real reference elsewhere (test_gpu_parity.py, test_oracle_vs_ref.py)."""
+    import torch
+    from hypersonic_rans_amd import pipeline
+    n = 1 << 30
+    base = _tiled(n)
+    host_out = torch.empty(n, dtype=torch.uint8).pin_memory()
+    d_in = torch.empty(n, dtype=torch.uint8, device="cuda")
+    d_enc = torch.empty(H.capacity(MT, 64, n), dtype=torch.uint8, device="cuda")
+    total_s = 0.0
+    for k in range(8):
+        data = base if k == 0 else synth._permutation(2000 + k)[base]
+        d_in.copy_(torch.from_numpy(data))
+        m, dplan = gpu_ctx.encode_device(MT, 64, 11, d_in, d_enc, block_size=1 << 18, index_interval=256, want_plan=True)
+        plan = gpu_ctx.read_device_plan(dplan, capacity=64 << 20)
+        host_stream = torch.empty(m, dtype=torch.uint8).pin_memory()
+        host_stream.copy_(d_enc[:m])
+        torch.cuda.synchronize()
+        dec = pipeline.PipelinedHostDecoder(gpu_ctx, plan, n_slices=8)
+        host_out.fill_(0xCC)
+        t0 = time.perf_counter()
+        dec.decode(host_stream, host_out)
+        total_s += time.perf_counter() - t0
+        assert np.array_equal(host_out.numpy(), data), k
+        dec.close()
+        del dec, dplan, host_stream
+    print(f"\n8 x 2^30 B, pipelined host decode: {8 * n / total_s / 1e9:.1f} GB/s decoded (PCIe-inclusive)")

@@ -156,7 +156,9 @@ def test_full_size_100mb_round_trip(gpu_ctx, bits):
 
 
 def test_slice_upload_is_enough_for_a_slice(gpu_ctx, zipf, nonstat):
-    """A rank that holds only hsrans_plan_stream_ranges of the stream (junk elsewhere) decodes its chains correctly."""
+    """A rank that holds only its WINDOW of the stream (hsrans_plan_stream_ranges body, a buffer as long as the window, not as
+    the stream) decodes its chains correctly through hsrans_decode_device_window; a raw stream's shared histogram is not in
+    the window at all (the plan carries its copy)."""
     import torch
     from hypersonic_rans_amd import sharded
     for container, src in ((H.RAW, zipf), (H.MT, nonstat[:1_500_000]), (H.BLOCK, nonstat[:1_500_000])):
@@ -164,15 +166,18 @@ def test_slice_upload_is_enough_for_a_slice(gpu_ctx, zipf, nonstat):
         stream, plan = H.encode(container, 64, 11, d, index_interval=32, block_size=0 if container == H.RAW else 65536)
         runs = sharded.shard_chains(plan, 3)
         out = torch.zeros(d.size, dtype=torch.uint8, device="cuda")
+        uploaded = 0
         for first, count in runs:
-            d_stream = sharded.upload_slice(stream, plan, first, count, torch.device("cuda"))
-            junk = torch.full_like(d_stream, 0xEE)
-            for lo, hi in H.plan_stream_ranges(plan, first, count):
-                junk[lo:hi] = d_stream[lo:hi]
+            (hb, he), (bb, be) = H.plan_stream_ranges(plan, first, count)
+            lo = bb & ~15
+            window = torch.full((be - lo + 16,), 0xEE, dtype=torch.uint8, device="cuda")
+            window[bb - lo: be - lo] = torch.from_numpy(stream[bb:be]).cuda()
+            uploaded += be - bb
             dplan = gpu_ctx.make_device_plan(H.plan_slice(plan, first, count))
-            gpu_ctx.decode_device(dplan, junk, out, stream_length=stream.size)
+            gpu_ctx.decode_device_window(dplan, window, lo, be - lo, out)
             assert gpu_ctx.status(dplan) == 0
         assert torch.equal(out.cpu(), torch.from_numpy(d)), container
+        assert uploaded < 1.1 * stream.size
 
 
 def test_pipelined_host_decode(gpu_ctx, nonstat, zipf):
@@ -197,8 +202,9 @@ def test_pipelined_host_decode(gpu_ctx, nonstat, zipf):
         assert np.array_equal(host_out.numpy(), d)
 
 
-def test_sharded_decode_single_rank(gpu_ctx, zipf):
-    """decode_sharded with a world of one rank (the N>1 host logic runs on CPU under gloo in tests/test_sharded_gloo.py)."""
+def test_sharded_decode_single_rank_over_rccl(gpu_ctx, zipf):
+    """decode_sharded on the `nccl` backend (= RCCL) with a world of one rank: the communicator is created on the GPU and the
+    status all-reduce runs through RCCL (the N>1 exchange logic runs on CPU under gloo in tests/test_sharded_gloo.py)."""
     import os
 
     import torch
@@ -208,16 +214,25 @@ def test_sharded_decode_single_rank(gpu_ctx, zipf):
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("gloo", rank=0, world_size=1)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
+        seen = torch.ones(1, dtype=torch.int32, device="cuda")
+        dist.all_reduce(seen)  # RCCL executes
+        assert int(seen.item()) == 1 and dist.get_backend() == "nccl"
         for container in (H.RAW, H.MT):
             s, plan = H.encode(container, 64, 11, zipf, index_interval=32)
             pad = (-s.size) % 16
             d_in = torch.from_numpy(np.concatenate([s, np.zeros(pad, np.uint8)])).cuda()
             out = sharded.decode_sharded(gpu_ctx, d_in, s.size, plan, gather=True)
             assert np.array_equal(out.cpu().numpy(), zipf)
-            out = sharded.decode_sharded_from_host(gpu_ctx, s, plan, gather=True)  # stream in host memory, slice upload on a side stream
+            out = sharded.decode_sharded_from_host(gpu_ctx, s, plan, gather=True)  # stream in host memory, window upload on a side stream
             assert np.array_equal(out.cpu().numpy(), zipf)
+            dec = sharded.ShardedDecoder(gpu_ctx, plan)
+            out = torch.zeros(zipf.size, dtype=torch.uint8, device="cuda")
+            for _ in range(3):  # prepared once, decoded repeatedly
+                dec.decode(d_in, out)
+            assert dec.global_status() == 0 and np.array_equal(out.cpu().numpy(), zipf)
     finally:
         dist.destroy_process_group()
 

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, container, q):
+def _worker(rank, world, port, container, root, q):
     from oracle_lib import Oracle
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -42,19 +42,24 @@ def _worker(rank, world, port, container, q):
             assert r == data.size
             b, e = ranges[rank]
             local[b:e] = torch.from_numpy(part[b:e].copy())
-        full = sharded.gather_ranges(local, ranges)
-        q.put((rank, bool(np.array_equal(full.numpy(), data)), ranges, upload, stream.size))
+        full = sharded.gather_ranges(local, ranges, root=root)  # in place: point-to-point straight into `local`
+        assert full.data_ptr() == local.data_ptr()
+        complete = bool(np.array_equal(full.numpy(), data))
+        if root is not None and rank != root:  # a root gather leaves the other ranks with their own range only
+            b, e = ranges[rank]
+            complete = bool(np.array_equal(full.numpy()[b:e], data[b:e])) and not bool(np.array_equal(full.numpy(), data))
+        q.put((rank, complete, ranges, upload, stream.size))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("container", (H.RAW, H.MT))
-def test_two_ranks_gather(container):
+@pytest.mark.parametrize("container,root", ((H.RAW, None), (H.MT, None), (H.MT, 0)))
+def test_two_ranks_gather(container, root):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, container, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, container, root, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(world)]

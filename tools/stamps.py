@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Diagnostic: where a persistent decode launch spends its time per wavefront (run with HSRANS_DEBUG_STAMPS=1 on the GPU box)."""
+"""Diagnostic: where a persistent / direct decode launch spends its time per wavefront (sets HSRANS_DEBUG_STAMPS=1).
+
+    python tools/stamps.py [--size N] [--bits B] [--index wave|G]
+"""
+import argparse
 import ctypes
 import os
 import sys
@@ -12,41 +16,53 @@ import torch
 import hypersonic_rans_amd as H
 from hypersonic_rans_amd import synth
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=100_000_000)
+ap.add_argument("--bits", type=int, default=11)
+ap.add_argument("--index", default="32")
+ap.add_argument("--states", type=int, default=64)
+a = ap.parse_args()
+n = a.size
 data = synth.enwik8_shaped(n)
-s, plan = H.encode(H.RAW, 64, 11, data, index_interval=32)
 ctx = H.Context(0)
+if a.index == "wave":
+    s, plan = H.encode(H.RAW, a.states, a.bits, data, index_groups=H.index_boundaries(a.states, a.bits, n, ctx))
+else:
+    s, plan = H.encode(H.RAW, a.states, a.bits, data, index_interval=int(a.index))
 d_in = torch.from_numpy(np.concatenate([s, np.zeros((-s.size) % 16, np.uint8)])).cuda()
 d_out = torch.zeros(n, dtype=torch.uint8, device="cuda")
 dp = ctx.make_device_plan(plan)
 for _ in range(5):
     ctx.decode_device(dp, d_in, d_out, stream_length=s.size)
 torch.cuda.synchronize()
+info = dp.launch_info()
+waves = info["waves_per_block"]
 L = H.load_library()
 L.hsrans_debug_read_stamps.restype = ctypes.c_size_t
 L.hsrans_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
-buf = np.zeros(8192 * 4, np.uint64)
+buf = np.zeros(16384 * 8, np.uint64)
 got = L.hsrans_debug_read_stamps(dp.handle, buf.ctypes.data, buf.size)
-st = buf.reshape(-1, 4).astype(np.int64)
-st = st[st[:, 3] > 0]
+allst = buf.reshape(-1, 8).astype(np.int64)
+valid = allst[:, 3] > 0
+st = allst[valid]
 t0 = st[:, 0].min()
 rel = (st - t0) / 100.0  # s_memtime ticks at 100 MHz -> us
-print("waves", len(st))
-for name, col in (("entry", 0), ("table built", 1), ("stream ready", 2), ("done", 3)):
+print(f"index {a.index}  bits {a.bits}  chains {H.plan_chain_count(plan)}  waves {len(st)}  launch {info}")
+for name, col in (("entry", 0), ("table built", 1), ("stream ready", 2), ("static done", 4), ("done", 3)):
     v = rel[:, col]
-    print(f"{name:13s} min {v.min():8.2f}  p50 {np.median(v):8.2f}  p99 {np.percentile(v, 99):8.2f}  max {v.max():8.2f} us")
-d = rel[:, 3] - rel[:, 2]
-print(f"decode span   min {d.min():8.2f}  p50 {np.median(d):8.2f}  max {d.max():8.2f} us")
+    print(f"{name:13s} min {v.min():8.2f}  p10 {np.percentile(v, 10):8.2f}  p50 {np.median(v):8.2f}  p90 {np.percentile(v, 90):8.2f}  p99 {np.percentile(v, 99):8.2f}  max {v.max():8.2f} us")
+d = rel[:, 4] - rel[:, 2]
+print(f"static span   min {d.min():8.2f}  p50 {np.median(d):8.2f}  max {d.max():8.2f} us")
 
 # who finishes late?  group by wave slot inside the workgroup and by workgroup half
-w = np.arange(len(buf) // 4)
-valid = buf.reshape(-1, 4)[:, 3] > 0
-done = (buf.reshape(-1, 4)[:, 3].astype(np.int64) - t0) / 100.0
-wave_in_wg = w % 16
-blk = w // 16
-print("done by wave-in-workgroup:", " ".join(f"{done[valid & (wave_in_wg == k)].mean():.1f}" for k in range(16)))
-print("done by SIMD slot (wave%4):", " ".join(f"{done[valid & (wave_in_wg % 4 == k)].mean():.1f}" for k in range(4)))
-print("done by wave//4:", " ".join(f"{done[valid & (wave_in_wg // 4 == k)].mean():.1f}" for k in range(4)))
-nb = blk.max() + 1
-print("done by workgroup half:", f"{done[valid & (blk < nb // 2)].mean():.1f} {done[valid & (blk >= nb // 2)].mean():.1f}")
+w = np.arange(len(allst))
+static_done = (allst[:, 4] - t0) / 100.0
+done = (allst[:, 3] - t0) / 100.0
+wave_in_wg = w % waves
+blk = w // waves
+pc = max(1, waves // 4)
+nb = blk[valid].max() + 1
+for label, arr in (("static done", static_done), ("done", done)):
+    print(f"{label} by wave//{pc} (age class), first half of the grid:", " ".join(f"{arr[valid & (wave_in_wg // pc == k) & (blk < (nb + 1) // 2)].mean():.1f}" for k in range(4)),
+          "| second half:", " ".join(f"{arr[valid & (wave_in_wg // pc == k) & (blk >= (nb + 1) // 2)].mean():.1f}" for k in range(4)) if nb > 1 else "")
 print("done by workgroup % 8 (XCD):", " ".join(f"{done[valid & (blk % 8 == k)].mean():.1f}" for k in range(8)))
