@@ -34,7 +34,7 @@ class EncodeOpts(ctypes.Structure):
 
 
 class LaunchInfo(ctypes.Structure):
-    _fields_ = [(n, _u32) for n in ("grid", "block", "lds_bytes", "waves_per_block", "chains", "shared_table", "walk", "two_level", "table_mode")]
+    _fields_ = [(n, _u32) for n in ("grid", "block", "lds_bytes", "waves_per_block", "chains", "shared_table", "walk", "two_level", "table_mode", "chains_per_wave")]
 
 
 def lib_path() -> str:

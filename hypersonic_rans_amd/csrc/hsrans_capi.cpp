@@ -315,8 +315,9 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
     {
       const uint16_t *counts = (const uint16_t *)(plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
       std::vector<uint2> tab;
-      uint32_t mode = 0;
-      if (h.bits <= pack64_max_bits() || table_spill())
+      const TableChoice tc = choose_table(h.bits, h.states, h.interval == 0);
+      uint32_t mode = tc.mode;
+      if (mode == 3 || mode == 5)
       {
         // decode table for the shared-table kernel (MODE 3): {freq | sym << 24, slot - cumul} per slot, the same
         // entries build_table<kModePack64> produces (hist.cpp:291-306 / :308-324 for the sum check)
@@ -331,16 +332,15 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
         }
         if (cum != total)
           return HSRANS_E_FORMAT;
-        mode = table_spill() ? 5 : 3;
       }
-      else if (h.bits >= 13 && h.states == 64 && getenv("HSRANS_NO_COARSE_TABLE") == nullptr)
+      else if (mode == 4)
       {
         // wider histograms: the coarse + fine table pair (kModeCoarse), 36 / 40 / 48 KiB instead of 64 / 128 / 256 KiB
         tab.resize(coarse_table_entries(h.bits));
         if (build_coarse_table(counts, h.bits, tab.data(), tab.size()) == 0)
           return HSRANS_E_FORMAT;
-        mode = 4;
       }
+      d->pa.dual = tc.dual ? 1 : 0;
       if (mode != 0)
       {
         if (!grow(&d->d_table, &d->d_table_cap, tab.size() * sizeof(uint2)) ||
@@ -733,6 +733,7 @@ int hsrans_dplan_launch_info(const hsrans_dplan *d, hsrans_launch_info *info)
   info->walk = d->info.walk;
   info->two_level = d->info.two_level;
   info->table_mode = d->info.table_mode;
+  info->chains_per_wave = d->info.chains_per_wave;
   return HSRANS_OK;
 }
 
@@ -899,6 +900,24 @@ static size_t index_build_impl(hsrans_ctx *ctx, int container, int states, uint3
   const bool walk = (h.flags & kPlanWalk) != 0;
   if (!walk && h.n_pieces != h.n_chains) // the planner only produces single-piece chains for raw and mt_
     return 0;
+  // A raw stream is one dependent chain: one wavefront records its checkpoints at ~0.65 GB/s, one host core with this
+  // library's SIMD decoder at 2-3 GB/s and without the upload — so raw streams are indexed on the host (same plan, byte for
+  // byte; HSRANS_INDEX_ON_GPU=1 keeps the wavefront pass).  mt_ blocks (one wavefront each, in parallel) and block_ streams
+  // (the walk that also reports the inline headers) stay on the GPU.
+  if (container == HSRANS_RAW && getenv("HSRANS_INDEX_ON_GPU") == nullptr)
+  {
+    std::vector<uint64_t> own;
+    if (groups == nullptr)
+    {
+      const uint64_t T = h.n_pieces == 1 ? pc0[0].steps : 0;
+      for (uint64_t g = index_interval; g < T; g += index_interval)
+        own.push_back(g);
+      if (own.empty())
+        return plan_capacity >= base_size ? (memcpy(plan_out, base.data(), base_size), base_size) : 0;
+    }
+    return cpu::index_build(cpu::best_level(), 1, container, states, bits, in, in_length, groups ? groups : own.data(), groups ? n_groups : own.size(), plan_out,
+                            plan_capacity, groups ? 0 : index_interval);
+  }
   const uint64_t n_ck = groups ? n_groups : out_len / S / index_interval + 2;
   // block_: room for blocks of >= 4 KiB on average (the reference's smallest block is 32 KiB, block_rANS32x64_16w_encode.cpp:21-39)
   const uint64_t max_blocks = walk ? out_len / 4096 + 16 : 0;
@@ -1340,9 +1359,7 @@ size_t hsrans_index_boundaries(const hsrans_ctx *ctx, int states, uint32_t bits,
   const DeviceGeom dg = ctx ? ctx->geom : default_geom();
   const uint64_t S = (uint64_t)states;
   const uint64_t T = decoded_size + 1 >= S ? (decoded_size - S + 1 + S - 1) / S : 0; // whole groups (rANS32x64_16w.cpp:223)
-  // the table layout the launch will pick for a plan that carries its histogram (hsrans_dplan_create)
-  const uint32_t table_mode = bits <= pack64_max_bits() ? 3 : (states == 64 && getenv("HSRANS_NO_COARSE_TABLE") == nullptr ? 4 : 0);
-  const size_t chains = direct_boundaries(dg, (uint32_t)states, bits, T, table_mode, groups_out, capacity);
+  const size_t chains = direct_boundaries(dg, (uint32_t)states, bits, T, groups_out, capacity);
   return chains > 1 ? chains - 1 : 0;
 }
 

@@ -487,7 +487,7 @@ size_t decode(int level, uint32_t threads, int container, int states, uint32_t b
 // Index of an existing raw / mt_ stream with checkpoints at the given groups: one sequential host decode that records
 // {states, cursor} there — what hsrans_index_build_at does with one wavefront on the GPU
 size_t index_build(int level, uint32_t threads, int container, int states, uint32_t bits, const uint8_t *in, size_t in_len, const uint64_t *groups, size_t n_groups,
-                   uint8_t *plan_out, size_t plan_cap)
+                   uint8_t *plan_out, size_t plan_cap, uint32_t uniform_interval)
 {
   if (in == nullptr || plan_out == nullptr || in_len < 16 || !valid_codec(container, states, bits) || container == HSRANS_BLOCK || groups == nullptr || n_groups == 0)
     return 0;
@@ -519,7 +519,7 @@ size_t index_build(int level, uint32_t threads, int container, int states, uint3
   const uint32_t *st0 = (const uint32_t *)(base.data() + plan_states_off(h.n_chains, h.n_pieces));
   PlanBuilder pb;
   pb.begin(container, states, bits, out_len, in_len);
-  pb.hdr.interval = 0;
+  pb.hdr.interval = uniform_interval; // != 0: the caller's groups are the multiples of it (the plan then equals the encoder's for that interval)
   if (container == HSRANS_RAW)
   {
     uint16_t counts[256];

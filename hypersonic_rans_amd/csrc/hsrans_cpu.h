@@ -19,7 +19,7 @@ const char *level_name(int level);
 size_t decode(int level, uint32_t threads, int container, int states, uint32_t bits, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap);
 size_t exec_plan(int level, uint32_t threads, const uint8_t *plan, size_t plan_size, const uint8_t *stream, size_t stream_len, uint8_t *out, size_t out_cap);
 size_t index_build(int level, uint32_t threads, int container, int states, uint32_t bits, const uint8_t *in, size_t in_len, const uint64_t *groups, size_t n_groups,
-                   uint8_t *plan_out, size_t plan_cap);
+                   uint8_t *plan_out, size_t plan_cap, uint32_t uniform_interval = 0);
 
 } // namespace cpu
 } // namespace hsrans

@@ -25,6 +25,9 @@ namespace hh = hsrans_hip;
 typedef size_t (*EncodeWithHist)(const uint8_t *, const size_t, uint8_t *, const size_t, const hh::hist_t *);
 typedef size_t (*EncodeNoHist)(const uint8_t *, const size_t, uint8_t *, const size_t);
 typedef size_t (*DecodeFunc)(const uint8_t *, const size_t, uint8_t *, const size_t);
+typedef size_t (*IndexCapacity)(const size_t);
+typedef size_t (*EncodeIndexed)(const uint8_t *, const size_t, uint8_t *, const size_t, uint8_t *, const size_t, size_t *);
+typedef size_t (*DecodeIndexed)(const uint8_t *, const size_t, uint8_t *, const size_t, const uint8_t *, const size_t);
 
 struct Codec
 {
@@ -34,11 +37,16 @@ struct Codec
   EncodeWithHist enc_hist; // raw
   EncodeNoHist enc;        // block_ / mt_
   DecodeFunc dec;
+  DecodeFunc dec_auto;       // runtime dispatch: one dependent chain -> host SIMD decoder, independent blocks -> GPU
+  IndexCapacity index_cap;   // the sidecar index through the drop-in names
+  EncodeIndexed enc_indexed;
+  DecodeIndexed dec_indexed, dec_indexed_pipelined;
 };
 
-#define RAW(S, N) {"rANS32x" #S " 16w (raw)", HSRANS_RAW, S, N, hh::rANS32x##S##_16w_encode_scalar_##N, nullptr, hh::rANS32x##S##_16w_decode_hip_##N}
-#define BLK(S, N) {"rANS32x" #S " 16w (variable block size)", HSRANS_BLOCK, S, N, nullptr, hh::block_rANS32x##S##_16w_encode_##N, hh::block_rANS32x##S##_16w_decode_hip_##N}
-#define MTB(S, N) {"rANS32x" #S " 16w (independent blocks)", HSRANS_MT, S, N, nullptr, hh::mt_rANS32x##S##_16w_encode_##N, hh::mt_rANS32x##S##_16w_decode_hip_##N}
+#define IDX(codec, N) hh::codec##_decode_auto_##N, hh::codec##_index_capacity_##N, hh::codec##_encode_with_index_##N, hh::codec##_decode_hip_with_index_##N, hh::codec##_decode_hip_pipelined_with_index_##N
+#define RAW(S, N) {"rANS32x" #S " 16w (raw)", HSRANS_RAW, S, N, hh::rANS32x##S##_16w_encode_scalar_##N, nullptr, hh::rANS32x##S##_16w_decode_hip_##N, IDX(rANS32x##S##_16w, N)}
+#define BLK(S, N) {"rANS32x" #S " 16w (variable block size)", HSRANS_BLOCK, S, N, nullptr, hh::block_rANS32x##S##_16w_encode_##N, hh::block_rANS32x##S##_16w_decode_hip_##N, IDX(block_rANS32x##S##_16w, N)}
+#define MTB(S, N) {"rANS32x" #S " 16w (independent blocks)", HSRANS_MT, S, N, nullptr, hh::mt_rANS32x##S##_16w_encode_##N, hh::mt_rANS32x##S##_16w_decode_hip_##N, IDX(mt_rANS32x##S##_16w, N)}
 #define ALL_BITS(M, S) M(S, 15), M(S, 14), M(S, 13), M(S, 12), M(S, 11), M(S, 10)
 static const Codec kCodecs[] = {ALL_BITS(MTB, 64), ALL_BITS(MTB, 32), ALL_BITS(BLK, 64), ALL_BITS(BLK, 32), ALL_BITS(RAW, 64), ALL_BITS(RAW, 32)};
 
@@ -219,6 +227,66 @@ int main(int argc, char **argv)
     const bool ok_host = got == n && validate(decoded.data(), input.data(), n);
     puts(ok_host ? " | valid" : " | FAILED TO VALIDATE");
     all_ok = all_ok && ok_host;
+
+    // ---- the runtime-dispatched entry (one dependent chain -> this library's host SIMD decoder; mt_ -> GPU) ----
+    {
+      Stats as;
+      size_t got_a = 0;
+      for (int run = -1; run < decode_runs; run++)
+      {
+        if (run == -1)
+          memset(decoded.data(), 0xCC, n);
+        const double t0 = now_s();
+        got_a = codec.dec_auto(compressed.data(), encoded, decoded.data(), n);
+        const double t1 = now_s();
+        if (run >= 0)
+          as.add(t1 - t0);
+      }
+      char label[64];
+      snprintf(label, sizeof(label), "dec auto (%s)", codec.container == HSRANS_MT ? "-> MI355X" : hsrans_cpu_level() == 2 ? "-> host avx512" : hsrans_cpu_level() == 1 ? "-> host avx2" : "-> host scalar");
+      printf("  %-44s |          ", label);
+      as.print(n);
+      const bool ok_auto = got_a == n && validate(decoded.data(), input.data(), n);
+      puts(ok_auto ? " | valid" : " | FAILED TO VALIDATE");
+      all_ok = all_ok && ok_auto;
+    }
+
+    // ---- the sidecar index through the drop-in names: encode_with_index, then host buffers + index (one launch, and with the
+    //      PCIe legs overlapped over page-locked buffers) ----
+    {
+      std::vector<uint8_t> index(codec.index_cap(n));
+      size_t index_len = 0;
+      const size_t enc_i = codec.enc_indexed(input.data(), n, compressed.data(), cap, index.data(), index.size(), &index_len);
+      bool ok_i = enc_i == encoded && index_len != 0;
+      const bool pinned = ok_i && hsrans_host_register(ctx, compressed.data(), cap) == HSRANS_OK && hsrans_host_register(ctx, decoded.data(), n) == HSRANS_OK;
+      for (int variant = 0; variant < 2 && ok_i; variant++)
+      {
+        Stats is;
+        size_t got_i = 0;
+        for (int run = -1; run < decode_runs; run++)
+        {
+          if (run == -1)
+            memset(decoded.data(), 0xCC, n);
+          const double t0 = now_s();
+          got_i = (variant ? codec.dec_indexed_pipelined : codec.dec_indexed)(compressed.data(), enc_i, decoded.data(), n, index.data(), index_len);
+          const double t1 = now_s();
+          if (run >= 0)
+            is.add(t1 - t0);
+        }
+        char label[80];
+        snprintf(label, sizeof(label), variant ? "dec MI355X, host buffers + index, pipelined" : "dec MI355X, host buffers + index (%.1f%%)", 100.0 * (double)index_len / (double)enc_i);
+        printf("  %-44s |          ", label);
+        is.print(n);
+        ok_i = got_i == n && validate(decoded.data(), input.data(), n);
+        puts(ok_i ? (pinned ? " | valid (page-locked)" : " | valid") : " | FAILED TO VALIDATE");
+      }
+      if (pinned)
+      {
+        (void)hsrans_host_unregister(ctx, compressed.data());
+        (void)hsrans_host_unregister(ctx, decoded.data());
+      }
+      all_ok = all_ok && ok_i;
+    }
 
     // ---- decoder with device-resident stream and output, sidecar plan with checkpoints every `interval` groups ----
     hsrans_encode_opts opts;

@@ -27,7 +27,8 @@ struct PersistentArgs
   // half_base[h] + b' * wg_chains[h] + class_off[k] + (j & 3) * run_len[k].  static_total = all static chains.
   uint32_t run_len[8], class_off[8], wg_chains[2], half_base[2], static_total;
   const uint2 *table;       // host-built decode table (kPlanHasHist plans) or null: build it in the kernel
-  uint32_t table_mode;      // 3: one uint2 per slot (bits <= 12); 4: coarse + fine tables (bits 13..15), see hsrans_kernels.hip
+  uint32_t table_mode;      // 3: one uint2 per slot; 4: coarse + fine tables (bits 13..15); 5: as 3, left in global memory; see hsrans_kernels.hip
+  uint32_t dual;            // two chains per wave: k_decode_dual
   const uint16_t *hist_copy; // the 256 counts that table was built from (device copy inside the plan)
   unsigned long long *counters; // [kDynQueues * kDynQueueStride] monotonic queue heads of THIS launch's counter set (never reset, see run_persistent)
 };
@@ -88,7 +89,7 @@ struct KParams
 
 struct LaunchInfo
 {
-  uint32_t grid, block, lds_bytes, waves_per_block, chains, shared_table, walk, two_level, table_mode;
+  uint32_t grid, block, lds_bytes, waves_per_block, chains, shared_table, walk, two_level, table_mode, chains_per_wave;
 };
 
 // what the launcher needs to know about the device a context lives on
@@ -101,7 +102,7 @@ struct DeviceGeom
 struct LaunchShape
 {
   int mode;         // decode-table layout (kMode* in hsrans_kernels.hip)
-  bool shared, walk;
+  bool shared, walk, dual;
   uint32_t waves, lds, grid, resident, private_pair;
   uint32_t weights[8]; // per-mille run length of the 8 wave classes
 };
@@ -121,9 +122,15 @@ hipError_t launch_mt_fill(const uint8_t *d_stream, uint64_t stream_len, uint32_t
                           uint64_t out_len, WalkResult *d_result, hipStream_t stream);
 
 DeviceGeom default_geom(); // MI355X: 256 CUs, 160 KiB LDS (used where no device is at hand: host-side index sizing)
-LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persistent, uint32_t table_mode, uint32_t n_groups, bool index_pass, bool direct);
+LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persistent, uint32_t table_mode, uint32_t n_groups, bool index_pass, bool direct, bool dual);
+struct TableChoice
+{
+  uint32_t mode; // 0: none (the kernel builds its own), else kMode* of the host-built table
+  bool dual;     // two chains per wave (k_decode_dual)
+};
+TableChoice choose_table(uint32_t bits, uint32_t states, bool direct);
 // chain boundaries (in groups) of the direct launch: one chain per resident wave, sized by class weight; see hsrans_kernels.hip
-size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, uint64_t total_groups, uint32_t table_mode, uint64_t *out, size_t cap);
+size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, uint64_t total_groups, uint64_t *out, size_t cap);
 bool table_spill(); // HSRANS_TABLE_SPILL: leave host-built tables in global memory (comparison only)
 // host-side builder of the bits >= 13 coarse/fine decode table (layout: kModeCoarse in hsrans_kernels.hip); returns entries written
 size_t build_coarse_table(const uint16_t counts[256], uint32_t bits, uint2 *out, size_t capacity_entries);

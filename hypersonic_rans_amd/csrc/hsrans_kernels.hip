@@ -76,6 +76,17 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v)
   return (uint64_t)uni((uint32_t)v) | ((uint64_t)uni((uint32_t)(v >> 32)) << 32);
 }
 
+// The decoded bytes are written once and never read again by this kernel: streaming (non-temporal) stores, so that the
+// lines leave L2 as they fill instead of waiting for the write-back at the end of the kernel (measured on two boxes:
+// 48.5 -> 46.1 us and 49.5 -> 48.2 us for the 100 MB headline decode; -DHSRANS_NT_STORES=0 builds the plain-store variant)
+#if !defined(HSRANS_NT_STORES) || HSRANS_NT_STORES
+#define HSRANS_STORE_U32(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#define HSRANS_STORE_U32_SADDR(base, voff, v) asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(voff), "v"(v), "s"(base) : "memory")
+#else
+#define HSRANS_STORE_U32(ptr, v) (*(ptr) = (v))
+#define HSRANS_STORE_U32_SADDR(base, voff, v) asm volatile("global_store_dword %0, %1, %2" : : "v"(voff), "v"(v), "s"(base) : "memory")
+#endif
+
 // are the 512 bytes of a histogram at stream offset `off` there to be read?
 #define HSRANS_HIST_IN_RANGE(c, off) ((off) >= (c).stream_lo && (off) <= (c).stream_len && (c).stream_len - (off) >= 512)
 
@@ -180,6 +191,15 @@ __device__ __forceinline__ void win_open(StreamWin &sw, const WaveCtx &c, uint64
   sw.base = a0;
 }
 
+// How far ahead of the chunk the cursor is in the ring requests stream bytes: 2 (round 1) keeps one slot spare; 3 uses all four
+// slots.  A request has (HSRANS_RING_AHEAD - 1) chunks of decoding (12.4 groups each = ~2.3 us at 8 waves per SIMD) to land:
+// enough for a stream that sits in the Infinity Cache (the same buffers replayed), NOT for one that comes from HBM under load —
+// with distinct buffers rotated through the benchmark the launch took 60.4 us at 2 against 46.6 us replayed; see DESIGN.md §5.
+#ifndef HSRANS_RING_AHEAD
+#define HSRANS_RING_AHEAD 3
+#endif
+static_assert(HSRANS_RING_AHEAD == 2 || HSRANS_RING_AHEAD == 3, "the ring has 4 slots: the cursor's chunk + 2 or 3 requested ones");
+
 // start streaming a chain whose first word is at absolute stream byte `pos` (>= sw.base, < sw.base + 4 GiB)
 __device__ __forceinline__ void ring_begin(const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t pos)
 {
@@ -192,11 +212,19 @@ __device__ __forceinline__ void ring_begin(const StreamWin &sw, Ring &r, const W
   ring_request(sw, r, c, 0);
   ring_request(sw, r, c, 1);
   ring_request(sw, r, c, 2);
+  if (HSRANS_RING_AHEAD == 3)
+    ring_request(sw, r, c, 3);
 }
 
-// chunks 0 and 1 (and the mirror) have landed: ring_begin issues {chunk 0, mirror, chunk 1, chunk 2} and anything issued
-// after it only makes this wait stricter
-__device__ __forceinline__ void ring_ready() { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+// chunks 0 and 1 (and the mirror) have landed: ring_begin issues {chunk 0, mirror, chunk 1, chunk 2 [, chunk 3]} and anything
+// issued after it only makes this wait stricter
+__device__ __forceinline__ void ring_ready()
+{
+  if (HSRANS_RING_AHEAD == 3)
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+}
 
 __device__ __forceinline__ void ring_init(StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t pos)
 {
@@ -211,8 +239,10 @@ __device__ __forceinline__ void ring_advance(const StreamWin &sw, Ring &r, const
   if ((r.cur >> (r.clog - 1)) > r.k)
   {
     r.k++;
-    ring_request(sw, r, c, r.k + 2);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); // chunk k+1 has landed (see the invariant above)
+    ring_request(sw, r, c, r.k + HSRANS_RING_AHEAD);
+    // chunk k+1 has landed: AHEAD 2: see the invariant above (the request just issued and a store are younger); AHEAD 3: the
+    // requests for k+2 and k+3 are both younger than the one for k+1, whatever the stores do
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   }
 }
 
@@ -462,8 +492,10 @@ __device__ __forceinline__ void run_groups_impl(uint32_t &x, const StreamWin &sw
     const uint32_t e3 = group_step<MODE, FULL>(x, r, c, act_mask);
     const uint32_t acc = pack4<kSymByte>(e0, e1, e2, e3, ol);
     uint8_t *row_base = c.out + o; // wave-uniform
-    if (act)
-      *(uint32_t *)(row_base + ol.store_off) = acc;
+    if (FULL) // scalar base + 32-bit lane offset: no 64-bit address arithmetic per store (the compiler's form adds one v_lshl_add_u64 per 4 groups)
+      HSRANS_STORE_U32_SADDR(row_base, ol.store_off, acc);
+    else if (act)
+      HSRANS_STORE_U32((uint32_t *)(row_base + ol.store_off), acc);
     o += 4 * S;
     ring_advance(sw, r, c);
   }
@@ -574,7 +606,7 @@ __device__ __forceinline__ void run_pair_groups(uint32_t &x, const StreamWin &sw
     const uint32_t e2 = group_step_pair<MODE>(x, ra, rb, c);
     const uint32_t e3 = group_step_pair<MODE>(x, ra, rb, c);
     const uint32_t hi = __builtin_amdgcn_perm(e3, e2, 0x0c0c0400u + kSymByte * 0x0101u);
-    *(uint32_t *)vout = quad_transpose(__builtin_amdgcn_perm(hi, lo, 0x05040100u), sel_a, sel_b);
+    HSRANS_STORE_U32((uint32_t *)vout, quad_transpose(__builtin_amdgcn_perm(hi, lo, 0x05040100u), sel_a, sel_b));
     vout += 128;
     ring_advance(sw, ra, c);
     ring_advance(sw, rb, c);
@@ -901,6 +933,7 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
   // the host-built table: one coalesced 16 B load + LDS store per thread (while the wave's first stream chunks and its
   // states are in flight); the first wave also checks that the stream really carries the histogram the table was built
   // from (else: status, as a failed sum check)
+  // (requesting the table BEFORE the piece record, so that its fetch overlaps that round trip, was measured: no gain)
   auto fetch_table = [&]() {
     if (MODE != kModeSpill)
     {
@@ -1551,6 +1584,293 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Two 64-state chains per wave (k_decode_dual): for the table layouts that leave room for only one workgroup per CU (the
+// 8-byte-per-slot table at 13 bits: 64 KiB) or whose group step is three dependent LDS round trips (coarse + fine at 14 / 15
+// bits), a wave's single dependent chain leaves the SIMD idle most of the time (4 waves per SIMD, each waiting on LDS).
+// Wave w decodes chains 2w and 2w + 1 of a one-chain-per-wave index side by side: two independent dependency chains in one
+// instruction stream, which the scheduler interleaves.
+//
+// Two rings per wave need exact waits: "vmcnt(2)" in ring_advance is right for ONE ring (derivation there) but would make
+// ring A wait for a request ring B issued a moment ago — a full memory round trip every few groups.  So this path COUNTS its
+// vector-memory instructions (the stream requests and the output stores are all issued from asm here, nothing else touches
+// vmcnt inside the loop) and waits with vmcnt(number of operations issued after the one it needs): exact, because vector
+// memory operations of a wave complete in issue order.
+// ---------------------------------------------------------------------------------------------------------------
+struct RingD
+{
+  Ring r;
+  uint32_t seq1, seq2, seq3; // value of the wave's VM-instruction count right after the requests for chunks k+1 / k+2 / k+3
+};
+
+__device__ __forceinline__ void wait_vm_outstanding(uint32_t n) // returns when at most n vector-memory operations are outstanding (n wave-uniform)
+{
+  switch (n)
+  {
+  case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+  case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+  case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+  case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+  case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+  case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+  case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+  case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+  case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+  case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+  case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+  case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+  case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+  case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+  case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+  default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break; // more than 16 younger operations: waiting for fewer is only stricter
+  }
+}
+
+__device__ __forceinline__ void ring_request_counted(const StreamWin &sw, const Ring &r, const WaveCtx &c, uint32_t chunk, uint32_t &vm)
+{
+  ring_request(sw, r, c, chunk);
+  vm += (chunk & (kRingSlots - 1)) == 0 ? 2 : 1; // slot 0 also refills the mirror
+}
+
+__device__ __forceinline__ void ring_begin_counted(const StreamWin &sw, RingD &d, const WaveCtx &c, uint64_t pos, uint32_t &vm)
+{
+  pos = uni64(pos);
+  const uint32_t rel = (uint32_t)(pos - sw.base);
+  d.r.voff0 = rel & ~15u;
+  d.r.cur = (rel - d.r.voff0) >> 1;
+  d.r.k = 0;
+  ring_request_counted(sw, d.r, c, 0, vm);
+  ring_request_counted(sw, d.r, c, 1, vm);
+  d.seq1 = vm;
+  ring_request_counted(sw, d.r, c, 2, vm);
+  d.seq2 = vm;
+  if (HSRANS_RING_AHEAD == 3)
+    ring_request_counted(sw, d.r, c, 3, vm);
+  d.seq3 = vm;
+}
+
+// call at least once per 256 consumed words (see ring_advance)
+__device__ __forceinline__ void ring_advance_counted(const StreamWin &sw, RingD &d, const WaveCtx &c, uint32_t &vm)
+{
+  if ((d.r.cur >> (d.r.clog - 1)) > d.r.k)
+  {
+    d.r.k++;
+    d.seq1 = d.seq2;
+    d.seq2 = d.seq3;
+    ring_request_counted(sw, d.r, c, d.r.k + HSRANS_RING_AHEAD, vm);
+    if (HSRANS_RING_AHEAD == 3)
+      d.seq3 = vm;
+    else
+      d.seq2 = d.seq3 = vm;
+    wait_vm_outstanding(vm - d.seq1); // everything up to the request for chunk k+1 has completed
+  }
+}
+
+__device__ __forceinline__ void store_counted(uint8_t *row_base, uint32_t voff, uint32_t v, uint32_t &vm)
+{
+  HSRANS_STORE_U32_SADDR(row_base, voff, v);
+  vm++;
+}
+
+// One group of chain A and one of chain B, written out side by side: inline asm with side effects (the EXEC-masked merge at the
+// end of group_step) is a scheduling barrier for the compiler, so two group_step calls in a row are emitted one after the other,
+// each LDS read followed by its own full wait (seen in the ISA).  Here both table gathers are issued before either is needed,
+// both word reads likewise, and ONE asm block at the end merges both chains.
+template <int MODE>
+__device__ __forceinline__ void group_step_dual(uint32_t &xa, uint32_t &xb, Ring &ra, Ring &rb, const WaveCtx &c, uint32_t &ea, uint32_t &eb)
+{
+  const uint32_t slot_a = xa & c.v_mask, slot_b = xb & c.v_mask;
+  const uint32_t qa = xa >> c.v_bits, qb = xb >> c.v_bits;
+  uint32_t nxa, nxb;
+  if (MODE == kModePack64)
+  {
+    const uint2 ta = ((const uint2 *)c.table)[slot_a];
+    const uint2 tb = ((const uint2 *)c.table)[slot_b];
+    ea = ta.x;
+    eb = tb.x;
+    nxa = __umul24(qa, ta.x) + ta.y;
+    nxb = __umul24(qb, tb.x) + tb.y;
+  }
+  else // kModeCoarse
+  {
+    uint2 ta = ((const uint2 *)c.table)[slot_a >> c.v_gshift];
+    uint2 tb = ((const uint2 *)c.table)[slot_b >> c.v_gshift];
+    const uint32_t ga = slot_a & c.v_gmask, gb = slot_b & c.v_gmask;
+    uint32_t bias_a = ta.y + ga, bias_b = tb.y + gb;
+    const bool mixed_a = (int32_t)ta.y < 0, mixed_b = (int32_t)tb.y < 0; // the granule straddles a symbol boundary: per-slot entry from the fine table
+    if (__builtin_amdgcn_ballot_w64(mixed_a || mixed_b) != 0)
+    {
+      const uint2 *fine = (const uint2 *)(c.table + 8 * kCoarseEntries);
+      // (lanes that are not mixed read entry 0 of the fine table: harmless, and both gathers stay unconditional inside this branch)
+      const uint2 fa = fine[mixed_a ? (ta.y & 0x7FFFFFFFu) + ga : 0];
+      const uint2 fb = fine[mixed_b ? (tb.y & 0x7FFFFFFFu) + gb : 0];
+      if (mixed_a)
+      {
+        ta = fa;
+        bias_a = fa.y;
+      }
+      if (mixed_b)
+      {
+        tb = fb;
+        bias_b = fb.y;
+      }
+    }
+    ea = ta.x;
+    eb = tb.x;
+    nxa = __umul24(qa, ta.x) + bias_a;
+    nxb = __umul24(qb, tb.x) + bias_b;
+  }
+  const unsigned long long ma = __builtin_amdgcn_ballot_w64(nxa < kConsume);
+  const unsigned long long mb = __builtin_amdgcn_ballot_w64(nxb < kConsume);
+  const uint32_t rank_a = __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0));
+  const uint32_t rank_b = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0));
+  uint32_t wa_addr, wb_addr;
+  asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(wa_addr) : "v"(rank_a), "s"(ra.lds + ((ra.cur << 1) & (ring_bytes(ra) - 1))));
+  asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(wb_addr) : "v"(rank_b), "s"(rb.lds + ((rb.cur << 1) & (ring_bytes(rb) - 1))));
+  const uint32_t wa = *(const __attribute__((address_space(3))) uint16_t *)(uintptr_t)wa_addr;
+  const uint32_t wb = *(const __attribute__((address_space(3))) uint16_t *)(uintptr_t)wb_addr;
+  xa = nxa;
+  xb = nxb;
+  // x = low ? (nx << 16 | w) : nx for both chains (EXEC is all ones here: wave-uniform control flow of a full wave)
+  asm volatile("s_mov_b64 exec, %4\n\tv_lshl_or_b32 %0, %0, 16, %2\n\ts_mov_b64 exec, %5\n\tv_lshl_or_b32 %1, %1, 16, %3\n\ts_mov_b64 exec, -1"
+               : "+v"(xa), "+v"(xb)
+               : "v"(wa), "v"(wb), "s"(ma), "s"(mb));
+  ra.cur += (uint32_t)__popcll(ma);
+  rb.cur += (uint32_t)__popcll(mb);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_decode_dual(KParams kp)
+{
+  extern __shared__ u32x4 smem_v[];
+  uint8_t *smem = (uint8_t *)smem_v;
+  const PersistentArgs &pa = kp.pa;
+  const uint32_t waves = blockDim.x >> 6;
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  WaveCtx c;
+  c.stream = kp.stream;
+  c.stream_len = kp.stream_len;
+  c.stream_lo = kp.stream_lo;
+  c.out = kp.out;
+  c.out_cap = kp.out_cap;
+  c.status = kp.status;
+  c.bits = pa.bits;
+  c.S = 64;
+  c.lane = threadIdx.x & 63;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gshift) : "s"(c.bits > 12 ? c.bits - 12 : 0));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gmask) : "s"(c.bits > 12 ? (1u << (c.bits - 12)) - 1 : 0));
+  c.rings = smem + wave * 2 * kWaveRingBytes;
+  c.table = smem + waves * 2 * kWaveRingBytes;
+  c.table_b = c.table;
+  c.gtable = pa.table;
+  c.scratch_cnt = (uint16_t *)smem;
+  c.scratch_cum = (uint16_t *)(smem + 512);
+  const uint32_t W = gridDim.x * waves;
+  const uint32_t w = blockIdx.x * waves + wave;
+  const uint64_t t_entry = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  uint64_t t_table = 0, t_ready = 0;
+
+  // the host-built table (always: the launcher only picks this kernel for plans that carry their histogram)
+  bool table_pending = true;
+  auto fetch_table = [&]() {
+    const uint32_t entries = table_bytes_for(MODE, c.bits) / 8;
+    for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
+      *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
+    if (blockIdx.x == 0 && threadIdx.x < 64)
+    {
+      bool same = HSRANS_HIST_IN_RANGE(c, pa.hist_off) || pa.hist_off + 512 <= c.stream_lo;
+      if (same && pa.hist_off >= c.stream_lo)
+      {
+        const uint64_t mine = *(const uint64_t *)(pa.hist_copy + 4 * c.lane);
+        uint64_t theirs = 0;
+        for (int b = 3; b >= 0; b--)
+          theirs = (theirs << 16) | *(const uint16_t *)(c.stream + pa.hist_off + 8 * c.lane + 2 * b);
+        same = mine == theirs;
+      }
+      if (__builtin_amdgcn_ballot_w64(!same) != 0 && c.lane == 0)
+        atomicOr(c.status, kStatusBadHist);
+    }
+    __syncthreads();
+    if (kp.stamps)
+      t_table = __builtin_amdgcn_s_memrealtime();
+  };
+
+  constexpr uint32_t kSymByte = 3;
+  const OutLanes ol = out_lanes(c.lane, 64);
+  for (uint32_t a = 2 * w; a < pa.n_chains; a += 2 * W)
+  {
+    const bool have_b = a + 1 < pa.n_chains;
+    const DirectPiece da = direct_piece(c, pa, a);
+    const DirectPiece db = have_b ? direct_piece(c, pa, a + 1) : da;
+    uint32_t xa = pa.states[(uint64_t)a * 64 + c.lane];
+    uint32_t xb = pa.states[(uint64_t)(have_b ? a + 1 : a) * 64 + c.lane];
+    StreamWin sw;
+    RingD ra, rb;
+    ring_bind(ra.r, c.rings);
+    ring_bind(rb.r, c.rings + kWaveRingBytes);
+    uint32_t vm = 0; // vector-memory instructions issued from here on (everything older completes before them anyway)
+    win_open(sw, c, da.words, have_b ? db.limit : da.limit); // the two chains are neighbours in the stream: one window
+    ring_begin_counted(sw, ra, c, da.words, vm);
+    if (have_b)
+      ring_begin_counted(sw, rb, c, db.words, vm);
+    else
+      rb = ra;
+    if (table_pending)
+    {
+      fetch_table();
+      table_pending = false;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // start of a chain pair: states, table and the first chunks of both rings
+    vm = 0;
+    ra.seq1 = ra.seq2 = ra.seq3 = rb.seq1 = rb.seq2 = rb.seq3 = 0;
+    if (kp.stamps && t_ready == 0)
+      t_ready = __builtin_amdgcn_s_memrealtime();
+    uint64_t oa = da.out, ob = db.out;
+    uint32_t sa = da.steps, sb = have_b ? db.steps : 0;
+    uint32_t both = have_b ? (sa < sb ? sa : sb) & ~3u : 0;
+    sa -= both;
+    sb -= both;
+    for (; both != 0; both -= 4)
+    {
+      uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
+      group_step_dual<MODE>(xa, xb, ra.r, rb.r, c, a0, b0);
+      group_step_dual<MODE>(xa, xb, ra.r, rb.r, c, a1, b1);
+      group_step_dual<MODE>(xa, xb, ra.r, rb.r, c, a2, b2);
+      group_step_dual<MODE>(xa, xb, ra.r, rb.r, c, a3, b3);
+      store_counted(c.out + oa, ol.store_off, pack4<kSymByte>(a0, a1, a2, a3, ol), vm);
+      store_counted(c.out + ob, ol.store_off, pack4<kSymByte>(b0, b1, b2, b3, ol), vm);
+      oa += 256;
+      ob += 256;
+      ring_advance_counted(sw, ra, c, vm);
+      ring_advance_counted(sw, rb, c, vm);
+    }
+    // what is left (a few groups of the longer chain, the stream's final partial group): one chain at a time, the ordinary way
+    // (the single-ring wait in ring_advance is only ever stricter than needed here: the other ring's requests are older or done)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    run_groups<MODE>(xa, sw, ra.r, c, oa, sa);
+    run_tail<MODE>(xa, ra.r, c, oa, da.tail);
+    if (have_b)
+    {
+      run_groups<MODE>(xb, sw, rb.r, c, ob, sb);
+      run_tail<MODE>(xb, rb.r, c, ob, db.tail);
+    }
+  }
+  if (table_pending)
+    fetch_table();
+  if (kp.stamps && c.lane == 0)
+  {
+    uint64_t *st = kp.stamps + (uint64_t)w * 8;
+    st[0] = t_entry;
+    st[1] = t_table;
+    st[2] = t_ready;
+    st[3] = __builtin_amdgcn_s_memrealtime();
+    st[4] = st[3];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // K2: mt_ header-chain walk on the device (one wavefront; lane 0 steers, all lanes copy states / sum counts).
 // Mirrors hsrans::plan_build's mt_ branch step by step, which mirrors mt_rANS32x64_16w_decode.cpp:41-96.
 // plan == nullptr: count only.  Otherwise plan is a blob sized for `n_chains` single-piece chains: the kernel fills
@@ -1731,8 +2051,12 @@ static uint32_t g_slot_weights4[8] = {1150, 1050, 950, 850, 1150, 1050, 950, 850
 // short tail chains), so these are fitted until all classes finish together (tools/tune_weights.py: the spread of the classes'
 // mean finish times goes from 19.8 us with the weights above to 0.1 us): the waves of a CU's first workgroup run ahead of
 // the second one's on every SIMD, and inside a workgroup the older waves a little ahead of the younger.
-static uint32_t g_direct_weights[8] = {1244, 1207, 1163, 1101, 973, 883, 771, 658};
-static uint32_t g_direct_weights4[8] = {1150, 1050, 950, 850, 1150, 1050, 950, 850};
+// One set per occupancy (waves per SIMD): 8 = two 16-wave workgroups per CU (bits <= 12), 6 = two 12-wave workgroups (15 bits,
+// coarse + fine tables), 4 = one 16-wave workgroup (13 bits), 3 = one 12-wave workgroup (14 bits).
+static uint32_t g_direct_weights[8] = {1241, 1204, 1160, 1100, 974, 886, 774, 660};
+static uint32_t g_direct_weights6[8] = {1124, 1102, 1076, 1047, 984, 941, 891, 834};
+static uint32_t g_direct_weights4[8] = {1067, 1038, 983, 911, 1068, 1038, 985, 911};
+static uint32_t g_direct_weights3[8] = {1040, 1018, 989, 952, 1039, 1018, 989, 953};
 // HSRANS_PRIVATE_PAIR: 0 = never, 1 = when there are more chains than wave slots (default), 2 = always pair the
 // chains of 32-state plans in private-table launches.  Measured: 2^30 B in 16,384 blocks 1.40 -> 1.33 ms, but 100 MB in 1,526
 // blocks 0.25 -> 0.30 ms (everything is latency-bound there and half as many waves are in flight)
@@ -1741,8 +2065,13 @@ static bool g_weights_two_level = false; // HSRANS_WEIGHTS_TWO_LEVEL: apply the 
 static bool g_table_spill = false;       // HSRANS_TABLE_SPILL: host-built tables stay in global memory (kModeSpill; comparison only)
 // one-chain-per-wave plans (hsrans_index_boundaries): share of the stream (per mille) left to short chains that the ticket
 // queues hand to waves that are done early, and the length of those chains in groups
-static uint32_t g_direct_dyn_permille = 70; // HSRANS_DIRECT_DYN_PERMILLE
+static uint32_t g_direct_dyn_permille = 0;  // HSRANS_DIRECT_DYN_PERMILLE (measured: a tail of short chains costs more in per-chain prologues than it evens out: 46.2 -> 49.8 us at 2-7 %)
 static uint32_t g_direct_dyn_groups = 32;   // HSRANS_DIRECT_DYN_GROUPS (multiple of 4)
+
+static void read_tuning_once();
+static uint32_t g_dual = 1; // HSRANS_DUAL: 0 = never run two chains per wave (k_decode_dual), 1 = where it pays (default), 2 = for every width (experiment)
+// the one-chain-per-wave weights of the dual kernel's launches (one 16-wave workgroup per CU, two chains per wave)
+static uint32_t g_dual_weights[8] = {1105, 1052, 977, 867, 1104, 1051, 976, 867};
 
 typedef void (*KernelFn)(KParams);
 static KernelFn kernel_for(int mode, bool shared)
@@ -1763,6 +2092,33 @@ static KernelFn kernel_for(int mode, bool shared)
 
 uint32_t pack64_max_bits() { return g_pack64_max_bits; }
 bool table_spill() { return g_table_spill; }
+
+// Which host-built decode table a plan that carries its histogram gets, and whether its launch runs two chains per wave.
+// `direct`: the plan has one chain per wave (PlanHeader::interval == 0), which is what the dual kernel is written for.
+TableChoice choose_table(uint32_t bits, uint32_t states, bool direct)
+{
+  read_tuning_once();
+  TableChoice t{0, false};
+  if (g_table_spill)
+    t.mode = kModeSpill;
+  else if (direct && g_dual == 2 && states == 64 && bits <= 12) // experiment: the dual kernel below 13 bits too
+  {
+    t.mode = kModePack64;
+    t.dual = true;
+  }
+  else if (direct && g_dual && states == 64 && bits >= 13)
+  {
+    // one workgroup of 16 waves per CU, two chains per wave: 13 bits keeps the 8-byte-per-slot table (64 KiB + 32 rings = 136 KiB);
+    // at 14 / 15 bits that table does not fit beside 32 rings, so coarse + fine (40 / 48 KiB)
+    t.mode = bits == 13 ? kModePack64 : kModeCoarse;
+    t.dual = true;
+  }
+  else if (bits <= g_pack64_max_bits)
+    t.mode = kModePack64;
+  else if (bits >= 13 && states == 64 && getenv("HSRANS_NO_COARSE_TABLE") == nullptr)
+    t.mode = kModeCoarse;
+  return t;
+}
 
 size_t coarse_table_entries(uint32_t bits) { return table_bytes_for(kModeCoarse, bits) / 8; }
 
@@ -1841,10 +2197,15 @@ static void read_tuning_once()
   read_weights("HSRANS_SLOT_WEIGHTS4", g_slot_weights4);
   read_weights("HSRANS_DIRECT_WEIGHTS", g_direct_weights);
   read_weights("HSRANS_DIRECT_WEIGHTS4", g_direct_weights4);
+  read_weights("HSRANS_DIRECT_WEIGHTS6", g_direct_weights6);
+  read_weights("HSRANS_DIRECT_WEIGHTS3", g_direct_weights3);
   g_weights_two_level = getenv("HSRANS_WEIGHTS_TWO_LEVEL") != nullptr;
   g_table_spill = getenv("HSRANS_TABLE_SPILL") != nullptr;
   if (const char *e = getenv("HSRANS_PRIVATE_PAIR"))
     g_private_pair = (uint32_t)atoi(e);
+  if (const char *e = getenv("HSRANS_DUAL"))
+    g_dual = (uint32_t)atoi(e);
+  read_weights("HSRANS_DUAL_WEIGHTS", g_dual_weights);
   if (const char *e = getenv("HSRANS_DIRECT_DYN_PERMILLE"))
     g_direct_dyn_permille = (uint32_t)atoi(e) > 500 ? 500 : (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_DIRECT_DYN_GROUPS"))
@@ -1868,6 +2229,12 @@ hipError_t prepare_kernels(DeviceGeom *geom)
       if (e != hipSuccess)
         return e;
     }
+  for (KernelFn fn : {(KernelFn)k_decode_dual<kModePack64>, (KernelFn)k_decode_dual<kModeCoarse>})
+  {
+    const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
+    if (e != hipSuccess)
+      return e;
+  }
   return hipSuccess;
 }
 
@@ -1882,7 +2249,7 @@ DeviceGeom default_geom()
 
 // Everything about a launch that follows from the plan header and the device alone (no pointers): the table layout, the
 // workgroup shape and the grid.  launch_decode uses it; direct_boundaries uses it to size one chain per resident wave.
-LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persistent, uint32_t table_mode, uint32_t n_groups, bool index_pass, bool direct)
+LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persistent, uint32_t table_mode, uint32_t n_groups, bool index_pass, bool direct, bool dual)
 {
   read_tuning_once();
   LaunchShape L{};
@@ -1898,7 +2265,18 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
   const uint32_t table_bytes = table_bytes_for(L.mode, h.bits);
   const uint32_t wave_bytes = kWaveRingBytes + ((table_bytes + 15) & ~15u); // private rings + table
   uint32_t waves, lds, grid;
-  if (L.shared)
+  L.dual = dual && L.shared && persistent && (L.mode == kModePack64 || L.mode == kModeCoarse) && 16 * 2 * kWaveRingBytes + table_bytes <= dg.max_lds;
+  if (L.dual)
+  {
+    // k_decode_dual: one workgroup of 16 waves per CU, two rings per wave, wave w decodes chains 2w and 2w + 1
+    waves = 16;
+    lds = waves * 2 * kWaveRingBytes + table_bytes;
+    L.resident = dg.num_cus * (dg.max_lds / lds ? dg.max_lds / lds : 1);
+    grid = (h.n_chains + 2 * waves - 1) / (2 * waves);
+    if (grid > L.resident)
+      grid = L.resident;
+  }
+  else if (L.shared)
   {
     waves = g_waves_per_wg;
     if (L.mode == kModeCoarse && waves * kWaveRingBytes + table_bytes > dg.max_lds / 2)
@@ -1937,7 +2315,10 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
   // run-length weights of the 8 wave classes (per mille of the mean): class = (workgroup in the grid's second half) * 4 + wave / (waves / 4)
   const bool weighted = (waves == 16 || waves == 12) && (!two_level || g_weights_two_level);
   for (uint32_t k = 0; k < 8; k++)
-    L.weights[k] = !weighted ? 1000 : direct ? (L.grid > dg.num_cus ? g_direct_weights : g_direct_weights4)[k] : (L.grid > dg.num_cus ? g_slot_weights : g_slot_weights4)[k];
+    L.weights[k] = !weighted ? 1000
+                   : L.dual   ? g_dual_weights[k]
+                   : direct   ? (L.grid > dg.num_cus ? (waves == 16 ? g_direct_weights : g_direct_weights6) : (waves == 16 ? g_direct_weights4 : g_direct_weights3))[k]
+                              : (L.grid > dg.num_cus ? g_slot_weights : g_slot_weights4)[k];
   return L;
 }
 
@@ -1945,15 +2326,16 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
 // for a mergeable plan of (states, bits): chain w belongs to wave w, its length follows the wave's class weight.
 // Boundaries are multiples of 4 groups (the decode loop stores 4 groups at a time).  Returns the number of chains;
 // out[k] = first group of chain k + 1 (k < chains - 1).
-size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, uint64_t total_groups, uint32_t table_mode, uint64_t *out, size_t cap)
+size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, uint64_t total_groups, uint64_t *out, size_t cap)
 {
   PlanHeader h{};
   h.states = states;
   h.bits = bits;
   h.shared_hist = 1;
   h.n_chains = 1u << 30; // "many": the full machine
-  const LaunchShape L = launch_shape(h, dg, true, table_mode, 0, false, true);
-  const uint32_t runs_per_wave = states == 32 ? 2 : 1;
+  const TableChoice tc = choose_table(bits, states, true);
+  const LaunchShape L = launch_shape(h, dg, true, tc.mode, 0, false, true, tc.dual);
+  const uint32_t runs_per_wave = (states == 32 || L.dual) ? 2 : 1;
   const uint64_t W = (uint64_t)L.grid * L.waves;
   uint64_t chains = W * runs_per_wave;
   const uint64_t all_units = total_groups / 4; // boundaries in units of 4 groups
@@ -2009,7 +2391,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
   KParams kp = kp_in;
   const bool persistent = kp.pa.pieces != nullptr;
   const bool index_pass = kp.ckpt_interval != 0 || kp.ckpt_groups != nullptr;
-  const LaunchShape L = launch_shape(h, dg, persistent, persistent && kp.pa.table != nullptr ? kp.pa.table_mode : 0, kp.groups != nullptr ? kp.n_groups : 0, index_pass, false);
+  const LaunchShape L = launch_shape(h, dg, persistent, persistent && kp.pa.table != nullptr ? kp.pa.table_mode : 0, kp.groups != nullptr ? kp.n_groups : 0, index_pass, persistent && kp.pa.interval == 0, persistent && kp.pa.dual != 0);
   const bool grouped = kp.groups != nullptr && !index_pass;
   const uint32_t waves = L.waves, grid = L.grid;
   kp.private_pair = L.private_pair;
@@ -2059,7 +2441,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
     if ((uint64_t)(longest ? longest : 1) * kp.pa.interval * h.states * 2 >= 0xFFFF0000ull)
       return hipErrorInvalidValue;
   }
-  KernelFn fn = kernel_for(L.mode, L.shared);
+  KernelFn fn = L.dual ? (L.mode == kModeCoarse ? (KernelFn)k_decode_dual<kModeCoarse> : (KernelFn)k_decode_dual<kModePack64>) : kernel_for(L.mode, L.shared);
   if (info)
   {
     info->grid = grid;
@@ -2071,6 +2453,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
     info->walk = L.walk;
     info->two_level = L.mode == kModeTwoLevel;
     info->table_mode = (uint32_t)L.mode;
+    info->chains_per_wave = L.dual ? 2 : 1;
   }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), L.lds, stream, kp);
   return hipGetLastError();

@@ -66,3 +66,14 @@ for label, arr in (("static done", static_done), ("done", done)):
     print(f"{label} by wave//{pc} (age class), first half of the grid:", " ".join(f"{arr[valid & (wave_in_wg // pc == k) & (blk < (nb + 1) // 2)].mean():.1f}" for k in range(4)),
           "| second half:", " ".join(f"{arr[valid & (wave_in_wg // pc == k) & (blk >= (nb + 1) // 2)].mean():.1f}" for k in range(4)) if nb > 1 else "")
 print("done by workgroup % 8 (XCD):", " ".join(f"{done[valid & (blk % 8 == k)].mean():.1f}" for k in range(8)))
+entry = (allst[:, 0] - t0) / 100.0
+nbk = 8
+print("by workgroup index (8 buckets over the grid): entry", " ".join(f"{entry[valid & (blk * nbk // nb == k)].mean():.1f}" for k in range(nbk)),
+      "| done", " ".join(f"{done[valid & (blk * nbk // nb == k)].mean():.1f}" for k in range(nbk)),
+      "| max done", " ".join(f"{done[valid & (blk * nbk // nb == k)].max():.1f}" for k in range(nbk)))
+cu_slot = blk % (nb // 2) if nb > 1 else blk
+late = np.argsort(-np.where(valid, done, 0))[:12]
+print("latest waves (workgroup, wave, entry, ready, done):", [(int(blk[i]), int(wave_in_wg[i]), round(float(entry[i]), 1), round(float((allst[i, 2] - t0) / 100.0), 1), round(float(done[i]), 1)) for i in late])
+wg_done = np.array([done[valid & (blk == b)].max() for b in range(nb)])
+wg_entry = np.array([entry[valid & (blk == b)].min() for b in range(nb)])
+print("per-workgroup last wave: p10 %.1f p50 %.1f p90 %.1f max %.1f; corr(entry, done) %.2f" % (np.percentile(wg_done, 10), np.median(wg_done), np.percentile(wg_done, 90), wg_done.max(), np.corrcoef(wg_entry, wg_done)[0, 1]))

@@ -13,7 +13,14 @@ import torch
 import hypersonic_rans_amd as H
 from hypersonic_rans_amd import synth
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
+import argparse
+
+ap = argparse.ArgumentParser()
+ap.add_argument("size", nargs="?", type=int, default=100_000_000)
+ap.add_argument("--only-raw", action="store_true", help="raw rows only (e.g. for the HSRANS_TABLE_SPILL=1 / HSRANS_DUAL=0 comparison runs)")
+ap.add_argument("--tag", default="", help="copied into every row (which environment the library ran under)")
+args = ap.parse_args()
+n = args.size
 ctx = H.Context(0)
 data = synth.enwik8_shaped(n)
 d_ref = torch.from_numpy(data).cuda()
@@ -21,8 +28,11 @@ names = {H.RAW: "raw", H.BLOCK: "block_", H.MT: "mt_"}
 
 
 def measure(container, S, bits, interval, block_size=0, reps=20):
+    """interval: checkpoints every `interval` groups, 0 = none, "wave" = one chain per resident wavefront (hsrans_index_boundaries)"""
     t0 = time.perf_counter()
-    if interval:
+    if interval == "wave":
+        s, plan = H.encode(container, S, bits, data, index_groups=H.index_boundaries(S, bits, n, ctx))
+    elif interval:
         s, plan = H.encode(container, S, bits, data, index_interval=interval, block_size=block_size)
     else:
         s = H.encode(container, S, bits, data, block_size=block_size) if block_size else H.encode(container, S, bits, data)
@@ -44,14 +54,19 @@ def measure(container, S, bits, interval, block_size=0, reps=20):
     info = dp.launch_info()
     row = {"container": names[container], "states": S, "bits": bits, "interval": interval, "block_size": block_size, "chains": H.plan_chain_count(plan),
            "ratio": round(s.size / n, 4), "ms": round(ms, 4), "MiB_s": round(n / 2**20 / (ms * 1e-3)), "hbm_frac": round((s.size + n) / (ms * 1e-3) / 8e12, 4),
-           "bit_exact": ok, "grid": info["grid"], "block": info["block"], "lds": info["lds_bytes"], "shared_table": info["shared_table"], "encode_s": round(t_enc, 2)}
+           "bit_exact": ok, "grid": info["grid"], "block": info["block"], "lds": info["lds_bytes"], "shared_table": info["shared_table"],
+           "table_mode": info["table_mode"], "chains_per_wave": info["chains_per_wave"], "plan_bytes": int(plan.size), "encode_s": round(t_enc, 2), "tag": args.tag}
     print(json.dumps(row), flush=True)
 
 
 for bits in (10, 11, 12, 13, 14, 15):
+    measure(H.RAW, 64, bits, "wave")
     measure(H.RAW, 64, bits, 32)
 for bits in (11, 14):
+    measure(H.RAW, 32, bits, "wave")
     measure(H.RAW, 32, bits, 32)
+if args.only_raw:
+    sys.exit(0)
 for bits in (11, 12, 14, 15):
     measure(H.MT, 64, bits, 0, block_size=1 << 16)       # as the reference's mt_ encoder typically emits: 64 KiB blocks, no sidecar
 measure(H.MT, 64, 11, 0, block_size=1 << 18)             # BASELINE config 4 block size (256 KiB)

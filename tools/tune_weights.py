@@ -16,7 +16,7 @@ ap.add_argument("--states", type=int, default=64)
 ap.add_argument("--damp", type=float, default=0.8)
 ap.add_argument("--dyn", default="0")
 a = ap.parse_args()
-w = [float(x) for x in a.start.split(",")] if a.start else [1244, 1207, 1163, 1101, 973, 883, 771, 658]
+w = [float(x) for x in a.start.split(",")] if a.start else [1241, 1204, 1160, 1100, 974, 886, 774, 660]
 for it in range(a.iters):
     env = dict(os.environ)
     env[a.var] = ",".join(str(int(round(x))) for x in w)
