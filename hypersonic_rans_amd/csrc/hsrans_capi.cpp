@@ -65,6 +65,7 @@ struct hsrans_dplan
   size_t d_groups_cap = 0;
   uint32_t n_groups = 0;
   PersistentArgs pa{};
+  SingleArgs single{};
   LaunchInfo info{};
 };
 
@@ -275,6 +276,7 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
   d->hdr = h;
   d->plan_bytes = plan_size;
   d->pa = PersistentArgs{};
+  d->single = SingleArgs{};
   d->n_groups = 0;
   if (!grow(&d->d_plan, &d->d_plan_cap, plan_size) || hipMemcpyAsync(d->d_plan, plan, plan_size, hipMemcpyHostToDevice, s) != hipSuccess)
     return HSRANS_E_HIP;
@@ -350,6 +352,23 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
         d->pa.table_mode = mode;
         d->pa.hist_copy = (const uint16_t *)(d->d_plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
       }
+    }
+  }
+  if (h.container == HSRANS_RAW && h.n_chains == 1 && h.n_pieces == 1 && !(h.flags & kPlanWalk) && h.bits <= 14)
+  {
+    // a raw stream without an index: one chain — the two-wave latency kernel (k_decode_single) instead of one wave of k_decode
+    const Piece &p = *(const Piece *)(plan + plan_pieces_off(1));
+    if (!(p.flags & kPieceFill))
+    {
+      d->single.valid = 1;
+      d->single.steps = p.steps;
+      d->single.tail = p.tail;
+      d->single.S = h.states;
+      d->single.bits = h.bits;
+      d->single.ring_entries = h.bits <= 13 ? 2048 : 1024; // 14 bits: 128 KiB of table leave room for 1,088 ring entries
+      d->single.hist_off = p.hist_off;
+      d->single.words_off = p.words_off;
+      d->single.out_off = p.out_off;
     }
   }
   if (!(h.flags & (kPlanWalk | kPlanMergeable)) && h.n_chains > 1)
@@ -448,6 +467,8 @@ static int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_len
   kp.status = d->d_status;
   kp.stamps = d->d_stamps;
   kp.pa = d->pa;
+  kp.single = d->single;
+  kp.single_states = (const uint32_t *)(d->d_plan + plan_states_off(d->hdr.n_chains, d->hdr.n_pieces));
   if (kp.pa.counters != nullptr) // uniform persistent launch: its own set of queue heads
     kp.pa.counters += (size_t)(d->epoch.fetch_add(1, std::memory_order_relaxed) % kCounterSets) * kDynQueues * kDynQueueStride;
   if (d->n_groups)
@@ -1178,8 +1199,8 @@ int hsrans_hpipe_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
   PlanHeader h;
   if (!read_header(plan, plan_size, &h) || !plan_validate(plan, plan_size, h.stream_len, h.decoded_len) || (h.flags & kPlanWalk))
     return HSRANS_E_FORMAT;
-  if (n_slices == 0)
-    n_slices = 8;
+  if (n_slices == 0) // auto: slices of >= 256 MiB of output (measured at 2^30 B: 4 slices 45.6 GB/s, 8 slices 34.7, 16 slices 34.3), 2..8
+    n_slices = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(2, h.decoded_len >> 28));
   if (n_slices > h.n_chains)
     n_slices = h.n_chains;
   if (hipSetDevice(ctx->device) != hipSuccess)

@@ -97,7 +97,7 @@ static size_t decode_indexed_any(int container, int states, uint32_t bits, const
   if (ctx == nullptr || index == nullptr)
     return 0;
   if (pipelined)
-    return hsrans_decode_host_pipelined(ctx, container, states, bits, in, inLength, out, outCapacity, index, indexLength, 8);
+    return hsrans_decode_host_pipelined(ctx, container, states, bits, in, inLength, out, outCapacity, index, indexLength, 0 /* slices: by size */);
   return hsrans_decode_host(ctx, container, states, bits, in, inLength, out, outCapacity, index, indexLength);
 }
 

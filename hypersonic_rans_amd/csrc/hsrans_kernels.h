@@ -51,6 +51,14 @@ struct Group
 constexpr uint32_t kGroupMergeable = 1;
 constexpr uint32_t kGroupFill = 2;
 
+// k_decode_single: a plan of ONE chain of ONE rANS piece (a raw stream without an index), filled by the host from the plan
+struct SingleArgs
+{
+  uint32_t valid;        // 0: not such a plan (or bits == 15: its 8-byte table does not fit LDS)
+  uint32_t steps, tail, S, bits, ring_entries;
+  uint64_t hist_off, words_off, out_off;
+};
+
 struct KParams
 {
   const uint8_t *stream; // device, 16-byte aligned: where stream byte 0 is (or would be: see stream_lo)
@@ -82,6 +90,8 @@ struct KParams
   // grouped launches: wave k of a workgroup in grid half h takes chains [count * cum[h][k] / cum[h][waves], count * cum[h][k+1] / cum[h][waves])
   // of its group (the same age-class weights as PersistentArgs::run_len)
   uint16_t group_cum[2][17];
+  SingleArgs single;
+  const uint32_t *single_states; // the chain's S start states (device)
   // private-table launches of 32-state plans: every wave takes TWO chains (2w, 2w+1), one per wave half, each with its own
   // table (run_private_pair); the LDS layout then holds two tables per wave
   uint32_t private_pair;

@@ -143,6 +143,11 @@ struct Ring
   uint32_t cur;   // next word to read, counted from voff0 (wave-uniform)
   uint32_t lds;   // LDS byte address of the ring (what M0 / ds_read take)
   uint32_t clog;  // log2 of the chunk size in bytes: 9 (32 lanes x 16 B; 64-state chains) or 8 (16 lanes; paired 32-state chains)
+  // Exact waits (ring_advance_exact): `vm` counts the vector-memory instructions this wave has issued through this file's asm
+  // (stream requests, the counted output stores); seqN = its value right after the request for chunk k+N.  Vector-memory
+  // operations of a wave complete in issue order, so "chunk k+1 has landed" == at most (vm - seq1) operations outstanding.
+  // Operations the compiler issues on its own are not counted: that only makes a wait stricter than needed, never weaker.
+  uint32_t vm, seq1, seq2, seq3;
 };
 
 // clog = 9: 2 KiB ring + 128 B mirror (a group reads <= 64 words); clog = 8: 1 KiB ring + 64 B mirror (<= 32 words)
@@ -209,11 +214,19 @@ __device__ __forceinline__ void ring_begin(const StreamWin &sw, Ring &r, const W
   r.cur = (rel - r.voff0) >> 1;
   r.k = 0;
   // every lane is done with the ring's previous contents (its ds_reads returned before their results were used)
+  r.vm = 0;
   ring_request(sw, r, c, 0);
   ring_request(sw, r, c, 1);
+  r.vm += 3; // chunk 0, its mirror, chunk 1
+  r.seq1 = r.vm;
   ring_request(sw, r, c, 2);
+  r.seq2 = ++r.vm;
   if (HSRANS_RING_AHEAD == 3)
+  {
     ring_request(sw, r, c, 3);
+    r.vm++;
+  }
+  r.seq3 = r.vm;
 }
 
 // chunks 0 and 1 (and the mirror) have landed: ring_begin issues {chunk 0, mirror, chunk 1, chunk 2 [, chunk 3]} and anything
@@ -240,9 +253,52 @@ __device__ __forceinline__ void ring_advance(const StreamWin &sw, Ring &r, const
   {
     r.k++;
     ring_request(sw, r, c, r.k + HSRANS_RING_AHEAD);
+    r.vm += ((r.k + HSRANS_RING_AHEAD) & (kRingSlots - 1)) == 0 ? 2 : 1;
+    r.seq1 = r.seq2;
+    r.seq2 = r.seq3;
+    r.seq3 = r.vm;
+    if (HSRANS_RING_AHEAD == 2)
+      r.seq2 = r.vm;
     // chunk k+1 has landed: AHEAD 2: see the invariant above (the request just issued and a store are younger); AHEAD 3: the
     // requests for k+2 and k+3 are both younger than the one for k+1, whatever the stores do
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  }
+}
+
+// wait until at most n vector-memory operations are outstanding, n rounded DOWN to one of a few immediates (s_waitcnt takes no
+// register operand; waiting for fewer outstanding operations than allowed is only stricter)
+__device__ __forceinline__ void wait_vm_at_most(uint32_t n)
+{
+  if (n >= 8)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n >= 6)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n >= 4)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n >= 2)
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (n == 1)
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// The same with the exact wait (for paths whose stores are counted in r.vm: run_groups_impl<FULL>): with vmcnt(2) the wave also
+// waits for the request of chunk k+2 — issued one chunk ago — and for every store in between, which makes a third chunk in
+// flight worthless; vmcnt(vm - seq1) waits for chunk k+1 and nothing younger.
+__device__ __forceinline__ void ring_advance_exact(const StreamWin &sw, Ring &r, const WaveCtx &c)
+{
+  if ((r.cur >> (r.clog - 1)) > r.k)
+  {
+    r.k++;
+    ring_request(sw, r, c, r.k + HSRANS_RING_AHEAD);
+    r.vm += ((r.k + HSRANS_RING_AHEAD) & (kRingSlots - 1)) == 0 ? 2 : 1;
+    r.seq1 = r.seq2;
+    r.seq2 = r.seq3;
+    r.seq3 = r.vm;
+    if (HSRANS_RING_AHEAD == 2)
+      r.seq2 = r.vm;
+    wait_vm_at_most(r.vm - r.seq1);
   }
 }
 
@@ -493,11 +549,17 @@ __device__ __forceinline__ void run_groups_impl(uint32_t &x, const StreamWin &sw
     const uint32_t acc = pack4<kSymByte>(e0, e1, e2, e3, ol);
     uint8_t *row_base = c.out + o; // wave-uniform
     if (FULL) // scalar base + 32-bit lane offset: no 64-bit address arithmetic per store (the compiler's form adds one v_lshl_add_u64 per 4 groups)
-      HSRANS_STORE_U32_SADDR(row_base, ol.store_off, acc);
+    {
+      HSRANS_STORE_U32_SADDR((uint8_t *)uni64((uint64_t)(uintptr_t)row_base), ol.store_off, acc); // (uni64: the asm needs the base in an SGPR pair whatever the compiler thinks of its uniformity)
+      r.vm++;
+    }
     else if (act)
       HSRANS_STORE_U32((uint32_t *)(row_base + ol.store_off), acc);
     o += 4 * S;
-    ring_advance(sw, r, c);
+    if (FULL)
+      ring_advance_exact(sw, r, c);
+    else
+      ring_advance(sw, r, c);
   }
   const uint32_t p = lane_to_byte(c.lane);
   for (; steps > 0; steps--)
@@ -817,7 +879,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
   const uint32_t cls = half * 4 + wave_in_wg / per_class;
   const uint32_t q0 = pa.run_len[cls];
   const uint32_t c_first = pa.half_base[half] + (blk - half * first_half) * pa.wg_chains[half] + pa.class_off[cls] + (wave_in_wg % per_class) * q0;
-  const bool host_table = (MODE == kModePack64 || MODE == kModeCoarse) && pa.table != nullptr; // kModeCoarse is host-built only
+  const bool host_table = (MODE == kModePack64 || MODE == kModeCoarse || MODE == kModeSpill) && pa.table != nullptr; // kModeCoarse / kModeSpill are host-built only
   if (!host_table) // the in-kernel build borrows ring space: it has to come before the first stream request
     build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
   if (q0 != 0)
@@ -826,7 +888,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
   {
     // the table was built on the host from the plan's histogram copy: one coalesced 16 B load + LDS store per thread,
     // while the first wave checks that the stream really carries that histogram (else: status, as a failed sum check)
-    const uint32_t entries = table_bytes_for(MODE, c.bits) / 8;
+    const uint32_t entries = table_bytes_for(MODE, c.bits) / 8; // (0 for the spilled table: it stays in global memory)
     for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
       *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
     if (blockIdx.x == 0 && threadIdx.x < 64)
@@ -1134,7 +1196,7 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
   const uint32_t cls = half * 4 + wave_in_wg / per_class;
   const uint32_t q0 = pa.run_len[cls];
   const uint32_t c_first = pa.half_base[half] + (blk - half * first_half) * pa.wg_chains[half] + pa.class_off[cls] + (wave_in_wg % per_class) * 2 * q0;
-  const bool host_table = MODE == kModePack64 && pa.table != nullptr;
+  const bool host_table = (MODE == kModePack64 || MODE == kModeSpill) && pa.table != nullptr;
   if (!host_table)
     build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
 
@@ -1164,7 +1226,7 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
     {
       // the table was built on the host from the plan's histogram copy: one coalesced 16 B load + LDS store per thread
       // (see run_persistent for the check of the copy against the stream)
-      const uint32_t entries = 1u << c.bits;
+      const uint32_t entries = MODE == kModeSpill ? 0 : 1u << c.bits;
       for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
         *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
       __syncthreads();
@@ -1203,7 +1265,7 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
     run(c_first, c_first + q0, c_first + 2 * q0, host_table);
   else if (host_table)
   {
-    const uint32_t entries = 1u << c.bits;
+    const uint32_t entries = MODE == kModeSpill ? 0 : 1u << c.bits;
     for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
       *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
     __syncthreads();
@@ -1536,15 +1598,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
     c.gtable = kp.pa.table;
     if (kp.pa.pieces != nullptr)
     {
-      // (the coarse + fine tables are only ever used for 64-state plans: no pair variants of that mode)
-      if (kp.pa.interval == 0)
-      {
-        if (MODE != kModeCoarse && c.S == 32)
-          run_direct_pair<MODE>(c, kp, waves, chain);
-        else
-          run_direct<MODE>(c, kp, waves, chain);
-      }
-      else if (MODE != kModeCoarse && c.S == 32)
+      // (the coarse + fine tables are only ever used for 64-state plans: no pair variants of that mode; one-chain-per-wave
+      // plans, interval == 0, have a kernel of their own: k_decode_direct)
+      if (MODE != kModeCoarse && c.S == 32)
         run_persistent_pair<MODE>(c, kp, waves, chain);
       else
         run_persistent<MODE>(c, kp, waves, chain);
@@ -1581,6 +1637,45 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
     else if (chain < pv.hdr->n_chains)
       run_planned_chain<MODE, false>(c, pv, chain, kp);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The kernel of the one-chain-per-wave launches (run_direct / run_direct_pair): a kernel of its own so that the headline path
+// gets its own register allocation and inlining budget instead of sharing k_decode's with five other launch shapes.
+// LDS: [waves x ring][table] as k_decode<MODE, true>.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_decode_direct(KParams kp)
+{
+  extern __shared__ u32x4 smem_v[];
+  uint8_t *smem = (uint8_t *)smem_v;
+  const uint32_t waves = blockDim.x >> 6;
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  WaveCtx c;
+  c.stream = kp.stream;
+  c.stream_len = kp.stream_len;
+  c.stream_lo = kp.stream_lo;
+  c.out = kp.out;
+  c.out_cap = kp.out_cap;
+  c.status = kp.status;
+  c.bits = kp.pa.bits;
+  c.S = kp.pa.S;
+  c.lane = threadIdx.x & 63;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gshift) : "s"(c.bits > 12 ? c.bits - 12 : 0));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gmask) : "s"(c.bits > 12 ? (1u << (c.bits - 12)) - 1 : 0));
+  c.rings = smem + wave * kWaveRingBytes;
+  c.table = smem + waves * kWaveRingBytes;
+  c.table_b = c.table;
+  c.gtable = kp.pa.table;
+  c.scratch_cnt = (uint16_t *)smem; // wave 0's ring (no request in flight while a table is built)
+  c.scratch_cum = (uint16_t *)(smem + 512);
+  const uint32_t chain = blockIdx.x * waves + wave;
+  if (MODE != kModeCoarse && c.S == 32)
+    run_direct_pair<MODE>(c, kp, waves, chain);
+  else
+    run_direct<MODE>(c, kp, waves, chain);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1871,6 +1966,211 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// ONE chain, as fast as one chain goes (k_decode_single): a raw stream without an index is a single dependent chain — one
+// wavefront, and its speed is the length of the dependency chain of one group.  In k_decode that chain has TWO LDS round trips
+// (table gather, then — after compare, prefix count and address — the word read, whose result the next gather needs):
+// ~200 cycles per 64 symbols = 0.65 GB/s.  Here a second wavefront (the producer) runs ahead through the word stream and
+// leaves, for every word k, {table entry of (word_k & mask), word_k} in an LDS ring: a lane that renormalises reads its word
+// AND the table entry its next step needs in one access while the other lanes gather their next entry from nx, so a group is
+// ONE LDS round trip long: mad -> compare -> prefix count -> address -> LDS -> merge.
+// Workgroup = 2 waves: wave 0 decodes, wave 1 produces.  LDS: [table 8 << bits][ring (entries + 64) x 16 B][flags 64 B].
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_decode_single(KParams kp)
+{
+  extern __shared__ u32x4 smem_v[];
+  uint8_t *smem = (uint8_t *)smem_v;
+  const SingleArgs &a = kp.single;
+  const uint32_t wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t table_bytes = 8u << a.bits;
+  const uint32_t R = a.ring_entries; // power of two
+  uint8_t *table = smem;
+  uint8_t *ew = smem + table_bytes;
+  // [0] words produced, [1] words released, [2] consumer done — LDS words, read with ds_read and made wave-uniform
+  volatile __attribute__((address_space(3))) uint32_t *flags =
+      (volatile __attribute__((address_space(3))) uint32_t *)(uintptr_t)lds_address(ew + (R + 64) * 16);
+  WaveCtx c{};
+  c.stream = kp.stream;
+  c.stream_len = kp.stream_len;
+  c.stream_lo = kp.stream_lo;
+  c.status = kp.status;
+  c.bits = a.bits;
+  c.S = a.S;
+  c.lane = lane;
+  c.table = table;
+  c.scratch_cnt = (uint16_t *)ew; // the ring area doubles as the table builder's scratch
+  c.scratch_cum = (uint16_t *)(ew + 512);
+  if (threadIdx.x < 3)
+    flags[threadIdx.x] = 0;
+  build_table<kModePack64, true>(c, a.hist_off, threadIdx.x, 128); // a bad histogram raises the status bit; the output is then discarded by the host
+  __syncthreads();
+  const uint32_t mask = (1u << a.bits) - 1;
+  const uint32_t ew_lds = uni(lds_address(ew)), table_lds = uni(lds_address(table));
+
+  if (wave == 1)
+  {
+    // ---- producer: 512 words per round = 16 bytes per lane (one round of loads in flight), 8 table gathers, 8 ring writes ----
+    const uint8_t *src = kp.stream + a.words_off;
+    auto fetch = [&](uint64_t first_word) {
+      const uint64_t byte = (first_word + 8 * lane) * 2;
+      uint32_t w[8];
+#pragma unroll
+      for (uint32_t j = 0; j < 8; j++) // the stream is only 2-byte aligned; past its end words read as zero (like the bounds-checked ring)
+        w[j] = a.words_off + byte + 2 * j + 2 <= kp.stream_len ? *(const uint16_t *)(src + byte + 2 * j) : 0;
+      const u32x4 v = {w[0] | (w[1] << 16), w[2] | (w[3] << 16), w[4] | (w[5] << 16), w[6] | (w[7] << 16)};
+      return v;
+    };
+    uint32_t produced = 0, released_seen = 0; // 32-bit word counters, compared by difference
+    uint64_t next_word = 0;
+    // four rounds of loads in flight: a round is consumed in ~2.5 us, a load from HBM takes about as long
+    u32x4 q0 = fetch(0), q1 = fetch(512), q2 = fetch(1024), q3 = fetch(1536);
+    next_word = 2048;
+    auto round = [&](u32x4 &blk) -> bool {
+      while (produced + 512 - released_seen > R) // never more than the ring ahead of what the consumer has released
+      {
+        if (uni(flags[2]) != 0)
+          return false;
+        released_seen = uni(flags[1]);
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const u32x4 cur = blk;
+      blk = fetch(next_word); // refill this slot: in flight for the next three rounds
+      next_word += 512;
+      const uint32_t w[8] = {cur.x & 0xFFFF, cur.x >> 16, cur.y & 0xFFFF, cur.y >> 16, cur.z & 0xFFFF, cur.z >> 16, cur.w & 0xFFFF, cur.w >> 16};
+      uint2 e[8];
+#pragma unroll
+      for (uint32_t j = 0; j < 8; j++)
+        e[j] = ((const uint2 *)table)[w[j] & mask];
+#pragma unroll
+      for (uint32_t j = 0; j < 8; j++)
+      {
+        const uint32_t idx = (produced + 8 * lane + j) & (R - 1);
+        const u32x4 t = {e[j].x, e[j].y, w[j], 0};
+        *(u32x4 *)(ew + idx * 16) = t;
+        if (idx < 64) // the first 64 entries once more behind the end: a group's reads never wrap
+          *(u32x4 *)(ew + (idx + R) * 16) = t;
+      }
+      produced += 512;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0)
+        flags[0] = produced;
+      return true;
+    };
+    while (round(q0) && round(q1) && round(q2) && round(q3))
+    {
+    }
+    return;
+  }
+
+  // ---- consumer: wave 0 ----
+  const uint32_t S = a.S;
+  const bool act_lane = lane < S;
+  const unsigned long long act = __builtin_amdgcn_ballot_w64(act_lane);
+  uint32_t x = act_lane ? kp.single_states[lane] : 0;
+  const OutLanes ol = out_lanes(lane, S);
+  uint32_t cur = 0, produced_seen = 0; // words
+  uint32_t refreshes = 0, starved = 0;  // diagnostics (HSRANS_DEBUG_STAMPS): reads of the producer's count / of those, how many found the ring short
+  const uint64_t t_begin = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  const uint64_t c_begin = kp.stamps ? __builtin_amdgcn_s_memtime() : 0; // shader clock: what does a lone wave run at?
+  uint64_t o = uni64(a.out_off);
+  uint32_t v_mask, v_bits;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v_mask) : "s"(mask));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v_bits) : "s"(a.bits));
+  unsigned long long e64 = *(const unsigned long long *)(table + (uint64_t)(x & mask) * 8); // entry of the start state
+  // one group: returns the table word whose byte 3 is this lane's symbol; `lanes` = the lanes that take part
+  // the ring must hold the words the next groups can take (64 each); checked on a cached count: one LDS read per ~R words.
+  // A lone wave issues one instruction per ~4-5 cycles whatever its kind, so even this scalar check is worth hoisting: with the
+  // big ring it is made once per 4 groups (the producer can always get 256 words ahead there), else once per group.
+  auto need_words = [&](uint32_t n) {
+    while (produced_seen - cur < n)
+    {
+      produced_seen = uni(flags[0]);
+      refreshes++;
+      if (produced_seen - cur < n)
+      {
+        __builtin_amdgcn_s_sleep(1);
+        starved++;
+      }
+    }
+  };
+  const bool big_ring = R >= 2048;
+  auto step = [&](unsigned long long lanes) -> uint32_t {
+    if (!big_ring)
+      need_words(64);
+    const uint32_t ex = (uint32_t)e64, ey = (uint32_t)(e64 >> 32);
+    const uint32_t nx = __umul24(x >> v_bits, ex) + ey;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(nx < kConsume) & lanes;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+    uint32_t ew_addr, tab_addr;
+    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(ew_addr) : "v"(rank), "s"(ew_lds + ((cur & (R - 1)) << 4)));
+    asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(tab_addr) : "v"(nx & v_mask), "s"(table_lds));
+    uint32_t w;
+    x = nx;
+    // lanes that renormalise: {entry, word} from the ring; the others: the entry of nx from the table — complementary EXEC
+    // masks, the same destination registers, all three reads in flight together; then x = nx << 16 | w on the first set
+    asm volatile("s_mov_b64 exec, %5\n\t"
+                 "ds_read_b64 %0, %3\n\t"
+                 "ds_read_b32 %1, %3 offset:8\n\t"
+                 "s_andn2_b64 exec, %6, %5\n\t"
+                 "ds_read_b64 %0, %4\n\t"
+                 "s_mov_b64 exec, %5\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_lshl_or_b32 %2, %2, 16, %1\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "=&v"(e64), "=&v"(w), "+v"(x)
+                 : "v"(ew_addr), "v"(tab_addr), "s"(m), "s"(lanes)
+                 : "memory");
+    cur += (uint32_t)__popcll(m);
+    return ex;
+  };
+  uint32_t steps = a.steps;
+  for (; steps >= 4; steps -= 4)
+  {
+    if (big_ring)
+      need_words(256);
+    const uint32_t e0 = step(act), e1 = step(act), e2 = step(act), e3 = step(act);
+    const uint32_t acc = pack4<3>(e0, e1, e2, e3, ol);
+    if (act_lane)
+      HSRANS_STORE_U32((uint32_t *)(kp.out + o + ol.store_off), acc);
+    o += 4 * S;
+    if (lane == 0)
+      flags[1] = cur; // released: the producer may overwrite everything before the cursor
+  }
+  const uint32_t p = lane_to_byte(lane);
+  for (; steps > 0; steps--)
+  {
+    if (big_ring)
+      need_words(64);
+    const uint32_t e = step(act);
+    if (act_lane)
+      kp.out[o + p] = (uint8_t)(e >> 24);
+    o += S;
+    if (lane == 0)
+      flags[1] = cur;
+  }
+  if (a.tail) // the final partial group: only lanes whose byte exists take part (rANS32x64_16w.cpp:252-280)
+  {
+    if (big_ring)
+      need_words(64);
+    const bool in_tail = act_lane && p < a.tail;
+    const uint32_t e = step(__builtin_amdgcn_ballot_w64(in_tail));
+    if (in_tail)
+      kp.out[o + p] = (uint8_t)(e >> 24);
+  }
+  if (lane == 0)
+    flags[2] = 1;
+  if (kp.stamps && lane == 0)
+  {
+    kp.stamps[0] = t_begin;
+    kp.stamps[1] = refreshes;
+    kp.stamps[2] = starved;
+    kp.stamps[3] = __builtin_amdgcn_s_memrealtime();
+    kp.stamps[4] = a.steps;
+    kp.stamps[5] = __builtin_amdgcn_s_memtime() - c_begin;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // K2: mt_ header-chain walk on the device (one wavefront; lane 0 steers, all lanes copy states / sum counts).
 // Mirrors hsrans::plan_build's mt_ branch step by step, which mirrors mt_rANS32x64_16w_decode.cpp:41-96.
 // plan == nullptr: count only.  Otherwise plan is a blob sized for `n_chains` single-piece chains: the kernel fills
@@ -2069,6 +2369,7 @@ static uint32_t g_direct_dyn_permille = 0;  // HSRANS_DIRECT_DYN_PERMILLE (measu
 static uint32_t g_direct_dyn_groups = 32;   // HSRANS_DIRECT_DYN_GROUPS (multiple of 4)
 
 static void read_tuning_once();
+static uint32_t g_single_fast = 1; // HSRANS_SINGLE_FAST: 0 = un-indexed raw streams on the general kernel (one wave, two LDS round trips per group)
 static uint32_t g_dual = 1; // HSRANS_DUAL: 0 = never run two chains per wave (k_decode_dual), 1 = where it pays (default), 2 = for every width (experiment)
 // the one-chain-per-wave weights of the dual kernel's launches (one 16-wave workgroup per CU, two chains per wave)
 static uint32_t g_dual_weights[8] = {1105, 1052, 977, 867, 1104, 1051, 976, 867};
@@ -2205,6 +2506,8 @@ static void read_tuning_once()
     g_private_pair = (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_DUAL"))
     g_dual = (uint32_t)atoi(e);
+  if (const char *e = getenv("HSRANS_SINGLE_FAST"))
+    g_single_fast = (uint32_t)atoi(e);
   read_weights("HSRANS_DUAL_WEIGHTS", g_dual_weights);
   if (const char *e = getenv("HSRANS_DIRECT_DYN_PERMILLE"))
     g_direct_dyn_permille = (uint32_t)atoi(e) > 500 ? 500 : (uint32_t)atoi(e);
@@ -2229,7 +2532,8 @@ hipError_t prepare_kernels(DeviceGeom *geom)
       if (e != hipSuccess)
         return e;
     }
-  for (KernelFn fn : {(KernelFn)k_decode_dual<kModePack64>, (KernelFn)k_decode_dual<kModeCoarse>})
+  for (KernelFn fn : {(KernelFn)k_decode_single, (KernelFn)k_decode_dual<kModePack64>, (KernelFn)k_decode_dual<kModeCoarse>, (KernelFn)k_decode_direct<kModePack>, (KernelFn)k_decode_direct<kModePackM1>,
+                      (KernelFn)k_decode_direct<kModeTwoLevel>, (KernelFn)k_decode_direct<kModePack64>, (KernelFn)k_decode_direct<kModeCoarse>, (KernelFn)k_decode_direct<kModeSpill>})
   {
     const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
     if (e != hipSuccess)
@@ -2441,7 +2745,37 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
     if ((uint64_t)(longest ? longest : 1) * kp.pa.interval * h.states * 2 >= 0xFFFF0000ull)
       return hipErrorInvalidValue;
   }
-  KernelFn fn = L.dual ? (L.mode == kModeCoarse ? (KernelFn)k_decode_dual<kModeCoarse> : (KernelFn)k_decode_dual<kModePack64>) : kernel_for(L.mode, L.shared);
+  if (kp.single.valid && !index_pass && g_single_fast)
+  {
+    // one chain of one piece (a raw stream without an index): the two-wave latency kernel
+    const uint32_t lds = (8u << h.bits) + (kp.single.ring_entries + 64) * 16 + 64;
+    if (info)
+    {
+      *info = LaunchInfo{};
+      info->grid = 1;
+      info->block = 128;
+      info->lds_bytes = lds;
+      info->waves_per_block = 2;
+      info->chains = 1;
+      info->table_mode = kModePack64;
+      info->chains_per_wave = 1;
+    }
+    hipLaunchKernelGGL(k_decode_single, dim3(1), dim3(128), lds, stream, kp);
+    return hipGetLastError();
+  }
+  KernelFn fn = kernel_for(L.mode, L.shared);
+  if (L.dual)
+    fn = L.mode == kModeCoarse ? (KernelFn)k_decode_dual<kModeCoarse> : (KernelFn)k_decode_dual<kModePack64>;
+  else if (persistent && kp.pa.interval == 0 && L.shared)
+    switch (L.mode)
+    {
+    case kModePack: fn = k_decode_direct<kModePack>; break;
+    case kModePackM1: fn = k_decode_direct<kModePackM1>; break;
+    case kModeTwoLevel: fn = k_decode_direct<kModeTwoLevel>; break;
+    case kModeCoarse: fn = k_decode_direct<kModeCoarse>; break;
+    case kModeSpill: fn = k_decode_direct<kModeSpill>; break;
+    default: fn = k_decode_direct<kModePack64>; break;
+    }
   if (info)
   {
     info->grid = grid;

@@ -219,7 +219,7 @@ size_t hsrans_index_build_at(hsrans_ctx *ctx, int container, int states, uint32_
  * inside the context (keyed by the plan's address, size and checksum).
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct hsrans_hpipe hsrans_hpipe;
-int hsrans_hpipe_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, uint32_t n_slices, hsrans_hpipe **out_pipe);
+int hsrans_hpipe_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, uint32_t n_slices /* 0 = by size: 2..8 slices of >= 256 MiB */, hsrans_hpipe **out_pipe);
 size_t hsrans_hpipe_decode(hsrans_hpipe *pipe, const uint8_t *in, size_t in_length, uint8_t *out, size_t out_capacity);
 void hsrans_hpipe_destroy(hsrans_hpipe *pipe);
 size_t hsrans_decode_host_pipelined(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out,

@@ -123,3 +123,33 @@ def test_config5_eight_gib_of_mt_streams_through_the_pipelined_host_path(gpu_ctx
         dec.close()
         del dec, dplan, host_stream
     print(f"\n8 x 2^30 B, pipelined host decode: {8 * n / total_s / 1e9:.1f} GB/s decoded (PCIe-inclusive)")
+
+
+def test_config3_spilled_table_and_single_chain_variants_are_bit_exact():
+    """The comparison builds of BASELINE config 3 (decode table left in global memory: HSRANS_TABLE_SPILL=1; no two-chain kernel:
+    HSRANS_DUAL=0; un-indexed streams on the general kernel: HSRANS_SINGLE_FAST=0) must be as exact as the defaults.  The
+    library reads these knobs once per process, hence the child processes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')
+import hypersonic_rans_amd as H
+from hypersonic_rans_amd import synth
+d = synth.enwik8_shaped(3_000_001, seed=9)
+ctx = H.Context(0)
+for S in (64, 32):
+    for bits in (11, 13, 15):
+        for kw in (dict(index_groups=H.index_boundaries(S, bits, d.size, ctx)), dict(index_interval=32)):
+            s, plan = H.encode(H.RAW, S, bits, d, **kw)
+            got = ctx.decode(H.RAW, S, bits, s, plan=plan)
+            assert np.array_equal(got, d), (S, bits, list(kw))
+        got = ctx.decode(H.RAW, S, bits, H.encode(H.RAW, S, bits, d[:200_003]))  # no index: one chain
+        assert np.array_equal(got, d[:200_003]), (S, bits, 'single chain')
+print('ok')
+""" % (root, root)
+    for env in ({"HSRANS_TABLE_SPILL": "1"}, {"HSRANS_DUAL": "0"}, {"HSRANS_SINGLE_FAST": "0"}, {"HSRANS_DUAL": "2"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])

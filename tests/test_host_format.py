@@ -32,6 +32,35 @@ def test_dropin_cpp_names_are_exported():
                 enc = f"hsrans_hip::rANS32x{S}_16w_encode_scalar_{bits}(" if cont == "" else f"hsrans_hip::{cont}rANS32x{S}_16w_encode_{bits}("
                 assert enc in out
             assert f"hsrans_hip::{cont}rANS32x{S}_16w_capacity(" in out
+            for bits in range(10, 16):  # round 2: runtime dispatch, sidecar index, the reference's thread-pool signature
+                for suffix in ("decode_auto", "index_capacity", "encode_with_index", "decode_hip_with_index", "decode_hip_pipelined_with_index"):
+                    assert f"hsrans_hip::{cont}rANS32x{S}_16w_{suffix}_{bits}(" in out, (cont, S, suffix, bits)
+            assert f"hsrans_hip::mt_rANS32x{S}_16w_decode_mt_11(unsigned char const*, unsigned long, unsigned char*, unsigned long, thread_pool*)" in out
+
+
+def test_auto_entries_decode_without_a_gpu(oracle):
+    """`*_decode_auto_N` (runtime dispatch, the role of block_rANS32x64_decode_wrapper): a single-chain stream goes to this library's
+    host SIMD decoder, so the drop-in works — and is not slower than the reference's CPU path — with or without a GPU; without one
+    mt_ streams go to the host decoder on all cores.  Called through the C++ names exactly as main.cpp would (mangled symbols)."""
+    import ctypes
+
+    import torch
+
+    out = subprocess.run(["nm", "-D", H.lib_path()], capture_output=True, text=True, check=True).stdout
+    lib = ctypes.CDLL(H.lib_path())
+    d = synth.enwik8_shaped(300_000, seed=5)
+    for cont, container in (("", H.RAW), ("block_", H.BLOCK), ("mt_", H.MT)):
+        if container == H.MT and torch.cuda.is_available():
+            continue  # with a GPU that entry launches kernels: covered by the -m gpu harness test
+        sym = next(l.split()[-1] for l in out.splitlines() if f"{cont}rANS32x64_16w_decode_auto_12E" in l and (cont != "" or "block_" not in l and "mt_" not in l))
+        fn = getattr(lib, sym)
+        fn.restype = ctypes.c_size_t
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+        s = H.encode(container, 64, 12, d)
+        got = np.full(d.size, 0xCC, np.uint8)
+        assert fn(s.ctypes.data, s.size, got.ctypes.data, d.size) == d.size
+        assert np.array_equal(got, d), cont
+        assert fn(s.ctypes.data, s.size, got.ctypes.data, d.size - 1) == 0  # outCapacity too small: 0, like the reference
 
 
 def test_no_gpu_means_loud_failure():

@@ -42,9 +42,9 @@ def test_shared_table_decode_occupancy():
     kernels = _report("hsrans_kernels")
     seen = 0
     for name, r in kernels.items():
-        m = re.search(r"k_decodeILi(\d)ELb1E", name)
-        if not m or int(m.group(1)) not in (0, 1, 3, 4, 5):
+        m = re.search(r"k_decodeILi(\d)ELb1E", name) or re.search(r"k_decode_directILi(\d)E", name) or re.search(r"k_decode_dualILi(\d)E", name)
+        if not m or ("k_decodeI" in name and int(m.group(1)) not in (0, 1, 3, 4, 5)):
             continue
         seen += 1
         assert r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] == 8, (name, r)
-    assert seen == 5
+    assert seen == 5 + 6 + 2

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Everything DESIGN.md §8 quotes, in one go on the GPU box:  bash tools/round_measure.sh <tag>   (outputs under gpurun_out/<tag>/)
+set -u
+TAG=${1:-r02}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
+python bench.py --workload sharded --steps 10 > $OUT/bench_sharded_line.json 2> $OUT/bench_sharded.err
+python tools/sweep_configs.py > $OUT/config_sweep.jsonl 2> $OUT/sweep.err
+HSRANS_TABLE_SPILL=1 python tools/sweep_configs.py --only-raw --tag "HSRANS_TABLE_SPILL=1 (tables left in global memory)" >> $OUT/config_sweep.jsonl 2>> $OUT/sweep.err
+HSRANS_DUAL=0 python tools/sweep_configs.py --only-raw --tag "HSRANS_DUAL=0 (one chain per wave at 13-15 bits)" >> $OUT/config_sweep.jsonl 2>> $OUT/sweep.err
+python - <<'PY' > /tmp/zipf100.bin.log 2>&1
+import sys; sys.path.insert(0, '.')
+from hypersonic_rans_amd import synth
+synth.enwik8_shaped(100_000_000).tofile('/tmp/zipf100.bin')
+PY
+hypersonic_rans_amd/bin/hsrans_harness /tmp/zipf100.bin --bits 11 --runs 2 --decode-runs 8 --test > $OUT/harness_100mb_11bit.txt 2>&1
+hypersonic_rans_amd/bin/hsrans_harness /tmp/zipf100.bin --bits 14 --only "(raw)" --runs 1 --decode-runs 8 --test > $OUT/harness_100mb_14bit_raw.txt 2>&1
+python tools/host_pipeline_rate.py > $OUT/host_pipeline_1gib.jsonl 2> $OUT/pipeline.err
+python tools/encode_rate.py > $OUT/encode_rate_100mb.jsonl 2> $OUT/encode.err
+python tools/cold_cache.py > $OUT/cold_cache.jsonl 2> $OUT/cold.err
+timeout 300 tools/microbench/stream_pattern > $OUT/stream_pattern.txt 2>&1
+python tools/stamps.py --index wave 2>/dev/null | grep -v amdgpu > $OUT/stamps_wave_warm.txt
+python tools/stamps.py --index wave --cold 4 2>/dev/null | grep -v amdgpu > $OUT/stamps_wave_cold.txt
+tail -c 400 $OUT/bench_line.json; echo; tail -3 $OUT/harness_100mb_11bit.txt
