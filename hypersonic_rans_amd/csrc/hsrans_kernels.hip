@@ -37,6 +37,9 @@ constexpr uint32_t kChunkBytes = 512; // 32 lanes x 16 B
 constexpr uint32_t kRingBytes = kRingSlots * kChunkBytes; // 2 KiB
 // (the mirror is 128 bytes: the first 64 words of the ring, copied behind its end)
 constexpr uint32_t kWaveRingBytes = kRingBytes + 256;     // per wave (ring + mirror, 256-byte granular)
+// the hand-scheduled loop of k_decode_direct (run_groups_fast) keeps its read cursor as a plain LDS address that is only
+// re-based every 4 groups, so it can run up to one chunk past the ring's end: the mirror there is a whole chunk
+constexpr uint32_t kFastRingBytes = kRingBytes + kChunkBytes;
 constexpr uint32_t kConsume = 1u << 15; // rans.h:8 DecodeConsumePoint16
 
 // decode-table layouts
@@ -130,6 +133,18 @@ struct WaveCtx
 // never weaker.  The loads are issued from asm, so the compiler never tracks them and never parks the decode loop on
 // vmcnt(0).  (Requesting one chunk further ahead, which makes the bound independent of the stores, measured 7 % slower.)
 // ---------------------------------------------------------------------------------------------------------------
+// cache-policy bits of the stream requests (experiments: -DHSRANS_STREAM_LOAD_POLICY=1 nt, 2 sc1, 3 sc0 sc1).  Measured on the
+// 100 MB headline decode: sc1 / sc0 sc1 change nothing; nt makes the requests bypass the Infinity Cache, i.e. even a replayed
+// stream comes from HBM every time (58.6 us against 44.0 us) — the default (no bits) is right.
+#if !defined(HSRANS_STREAM_LOAD_POLICY) || HSRANS_STREAM_LOAD_POLICY == 0
+#define HSRANS_STREAM_LOAD_FLAGS ""
+#elif HSRANS_STREAM_LOAD_POLICY == 1
+#define HSRANS_STREAM_LOAD_FLAGS " nt"
+#elif HSRANS_STREAM_LOAD_POLICY == 2
+#define HSRANS_STREAM_LOAD_FLAGS " sc1"
+#else
+#define HSRANS_STREAM_LOAD_FLAGS " sc0 sc1"
+#endif
 struct StreamWin // the stream as the ring's requests see it
 {
   u32x4 rs;      // buffer descriptor (SGPRs): base = stream + `base`, num_records = bytes up to `limit`
@@ -143,6 +158,7 @@ struct Ring
   uint32_t cur;   // next word to read, counted from voff0 (wave-uniform)
   uint32_t lds;   // LDS byte address of the ring (what M0 / ds_read take)
   uint32_t clog;  // log2 of the chunk size in bytes: 9 (32 lanes x 16 B; 64-state chains) or 8 (16 lanes; paired 32-state chains)
+  uint32_t mirror_lanes; // EXEC mask of the mirror request that goes with slot 0: 0xFF (128 B: a group reads <= 64 words) or all 32 lanes (kFastRingBytes)
   // Exact waits (ring_advance_exact): `vm` counts the vector-memory instructions this wave has issued through this file's asm
   // (stream requests, the counted output stores); seqN = its value right after the request for chunk k+N.  Vector-memory
   // operations of a wave complete in issue order, so "chunk k+1 has landed" == at most (vm - seq1) operations outstanding.
@@ -151,10 +167,11 @@ struct Ring
 };
 
 // clog = 9: 2 KiB ring + 128 B mirror (a group reads <= 64 words); clog = 8: 1 KiB ring + 64 B mirror (<= 32 words)
-__device__ __forceinline__ void ring_bind(Ring &r, const uint8_t *lds_ring, uint32_t clog = 9)
+__device__ __forceinline__ void ring_bind(Ring &r, const uint8_t *lds_ring, uint32_t clog = 9, bool whole_chunk_mirror = false)
 {
   r.lds = uni(lds_address(lds_ring));
   r.clog = clog;
+  r.mirror_lanes = whole_chunk_mirror ? 0xFFFFFFFFu : clog == 9 ? 0xFFu : 0xFu;
 }
 __device__ __forceinline__ uint32_t ring_bytes(const Ring &r) { return kRingSlots << r.clog; }
 
@@ -164,14 +181,14 @@ __device__ __forceinline__ void ring_request(const StreamWin &sw, const Ring &r,
   const uint32_t slot = chunk & (kRingSlots - 1);
   const uint32_t dst = uni(r.lds + (slot << r.clog));
   const uint32_t lanes = r.clog == 9 ? 0xFFFFFFFFu : 0xFFFFu; // 32 or 16 lanes x 16 B
-  asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds\n\ts_mov_b64 exec, -1"
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen" HSRANS_STREAM_LOAD_FLAGS " lds\n\ts_mov_b64 exec, -1"
                :
                : "v"(voff), "s"(dst), "s"(sw.rs), "s"(lanes)
                : "memory");
   if (slot == 0) // wave-uniform: the ring's first 128 (64) bytes once more, behind its end (lanes 0..7 / 0..3)
-    asm volatile("s_mov_b32 m0, %1\n\ts_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds\n\ts_mov_b64 exec, -1"
+    asm volatile("s_mov_b32 m0, %1\n\ts_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen" HSRANS_STREAM_LOAD_FLAGS " lds\n\ts_mov_b64 exec, -1"
                  :
-                 : "v"(voff), "s"(uni(r.lds + ring_bytes(r))), "s"(sw.rs), "s"(r.clog == 9 ? 0xFFu : 0xFu)
+                 : "v"(voff), "s"(uni(r.lds + ring_bytes(r))), "s"(sw.rs), "s"(r.mirror_lanes)
                  : "memory");
 }
 
@@ -184,6 +201,7 @@ __device__ __forceinline__ void win_open(StreamWin &sw, const WaveCtx &c, uint64
   limit = uni64(limit);
   if (limit > c.stream_len)
     limit = c.stream_len;
+  // (starting the requests on a 128-byte line instead was measured: no difference, warm or cold)
   const uint64_t a0 = pos & ~(uint64_t)15;
   // range in whole 16-byte lanes: a dwordx4 that straddles num_records is dropped as a whole, and a0 is 16-aligned
   // inside a 16-aligned allocation, so rounding up never leaves the page the last stream byte is on
@@ -490,6 +508,11 @@ __device__ __forceinline__ uint32_t group_step(uint32_t &x, Ring &r, const WaveC
   x = nx;
   asm volatile("s_mov_b64 exec, %2\n\tv_lshl_or_b32 %0, %0, 16, %1\n\ts_mov_b64 exec, -1" : "+v"(x) : "v"(w), "s"(m_all));
   r.cur += (uint32_t)__popcll(m);
+#if defined(HSRANS_EXTRA_SALU) // experiment: is the scalar unit (one instruction per cycle per CU, shared by the four SIMDs) a limiter?
+  uint32_t scratch_s = uni(c.bits);
+  for (int k = 0; k < 2 * HSRANS_EXTRA_SALU; k++)
+    asm volatile("s_add_u32 %0, %0, 1" : "+s"(scratch_s));
+#endif
   return e;
 }
 
@@ -570,6 +593,94 @@ __device__ __forceinline__ void run_groups_impl(uint32_t &x, const StreamWin &sw
     o += S;
   }
   ring_advance(sw, r, c);
+  o_ref = o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The headline loop, hand-scheduled (64 states, 8-byte table entries; k_decode_direct).  Measured on MI355X: the SCALAR unit is
+// a limiter of this kernel — one scalar instruction per cycle per CU, shared by the four SIMDs: two more s_add per group cost
+// +10 us per 100 MB (tools/build_variants.sh salu2 / salu4) — and the compiler's version of the group spends 11 scalar
+// instructions (cursor arithmetic with wrap, two EXEC writes, loop control).  Here a group costs 3:
+//   * the read cursor is a plain LDS byte address (s_bcnt1 + s_lshl1_add per group); it is re-based only when run_groups_fast
+//     looks at it every 4 groups, which is why the ring's mirror is a whole chunk (kFastRingBytes);
+//   * v_cmpx writes the renormalisation mask to VCC and to EXEC in one VALU instruction: rank, address, word read and merge then
+//     run under EXEC = renormalising lanes (the word read touches only those lanes' banks) and ONE s_mov restores EXEC.
+// Per group: 9 vector, 2 LDS, 3 scalar instructions (+ 2 s_waitcnt); the packing of the 4 symbols is inside the block as well.
+// ---------------------------------------------------------------------------------------------------------------
+#define HSRANS_FAST_GROUP(P0, P1)                                                                                                                    \
+  "v_and_b32 %[t], %[x], %[vmask]\n\t"                                                                                                               \
+  "v_lshl_add_u32 %[t], %[t], 3, %[stab]\n\t"                                                                                                        \
+  "ds_read_b64 v[" #P0 ":" #P1 "], %[t]\n\t"                                                                                                         \
+  "v_lshrrev_b32 %[x], %[vbits], %[x]\n\t"                                                                                                           \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
+  "v_mad_u32_u24 %[x], v" #P0 ", %[x], v" #P1 "\n\t"                                                                                                 \
+  "v_cmpx_gt_u32 vcc, %[lim], %[x]\n\t"                                                                                                              \
+  "s_nop 1\n\t"                                                                                                                                      \
+  "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"                                                                                                           \
+  "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"                                                                                                        \
+  "v_lshl_add_u32 %[t], %[t], 1, %[sa]\n\t"                                                                                                          \
+  "ds_read_u16 %[t], %[t]\n\t"                                                                                                                       \
+  "s_bcnt1_i32_b64 %[st], vcc\n\t"                                                                                                                   \
+  "s_lshl1_add_u32 %[sa], %[st], %[sa]\n\t"                                                                                                          \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
+  "v_lshl_or_b32 %[x], %[x], 16, %[t]\n\t"                                                                                                           \
+  "s_mov_b64 exec, -1\n\t"
+
+// four groups from state x; returns the dword of this lane's four symbols (byte t = group t), before the quad transpose
+__device__ __forceinline__ uint32_t fast_groups4(uint32_t &x, uint32_t &s_addr, const WaveCtx &c, uint32_t s_table)
+{
+  uint32_t acc, t, st;
+  asm volatile(HSRANS_FAST_GROUP(52, 53) HSRANS_FAST_GROUP(54, 55) HSRANS_FAST_GROUP(56, 57) HSRANS_FAST_GROUP(58, 59)
+               "v_perm_b32 %[acc], v54, v52, %[selp]\n\t"
+               "v_perm_b32 %[t], v58, v56, %[selp]\n\t"
+               "v_perm_b32 %[acc], %[t], %[acc], %[selq]"
+               : [x] "+v"(x), [sa] "+s"(s_addr), [acc] "=&v"(acc), [t] "=&v"(t), [st] "=&s"(st)
+               : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [stab] "s"(s_table), [lim] "s"(kConsume), [selp] "s"(0x0c0c0703u), [selq] "s"(0x05040100u)
+               : "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "vcc", "scc", "memory");
+  return acc;
+}
+
+// `steps` whole groups (64 states, kModePack64) with the loop above; what is left over (< 4 groups) goes to the ordinary path
+__device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o_ref, uint32_t &steps)
+{
+  uint64_t o = uni64(o_ref);
+  const OutLanes ol = out_lanes(c.lane, 64);
+  const uint32_t s_table = uni(lds_address(c.table));
+  // the cursor as an LDS address, and the address at which it enters the next chunk
+  uint32_t s_addr = uni(r.lds + ((r.cur << 1) & (kRingBytes - 1)));
+  uint32_t next_cross = uni(r.lds + (((r.k + 1) & (kRingSlots - 1)) << 9));
+  if (next_cross == r.lds)
+    next_cross += kRingBytes; // the chunk in slot 3 ends at the ring's end, not at its start
+  uint32_t words0 = r.cur; // to rebuild r.cur afterwards: words consumed = (bytes the address moved) / 2
+  uint32_t moved = 0;      // bytes the address has moved, including the re-basings
+  const uint32_t s_addr0 = s_addr;
+  for (; steps >= 4; steps -= 4)
+  {
+    const uint32_t acc = quad_transpose(fast_groups4(x, s_addr, c, s_table), ol.sel_a, ol.sel_b);
+    HSRANS_STORE_U32_SADDR((uint8_t *)uni64((uint64_t)(uintptr_t)(c.out + o)), ol.store_off, acc);
+    r.vm++;
+    o += 256;
+    if (s_addr >= next_cross) // entered the next chunk (at most one per 4 groups: they take <= 512 bytes)
+    {
+      r.k++;
+      next_cross += kChunkBytes;
+      if (s_addr >= r.lds + kRingBytes) // ... which was slot 0, read through the mirror so far: back to the ring proper
+      {
+        s_addr -= kRingBytes;
+        next_cross -= kRingBytes;
+        moved += kRingBytes;
+      }
+      ring_request(sw, r, c, r.k + HSRANS_RING_AHEAD);
+      r.vm += ((r.k + HSRANS_RING_AHEAD) & (kRingSlots - 1)) == 0 ? 2 : 1;
+      r.seq1 = r.seq2;
+      r.seq2 = r.seq3;
+      r.seq3 = r.vm;
+      if (HSRANS_RING_AHEAD == 2)
+        r.seq2 = r.vm;
+      wait_vm_at_most(r.vm - r.seq1);
+    }
+  }
+  r.cur = words0 + ((s_addr + moved - s_addr0) >> 1);
   o_ref = o;
 }
 
@@ -987,6 +1098,7 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
   const PersistentArgs &pa = kp.pa;
   const uint32_t W = gridDim.x * waves;
   const uint64_t t_entry = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  const uint64_t c_entry = kp.stamps ? __builtin_amdgcn_s_memtime() : 0; // shader clock (diagnostics: what does the chip run at under this load?)
   uint64_t t_table = 0, t_ready = 0, t_static = 0;
   const bool host_table = (MODE == kModePack64 || MODE == kModeCoarse || MODE == kModeSpill) && pa.table != nullptr;
   if (!host_table) // the in-kernel build borrows ring space: it has to come before the first stream request
@@ -1040,7 +1152,7 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
     {
       StreamWin sw;
       Ring r;
-      ring_bind(r, c.rings);
+      ring_bind(r, c.rings, 9, MODE == kModePack64 && c.S == 64);
       uint32_t x = c.lane < c.S ? pa.states[(uint64_t)ch * c.S + c.lane] : 0; // address known up front: in flight beside the piece record
       const DirectPiece d = direct_piece(c, pa, ch);
       win_open(sw, c, d.words, d.limit);
@@ -1054,7 +1166,10 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
       if (kp.stamps && t_ready == 0)
         t_ready = __builtin_amdgcn_s_memrealtime();
       uint64_t o = d.out;
-      run_groups<MODE>(x, sw, r, c, o, d.steps);
+      uint32_t steps = d.steps;
+      if (MODE == kModePack64 && c.S == 64)
+        run_groups_fast(x, sw, r, c, o, steps); // the hand-scheduled loop; leaves < 4 groups
+      run_groups<MODE>(x, sw, r, c, o, steps);
       run_tail<MODE>(x, r, c, o, d.tail);
     }
     if (kp.stamps && t_static == 0)
@@ -1080,6 +1195,11 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
     st[2] = t_ready;
     st[3] = __builtin_amdgcn_s_memrealtime();
     st[4] = t_static;
+    st[5] = __builtin_amdgcn_s_memtime() - c_entry;
+    // where the wave really ran (HW_ID: wave/SIMD/CU/SH/SE fields; XCC_ID): tools/stamps.py groups the finish times by it
+    uint32_t hw_id, xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_id), "=s"(xcc_id));
+    st[6] = (uint64_t)hw_id | ((uint64_t)xcc_id << 32);
   }
 }
 
@@ -1665,8 +1785,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gshift) : "s"(c.bits > 12 ? c.bits - 12 : 0));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gmask) : "s"(c.bits > 12 ? (1u << (c.bits - 12)) - 1 : 0));
-  c.rings = smem + wave * kWaveRingBytes;
-  c.table = smem + waves * kWaveRingBytes;
+  const uint32_t ring_stride = MODE == kModePack64 && c.S == 64 ? kFastRingBytes : kWaveRingBytes; // (launch_shape sizes the LDS the same way)
+  c.rings = smem + wave * ring_stride;
+  c.table = smem + waves * ring_stride;
   c.table_b = c.table;
   c.gtable = kp.pa.table;
   c.scratch_cnt = (uint16_t *)smem; // wave 0's ring (no request in flight while a table is built)
@@ -2078,9 +2199,7 @@ __global__ void __launch_bounds__(128) k_decode_single(KParams kp)
   asm volatile("v_mov_b32 %0, %1" : "=v"(v_bits) : "s"(a.bits));
   unsigned long long e64 = *(const unsigned long long *)(table + (uint64_t)(x & mask) * 8); // entry of the start state
   // one group: returns the table word whose byte 3 is this lane's symbol; `lanes` = the lanes that take part
-  // the ring must hold the words the next groups can take (64 each); checked on a cached count: one LDS read per ~R words.
-  // A lone wave issues one instruction per ~4-5 cycles whatever its kind, so even this scalar check is worth hoisting: with the
-  // big ring it is made once per 4 groups (the producer can always get 256 words ahead there), else once per group.
+  // the ring must hold the words the next group can take (64); checked on a cached count: one LDS read per ~R words
   auto need_words = [&](uint32_t n) {
     while (produced_seen - cur < n)
     {
@@ -2093,10 +2212,10 @@ __global__ void __launch_bounds__(128) k_decode_single(KParams kp)
       }
     }
   };
-  const bool big_ring = R >= 2048;
+  // (checking once per 4 groups instead — the producer can always be 256 words ahead with the big ring — measured SLOWER: 260
+  // instead of 226 shader clocks per group; the per-group scalar check stays)
   auto step = [&](unsigned long long lanes) -> uint32_t {
-    if (!big_ring)
-      need_words(64);
+    need_words(64);
     const uint32_t ex = (uint32_t)e64, ey = (uint32_t)(e64 >> 32);
     const uint32_t nx = __umul24(x >> v_bits, ex) + ey;
     const unsigned long long m = __builtin_amdgcn_ballot_w64(nx < kConsume) & lanes;
@@ -2126,8 +2245,6 @@ __global__ void __launch_bounds__(128) k_decode_single(KParams kp)
   uint32_t steps = a.steps;
   for (; steps >= 4; steps -= 4)
   {
-    if (big_ring)
-      need_words(256);
     const uint32_t e0 = step(act), e1 = step(act), e2 = step(act), e3 = step(act);
     const uint32_t acc = pack4<3>(e0, e1, e2, e3, ol);
     if (act_lane)
@@ -2139,8 +2256,6 @@ __global__ void __launch_bounds__(128) k_decode_single(KParams kp)
   const uint32_t p = lane_to_byte(lane);
   for (; steps > 0; steps--)
   {
-    if (big_ring)
-      need_words(64);
     const uint32_t e = step(act);
     if (act_lane)
       kp.out[o + p] = (uint8_t)(e >> 24);
@@ -2150,8 +2265,6 @@ __global__ void __launch_bounds__(128) k_decode_single(KParams kp)
   }
   if (a.tail) // the final partial group: only lanes whose byte exists take part (rANS32x64_16w.cpp:252-280)
   {
-    if (big_ring)
-      need_words(64);
     const bool in_tail = act_lane && p < a.tail;
     const uint32_t e = step(__builtin_amdgcn_ballot_w64(in_tail));
     if (in_tail)
@@ -2353,7 +2466,7 @@ static uint32_t g_slot_weights4[8] = {1150, 1050, 950, 850, 1150, 1050, 950, 850
 // the second one's on every SIMD, and inside a workgroup the older waves a little ahead of the younger.
 // One set per occupancy (waves per SIMD): 8 = two 16-wave workgroups per CU (bits <= 12), 6 = two 12-wave workgroups (15 bits,
 // coarse + fine tables), 4 = one 16-wave workgroup (13 bits), 3 = one 12-wave workgroup (14 bits).
-static uint32_t g_direct_weights[8] = {1241, 1204, 1160, 1100, 974, 886, 774, 660};
+static uint32_t g_direct_weights[8] = {1221, 1189, 1153, 1098, 970, 892, 792, 684};
 static uint32_t g_direct_weights6[8] = {1124, 1102, 1076, 1047, 984, 941, 891, 834};
 static uint32_t g_direct_weights4[8] = {1067, 1038, 983, 911, 1068, 1038, 985, 911};
 static uint32_t g_direct_weights3[8] = {1040, 1018, 989, 952, 1039, 1018, 989, 953};
@@ -2370,6 +2483,7 @@ static uint32_t g_direct_dyn_groups = 32;   // HSRANS_DIRECT_DYN_GROUPS (multipl
 
 static void read_tuning_once();
 static uint32_t g_single_fast = 1; // HSRANS_SINGLE_FAST: 0 = un-indexed raw streams on the general kernel (one wave, two LDS round trips per group)
+static uint32_t g_dual_waves = 16; // HSRANS_DUAL_WAVES: waves per workgroup of k_decode_dual (12: two workgroups per CU fit beside a 16 KiB table)
 static uint32_t g_dual = 1; // HSRANS_DUAL: 0 = never run two chains per wave (k_decode_dual), 1 = where it pays (default), 2 = for every width (experiment)
 // the one-chain-per-wave weights of the dual kernel's launches (one 16-wave workgroup per CU, two chains per wave)
 static uint32_t g_dual_weights[8] = {1105, 1052, 977, 867, 1104, 1051, 976, 867};
@@ -2506,6 +2620,9 @@ static void read_tuning_once()
     g_private_pair = (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_DUAL"))
     g_dual = (uint32_t)atoi(e);
+  if (const char *e = getenv("HSRANS_DUAL_WAVES"))
+    if (atoi(e) == 8 || atoi(e) == 12 || atoi(e) == 16)
+      g_dual_waves = (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_SINGLE_FAST"))
     g_single_fast = (uint32_t)atoi(e);
   read_weights("HSRANS_DUAL_WEIGHTS", g_dual_weights);
@@ -2569,27 +2686,30 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
   const uint32_t table_bytes = table_bytes_for(L.mode, h.bits);
   const uint32_t wave_bytes = kWaveRingBytes + ((table_bytes + 15) & ~15u); // private rings + table
   uint32_t waves, lds, grid;
-  L.dual = dual && L.shared && persistent && (L.mode == kModePack64 || L.mode == kModeCoarse) && 16 * 2 * kWaveRingBytes + table_bytes <= dg.max_lds;
+  L.dual = dual && L.shared && persistent && (L.mode == kModePack64 || L.mode == kModeCoarse) && g_dual_waves * 2 * kWaveRingBytes + table_bytes <= dg.max_lds;
   if (L.dual)
   {
-    // k_decode_dual: one workgroup of 16 waves per CU, two rings per wave, wave w decodes chains 2w and 2w + 1
-    waves = 16;
+    // k_decode_dual: workgroups of 16 (or HSRANS_DUAL_WAVES) waves, two rings per wave, wave w decodes chains 2w and 2w + 1
+    waves = g_dual_waves;
     lds = waves * 2 * kWaveRingBytes + table_bytes;
-    L.resident = dg.num_cus * (dg.max_lds / lds ? dg.max_lds / lds : 1);
+    const uint32_t per_cu = dg.max_lds / lds ? dg.max_lds / lds : 1;
+    L.resident = dg.num_cus * (per_cu * waves > 32 ? 32 / waves : per_cu);
     grid = (h.n_chains + 2 * waves - 1) / (2 * waves);
     if (grid > L.resident)
       grid = L.resident;
   }
   else if (L.shared)
   {
+    // (k_decode_direct's hand-scheduled loop wants a whole-chunk mirror behind every ring)
+    const uint32_t ring = direct && persistent && L.mode == kModePack64 && h.states == 64 ? kFastRingBytes : kWaveRingBytes;
     waves = g_waves_per_wg;
-    if (L.mode == kModeCoarse && waves * kWaveRingBytes + table_bytes > dg.max_lds / 2)
+    if (L.mode == kModeCoarse && waves * ring + table_bytes > dg.max_lds / 2)
       waves = 12; // 15 bits: 48 KiB of tables + 12 rings = 75 KiB, two workgroups per CU
-    if (waves * kWaveRingBytes + table_bytes > dg.max_lds && table_bytes + 4 * kWaveRingBytes <= dg.max_lds)
-      waves = (dg.max_lds - table_bytes) / kWaveRingBytes / 4 * 4; // a big table: as many waves as still fit (multiple of 4: one per SIMD)
-    while (waves > 1 && (waves / 2 >= h.n_chains || waves * kWaveRingBytes + table_bytes > dg.max_lds))
+    if (waves * ring + table_bytes > dg.max_lds && table_bytes + 4 * ring <= dg.max_lds)
+      waves = (dg.max_lds - table_bytes) / ring / 4 * 4; // a big table: as many waves as still fit (multiple of 4: one per SIMD)
+    while (waves > 1 && (waves / 2 >= h.n_chains || waves * ring + table_bytes > dg.max_lds))
       waves /= 2;
-    lds = waves * kWaveRingBytes + table_bytes;
+    lds = waves * ring + table_bytes;
     grid = (h.n_chains + waves - 1) / waves;
     if (grouped)
       grid = n_groups;

@@ -19,8 +19,31 @@ ap.add_argument("--pairs", type=int, default=4)
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--bits", type=int, default=11)
 ap.add_argument("--stamps", action="store_true")
+ap.add_argument("--size", type=int, default=100_000_000)
+ap.add_argument("--slab", action="store_true", help="carve every stream and output from ONE 2 GiB allocation made first (2 MiB-aligned pieces)")
+ap.add_argument("--quick", action="store_true", help="only the warm / streams-rotated / both-rotated lines")
 a = ap.parse_args()
-n, S, bits, P = 100_000_000, 64, a.bits, a.pairs
+n, S, bits, P = a.size, 64, a.bits, a.pairs
+slab, slab_off = None, 0
+if a.slab:
+    slab = torch.empty(2 << 30, dtype=torch.uint8, device="cuda")
+    slab_off = (-slab.data_ptr()) % (2 << 20)
+
+
+def dev_bytes(nbytes, src=None):
+    """a device buffer of nbytes (zeroed, or a copy of the numpy array `src`)"""
+    global slab_off
+    if slab is None:
+        return torch.zeros(nbytes, dtype=torch.uint8, device="cuda") if src is None else torch.from_numpy(src).cuda()
+    t = slab[slab_off:slab_off + nbytes]
+    slab_off += (nbytes + (2 << 20) - 1) & ~((2 << 20) - 1)
+    if src is None:
+        t.zero_()
+    else:
+        t.copy_(torch.from_numpy(src))
+    return t
+
+
 ctx = H.Context(0)
 base = synth.enwik8_shaped(n)
 g = H.index_boundaries(S, bits, n, ctx)
@@ -28,8 +51,10 @@ ins, outs, plans, lens = [], [], [], []
 for k in range(P):
     d = base if k == 0 else synth._permutation(1000 + k)[base]
     s, plan = H.encode(H.RAW, S, bits, d, index_groups=g)
-    ins.append(torch.from_numpy(np.concatenate([s, np.zeros((-s.size) % 16, np.uint8)])).cuda())
-    outs.append(torch.zeros(n, dtype=torch.uint8, device="cuda"))
+    ins.append(dev_bytes(s.size + (-s.size) % 16, np.concatenate([s, np.zeros((-s.size) % 16, np.uint8)])))
+    outs.append(dev_bytes(n))
+    if k == 0:
+        first = d
     plans.append(ctx.make_device_plan(plan))
     lens.append(s.size)
 flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
@@ -62,9 +87,14 @@ def run(label, pick_in, pick_out, flush_between=False):
 
 
 run("warm: one stream, one output replayed", lambda i: 0, lambda i: 0)
+if not np.array_equal(outs[0].cpu().numpy(), first):
+    print(json.dumps({"error": "decoded bytes differ"}), flush=True)
+    sys.exit(1)
 run("streams rotated, one output", lambda i: i % P, lambda i: 0)
 run("one stream, outputs rotated", lambda i: 0, lambda i: i % P)
 run("both rotated", lambda i: i % P, lambda i: i % P)
+if a.quick:
+    sys.exit(0)
 # the SAME stream in P different buffers, one plan: only the stream bytes are cold (plan, states, table stay warm)
 copies = [ins[0]] + [ins[0].clone() for _ in range(P - 1)]
 

@@ -22,6 +22,8 @@ ap.add_argument("--bits", type=int, default=11)
 ap.add_argument("--index", default="32")
 ap.add_argument("--states", type=int, default=64)
 ap.add_argument("--cold", type=int, default=0, help="rotate this many distinct streams (with their own outputs and plans) so that every launch reads from HBM")
+ap.add_argument("--flush", action="store_true", help="write 512 MiB between the dumped launches (everything leaves the Infinity Cache)")
+ap.add_argument("--dump-launches", type=int, default=0, help="with HSRANS_STAMPS_DUMP: also record this many further launches (stamps_all[k], set_idx[k])")
 a = ap.parse_args()
 n = a.size
 data = synth.enwik8_shaped(n)
@@ -67,6 +69,9 @@ print(f"index {a.index}  bits {a.bits}  chains {H.plan_chain_count(plan)}  waves
 for name, col in (("entry", 0), ("table built", 1), ("stream ready", 2), ("static done", 4), ("done", 3)):
     v = rel[:, col]
     print(f"{name:13s} min {v.min():8.2f}  p10 {np.percentile(v, 10):8.2f}  p50 {np.median(v):8.2f}  p90 {np.percentile(v, 90):8.2f}  p99 {np.percentile(v, 99):8.2f}  max {v.max():8.2f} us")
+if st[:, 5].max() > 0:
+    ghz = st[:, 5] / ((st[:, 3] - st[:, 0]) * 10.0)
+    print(f"shader clock over the wave's lifetime: min {ghz.min():.2f}  p50 {np.median(ghz):.2f}  max {ghz.max():.2f} GHz")
 d = rel[:, 4] - rel[:, 2]
 print(f"static span   min {d.min():8.2f}  p50 {np.median(d):8.2f}  max {d.max():8.2f} us")
 
@@ -93,3 +98,32 @@ print("latest waves (workgroup, wave, entry, ready, done):", [(int(blk[i]), int(
 wg_done = np.array([done[valid & (blk == b)].max() for b in range(nb)])
 wg_entry = np.array([entry[valid & (blk == b)].min() for b in range(nb)])
 print("per-workgroup last wave: p10 %.1f p50 %.1f p90 %.1f max %.1f; corr(entry, done) %.2f" % (np.percentile(wg_done, 10), np.median(wg_done), np.percentile(wg_done, 90), wg_done.max(), np.corrcoef(wg_entry, wg_done)[0, 1]))
+if allst[valid, 6].max() > 0:  # HW_ID | XCC_ID << 32 (k_decode_direct): where the waves really ran
+    hw = allst[:, 6] & 0xFFFFFFFF
+    xcc = (allst[:, 6] >> 32) & 0xF
+    cu = ((xcc * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 16 + ((hw >> 8) & 0xF)
+    ids = np.unique(cu[valid])
+    per_cu = np.array([done[valid & (cu == i)].max() for i in ids])
+    print(f"hardware CUs used: {len(ids)}; last wave per CU: p10 {np.percentile(per_cu, 10):.1f} p50 {np.median(per_cu):.1f} p90 {np.percentile(per_cu, 90):.1f} max {per_cu.max():.1f} us;",
+          "done by XCC:", " ".join(f"{done[valid & (xcc == k)].mean():.1f}" for k in range(8)))
+if os.environ.get("HSRANS_STAMPS_DUMP"):
+    from hypersonic_rans_amd import api as _api
+    hdr, cf, pieces = _api.plan_tables(plan if a.cold <= 1 else pk)
+    more, which = [], []
+    for i in range(a.dump_launches):
+        k = i % a.cold if a.cold > 1 else 0
+        dpk, ik, ok, lk = sets[k] if a.cold > 1 else (dp, d_in, d_out, s.size)
+        if a.flush:
+            if i == 0:
+                flush_buf = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+            flush_buf.fill_(i & 0xFF)
+        ctx.decode_device(dpk, ik, ok, stream_length=lk)
+        torch.cuda.synchronize()
+        b2 = np.zeros(16384 * 8, np.uint64)
+        L.hsrans_debug_read_stamps(dpk.handle, b2.ctypes.data, b2.size)
+        more.append(b2.reshape(-1, 8).astype(np.int64))
+        which.append(k)
+    np.savez(os.environ["HSRANS_STAMPS_DUMP"], stamps=allst, words_off=pieces["words_off"], out_off=pieces["out_off"], steps=pieces["steps"],
+             in_ptr=np.array([(sets[(3 * a.cold - 1) % a.cold][1] if a.cold > 1 else d_in).data_ptr()]), out_ptr=np.array([(sets[(3 * a.cold - 1) % a.cold][2] if a.cold > 1 else d_out).data_ptr()]),
+             stamps_all=np.array(more), set_idx=np.array(which),
+             in_ptrs=np.array([t[1].data_ptr() for t in sets] if a.cold > 1 else [d_in.data_ptr()]), out_ptrs=np.array([t[2].data_ptr() for t in sets] if a.cold > 1 else [d_out.data_ptr()]))
