@@ -248,7 +248,12 @@ __device__ __forceinline__ void ring_begin(const StreamWin &sw, Ring &r, const W
 }
 
 // chunks 0 and 1 (and the mirror) have landed: ring_begin issues {chunk 0, mirror, chunk 1, chunk 2 [, chunk 3]} and anything
-// issued after it only makes this wait stricter
+// issued after it only makes this wait stricter.
+// The chain's state register(s) pass through the wait as asm operands.  Reason: the states are fetched by an ordinary load and
+// are first USED inside the decode loop; the compiler then places its "s_waitcnt vmcnt(0)" for that load at the loop header,
+// where it runs on EVERY iteration and drains the whole vector-memory queue (the previous iteration's store, the stream
+// requests in flight) — the loop never had more than one request outstanding.  With the register as an operand here the
+// compiler's wait lands in front of this statement, once per chain.  (tests/test_kernel_resources.py checks the ISA for it.)
 __device__ __forceinline__ void ring_ready()
 {
   if (HSRANS_RING_AHEAD == 3)
@@ -256,12 +261,26 @@ __device__ __forceinline__ void ring_ready()
   else
     asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
 }
+__device__ __forceinline__ void ring_ready(uint32_t &x)
+{
+  if (HSRANS_RING_AHEAD == 3)
+    asm volatile("s_waitcnt vmcnt(2)" : "+v"(x)::"memory");
+  else
+    asm volatile("s_waitcnt vmcnt(1)" : "+v"(x)::"memory");
+}
+__device__ __forceinline__ void ring_ready(uint32_t &xa, uint32_t &xb)
+{
+  if (HSRANS_RING_AHEAD == 3)
+    asm volatile("s_waitcnt vmcnt(2)" : "+v"(xa), "+v"(xb)::"memory");
+  else
+    asm volatile("s_waitcnt vmcnt(1)" : "+v"(xa), "+v"(xb)::"memory");
+}
 
-__device__ __forceinline__ void ring_init(StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t pos)
+__device__ __forceinline__ void ring_init(StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t pos, uint32_t &x)
 {
   win_open(sw, c, pos, c.stream_len);
   ring_begin(sw, r, c, pos);
-  ring_ready();
+  ring_ready(x);
 }
 
 // call at least once per 256 consumed words
@@ -872,7 +891,7 @@ __device__ void run_planned_chain(const WaveCtx &c, const PlanView &pv, uint32_t
         return;
       have_hist = hist_off;
     }
-    ring_init(sw, r, c, uni64(pc->words_off));
+    ring_init(sw, r, c, uni64(pc->words_off), x);
     uint64_t o = uni64(pc->out_off);
     uint32_t steps = uni(pc->steps);
 
@@ -1022,7 +1041,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
     t_table = __builtin_amdgcn_s_memrealtime();
   if (q0 != 0)
   {
-    ring_ready();
+    ring_ready(x);
     if (kp.stamps)
       t_ready = __builtin_amdgcn_s_memrealtime();
     run_groups<MODE>(x, sw, r, c, g.o, g.steps);
@@ -1049,7 +1068,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
       break;
     const uint32_t ch = lo + (uint32_t)t;
     g = run_begin<MODE>(c, pa, sw, ch, ch + 1, x, r);
-    ring_ready();
+    ring_ready(x);
     run_groups<MODE>(x, sw, r, c, g.o, g.steps);
     run_tail<MODE>(x, r, c, g.o, g.tail);
   }
@@ -1162,7 +1181,7 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
         fetch_table();
         table_pending = false;
       }
-      ring_ready();
+      ring_ready(x);
       if (kp.stamps && t_ready == 0)
         t_ready = __builtin_amdgcn_s_memrealtime();
       uint64_t o = d.out;
@@ -1266,7 +1285,7 @@ __device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t wa
         copy_table();
         table_pending = false;
       }
-      ring_ready();
+      ring_ready(x);
       uint64_t oa = da.out, ob = db.out;
       uint32_t sa = da.steps, sb = have_b ? db.steps : 0;
       const uint32_t both = have_b ? (sa < sb ? sa : sb) & ~3u : 0;
@@ -1351,7 +1370,7 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
         *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
       __syncthreads();
     }
-    ring_ready();
+    ring_ready(x);
     if (have_b)
     {
       const uint32_t both = (sa < sb ? sa : sb) & ~3u;
@@ -1456,7 +1475,7 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
       uint64_t oa = uni64(a0->out_off), ob = have_b ? uni64(b0->out_off) : 0;
       uint32_t sa = (uint32_t)((uni64(a1->out_off) - oa) / 32) + uni(a1->steps);
       uint32_t sb = have_b ? (uint32_t)((uni64(b1->out_off) - ob) / 32) + uni(b1->steps) : 0;
-      ring_ready();
+      ring_ready(x);
       if (have_b)
       {
         const uint32_t both = (sa < sb ? sa : sb) & ~3u;
@@ -1483,7 +1502,7 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
       ring_begin(sw, r, c, uni64(p0->words_off));
       uint64_t o = uni64(p0->out_off);
       const uint64_t steps = (uni64(p1->out_off) - o) / c.S + uni(p1->steps);
-      ring_ready();
+      ring_ready(x);
       run_groups<MODE>(x, sw, r, c, o, (uint32_t)steps);
       run_tail<MODE>(x, r, c, o, uni(p1->tail));
     }
@@ -1526,7 +1545,7 @@ __device__ void run_private_pair(WaveCtx &c, const PlanView &pv, uint32_t ca, co
       uint32_t x = pv.states[(uint64_t)(c.lane < 32 ? uni(pa->state_idx) : uni(pb->state_idx)) * 32 + (c.lane & 31)];
       uint64_t oa = uni64(pa->out_off), ob = uni64(pb->out_off);
       uint32_t sa = uni(pa->steps), sb = uni(pb->steps);
-      ring_ready();
+      ring_ready(x);
       const uint32_t both = (sa < sb ? sa : sb) & ~3u;
       run_pair_groups<MODE>(x, sw, ra, rb, c, oa, ob, both);
       sa -= both;
@@ -1626,7 +1645,7 @@ __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv, const KPara
           atomicOr(c.status, kStatusBadBlock);
         return;
       }
-      ring_init(sw, r, c, pos);
+      ring_init(sw, r, c, pos, x);
       uint64_t steps = end > i ? (end - i + S - 1) / S : 0;
       if (kp.ckpt_interval != 0)
       {
@@ -1669,7 +1688,7 @@ __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv, const KPara
         atomicOr(c.status, kStatusBadHist);
       return;
     }
-    ring_init(sw, r, c, pos);
+    ring_init(sw, r, c, pos, x);
     run_tail<MODE>(x, r, c, i, (uint32_t)(out_len - i));
   }
 }
@@ -2038,7 +2057,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
       fetch_table();
       table_pending = false;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // start of a chain pair: states, table and the first chunks of both rings
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa), "+v"(xb)::"memory"); // start of a chain pair: states, table and the first chunks of both rings
     vm = 0;
     ra.seq1 = ra.seq2 = ra.seq3 = rb.seq1 = rb.seq2 = rb.seq3 = 0;
     if (kp.stamps && t_ready == 0)

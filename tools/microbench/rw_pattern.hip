@@ -14,12 +14,21 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // WIDE: 0 = three 256-byte stores (a dword per lane) per 512 bytes read; 1 = one 768-byte store (dwordx4 on 48 lanes)
 // Requests AHEAD chunks in front and waits for "all but the operations younger than chunk c's request" (exact count: the in-order
 // rule the decoder lives with too); stores are fire-and-forget.
-template <int LANES, int AHEAD, int WIDE>
+// SPLIT: even waves only read (their own and their odd neighbour's region), odd waves only write (both outputs), each at half
+// the pace per chunk: the same traffic in the same time, but no wave has loads and stores in one in-order vmcnt queue
+template <int LANES, int AHEAD, int WIDE, bool SPLIT = false>
 __global__ void __launch_bounds__(1024) k_rw_relaxed(const uint8_t *src, uint64_t bytes_per_wave, uint32_t pace, uint32_t *sink, uint8_t *dst)
 {
   extern __shared__ u32x4 smem[];
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const uint32_t w = blockIdx.x * (blockDim.x >> 6) + wave;
+  uint32_t w = blockIdx.x * (blockDim.x >> 6) + wave;
+  const bool reader = !SPLIT || (w & 1) == 0, writer = !SPLIT || (w & 1) == 1;
+  if (SPLIT)
+  {
+    w >>= 1;
+    bytes_per_wave *= 2;
+    pace /= 2;
+  }
   constexpr uint32_t kChunk = LANES * 16;
   constexpr uint32_t kSlots = AHEAD < 4 ? 4 : 8;
   const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem + wave * kSlots * kChunk);
@@ -38,7 +47,7 @@ __global__ void __launch_bounds__(1024) k_rw_relaxed(const uint8_t *src, uint64_
                  : "v"(voff), "s"(d), "s"(rs), "s"(LANES == 64 ? ~0ull : (1ull << LANES) - 1)
                  : "memory");
   };
-  for (uint32_t c = 0; c < AHEAD && c < chunks; c++)
+  for (uint32_t c = 0; reader && c < AHEAD && c < chunks; c++)
     request(c);
   uint32_t acc = 0;
   uint8_t *o = dst + (uint64_t)w * (bytes_per_wave / 2 * 3);
@@ -47,15 +56,21 @@ __global__ void __launch_bounds__(1024) k_rw_relaxed(const uint8_t *src, uint64_
   constexpr int kYoung = AHEAD * (1 + kStoresPerChunk * (int)(kChunk / 512));
   for (uint32_t c = 0; c < chunks; c++)
   {
-    if (c + AHEAD < chunks)
+    if (reader && c + AHEAD < chunks)
       request(c + AHEAD);
     // younger than chunk c's request: AHEAD requests and the stores of AHEAD chunks
     static_assert(kYoung <= 63, "vmcnt is 6 bits");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYoung) : "memory");
+    if (SPLIT)
+    {
+      if (reader)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD) : "memory");
+    }
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYoung) : "memory");
     acc += ((const uint32_t *)((const uint8_t *)smem + wave * kSlots * kChunk + (c & (kSlots - 1)) * kChunk))[lane % (LANES * 4)];
     for (uint32_t u = 0; u < kChunk / 512; u++, units++)
     {
-      if (WIDE == 2)
+      if (WIDE == 2 || !writer)
       {
       }
       else if (WIDE == 0)
@@ -87,7 +102,7 @@ struct Bufs
   uint32_t *sink;
 };
 
-template <int LANES, int AHEAD, int WIDE>
+template <int LANES, int AHEAD, int WIDE, bool SPLIT = false>
 static void run(const char *label, Bufs &b, size_t bytes, uint32_t pace, int mode)
 {
   const uint32_t grid = 512, waves = 16;
@@ -95,7 +110,7 @@ static void run(const char *label, Bufs &b, size_t bytes, uint32_t pace, int mod
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  (void)hipFuncSetAttribute((const void *)k_rw_relaxed<LANES, AHEAD, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  (void)hipFuncSetAttribute((const void *)k_rw_relaxed<LANES, AHEAD, WIDE, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   float best = 1e30f, sum = 0;
   const int reps = 10;
   for (int i = 0; i < reps + 2; i++)
@@ -103,7 +118,7 @@ static void run(const char *label, Bufs &b, size_t bytes, uint32_t pace, int mod
     if (mode == 3)
       hipMemsetAsync(b.scratch, i, b.scratch_bytes, 0);
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k_rw_relaxed<LANES, AHEAD, WIDE>), dim3(grid), dim3(waves * 64), waves * (AHEAD < 4 ? 4 : 8) * LANES * 16, 0, b.src[mode >= 1 ? i % b.src.size() : 0], per_wave, pace, b.sink,
+    hipLaunchKernelGGL((k_rw_relaxed<LANES, AHEAD, WIDE, SPLIT>), dim3(grid), dim3(waves * 64), waves * (AHEAD < 4 ? 4 : 8) * LANES * 16, 0, b.src[mode >= 1 ? i % b.src.size() : 0], per_wave, pace, b.sink,
                        b.dst[mode >= 2 ? i % b.dst.size() : 0]);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
@@ -150,6 +165,7 @@ int main()
       run<32, 3, 1>("768 B stores", b, bytes, pace, mode);
       run<64, 3, 0>("256 B stores, 1 KiB reads", b, bytes, pace, mode);
       run<32, 6, 0>("256 B stores, deeper ring", b, bytes, pace, mode);
+      run<32, 3, 0, true>("256 B stores, split waves", b, bytes, pace, mode);
     }
   return 0;
 }
