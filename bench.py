@@ -208,7 +208,7 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
     else:
         # warm: ONE pair replayed back to back (stream + output + index stay in the Infinity Cache); outside the timed region
         wa, wb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(3):
+        for _ in range(args.warmup + args.steps):  # (a long run-in: with 3 launches this leg read 47 us where the timed region read 40.6 us for the very same replay)
             step(0)
         wa.record()
         for _ in range(args.steps):

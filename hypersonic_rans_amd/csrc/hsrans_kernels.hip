@@ -304,9 +304,16 @@ __device__ __forceinline__ void ring_advance(const StreamWin &sw, Ring &r, const
 
 // wait until at most n vector-memory operations are outstanding, n rounded DOWN to one of a few immediates (s_waitcnt takes no
 // register operand; waiting for fewer outstanding operations than allowed is only stricter)
+#ifndef HSRANS_WAIT_MAX
+#define HSRANS_WAIT_MAX 8
+#endif
 __device__ __forceinline__ void wait_vm_at_most(uint32_t n)
 {
-  if (n >= 8)
+  if (HSRANS_WAIT_MAX >= 12 && n >= 12)
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (HSRANS_WAIT_MAX >= 10 && n >= 10)
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if (n >= 8)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (n >= 6)
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -2485,10 +2492,14 @@ static uint32_t g_slot_weights4[8] = {1150, 1050, 950, 850, 1150, 1050, 950, 850
 // the second one's on every SIMD, and inside a workgroup the older waves a little ahead of the younger.
 // One set per occupancy (waves per SIMD): 8 = two 16-wave workgroups per CU (bits <= 12), 6 = two 12-wave workgroups (15 bits,
 // coarse + fine tables), 4 = one 16-wave workgroup (13 bits), 3 = one 12-wave workgroup (14 bits).
-static uint32_t g_direct_weights[8] = {1221, 1189, 1153, 1098, 970, 892, 792, 684};
-static uint32_t g_direct_weights6[8] = {1124, 1102, 1076, 1047, 984, 941, 891, 834};
-static uint32_t g_direct_weights4[8] = {1067, 1038, 983, 911, 1068, 1038, 985, 911};
-static uint32_t g_direct_weights3[8] = {1040, 1018, 989, 952, 1039, 1018, 989, 953};
+// (Re-fitted after the decode loops stopped draining the memory queue every iteration: the oldest class now runs three times as
+// many groups as the youngest in the same time.  The same fit with the buffers rotated through HBM lands within 2 % of these.)
+static uint32_t g_direct_weights[8] = {1424, 1371, 1283, 1165, 920, 768, 606, 464};
+static uint32_t g_direct_weights6[8] = {1192, 1159, 1120, 1072, 976, 907, 829, 745};
+static uint32_t g_direct_weights4[8] = {1097, 1053, 977, 873, 1098, 1053, 977, 873};
+static uint32_t g_direct_weights3[8] = {1052, 1025, 986, 936, 1052, 1025, 986, 936};
+// 32-state plans (two chains per wave, one per half: run_direct_pair) keep the earlier fit
+static uint32_t g_direct_weights_pair[8] = {1221, 1189, 1153, 1098, 970, 892, 792, 684};
 // HSRANS_PRIVATE_PAIR: 0 = never, 1 = when there are more chains than wave slots (default), 2 = always pair the
 // chains of 32-state plans in private-table launches.  Measured: 2^30 B in 16,384 blocks 1.40 -> 1.33 ms, but 100 MB in 1,526
 // blocks 0.25 -> 0.30 ms (everything is latency-bound there and half as many waves are in flight)
@@ -2505,7 +2516,7 @@ static uint32_t g_single_fast = 1; // HSRANS_SINGLE_FAST: 0 = un-indexed raw str
 static uint32_t g_dual_waves = 16; // HSRANS_DUAL_WAVES: waves per workgroup of k_decode_dual (12: two workgroups per CU fit beside a 16 KiB table)
 static uint32_t g_dual = 1; // HSRANS_DUAL: 0 = never run two chains per wave (k_decode_dual), 1 = where it pays (default), 2 = for every width (experiment)
 // the one-chain-per-wave weights of the dual kernel's launches (one 16-wave workgroup per CU, two chains per wave)
-static uint32_t g_dual_weights[8] = {1105, 1052, 977, 867, 1104, 1051, 976, 867};
+static uint32_t g_dual_weights[8] = {1207, 1093, 940, 760, 1207, 1093, 940, 760};
 
 typedef void (*KernelFn)(KParams);
 static KernelFn kernel_for(int mode, bool shared)
@@ -2540,10 +2551,12 @@ TableChoice choose_table(uint32_t bits, uint32_t states, bool direct)
     t.mode = kModePack64;
     t.dual = true;
   }
-  else if (direct && g_dual && states == 64 && bits >= 13)
+  else if (direct && g_dual && states == 64 && (bits == 13 || bits == 15 || (bits == 14 && g_dual == 2)))
   {
     // one workgroup of 16 waves per CU, two chains per wave: 13 bits keeps the 8-byte-per-slot table (64 KiB + 32 rings = 136 KiB);
-    // at 14 / 15 bits that table does not fit beside 32 rings, so coarse + fine (40 / 48 KiB)
+    // at 14 / 15 bits that table does not fit beside 32 rings, so coarse + fine (40 / 48 KiB).  Measured per width (100 MB, last
+    // wave done, each with its own fitted weights): 13 bits 48.8 us against 49.7 us one chain per wave; 15 bits 69.8 against
+    // 77.3; 14 bits 69.4 against 63.3 — there the 128 KiB one-lookup table with 12 waves wins, so 14 bits stays single
     t.mode = bits == 13 ? kModePack64 : kModeCoarse;
     t.dual = true;
   }
@@ -2760,7 +2773,7 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
   for (uint32_t k = 0; k < 8; k++)
     L.weights[k] = !weighted ? 1000
                    : L.dual   ? g_dual_weights[k]
-                   : direct   ? (L.grid > dg.num_cus ? (waves == 16 ? g_direct_weights : g_direct_weights6) : (waves == 16 ? g_direct_weights4 : g_direct_weights3))[k]
+                   : direct   ? (L.grid > dg.num_cus ? (waves == 16 ? (h.states == 32 ? g_direct_weights_pair : g_direct_weights) : g_direct_weights6) : (waves == 16 ? g_direct_weights4 : g_direct_weights3))[k]
                               : (L.grid > dg.num_cus ? g_slot_weights : g_slot_weights4)[k];
   return L;
 }
