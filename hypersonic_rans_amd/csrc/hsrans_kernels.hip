@@ -710,9 +710,13 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
   o_ref = o;
 }
 
-template <int MODE>
+// FAST: the call sites that carry the bulk of a launch's groups (every inlined copy of the hand-scheduled loop pins v52-v59 and
+// costs the big multi-path kernel registers: with it at every call site k_decode<3, true> went to 97 VGPRs and spilled)
+template <int MODE, bool FAST = false>
 __device__ __forceinline__ void run_groups(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps)
 {
+  if (FAST && MODE == kModePack64 && c.S == 64 && r.mirror_lanes == 0xFFFFFFFFu)
+    run_groups_fast(x, sw, r, c, o, steps); // the hand-scheduled loop; leaves < 4 groups
   if (c.S == 64)
     run_groups_impl<MODE, true>(x, sw, r, c, o, steps);
   else
@@ -879,7 +883,7 @@ __device__ void run_planned_chain(const WaveCtx &c, const PlanView &pv, uint32_t
   uint64_t have_hist = ~(uint64_t)0;
   StreamWin sw;
   Ring r;
-  ring_bind(r, c.rings);
+  ring_bind(r, c.rings, 9, MODE == kModePack64);
   for (uint32_t pi = first; pi < last; pi++)
   {
     const Piece *pc = pv.pieces + pi;
@@ -1006,7 +1010,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
   uint32_t x = 0;
   StreamWin sw;
   Ring r;
-  ring_bind(r, c.rings);
+  ring_bind(r, c.rings, 9, MODE == kModePack64);
   RunGeom g{};
   // static run of this wave: run_len[class] chains (host guarantees static_total <= n_chains)
   const uint32_t wave_in_wg = w % waves, blk = w / waves;
@@ -1051,7 +1055,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
     ring_ready(x);
     if (kp.stamps)
       t_ready = __builtin_amdgcn_s_memrealtime();
-    run_groups<MODE>(x, sw, r, c, g.o, g.steps);
+    run_groups<MODE, true>(x, sw, r, c, g.o, g.steps);
     run_tail<MODE>(x, r, c, g.o, g.tail);
   }
   const uint64_t t_static = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -1076,7 +1080,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
     const uint32_t ch = lo + (uint32_t)t;
     g = run_begin<MODE>(c, pa, sw, ch, ch + 1, x, r);
     ring_ready(x);
-    run_groups<MODE>(x, sw, r, c, g.o, g.steps);
+    run_groups<MODE, true>(x, sw, r, c, g.o, g.steps);
     run_tail<MODE>(x, r, c, g.o, g.tail);
   }
 
@@ -1193,9 +1197,7 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
         t_ready = __builtin_amdgcn_s_memrealtime();
       uint64_t o = d.out;
       uint32_t steps = d.steps;
-      if (MODE == kModePack64 && c.S == 64)
-        run_groups_fast(x, sw, r, c, o, steps); // the hand-scheduled loop; leaves < 4 groups
-      run_groups<MODE>(x, sw, r, c, o, steps);
+      run_groups<MODE, true>(x, sw, r, c, o, steps);
       run_tail<MODE>(x, r, c, o, d.tail);
     }
     if (kp.stamps && t_static == 0)
@@ -1504,13 +1506,13 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
       uint32_t x = c.lane < c.S ? pv.states[(uint64_t)uni(p0->state_idx) * c.S + c.lane] : 0;
       StreamWin sw;
       Ring r;
-      ring_bind(r, c.rings);
+      ring_bind(r, c.rings, 9, MODE == kModePack64);
       win_open(sw, c, uni64(p0->words_off), limit);
       ring_begin(sw, r, c, uni64(p0->words_off));
       uint64_t o = uni64(p0->out_off);
       const uint64_t steps = (uni64(p1->out_off) - o) / c.S + uni(p1->steps);
       ring_ready(x);
-      run_groups<MODE>(x, sw, r, c, o, (uint32_t)steps);
+      run_groups<MODE, true>(x, sw, r, c, o, (uint32_t)steps);
       run_tail<MODE>(x, r, c, o, uni(p1->tail));
     }
     else
@@ -1586,7 +1588,7 @@ __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv, const KPara
   uint32_t n_blocks = 0;
   StreamWin sw;
   Ring r;
-  ring_bind(r, c.rings);
+  ring_bind(r, c.rings, 9, MODE == kModePack64);
   do
   {
     if (pos + 8 > c.stream_len)
@@ -1735,8 +1737,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
 
   if (SHARED)
   {
-    c.rings = smem + wave * kWaveRingBytes;
-    c.table = smem + waves * kWaveRingBytes;
+    const uint32_t ring_stride = MODE == kModePack64 ? kFastRingBytes : kWaveRingBytes; // (launch_shape sizes the LDS the same way)
+    c.rings = smem + wave * ring_stride;
+    c.table = smem + waves * ring_stride;
     c.table_b = c.table;
     c.scratch_cnt = (uint16_t *)smem;         // wave 0's ring (no request in flight while a table is built)
     c.scratch_cum = (uint16_t *)(smem + 512);
@@ -1811,7 +1814,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gshift) : "s"(c.bits > 12 ? c.bits - 12 : 0));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gmask) : "s"(c.bits > 12 ? (1u << (c.bits - 12)) - 1 : 0));
-  const uint32_t ring_stride = MODE == kModePack64 && c.S == 64 ? kFastRingBytes : kWaveRingBytes; // (launch_shape sizes the LDS the same way)
+  const uint32_t ring_stride = MODE == kModePack64 ? kFastRingBytes : kWaveRingBytes; // (launch_shape sizes the LDS the same way)
   c.rings = smem + wave * ring_stride;
   c.table = smem + waves * ring_stride;
   c.table_b = c.table;
@@ -2733,7 +2736,7 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
   else if (L.shared)
   {
     // (k_decode_direct's hand-scheduled loop wants a whole-chunk mirror behind every ring)
-    const uint32_t ring = direct && persistent && L.mode == kModePack64 && h.states == 64 ? kFastRingBytes : kWaveRingBytes;
+    const uint32_t ring = L.mode == kModePack64 ? kFastRingBytes : kWaveRingBytes;
     waves = g_waves_per_wg;
     if (L.mode == kModeCoarse && waves * ring + table_bytes > dg.max_lds / 2)
       waves = 12; // 15 bits: 48 KiB of tables + 12 rings = 75 KiB, two workgroups per CU
