@@ -309,7 +309,11 @@ __device__ __forceinline__ void ring_advance(const StreamWin &sw, Ring &r, const
 #endif
 __device__ __forceinline__ void wait_vm_at_most(uint32_t n)
 {
-  if (HSRANS_WAIT_MAX >= 12 && n >= 12)
+  if (HSRANS_WAIT_MAX >= 24 && n >= 24)
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if (HSRANS_WAIT_MAX >= 16 && n >= 16)
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (HSRANS_WAIT_MAX >= 12 && n >= 12)
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if (HSRANS_WAIT_MAX >= 10 && n >= 10)
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -666,6 +670,10 @@ __device__ __forceinline__ uint32_t fast_groups4(uint32_t &x, uint32_t &s_addr, 
   return acc;
 }
 
+// (Measured and dropped: the four groups' symbols as four byte stores — global_store_byte / _d16_hi, lane j writing byte idx2idx(j)
+// of its group — instead of pack + quad transpose + one dword store: 1.25 vector instructions per group fewer, the replayed
+// decode unchanged (38.2-38.9 us against 38.8-39.4), the rotated one 4-6 us slower: the loop is not bound by vector issue alone
+// — the table gather keeps the LDS busy two thirds of the time — and four times as many store instructions crowd vmcnt.)
 // `steps` whole groups (64 states, kModePack64) with the loop above; what is left over (< 4 groups) goes to the ordinary path
 __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o_ref, uint32_t &steps)
 {
@@ -1137,7 +1145,7 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
   // the host-built table: one coalesced 16 B load + LDS store per thread (while the wave's first stream chunks and its
   // states are in flight); the first wave also checks that the stream really carries the histogram the table was built
   // from (else: status, as a failed sum check)
-  // (requesting the table BEFORE the piece record, so that its fetch overlaps that round trip, was measured: no gain)
+  // (requesting the table BEFORE the piece record, so that its fetch overlaps that round trip, was measured twice: no gain)
   auto fetch_table = [&]() {
     if (MODE != kModeSpill)
     {
