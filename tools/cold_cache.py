@@ -93,6 +93,8 @@ if not np.array_equal(outs[0].cpu().numpy(), first):
 run("streams rotated, one output", lambda i: i % P, lambda i: 0)
 run("one stream, outputs rotated", lambda i: 0, lambda i: i % P)
 run("both rotated", lambda i: i % P, lambda i: i % P)
+for k in range(1, P):  # does the replayed number depend on WHICH pair (where its buffers landed physically)?
+    run("warm: pair %d replayed" % k, lambda i, k=k: k, lambda i, k=k: k)
 if a.quick:
     sys.exit(0)
 # the SAME stream in P different buffers, one plan: only the stream bytes are cold (plan, states, table stay warm)
