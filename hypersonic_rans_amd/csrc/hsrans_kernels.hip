@@ -1992,6 +1992,210 @@ __device__ __forceinline__ void group_step_dual(uint32_t &xa, uint32_t &xb, Ring
   rb.cur += (uint32_t)__popcll(mb);
 }
 
+// The same step hand-scheduled (8-byte table entries): at 4 waves per SIMD a wave issues one instruction every 4-5 cycles, so
+// the instruction COUNT per group is what a two-chain wave is bound by — the compiler's version of the loop above spends ~59
+// instructions per group (31 of them scalar: two wrapped cursors, two rings' advance logic, mask bookkeeping); this one 16.5:
+// cursors are plain LDS addresses (re-based every 4 groups: whole-chunk mirrors), chain A's mask lives in s[92:93], chain B's
+// in VCC, the word reads and the merges run under EXEC = mask.
+#define HSRANS_DUAL_GROUP(A0, A1, B0, B1)                                                                                                            \
+  "v_and_b32 %[ta], %[xa], %[vmask]\n\t"                                                                                                             \
+  "v_and_b32 %[tb], %[xb], %[vmask]\n\t"                                                                                                             \
+  "v_lshl_add_u32 %[ta], %[ta], 3, %[stab]\n\t"                                                                                                      \
+  "v_lshl_add_u32 %[tb], %[tb], 3, %[stab]\n\t"                                                                                                      \
+  "ds_read_b64 v[" #A0 ":" #A1 "], %[ta]\n\t"                                                                                                        \
+  "ds_read_b64 v[" #B0 ":" #B1 "], %[tb]\n\t"                                                                                                        \
+  "v_lshrrev_b32 %[xa], %[vbits], %[xa]\n\t"                                                                                                         \
+  "v_lshrrev_b32 %[xb], %[vbits], %[xb]\n\t"                                                                                                         \
+  "s_waitcnt lgkmcnt(1)\n\t"                                                                                                                        \
+  "v_mad_u32_u24 %[xa], v" #A0 ", %[xa], v" #A1 "\n\t"                                                                                               \
+  "v_cmp_gt_u32 s[92:93], %[lim], %[xa]\n\t"                                                                                                        \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                        \
+  "v_mad_u32_u24 %[xb], v" #B0 ", %[xb], v" #B1 "\n\t"                                                                                               \
+  "v_cmp_gt_u32 vcc, %[lim], %[xb]\n\t"                                                                                                             \
+  "v_mbcnt_lo_u32_b32 %[ta], s92, 0\n\t"                                                                                                            \
+  "v_mbcnt_hi_u32_b32 %[ta], s93, %[ta]\n\t"                                                                                                        \
+  "v_lshl_add_u32 %[ta], %[ta], 1, %[sa]\n\t"                                                                                                       \
+  "v_mbcnt_lo_u32_b32 %[tb], vcc_lo, 0\n\t"                                                                                                         \
+  "v_mbcnt_hi_u32_b32 %[tb], vcc_hi, %[tb]\n\t"                                                                                                     \
+  "v_lshl_add_u32 %[tb], %[tb], 1, %[sb]\n\t"                                                                                                       \
+  "s_mov_b64 exec, s[92:93]\n\t"                                                                                                                    \
+  "ds_read_u16 %[ta], %[ta]\n\t"                                                                                                                    \
+  "s_mov_b64 exec, vcc\n\t"                                                                                                                         \
+  "ds_read_u16 %[tb], %[tb]\n\t"                                                                                                                    \
+  "s_bcnt1_i32_b64 %[st], s[92:93]\n\t"                                                                                                             \
+  "s_lshl1_add_u32 %[sa], %[st], %[sa]\n\t"                                                                                                         \
+  "s_bcnt1_i32_b64 %[st], vcc\n\t"                                                                                                                  \
+  "s_lshl1_add_u32 %[sb], %[st], %[sb]\n\t"                                                                                                         \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                        \
+  "v_lshl_or_b32 %[xb], %[xb], 16, %[tb]\n\t"                                                                                                       \
+  "s_mov_b64 exec, s[92:93]\n\t"                                                                                                                    \
+  "v_lshl_or_b32 %[xa], %[xa], 16, %[ta]\n\t"                                                                                                       \
+  "s_mov_b64 exec, -1\n\t"
+
+// four groups of chain A and four of chain B; acc_a / acc_b = this lane's four symbols of each (before the quad transpose)
+__device__ __forceinline__ void dual_groups4(uint32_t &xa, uint32_t &xb, uint32_t &s_a, uint32_t &s_b, const WaveCtx &c, uint32_t s_table, uint32_t &acc_a, uint32_t &acc_b)
+{
+  uint32_t ta, tb, st;
+  asm volatile(HSRANS_DUAL_GROUP(64, 65, 72, 73) HSRANS_DUAL_GROUP(66, 67, 74, 75) HSRANS_DUAL_GROUP(68, 69, 76, 77) HSRANS_DUAL_GROUP(70, 71, 78, 79)
+               "v_perm_b32 %[aa], v66, v64, %[selp]\n\t"
+               "v_perm_b32 %[ta], v70, v68, %[selp]\n\t"
+               "v_perm_b32 %[aa], %[ta], %[aa], %[selq]\n\t"
+               "v_perm_b32 %[ab], v74, v72, %[selp]\n\t"
+               "v_perm_b32 %[tb], v78, v76, %[selp]\n\t"
+               "v_perm_b32 %[ab], %[tb], %[ab], %[selq]"
+               : [xa] "+v"(xa), [xb] "+v"(xb), [sa] "+s"(s_a), [sb] "+s"(s_b), [aa] "=&v"(acc_a), [ab] "=&v"(acc_b), [ta] "=&v"(ta), [tb] "=&v"(tb), [st] "=&s"(st)
+               : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [stab] "s"(s_table), [lim] "s"(kConsume), [selp] "s"(0x0c0c0703u), [selq] "s"(0x05040100u)
+               : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "s92", "s93", "vcc", "scc", "memory");
+}
+
+// The step for the coarse + fine tables (kModeCoarse; 14 / 15 bits): the granule's entry, then — for the lanes whose granule
+// straddles a symbol boundary (entry.y < 0 after the slot's offset in the granule was added: ptr + g with bit 31 set) — the per-slot
+// entry from the fine table, read under EXEC = those lanes straight over the coarse one.  Masks: A's boundary lanes in s[90:91],
+// B's in VCC; the branch skips the second gather only when no lane of either chain needs it (rare at 15 bits).
+#define HSRANS_DUAL_GROUP_COARSE(A0, A1, B0, B1)                                                                                                     \
+  "v_and_b32 %[ta], %[xa], %[vmask]\n\t"                                                                                                             \
+  "v_and_b32 %[tb], %[xb], %[vmask]\n\t"                                                                                                             \
+  "v_and_b32 %[ga], %[ta], %[vgmask]\n\t"                                                                                                            \
+  "v_and_b32 %[gb], %[tb], %[vgmask]\n\t"                                                                                                            \
+  "v_lshrrev_b32 %[ta], %[vgshift], %[ta]\n\t"                                                                                                       \
+  "v_lshrrev_b32 %[tb], %[vgshift], %[tb]\n\t"                                                                                                       \
+  "v_lshl_add_u32 %[ta], %[ta], 3, %[stab]\n\t"                                                                                                      \
+  "v_lshl_add_u32 %[tb], %[tb], 3, %[stab]\n\t"                                                                                                      \
+  "ds_read_b64 v[" #A0 ":" #A1 "], %[ta]\n\t"                                                                                                        \
+  "ds_read_b64 v[" #B0 ":" #B1 "], %[tb]\n\t"                                                                                                        \
+  "v_lshrrev_b32 %[xa], %[vbits], %[xa]\n\t"                                                                                                         \
+  "v_lshrrev_b32 %[xb], %[vbits], %[xb]\n\t"                                                                                                         \
+  "s_waitcnt lgkmcnt(1)\n\t"                                                                                                                        \
+  "v_add_u32 v" #A1 ", v" #A1 ", %[ga]\n\t"                                                                                                          \
+  "v_cmp_gt_i32 s[90:91], 0, v" #A1 "\n\t"                                                                                                           \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                        \
+  "v_add_u32 v" #B1 ", v" #B1 ", %[gb]\n\t"                                                                                                          \
+  "v_cmp_gt_i32 vcc, 0, v" #B1 "\n\t"                                                                                                                \
+  "s_or_b64 s[92:93], s[90:91], vcc\n\t"                                                                                                            \
+  "s_cbranch_scc0 1f\n\t"                                                                                                                           \
+  "s_mov_b64 exec, s[90:91]\n\t"                                                                                                                    \
+  "v_lshl_add_u32 %[ta], v" #A1 ", 3, %[sfine]\n\t"                                                                                                  \
+  "ds_read_b64 v[" #A0 ":" #A1 "], %[ta]\n\t"                                                                                                        \
+  "s_mov_b64 exec, vcc\n\t"                                                                                                                         \
+  "v_lshl_add_u32 %[tb], v" #B1 ", 3, %[sfine]\n\t"                                                                                                  \
+  "ds_read_b64 v[" #B0 ":" #B1 "], %[tb]\n\t"                                                                                                        \
+  "s_mov_b64 exec, -1\n\t"                                                                                                                          \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                        \
+  "1:\n\t"                                                                                                                                          \
+  "v_mad_u32_u24 %[xa], v" #A0 ", %[xa], v" #A1 "\n\t"                                                                                               \
+  "v_cmp_gt_u32 s[88:89], %[lim], %[xa]\n\t"                                                                                                        \
+  "v_mad_u32_u24 %[xb], v" #B0 ", %[xb], v" #B1 "\n\t"                                                                                               \
+  "v_cmp_gt_u32 vcc, %[lim], %[xb]\n\t"                                                                                                             \
+  "s_nop 0\n\t"                                                                                                                                     \
+  "v_mbcnt_lo_u32_b32 %[ta], s88, 0\n\t"                                                                                                            \
+  "v_mbcnt_hi_u32_b32 %[ta], s89, %[ta]\n\t"                                                                                                        \
+  "v_lshl_add_u32 %[ta], %[ta], 1, %[sa]\n\t"                                                                                                       \
+  "v_mbcnt_lo_u32_b32 %[tb], vcc_lo, 0\n\t"                                                                                                         \
+  "v_mbcnt_hi_u32_b32 %[tb], vcc_hi, %[tb]\n\t"                                                                                                     \
+  "v_lshl_add_u32 %[tb], %[tb], 1, %[sb]\n\t"                                                                                                       \
+  "s_mov_b64 exec, s[88:89]\n\t"                                                                                                                    \
+  "ds_read_u16 %[ta], %[ta]\n\t"                                                                                                                    \
+  "s_mov_b64 exec, vcc\n\t"                                                                                                                         \
+  "ds_read_u16 %[tb], %[tb]\n\t"                                                                                                                    \
+  "s_bcnt1_i32_b64 %[st], s[88:89]\n\t"                                                                                                             \
+  "s_lshl1_add_u32 %[sa], %[st], %[sa]\n\t"                                                                                                         \
+  "s_bcnt1_i32_b64 %[st], vcc\n\t"                                                                                                                  \
+  "s_lshl1_add_u32 %[sb], %[st], %[sb]\n\t"                                                                                                         \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                        \
+  "v_lshl_or_b32 %[xb], %[xb], 16, %[tb]\n\t"                                                                                                       \
+  "s_mov_b64 exec, s[88:89]\n\t"                                                                                                                    \
+  "v_lshl_or_b32 %[xa], %[xa], 16, %[ta]\n\t"                                                                                                       \
+  "s_mov_b64 exec, -1\n\t"
+
+__device__ __forceinline__ void dual_groups4_coarse(uint32_t &xa, uint32_t &xb, uint32_t &s_a, uint32_t &s_b, const WaveCtx &c, uint32_t s_table, uint32_t &acc_a, uint32_t &acc_b)
+{
+  uint32_t ta, tb, ga, gb, st;
+  asm volatile(HSRANS_DUAL_GROUP_COARSE(64, 65, 72, 73) HSRANS_DUAL_GROUP_COARSE(66, 67, 74, 75) HSRANS_DUAL_GROUP_COARSE(68, 69, 76, 77) HSRANS_DUAL_GROUP_COARSE(70, 71, 78, 79)
+               "v_perm_b32 %[aa], v66, v64, %[selp]\n\t"
+               "v_perm_b32 %[ta], v70, v68, %[selp]\n\t"
+               "v_perm_b32 %[aa], %[ta], %[aa], %[selq]\n\t"
+               "v_perm_b32 %[ab], v74, v72, %[selp]\n\t"
+               "v_perm_b32 %[tb], v78, v76, %[selp]\n\t"
+               "v_perm_b32 %[ab], %[tb], %[ab], %[selq]"
+               : [xa] "+v"(xa), [xb] "+v"(xb), [sa] "+s"(s_a), [sb] "+s"(s_b), [aa] "=&v"(acc_a), [ab] "=&v"(acc_b), [ta] "=&v"(ta), [tb] "=&v"(tb), [ga] "=&v"(ga), [gb] "=&v"(gb),
+                 [st] "=&s"(st)
+               : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [vgmask] "v"(c.v_gmask), [vgshift] "v"(c.v_gshift), [stab] "s"(s_table), [sfine] "s"(s_table + 8 * kCoarseEntries),
+                 [lim] "s"(kConsume), [selp] "s"(0x0c0c0703u), [selq] "s"(0x05040100u)
+               : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "s88", "s89", "s90", "s91", "s92", "s93", "vcc", "scc",
+                 "memory");
+}
+
+// the cursor of one ring as an LDS address, for the loops that re-base it every 4 groups (run_groups_fast, run_dual_fast)
+struct FastCursor
+{
+  uint32_t addr, next_cross, addr0, words0, moved;
+};
+__device__ __forceinline__ FastCursor fast_cursor_open(const Ring &r)
+{
+  FastCursor f;
+  f.addr = uni(r.lds + ((r.cur << 1) & (kRingBytes - 1)));
+  f.next_cross = uni(r.lds + (((r.k + 1) & (kRingSlots - 1)) << 9));
+  if (f.next_cross == r.lds)
+    f.next_cross += kRingBytes; // the chunk in slot 3 ends at the ring's end, not at its start
+  f.addr0 = f.addr;
+  f.words0 = r.cur;
+  f.moved = 0;
+  return f;
+}
+__device__ __forceinline__ void fast_cursor_close(const FastCursor &f, Ring &r) { r.cur = f.words0 + ((f.addr + f.moved - f.addr0) >> 1); }
+
+// `both` (a multiple of 4) groups of each of the two chains
+template <int MODE>
+__device__ __forceinline__ void run_dual_fast(uint32_t &xa, uint32_t &xb, const StreamWin &sw, RingD &ra, RingD &rb, const WaveCtx &c, uint64_t &oa_ref, uint64_t &ob_ref, uint32_t both,
+                                              uint32_t &vm)
+{
+  uint64_t oa = uni64(oa_ref), ob = uni64(ob_ref);
+  const OutLanes ol = out_lanes(c.lane, 64);
+  const uint32_t s_table = uni(lds_address(c.table));
+  FastCursor fa = fast_cursor_open(ra.r), fb = fast_cursor_open(rb.r);
+  auto crossed = [&](FastCursor &f, RingD &d) {
+    d.r.k++;
+    f.next_cross += kChunkBytes;
+    if (f.addr >= d.r.lds + kRingBytes) // the chunk entered was slot 0, read through the mirror so far: back to the ring proper
+    {
+      f.addr -= kRingBytes;
+      f.next_cross -= kRingBytes;
+      f.moved += kRingBytes;
+    }
+    d.seq1 = d.seq2;
+    d.seq2 = d.seq3;
+    ring_request_counted(sw, d.r, c, d.r.k + HSRANS_RING_AHEAD, vm);
+    if (HSRANS_RING_AHEAD == 3)
+      d.seq3 = vm;
+    else
+      d.seq2 = d.seq3 = vm;
+    wait_vm_at_most(vm - d.seq1);
+  };
+  for (; both != 0; both -= 4)
+  {
+    uint32_t acc_a, acc_b;
+    if (MODE == kModeCoarse)
+      dual_groups4_coarse(xa, xb, fa.addr, fb.addr, c, s_table, acc_a, acc_b);
+    else
+      dual_groups4(xa, xb, fa.addr, fb.addr, c, s_table, acc_a, acc_b);
+    acc_a = quad_transpose(acc_a, ol.sel_a, ol.sel_b);
+    acc_b = quad_transpose(acc_b, ol.sel_a, ol.sel_b);
+    HSRANS_STORE_U32_SADDR((uint8_t *)uni64((uint64_t)(uintptr_t)(c.out + oa)), ol.store_off, acc_a);
+    HSRANS_STORE_U32_SADDR((uint8_t *)uni64((uint64_t)(uintptr_t)(c.out + ob)), ol.store_off, acc_b);
+    vm += 2;
+    oa += 256;
+    ob += 256;
+    if (fa.addr >= fa.next_cross)
+      crossed(fa, ra);
+    if (fb.addr >= fb.next_cross)
+      crossed(fb, rb);
+  }
+  fast_cursor_close(fa, ra.r);
+  fast_cursor_close(fb, rb.r);
+  oa_ref = oa;
+  ob_ref = ob;
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_decode_dual(KParams kp)
 {
@@ -2014,8 +2218,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gshift) : "s"(c.bits > 12 ? c.bits - 12 : 0));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gmask) : "s"(c.bits > 12 ? (1u << (c.bits - 12)) - 1 : 0));
-  c.rings = smem + wave * 2 * kWaveRingBytes;
-  c.table = smem + waves * 2 * kWaveRingBytes;
+  constexpr uint32_t kDualRing = kFastRingBytes; // whole-chunk mirrors for the hand-scheduled loop (launch_shape sizes the LDS the same way)
+  c.rings = smem + wave * 2 * kDualRing;
+  c.table = smem + waves * 2 * kDualRing;
   c.table_b = c.table;
   c.gtable = pa.table;
   c.scratch_cnt = (uint16_t *)smem;
@@ -2061,8 +2266,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
     uint32_t xb = pa.states[(uint64_t)(have_b ? a + 1 : a) * 64 + c.lane];
     StreamWin sw;
     RingD ra, rb;
-    ring_bind(ra.r, c.rings);
-    ring_bind(rb.r, c.rings + kWaveRingBytes);
+    ring_bind(ra.r, c.rings, 9, true);
+    ring_bind(rb.r, c.rings + kDualRing, 9, true);
     uint32_t vm = 0; // vector-memory instructions issued from here on (everything older completes before them anyway)
     win_open(sw, c, da.words, have_b ? db.limit : da.limit); // the two chains are neighbours in the stream: one window
     ring_begin_counted(sw, ra, c, da.words, vm);
@@ -2085,6 +2290,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
     uint32_t both = have_b ? (sa < sb ? sa : sb) & ~3u : 0;
     sa -= both;
     sb -= both;
+#if !defined(HSRANS_DUAL_ASM) || HSRANS_DUAL_ASM
+    run_dual_fast<MODE>(xa, xb, sw, ra, rb, c, oa, ob, both, vm);
+#else // the compiler's version of the same loop (A/B builds)
     for (; both != 0; both -= 4)
     {
       uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
@@ -2099,6 +2307,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
       ring_advance_counted(sw, ra, c, vm);
       ring_advance_counted(sw, rb, c, vm);
     }
+#endif
     // what is left (a few groups of the longer chain, the stream's final partial group): one chain at a time, the ordinary way
     // (the single-ring wait in ring_advance is only ever stricter than needed here: the other ring's requests are older or done)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2493,7 +2702,7 @@ static uint32_t g_static_percent = 100; // HSRANS_STATIC_PERCENT: share of the c
 // MI355X at 8 waves per SIMD (bits <= 12): with equal runs the four age classes of a workgroup finish at 33/36/39/42 us,
 // with these weights all at 39 us (tools/stamps.py), 3-7 % less kernel time; at 4 waves per SIMD (bits >= 13) equal
 // runs are better and are kept.
-static uint32_t g_slot_weights[8] = {1350, 1100, 870, 680, 1300, 1080, 860, 660};
+static uint32_t g_slot_weights[8] = {1328, 1268, 1211, 1145, 1018, 875, 665, 490}; // (re-fitted after the wait fix; runs are whole chains, so this fit is coarse)
 // HSRANS_SLOT_WEIGHTS4: the same for launches with one 16-wave workgroup per CU (4 waves per SIMD: 13-bit tables)
 static uint32_t g_slot_weights4[8] = {1150, 1050, 950, 850, 1150, 1050, 950, 850};
 // HSRANS_DIRECT_WEIGHTS / HSRANS_DIRECT_WEIGHTS4: the chain lengths of the one-chain-per-wave index (hsrans_index_boundaries),
@@ -2527,7 +2736,8 @@ static uint32_t g_single_fast = 1; // HSRANS_SINGLE_FAST: 0 = un-indexed raw str
 static uint32_t g_dual_waves = 16; // HSRANS_DUAL_WAVES: waves per workgroup of k_decode_dual (12: two workgroups per CU fit beside a 16 KiB table)
 static uint32_t g_dual = 1; // HSRANS_DUAL: 0 = never run two chains per wave (k_decode_dual), 1 = where it pays (default), 2 = for every width (experiment)
 // the one-chain-per-wave weights of the dual kernel's launches (one 16-wave workgroup per CU, two chains per wave)
-static uint32_t g_dual_weights[8] = {1207, 1093, 940, 760, 1207, 1093, 940, 760};
+static uint32_t g_dual_weights[8] = {1249, 1118, 925, 708, 1249, 1118, 925, 708};        // 13 bits (8-byte table)
+static uint32_t g_dual_weights_coarse[8] = {1239, 1102, 927, 732, 1239, 1102, 927, 732}; // 14 / 15 bits (coarse + fine tables)
 
 typedef void (*KernelFn)(KParams);
 static KernelFn kernel_for(int mode, bool shared)
@@ -2562,12 +2772,12 @@ TableChoice choose_table(uint32_t bits, uint32_t states, bool direct)
     t.mode = kModePack64;
     t.dual = true;
   }
-  else if (direct && g_dual && states == 64 && (bits == 13 || bits == 15 || (bits == 14 && g_dual == 2)))
+  else if (direct && g_dual && states == 64 && bits >= 13)
   {
-    // one workgroup of 16 waves per CU, two chains per wave: 13 bits keeps the 8-byte-per-slot table (64 KiB + 32 rings = 136 KiB);
-    // at 14 / 15 bits that table does not fit beside 32 rings, so coarse + fine (40 / 48 KiB).  Measured per width (100 MB, last
-    // wave done, each with its own fitted weights): 13 bits 48.8 us against 49.7 us one chain per wave; 15 bits 69.8 against
-    // 77.3; 14 bits 69.4 against 63.3 — there the 128 KiB one-lookup table with 12 waves wins, so 14 bits stays single
+    // one workgroup of 16 waves per CU, two chains per wave: 13 bits keeps the 8-byte-per-slot table (64 KiB + 32 rings = 144 KiB);
+    // at 14 / 15 bits that table does not fit beside 32 rings, so coarse + fine (40 / 48 KiB).  Measured (100 MB, last wave
+    // done, fitted weights, hand-scheduled loops): 13 bits 42.7 us against 49.7 us one chain per wave; 14 bits 57.8 against 63.3
+    // (one chain per wave beside the 128 KiB one-lookup table); 15 bits 57.7 against 77.3
     t.mode = bits == 13 ? kModePack64 : kModeCoarse;
     t.dual = true;
   }
@@ -2669,6 +2879,7 @@ static void read_tuning_once()
   if (const char *e = getenv("HSRANS_SINGLE_FAST"))
     g_single_fast = (uint32_t)atoi(e);
   read_weights("HSRANS_DUAL_WEIGHTS", g_dual_weights);
+  read_weights("HSRANS_DUAL_WEIGHTS", g_dual_weights_coarse);
   if (const char *e = getenv("HSRANS_DIRECT_DYN_PERMILLE"))
     g_direct_dyn_permille = (uint32_t)atoi(e) > 500 ? 500 : (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_DIRECT_DYN_GROUPS"))
@@ -2729,12 +2940,13 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
   const uint32_t table_bytes = table_bytes_for(L.mode, h.bits);
   const uint32_t wave_bytes = kWaveRingBytes + ((table_bytes + 15) & ~15u); // private rings + table
   uint32_t waves, lds, grid;
-  L.dual = dual && L.shared && persistent && (L.mode == kModePack64 || L.mode == kModeCoarse) && g_dual_waves * 2 * kWaveRingBytes + table_bytes <= dg.max_lds;
+  const uint32_t dual_ring = kFastRingBytes;
+  L.dual = dual && L.shared && persistent && (L.mode == kModePack64 || L.mode == kModeCoarse) && g_dual_waves * 2 * dual_ring + table_bytes <= dg.max_lds;
   if (L.dual)
   {
     // k_decode_dual: workgroups of 16 (or HSRANS_DUAL_WAVES) waves, two rings per wave, wave w decodes chains 2w and 2w + 1
     waves = g_dual_waves;
-    lds = waves * 2 * kWaveRingBytes + table_bytes;
+    lds = waves * 2 * dual_ring + table_bytes;
     const uint32_t per_cu = dg.max_lds / lds ? dg.max_lds / lds : 1;
     L.resident = dg.num_cus * (per_cu * waves > 32 ? 32 / waves : per_cu);
     grid = (h.n_chains + 2 * waves - 1) / (2 * waves);
@@ -2783,7 +2995,7 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
   const bool weighted = (waves == 16 || waves == 12) && (!two_level || g_weights_two_level);
   for (uint32_t k = 0; k < 8; k++)
     L.weights[k] = !weighted ? 1000
-                   : L.dual   ? g_dual_weights[k]
+                   : L.dual   ? (L.mode == kModeCoarse ? g_dual_weights_coarse : g_dual_weights)[k]
                    : direct   ? (L.grid > dg.num_cus ? (waves == 16 ? (h.states == 32 ? g_direct_weights_pair : g_direct_weights) : g_direct_weights6) : (waves == 16 ? g_direct_weights4 : g_direct_weights3))[k]
                               : (L.grid > dg.num_cus ? g_slot_weights : g_slot_weights4)[k];
   return L;

@@ -46,7 +46,10 @@ def test_shared_table_decode_occupancy():
         if not m or ("k_decodeI" in name and int(m.group(1)) not in (0, 1, 3, 4, 5)):
             continue
         seen += 1
-        assert r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] == 8, (name, r)
+        if "k_decode_dual" in name:  # one 16-wave workgroup per CU (LDS-limited): 4 waves per SIMD; the asm loop pins v64-v79
+            assert r["VGPRs"] <= 128 and r["Occupancy [waves/SIMD]"] >= 4, (name, r)
+        else:
+            assert r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] == 8, (name, r)
     assert seen == 5 + 6 + 2
 
 

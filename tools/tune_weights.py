@@ -15,6 +15,7 @@ ap.add_argument("--var", default="HSRANS_DIRECT_WEIGHTS")
 ap.add_argument("--states", type=int, default=64)
 ap.add_argument("--damp", type=float, default=0.8)
 ap.add_argument("--dyn", default="0")
+ap.add_argument("--index", default="wave", help="stamps.py --index: wave (one chain per wave) or a checkpoint interval in groups (uniform plans: HSRANS_SLOT_WEIGHTS)")
 ap.add_argument("--cold", type=int, default=0, help="tune with this many stream/output pairs rotated (stamps.py --cold)")
 a = ap.parse_args()
 w = [float(x) for x in a.start.split(",")] if a.start else [1241, 1204, 1160, 1100, 974, 886, 774, 660]
@@ -22,7 +23,7 @@ for it in range(a.iters):
     env = dict(os.environ)
     env[a.var] = ",".join(str(int(round(x))) for x in w)
     env["HSRANS_DIRECT_DYN_PERMILLE"] = a.dyn
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stamps.py"), "--index", "wave", "--bits", str(a.bits), "--states", str(a.states)] + (["--cold", str(a.cold)] if a.cold > 1 else []), env=env, capture_output=True, text=True).stdout
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stamps.py"), "--index", a.index, "--bits", str(a.bits), "--states", str(a.states)] + (["--cold", str(a.cold)] if a.cold > 1 else []), env=env, capture_output=True, text=True).stdout
     m = re.search(r"^static done by wave.*?: ([\d. ]+)\| second half: ([\d. ]+)$", out, re.M)
     done = re.search(r"^done\s+min.*max\s+([\d.]+) us", out, re.M)
     t = [float(x) for x in (m.group(1) + " " + m.group(2)).split()]
