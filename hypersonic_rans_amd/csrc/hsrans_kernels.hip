@@ -171,7 +171,7 @@ __device__ __forceinline__ void ring_bind(Ring &r, const uint8_t *lds_ring, uint
 {
   r.lds = uni(lds_address(lds_ring));
   r.clog = clog;
-  r.mirror_lanes = whole_chunk_mirror ? 0xFFFFFFFFu : clog == 9 ? 0xFFu : 0xFu;
+  r.mirror_lanes = whole_chunk_mirror ? (clog == 9 ? 0xFFFFFFFFu : 0xFFFFu) : clog == 9 ? 0xFFu : 0xFu;
 }
 __device__ __forceinline__ uint32_t ring_bytes(const Ring &r) { return kRingSlots << r.clog; }
 
@@ -796,8 +796,90 @@ __device__ __forceinline__ uint32_t group_step_pair(uint32_t &x, Ring &ra, Ring 
   return e;
 }
 
-// `steps` whole 32-symbol groups of chain A (lanes 0..31, output at oa) and of chain B (lanes 32..63, output at ob)
+// the cursor of one ring as an LDS address, for the loops that re-base it only every 4 groups (they need a whole chunk mirrored
+// behind the ring's end: ring_bind(..., whole_chunk_mirror = true))
+struct FastCursor
+{
+  uint32_t addr, next_cross, addr0, words0, moved;
+};
+__device__ __forceinline__ FastCursor fast_cursor_open(const Ring &r)
+{
+  FastCursor f;
+  f.addr = uni(r.lds + ((r.cur << 1) & (ring_bytes(r) - 1)));
+  f.next_cross = uni(r.lds + (((r.k + 1) & (kRingSlots - 1)) << r.clog));
+  if (f.next_cross == r.lds)
+    f.next_cross += ring_bytes(r); // the chunk in the last slot ends at the ring's end, not at its start
+  f.addr0 = f.addr;
+  f.words0 = r.cur;
+  f.moved = 0;
+  return f;
+}
+// the cursor has entered the next chunk (at most one per 4 groups): bookkeeping only, the caller requests and waits
+__device__ __forceinline__ void fast_cursor_cross(FastCursor &f, Ring &r)
+{
+  r.k++;
+  f.next_cross += 1u << r.clog;
+  if (f.addr >= r.lds + ring_bytes(r)) // ... which was slot 0, read through the mirror so far: back to the ring proper
+  {
+    f.addr -= ring_bytes(r);
+    f.next_cross -= ring_bytes(r);
+    f.moved += ring_bytes(r);
+  }
+}
+__device__ __forceinline__ void fast_cursor_close(const FastCursor &f, Ring &r) { r.cur = f.words0 + ((f.addr + f.moved - f.addr0) >> 1); }
+
+// Two 32-state chains per wave: ring A and ring B of one wave (4 x 256 B each).  With the 8-byte table the pair loop is
+// hand-scheduled and wants whole-chunk mirrors: 2 x (1 KiB + 256 B) = the 2.5 KiB every wave of a kModePack64 launch owns.
 template <int MODE>
+__device__ __forceinline__ void pair_bind(Ring &ra, Ring &rb, const WaveCtx &c)
+{
+  ring_bind(ra, c.rings, 8, MODE == kModePack64);
+  ring_bind(rb, c.rings + (MODE == kModePack64 ? 1280 : 1152), 8, MODE == kModePack64);
+}
+
+// One group of both chains (lanes 0..31 chain A, 32..63 chain B; 8-byte table entries), hand-scheduled like HSRANS_FAST_GROUP:
+// v_cmpx puts the renormalisation mask of both halves in VCC and EXEC; chain A's ranks come from v_mbcnt_lo, chain B's from
+// v_mbcnt_hi alone (issued under EXEC = mask & upper half, like B's word address), so each half counts from its own scalar
+// cursor.  10 vector, 2 LDS, 7 scalar instructions (the compiler's version: 14 + 2 + 19).
+#define HSRANS_PAIR_GROUP(P0, P1)                                                                                                                    \
+  "v_and_b32 %[t], %[x], %[vmask]\n\t"                                                                                                               \
+  "v_lshl_add_u32 %[t], %[t], 3, %[stab]\n\t"                                                                                                        \
+  "ds_read_b64 v[" #P0 ":" #P1 "], %[t]\n\t"                                                                                                         \
+  "v_lshrrev_b32 %[x], %[vbits], %[x]\n\t"                                                                                                           \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
+  "v_mad_u32_u24 %[x], v" #P0 ", %[x], v" #P1 "\n\t"                                                                                                 \
+  "v_cmpx_gt_u32 vcc, %[lim], %[x]\n\t"                                                                                                              \
+  "s_nop 1\n\t"                                                                                                                                      \
+  "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"                                                                                                           \
+  "v_lshl_add_u32 %[w], %[t], 1, %[sa]\n\t"                                                                                                          \
+  "s_mov_b32 exec_lo, 0\n\t"                                                                                                                         \
+  "v_mbcnt_hi_u32_b32 %[t], vcc_hi, 0\n\t"                                                                                                           \
+  "v_lshl_add_u32 %[w], %[t], 1, %[sb]\n\t"                                                                                                          \
+  "s_mov_b32 exec_lo, vcc_lo\n\t"                                                                                                                    \
+  "ds_read_u16 %[w], %[w]\n\t"                                                                                                                       \
+  "s_bcnt1_i32_b32 %[st], vcc_lo\n\t"                                                                                                                \
+  "s_lshl1_add_u32 %[sa], %[st], %[sa]\n\t"                                                                                                          \
+  "s_bcnt1_i32_b32 %[st], vcc_hi\n\t"                                                                                                                \
+  "s_lshl1_add_u32 %[sb], %[st], %[sb]\n\t"                                                                                                          \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
+  "v_lshl_or_b32 %[x], %[x], 16, %[w]\n\t"                                                                                                           \
+  "s_mov_b64 exec, -1\n\t"
+
+__device__ __forceinline__ uint32_t pair_groups4(uint32_t &x, uint32_t &s_a, uint32_t &s_b, const WaveCtx &c, uint32_t s_table)
+{
+  uint32_t acc, t, w, st;
+  asm volatile(HSRANS_PAIR_GROUP(52, 53) HSRANS_PAIR_GROUP(54, 55) HSRANS_PAIR_GROUP(56, 57) HSRANS_PAIR_GROUP(58, 59)
+               "v_perm_b32 %[acc], v54, v52, %[selp]\n\t"
+               "v_perm_b32 %[t], v58, v56, %[selp]\n\t"
+               "v_perm_b32 %[acc], %[t], %[acc], %[selq]"
+               : [x] "+v"(x), [sa] "+s"(s_a), [sb] "+s"(s_b), [acc] "=&v"(acc), [t] "=&v"(t), [w] "=&v"(w), [st] "=&s"(st)
+               : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [stab] "s"(s_table), [lim] "s"(kConsume), [selp] "s"(0x0c0c0703u), [selq] "s"(0x05040100u)
+               : "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "vcc", "scc", "memory");
+  return acc;
+}
+
+// `steps` whole 32-symbol groups of chain A (lanes 0..31, output at oa) and of chain B (lanes 32..63, output at ob)
+template <int MODE, bool FAST = false> // FAST: see run_groups
 __device__ __forceinline__ void run_pair_groups(uint32_t &x, const StreamWin &sw, Ring &ra, Ring &rb, const WaveCtx &c, uint64_t &oa_ref, uint64_t &ob_ref,
                                                 uint32_t steps)
 {
@@ -809,6 +891,38 @@ __device__ __forceinline__ void run_pair_groups(uint32_t &x, const StreamWin &sw
   const uint32_t sel_b = (c.lane & 2) ? 0x03020706u : 0x05040100u;
   uint8_t *vout = c.out + (c.lane < 32 ? oa : ob) + row * 32 + dcol * 4; // per-lane: this half's output row
   uint32_t done = 0;
+  if (FAST && MODE == kModePack64 && ra.mirror_lanes == 0xFFFFu)
+  {
+    // the hand-scheduled loop; its waits are counted from here on (everything issued before is older than anything it waits for)
+    const uint32_t s_table = uni(lds_address(c.table));
+    FastCursor fa = fast_cursor_open(ra), fb = fast_cursor_open(rb);
+    uint32_t vm = 0, seq_a[3] = {0, 0, 0}, seq_b[3] = {0, 0, 0};
+    auto crossed = [&](FastCursor &f, Ring &r, uint32_t(&seq)[3]) {
+      fast_cursor_cross(f, r);
+      ring_request(sw, r, c, r.k + HSRANS_RING_AHEAD);
+      vm += ((r.k + HSRANS_RING_AHEAD) & (kRingSlots - 1)) == 0 ? 2 : 1;
+      seq[0] = seq[1];
+      seq[1] = seq[2];
+      seq[2] = vm;
+      if (HSRANS_RING_AHEAD == 2)
+        seq[1] = vm;
+      wait_vm_at_most(vm - seq[0]);
+    };
+    for (; steps - done >= 4; done += 4)
+    {
+      const uint32_t acc = quad_transpose(pair_groups4(x, fa.addr, fb.addr, c, s_table), sel_a, sel_b);
+      asm volatile("global_store_dword %0, %1, off nt" : : "v"(vout), "v"(acc) : "memory");
+      vm++;
+      vout += 128;
+      if (fa.addr >= fa.next_cross)
+        crossed(fa, ra, seq_a);
+      if (fb.addr >= fb.next_cross)
+        crossed(fb, rb, seq_b);
+    }
+    fast_cursor_close(fa, ra);
+    fast_cursor_close(fb, rb);
+    ra.vm = ra.seq1 = ra.seq2 = ra.seq3 = rb.vm = rb.seq1 = rb.seq2 = rb.seq3 = 0; // (stale otherwise; zero only makes later waits stricter)
+  }
   for (; steps - done >= 4; done += 4)
   {
     const uint32_t e0 = group_step_pair<MODE>(x, ra, rb, c);
@@ -1246,10 +1360,11 @@ __device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t wa
 {
   const PersistentArgs &pa = kp.pa;
   const uint32_t W = gridDim.x * waves;
+  const uint64_t t_entry = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  uint64_t t_ready = 0, t_static = 0;
   StreamWin sw;
   Ring ra, rb;
-  ring_bind(ra, c.rings, 8);
-  ring_bind(rb, c.rings + 1152, 8);
+  pair_bind<MODE>(ra, rb, c);
   const bool host_table = (MODE == kModePack64 || MODE == kModeSpill) && pa.table != nullptr;
   if (!host_table)
     build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
@@ -1303,10 +1418,12 @@ __device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t wa
         table_pending = false;
       }
       ring_ready(x);
+      if (kp.stamps && t_ready == 0)
+        t_ready = __builtin_amdgcn_s_memrealtime();
       uint64_t oa = da.out, ob = db.out;
       uint32_t sa = da.steps, sb = have_b ? db.steps : 0;
       const uint32_t both = have_b ? (sa < sb ? sa : sb) & ~3u : 0;
-      run_pair_groups<MODE>(x, sw, ra, rb, c, oa, ob, both);
+      run_pair_groups<MODE, true>(x, sw, ra, rb, c, oa, ob, both);
       sa -= both;
       sb -= both;
       uint32_t xb = __shfl(x, (c.lane & 31) + 32, 64); // B's states move down to lanes 0..31 and B is finished alone
@@ -1315,6 +1432,8 @@ __device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t wa
       run_groups<MODE>(x, sw, ra, c, oa, sa);
       run_tail<MODE>(x, ra, c, oa, da.tail);
     }
+    if (kp.stamps && t_static == 0)
+      t_static = __builtin_amdgcn_s_memrealtime();
     if (!have_dynamic)
       break;
     unsigned long long t = 0;
@@ -1329,6 +1448,17 @@ __device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t wa
   }
   if (table_pending) // a wave without chains still takes part in the workgroup's table copy
     copy_table();
+  if (kp.stamps && c.lane == 0) // (tools/stamps.py, tools/tune_weights.py --states 32)
+  {
+    uint64_t *st = kp.stamps + (uint64_t)w * 8;
+    st[0] = t_entry;
+    st[1] = t_ready;
+    st[2] = t_ready;
+    st[3] = __builtin_amdgcn_s_memrealtime();
+    st[4] = t_static;
+    st[5] = 0;
+    st[6] = 0;
+  }
 }
 
 // Persistent launch for 32-state streams: every wave runs TWO runs of chains side by side (group_step_pair), A = run 2u,
@@ -1342,8 +1472,7 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
   const uint32_t W = gridDim.x * waves;
   StreamWin sw;
   Ring ra, rb;
-  ring_bind(ra, c.rings, 8);
-  ring_bind(rb, c.rings + 1152, 8);
+  pair_bind<MODE>(ra, rb, c);
   // static runs of this wave: two of run_len[class] chains each (PersistentArgs::run_len; host guarantees static_total <= n_chains)
   const uint32_t wave_in_wg = w % waves, blk = w / waves;
   const uint32_t first_half = (gridDim.x + 1) / 2;
@@ -1481,8 +1610,7 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
       const uint64_t limit = last < begin + count ? uni64(pv.pieces[uni(pv.chain_first[last])].words_off) : uni64(G->words_end);
       StreamWin sw;
       Ring ra, rb;
-      ring_bind(ra, c.rings, 8);
-      ring_bind(rb, c.rings + 1152, 8);
+      pair_bind<MODE>(ra, rb, c);
       win_open(sw, c, uni64(a0->words_off), limit);
       ring_begin(sw, ra, c, uni64(a0->words_off));
       if (have_b)
@@ -1553,8 +1681,7 @@ __device__ void run_private_pair(WaveCtx &c, const PlanView &pv, uint32_t ca, co
     {
       StreamWin sw;
       Ring ra, rb;
-      ring_bind(ra, c.rings, 8);
-      ring_bind(rb, c.rings + 1152, 8);
+      pair_bind<MODE>(ra, rb, c);
       const uint64_t wa = uni64(pa->words_off), wb = uni64(pb->words_off);
       win_open(sw, c, wa < wb ? wa : wb, c.stream_len);
       ring_begin(sw, ra, c, wa);
@@ -2125,25 +2252,6 @@ __device__ __forceinline__ void dual_groups4_coarse(uint32_t &xa, uint32_t &xb, 
                  "memory");
 }
 
-// the cursor of one ring as an LDS address, for the loops that re-base it every 4 groups (run_groups_fast, run_dual_fast)
-struct FastCursor
-{
-  uint32_t addr, next_cross, addr0, words0, moved;
-};
-__device__ __forceinline__ FastCursor fast_cursor_open(const Ring &r)
-{
-  FastCursor f;
-  f.addr = uni(r.lds + ((r.cur << 1) & (kRingBytes - 1)));
-  f.next_cross = uni(r.lds + (((r.k + 1) & (kRingSlots - 1)) << 9));
-  if (f.next_cross == r.lds)
-    f.next_cross += kRingBytes; // the chunk in slot 3 ends at the ring's end, not at its start
-  f.addr0 = f.addr;
-  f.words0 = r.cur;
-  f.moved = 0;
-  return f;
-}
-__device__ __forceinline__ void fast_cursor_close(const FastCursor &f, Ring &r) { r.cur = f.words0 + ((f.addr + f.moved - f.addr0) >> 1); }
-
 // `both` (a multiple of 4) groups of each of the two chains
 template <int MODE>
 __device__ __forceinline__ void run_dual_fast(uint32_t &xa, uint32_t &xb, const StreamWin &sw, RingD &ra, RingD &rb, const WaveCtx &c, uint64_t &oa_ref, uint64_t &ob_ref, uint32_t both,
@@ -2154,14 +2262,7 @@ __device__ __forceinline__ void run_dual_fast(uint32_t &xa, uint32_t &xb, const 
   const uint32_t s_table = uni(lds_address(c.table));
   FastCursor fa = fast_cursor_open(ra.r), fb = fast_cursor_open(rb.r);
   auto crossed = [&](FastCursor &f, RingD &d) {
-    d.r.k++;
-    f.next_cross += kChunkBytes;
-    if (f.addr >= d.r.lds + kRingBytes) // the chunk entered was slot 0, read through the mirror so far: back to the ring proper
-    {
-      f.addr -= kRingBytes;
-      f.next_cross -= kRingBytes;
-      f.moved += kRingBytes;
-    }
+    fast_cursor_cross(f, d.r);
     d.seq1 = d.seq2;
     d.seq2 = d.seq3;
     ring_request_counted(sw, d.r, c, d.r.k + HSRANS_RING_AHEAD, vm);
@@ -2718,8 +2819,9 @@ static uint32_t g_direct_weights[8] = {1424, 1371, 1283, 1165, 920, 768, 606, 46
 static uint32_t g_direct_weights6[8] = {1192, 1159, 1120, 1072, 976, 907, 829, 745};
 static uint32_t g_direct_weights4[8] = {1097, 1053, 977, 873, 1098, 1053, 977, 873};
 static uint32_t g_direct_weights3[8] = {1052, 1025, 986, 936, 1052, 1025, 986, 936};
-// 32-state plans (two chains per wave, one per half: run_direct_pair) keep the earlier fit
-static uint32_t g_direct_weights_pair[8] = {1221, 1189, 1153, 1098, 970, 892, 792, 684};
+// 32-state plans (two chains per wave, one per half: run_direct_pair, hand-scheduled pair loop; HSRANS_DIRECT_WEIGHTS_PAIR): with 7
+// scalar instructions per group the CU's scalar unit is contended and the oldest waves get nearly all of it
+static uint32_t g_direct_weights_pair[8] = {1847, 1695, 1471, 1174, 780, 512, 317, 204};
 // HSRANS_PRIVATE_PAIR: 0 = never, 1 = when there are more chains than wave slots (default), 2 = always pair the
 // chains of 32-state plans in private-table launches.  Measured: 2^30 B in 16,384 blocks 1.40 -> 1.33 ms, but 100 MB in 1,526
 // blocks 0.25 -> 0.30 ms (everything is latency-bound there and half as many waves are in flight)
@@ -2867,6 +2969,7 @@ static void read_tuning_once()
   read_weights("HSRANS_DIRECT_WEIGHTS4", g_direct_weights4);
   read_weights("HSRANS_DIRECT_WEIGHTS6", g_direct_weights6);
   read_weights("HSRANS_DIRECT_WEIGHTS3", g_direct_weights3);
+  read_weights("HSRANS_DIRECT_WEIGHTS_PAIR", g_direct_weights_pair);
   g_weights_two_level = getenv("HSRANS_WEIGHTS_TWO_LEVEL") != nullptr;
   g_table_spill = getenv("HSRANS_TABLE_SPILL") != nullptr;
   if (const char *e = getenv("HSRANS_PRIVATE_PAIR"))
