@@ -124,7 +124,7 @@ def _mt_cpu_baseline(stream, data, states, bits):
     return out
 
 
-def _pmc_profile(n: int, states: int, bits: int, index: str):
+def _pmc_profile(n: int, states: int, bits: int, index: str, pairs: int = 0):
     """The committed rocprofv3 PMC run of this very workload (profiles/*_pmc.json, written by tools/pmc_summary.py: FETCH_SIZE /
     WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  PMC counters cannot be collected
     from inside this process, so traffic is null unless such a run matches the workload; the source file is named."""
@@ -134,7 +134,9 @@ def _pmc_profile(n: int, states: int, bits: int, index: str):
             j = json.load(open(f))
             cfg = j["bench_line_under_trace"]["config"]
             if (cfg["decoded_bytes"], cfg["states"], cfg["bits"], str(cfg.get("index", cfg.get("index_interval_groups")))) == (n, states, bits, index):
-                best = (os.path.relpath(f, ROOT), j)
+                if best is None or cfg.get("pairs") == pairs:  # same rotation (cache state) preferred; counters carry FETCH_SIZE and WRITE_SIZE
+                    if "hbm_traffic_bytes_per_launch" in j or best is None:
+                        best = (os.path.relpath(f, ROOT), j)
         except (KeyError, ValueError, OSError):
             continue
     return best
@@ -251,7 +253,7 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
     alg_bytes = int(np.mean([p["stream"].size for p in pairs])) + n  # compressed bytes read once + decoded bytes written once
     achieved = alg_bytes / (k_avg * 1e-3) / 1e9
     groups_per_launch = n // S
-    prof = _pmc_profile(n, S, bits, args.index)
+    prof = _pmc_profile(n, S, bits, args.index, P)
     traffic, traffic_source, issue = None, None, None
     if prof is not None:
         traffic_source, j = prof
