@@ -82,7 +82,10 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v)
 // The decoded bytes are written once and never read again by this kernel: streaming (non-temporal) stores, so that the
 // lines leave L2 as they fill instead of waiting for the write-back at the end of the kernel (measured on two boxes:
 // 48.5 -> 46.1 us and 49.5 -> 48.2 us for the 100 MB headline decode; -DHSRANS_NT_STORES=0 builds the plain-store variant)
-#if !defined(HSRANS_NT_STORES) || HSRANS_NT_STORES
+#if defined(HSRANS_STORE_POLICY) // experiments: cache-policy bits of the scalar-base output store, e.g. -DHSRANS_STORE_POLICY='" sc1"'
+#define HSRANS_STORE_U32(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#define HSRANS_STORE_U32_SADDR(base, voff, v) asm volatile("global_store_dword %0, %1, %2" HSRANS_STORE_POLICY : : "v"(voff), "v"(v), "s"(base) : "memory")
+#elif !defined(HSRANS_NT_STORES) || HSRANS_NT_STORES
 #define HSRANS_STORE_U32(ptr, v) __builtin_nontemporal_store((v), (ptr))
 #define HSRANS_STORE_U32_SADDR(base, voff, v) asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(voff), "v"(v), "s"(base) : "memory")
 #else
@@ -215,9 +218,9 @@ __device__ __forceinline__ void win_open(StreamWin &sw, const WaveCtx &c, uint64
 }
 
 // How far ahead of the chunk the cursor is in the ring requests stream bytes: 2 (round 1) keeps one slot spare; 3 uses all four
-// slots.  A request has (HSRANS_RING_AHEAD - 1) chunks of decoding (12.4 groups each = ~2.3 us at 8 waves per SIMD) to land:
-// enough for a stream that sits in the Infinity Cache (the same buffers replayed), NOT for one that comes from HBM under load —
-// with distinct buffers rotated through the benchmark the launch took 60.4 us at 2 against 46.6 us replayed; see DESIGN.md §5.
+// slots.  A request has (HSRANS_RING_AHEAD - 1) chunks of decoding (12.4 groups each = ~2 us at 8 waves per SIMD) to land.
+// Measured after the loop-header wait was removed (ring_ready): 2 and 3 are within noise of each other, replayed or rotated
+// (39.3 / 45.6 us at 3, 40.4 / 46.7 us at 2); before that fix neither mattered, because the loop drained the queue anyway.
 #ifndef HSRANS_RING_AHEAD
 #define HSRANS_RING_AHEAD 3
 #endif
