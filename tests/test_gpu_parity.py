@@ -45,6 +45,34 @@ def test_raw_indexed(gpu_ctx, oracle, zipf, states, bits, interval):
         assert r == n and np.array_equal(got, d), (states, bits, interval, n)
 
 
+@pytest.mark.parametrize("states", (32, 64))
+@pytest.mark.parametrize("bits", (10, 11, 12, 13, 14, 15))
+def test_raw_one_chain_per_wave_odd_shapes(gpu_ctx, oracle, nonstat, states, bits):
+    """The one-chain-per-wave launches (k_decode_direct, the two-chain kernel at 13-15 bits, the 32-state pair loop): their
+    hand-scheduled loops re-base the stream cursor every 4 groups and wrap the LDS ring — so: few LONG chains (every ring
+    wraps many times), chains of unequal length (checkpoints sit on multiples of 4 groups: the API's rule), partial last groups, a
+    single chain pair, and the device's own boundaries at sizes that leave most waves without a chain."""
+    rng = np.random.default_rng(1000 * states + bits)
+    for n in (70_001, 1_000_003, 3_000_000):
+        d = nonstat[:n]
+        groups_total = n // states
+        cases = [H.index_boundaries(states, bits, n, gpu_ctx)]
+        # a handful of long chains of unequal length
+        for k in (1, 2, 5, 33):
+            if groups_total > 8 * (k + 1):
+                cuts = (np.unique(rng.integers(1, groups_total // 4 - 1, size=k)) * 4).astype(np.uint64)
+                cases.append(cuts)
+        cases.append((np.arange(1, min(64, groups_total // 8)) * 8).astype(np.uint64))  # many tiny chains at the front, one long one behind
+        for g in cases:
+            if g.size == 0:
+                continue
+            s, plan = H.encode(H.RAW, states, bits, d, index_groups=g)
+            r0, want = oracle.decode(RAW, states, bits, s, n)
+            assert r0 == n and np.array_equal(want, d)
+            got = gpu_ctx.decode(H.RAW, states, bits, s, plan=plan)
+            assert got.size == n and np.array_equal(got, want), (states, bits, n, g[:6], int(np.argmax(got != want)) if got.size == n else got.size)
+
+
 @pytest.mark.parametrize("container", (BLOCK, MT))
 @pytest.mark.parametrize("states", (32, 64))
 @pytest.mark.parametrize("bits", (10, 11, 12, 13, 14, 15))
