@@ -1468,7 +1468,7 @@ __device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t wa
 // B = run 2u+1 of a numbering in which run j of the static part is chains [j*q0, (j+1)*q0) and a dynamic ticket t of
 // queue k is the pair of adjacent chains lo+2t, lo+2t+1.  Whatever the pair loop leaves (unequal lengths, < 4 groups,
 // the stream's final partial group) is finished one chain at a time on lanes 0..31.
-template <int MODE>
+template <int MODE, bool FAST = false> // FAST: the hand-scheduled pair loop (k_decode_persist only: it spills k_decode<3, true>)
 __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_t waves, uint32_t w)
 {
   const PersistentArgs &pa = kp.pa;
@@ -1523,7 +1523,7 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
     if (have_b)
     {
       const uint32_t both = (sa < sb ? sa : sb) & ~3u;
-      run_pair_groups<MODE>(x, sw, ra, rb, c, oa, ob, both);
+      run_pair_groups<MODE, FAST>(x, sw, ra, rb, c, oa, ob, both);
       sa -= both;
       sb -= both;
       // chain B's states move down to lanes 0..31 and B is finished alone
@@ -1964,6 +1964,41 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
     run_direct_pair<MODE>(c, kp, waves, chain);
   else
     run_direct<MODE>(c, kp, waves, chain);
+}
+
+// The same for uniform-interval raw plans with the 8-byte table (run_persistent / run_persistent_pair): in a kernel of their own
+// the 32-state pair loop can be the hand-scheduled one as well (inside k_decode<3, true> its pinned registers mean scratch).
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_decode_persist(KParams kp)
+{
+  constexpr int MODE = kModePack64;
+  extern __shared__ u32x4 smem_v[];
+  uint8_t *smem = (uint8_t *)smem_v;
+  const uint32_t waves = blockDim.x >> 6;
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  WaveCtx c;
+  c.stream = kp.stream;
+  c.stream_len = kp.stream_len;
+  c.stream_lo = kp.stream_lo;
+  c.out = kp.out;
+  c.out_cap = kp.out_cap;
+  c.status = kp.status;
+  c.bits = kp.pa.bits;
+  c.S = kp.pa.S;
+  c.lane = threadIdx.x & 63;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
+  c.v_gshift = c.v_gmask = 0;
+  c.rings = smem + wave * kFastRingBytes;
+  c.table = smem + waves * kFastRingBytes;
+  c.table_b = c.table;
+  c.gtable = kp.pa.table;
+  c.scratch_cnt = (uint16_t *)smem;
+  c.scratch_cum = (uint16_t *)(smem + 512);
+  const uint32_t chain = blockIdx.x * waves + wave;
+  if (c.S == 32)
+    run_persistent_pair<MODE, true>(c, kp, waves, chain);
+  else
+    run_persistent<MODE>(c, kp, waves, chain);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2837,6 +2872,7 @@ static uint32_t g_direct_dyn_permille = 0;  // HSRANS_DIRECT_DYN_PERMILLE (measu
 static uint32_t g_direct_dyn_groups = 32;   // HSRANS_DIRECT_DYN_GROUPS (multiple of 4)
 
 static void read_tuning_once();
+static uint32_t g_persist_kernel = 1; // HSRANS_PERSIST_KERNEL: 0 = uniform-interval plans on k_decode<3, true> (A/B)
 static uint32_t g_single_fast = 1; // HSRANS_SINGLE_FAST: 0 = un-indexed raw streams on the general kernel (one wave, two LDS round trips per group)
 static uint32_t g_dual_waves = 16; // HSRANS_DUAL_WAVES: waves per workgroup of k_decode_dual (12: two workgroups per CU fit beside a 16 KiB table)
 static uint32_t g_dual = 1; // HSRANS_DUAL: 0 = never run two chains per wave (k_decode_dual), 1 = where it pays (default), 2 = for every width (experiment)
@@ -2982,6 +3018,8 @@ static void read_tuning_once()
   if (const char *e = getenv("HSRANS_DUAL_WAVES"))
     if (atoi(e) == 8 || atoi(e) == 12 || atoi(e) == 16)
       g_dual_waves = (uint32_t)atoi(e);
+  if (const char *e = getenv("HSRANS_PERSIST_KERNEL"))
+    g_persist_kernel = (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_SINGLE_FAST"))
     g_single_fast = (uint32_t)atoi(e);
   read_weights("HSRANS_DUAL_WEIGHTS", g_dual_weights);
@@ -3009,7 +3047,7 @@ hipError_t prepare_kernels(DeviceGeom *geom)
       if (e != hipSuccess)
         return e;
     }
-  for (KernelFn fn : {(KernelFn)k_decode_single, (KernelFn)k_decode_dual<kModePack64>, (KernelFn)k_decode_dual<kModeCoarse>, (KernelFn)k_decode_direct<kModePack>, (KernelFn)k_decode_direct<kModePackM1>,
+  for (KernelFn fn : {(KernelFn)k_decode_single, (KernelFn)k_decode_persist, (KernelFn)k_decode_dual<kModePack64>, (KernelFn)k_decode_dual<kModeCoarse>, (KernelFn)k_decode_direct<kModePack>, (KernelFn)k_decode_direct<kModePackM1>,
                       (KernelFn)k_decode_direct<kModeTwoLevel>, (KernelFn)k_decode_direct<kModePack64>, (KernelFn)k_decode_direct<kModeCoarse>, (KernelFn)k_decode_direct<kModeSpill>})
   {
     const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
@@ -3103,7 +3141,7 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
     L.weights[k] = !weighted ? 1000
                    : L.dual   ? (L.mode == kModeCoarse ? g_dual_weights_coarse : g_dual_weights)[k]
                    : direct   ? (L.grid > dg.num_cus ? (waves == 16 ? (h.states == 32 ? g_direct_weights_pair : g_direct_weights) : g_direct_weights6) : (waves == 16 ? g_direct_weights4 : g_direct_weights3))[k]
-                              : (L.grid > dg.num_cus ? g_slot_weights : g_slot_weights4)[k];
+                              : (L.grid > dg.num_cus ? (persistent && !grouped && h.states == 32 ? g_direct_weights_pair : g_slot_weights) : g_slot_weights4)[k];
   return L;
 }
 
@@ -3247,6 +3285,8 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
   KernelFn fn = kernel_for(L.mode, L.shared);
   if (L.dual)
     fn = L.mode == kModeCoarse ? (KernelFn)k_decode_dual<kModeCoarse> : (KernelFn)k_decode_dual<kModePack64>;
+  else if (persistent && kp.pa.interval != 0 && L.shared && L.mode == kModePack64 && !index_pass && g_persist_kernel)
+    fn = k_decode_persist;
   else if (persistent && kp.pa.interval == 0 && L.shared)
     switch (L.mode)
     {

@@ -51,6 +51,8 @@ def test_shared_table_decode_occupancy():
         else:
             assert r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] == 8, (name, r)
     assert seen == 5 + 6 + 2
+    persist = [r for name, r in kernels.items() if "k_decode_persist" in name]
+    assert len(persist) == 1 and persist[0]["VGPRs"] <= 64 and persist[0]["Occupancy [waves/SIMD]"] == 8, persist
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -94,7 +96,7 @@ def test_decode_loops_do_not_drain_the_memory_queue(tmp_path):
         cur.append((int(m.group(2), 16), m.group(1), target))
     checked = 0
     for name, ins in funcs.items():
-        if not re.search(r"k_decode(_direct|_dual)?ILi[0-4]E", name):  # (table mode 5 gathers its table from global memory: it has to wait)
+        if not re.search(r"k_decode(_direct|_dual)?ILi[0-4]E", name) and "k_decode_persist" not in name:  # (table mode 5 gathers its table from global memory: it has to wait)
             continue
         addr_index = {a: i for i, (a, _, _) in enumerate(ins)}
         loops = [(addr_index[t], i) for i, (a, _, t) in enumerate(ins) if t is not None and t < a and t in addr_index]
