@@ -1581,7 +1581,7 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
 
 // Grouped launch: workgroup b walks groups b, b + gridDim.x, ...; per group one table build, then every wave decodes an
 // equal contiguous share of the group's chains.
-template <int MODE>
+template <int MODE, bool FAST = false> // FAST: the hand-scheduled 32-state pair loop too (measured in a kernel of its own: 71 VGPRs, 7 waves per SIMD — not used)
 __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams &kp, uint32_t waves, uint32_t wave)
 {
   for (uint32_t gi = blockIdx.x; gi < kp.n_groups; gi += gridDim.x)
@@ -1627,7 +1627,7 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
       if (have_b)
       {
         const uint32_t both = (sa < sb ? sa : sb) & ~3u;
-        run_pair_groups<MODE>(x, sw, ra, rb, c, oa, ob, both);
+        run_pair_groups<MODE, FAST>(x, sw, ra, rb, c, oa, ob, both);
         sa -= both;
         sb -= both;
         uint32_t xb = __shfl(x, (c.lane & 31) + 32, 64); // B's states move down to lanes 0..31 and B is finished alone
@@ -3287,6 +3287,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
     fn = L.mode == kModeCoarse ? (KernelFn)k_decode_dual<kModeCoarse> : (KernelFn)k_decode_dual<kModePack64>;
   else if (persistent && kp.pa.interval != 0 && L.shared && L.mode == kModePack64 && !index_pass && g_persist_kernel)
     fn = k_decode_persist;
+
   else if (persistent && kp.pa.interval == 0 && L.shared)
     switch (L.mode)
     {
