@@ -41,6 +41,7 @@ constexpr uint32_t kWaveRingBytes = kRingBytes + 256;     // per wave (ring + mi
 // re-based every 4 groups, so it can run up to one chunk past the ring's end: the mirror there is a whole chunk
 constexpr uint32_t kFastRingBytes = kRingBytes + kChunkBytes;
 constexpr uint32_t kConsume = 1u << 15; // rans.h:8 DecodeConsumePoint16
+constexpr uint32_t kSingleMirror = 256;  // k_decode_single: ring entries mirrored behind the ring's end (4 groups x 64 words)
 
 // decode-table layouts
 constexpr int kModePack = 0;     // bits <= 11: uint32 per slot = sym | freq << 8 | (slot - cumul) << 20
@@ -2394,8 +2395,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
       t_table = __builtin_amdgcn_s_memrealtime();
   };
 
+#if defined(HSRANS_DUAL_ASM) && !HSRANS_DUAL_ASM
   constexpr uint32_t kSymByte = 3;
   const OutLanes ol = out_lanes(c.lane, 64);
+#endif
   for (uint32_t a = 2 * w; a < pa.n_chains; a += 2 * W)
   {
     const bool have_b = a + 1 < pa.n_chains;
@@ -2479,8 +2482,34 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
 // leaves, for every word k, {table entry of (word_k & mask), word_k} in an LDS ring: a lane that renormalises reads its word
 // AND the table entry its next step needs in one access while the other lanes gather their next entry from nx, so a group is
 // ONE LDS round trip long: mad -> compare -> prefix count -> address -> LDS -> merge.
-// Workgroup = 2 waves: wave 0 decodes, wave 1 produces.  LDS: [table 8 << bits][ring (entries + 64) x 16 B][flags 64 B].
+// Workgroup = 2 waves: wave 0 decodes, wave 1 produces.  LDS: [table 8 << bits][ring (entries + kSingleMirror) x 16 B][flags 64 B].
 // ---------------------------------------------------------------------------------------------------------------
+// The consumer's group, hand-scheduled (64 states): the current table entry lives in v60:v61, the word in v62 (register
+// variables pinned there, see the loop).  All lanes form the table address of nx right after the multiply; the lanes that
+// renormalise then read {next entry, word} from the ring under EXEC = mask while the others gather their next entry under
+// EXEC = ~mask into the same registers.  10 vector, 3 LDS, 6 scalar instructions; one LDS round trip on the dependent chain.
+#define HSRANS_SINGLE_GROUP(SEL)                                                                                                                     \
+  "v_lshrrev_b32 %[t], %[vbits], %[x]\n\t"                                                                                                           \
+  "v_mad_u32_u24 %[x], v60, %[t], v61\n\t"                                                                                                           \
+  "v_perm_b32 %[acc], v60, %[acc], %[" #SEL "]\n\t"                                                                                                  \
+  "v_and_b32 %[t2], %[x], %[vmask]\n\t"                                                                                                              \
+  "v_lshl_add_u32 %[t2], %[t2], 3, %[stab]\n\t"                                                                                                      \
+  "v_cmpx_gt_u32 vcc, %[lim], %[x]\n\t"                                                                                                              \
+  "s_nop 1\n\t"                                                                                                                                      \
+  "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"                                                                                                           \
+  "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"                                                                                                        \
+  "v_lshl_add_u32 %[t], %[t], 4, %[sew]\n\t"                                                                                                         \
+  "ds_read_b64 v[60:61], %[t]\n\t"                                                                                                                   \
+  "ds_read_b32 v62, %[t] offset:8\n\t"                                                                                                               \
+  "s_not_b64 exec, vcc\n\t"                                                                                                                          \
+  "ds_read_b64 v[60:61], %[t2]\n\t"                                                                                                                  \
+  "s_mov_b64 exec, vcc\n\t"                                                                                                                          \
+  "s_bcnt1_i32_b64 %[st], vcc\n\t"                                                                                                                   \
+  "s_lshl4_add_u32 %[sew], %[st], %[sew]\n\t"                                                                                                        \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
+  "v_lshl_or_b32 %[x], %[x], 16, v62\n\t"                                                                                                            \
+  "s_mov_b64 exec, -1\n\t"
+
 __global__ void __launch_bounds__(128) k_decode_single(KParams kp)
 {
   extern __shared__ u32x4 smem_v[];
@@ -2493,7 +2522,7 @@ __global__ void __launch_bounds__(128) k_decode_single(KParams kp)
   uint8_t *ew = smem + table_bytes;
   // [0] words produced, [1] words released, [2] consumer done — LDS words, read with ds_read and made wave-uniform
   volatile __attribute__((address_space(3))) uint32_t *flags =
-      (volatile __attribute__((address_space(3))) uint32_t *)(uintptr_t)lds_address(ew + (R + 64) * 16);
+      (volatile __attribute__((address_space(3))) uint32_t *)(uintptr_t)lds_address(ew + (R + kSingleMirror) * 16);
   WaveCtx c{};
   c.stream = kp.stream;
   c.stream_len = kp.stream_len;
@@ -2552,7 +2581,7 @@ __global__ void __launch_bounds__(128) k_decode_single(KParams kp)
         const uint32_t idx = (produced + 8 * lane + j) & (R - 1);
         const u32x4 t = {e[j].x, e[j].y, w[j], 0};
         *(u32x4 *)(ew + idx * 16) = t;
-        if (idx < 64) // the first 64 entries once more behind the end: a group's reads never wrap
+        if (idx < kSingleMirror) // the first entries once more behind the end: the reads of 4 groups never wrap
           *(u32x4 *)(ew + (idx + R) * 16) = t;
       }
       produced += 512;
@@ -2628,6 +2657,32 @@ __global__ void __launch_bounds__(128) k_decode_single(KParams kp)
     return ex;
   };
   uint32_t steps = a.steps;
+  if (S == 64 && steps >= 4)
+  {
+    // the hand-scheduled loop: entry and word registers pinned (the asm names them), cursor as a plain LDS address
+    register uint32_t r_e0 asm("v60") = (uint32_t)e64;
+    register uint32_t r_e1 asm("v61") = (uint32_t)(e64 >> 32);
+    const uint8_t *out_base = kp.out;
+    for (; steps >= 4; steps -= 4)
+    {
+      need_words(256);
+      uint32_t s_ew = uni(ew_lds + ((cur & (R - 1)) << 4));
+      const uint32_t s_ew0 = s_ew;
+      uint32_t acc, t, t2, st;
+      asm volatile(HSRANS_SINGLE_GROUP(s0) HSRANS_SINGLE_GROUP(s1) HSRANS_SINGLE_GROUP(s2) HSRANS_SINGLE_GROUP(s3)
+                   : [x] "+v"(x), "+v"(r_e0), "+v"(r_e1), [acc] "=&v"(acc), [t] "=&v"(t), [t2] "=&v"(t2), [st] "=&s"(st), [sew] "+s"(s_ew)
+                   : [vmask] "v"(v_mask), [vbits] "v"(v_bits), [stab] "s"(table_lds), [lim] "s"(kConsume), [s0] "s"(0x0c0c0c07u), [s1] "s"(0x0c0c0700u), [s2] "s"(0x0c070100u),
+                     [s3] "s"(0x07020100u)
+                   : "v62", "vcc", "scc", "memory");
+      cur += (s_ew - s_ew0) >> 4;
+      acc = quad_transpose(acc, ol.sel_a, ol.sel_b);
+      HSRANS_STORE_U32_SADDR((uint8_t *)uni64((uint64_t)(uintptr_t)(out_base + o)), ol.store_off, acc);
+      o += 256;
+      if (lane == 0)
+        flags[1] = cur; // released: the producer may overwrite everything before the cursor
+    }
+    e64 = (unsigned long long)r_e0 | ((unsigned long long)r_e1 << 32);
+  }
   for (; steps >= 4; steps -= 4)
   {
     const uint32_t e0 = step(act), e1 = step(act), e2 = step(act), e3 = step(act);
@@ -3267,7 +3322,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
   if (kp.single.valid && !index_pass && g_single_fast)
   {
     // one chain of one piece (a raw stream without an index): the two-wave latency kernel
-    const uint32_t lds = (8u << h.bits) + (kp.single.ring_entries + 64) * 16 + 64;
+    const uint32_t lds = (8u << h.bits) + (kp.single.ring_entries + kSingleMirror) * 16 + 64;
     if (info)
     {
       *info = LaunchInfo{};
