@@ -96,7 +96,7 @@ def test_decode_loops_do_not_drain_the_memory_queue(tmp_path):
         cur.append((int(m.group(2), 16), m.group(1), target))
     checked = 0
     for name, ins in funcs.items():
-        if not re.search(r"k_decode(_direct|_dual)?ILi[0-4]E", name) and "k_decode_persist" not in name:  # (table mode 5 gathers its table from global memory: it has to wait)
+        if not re.search(r"k_decode(_direct|_dual)?ILi[0-4]E", name) and "k_decode_persist" not in name and "k_decode_single" not in name:  # (table mode 5 gathers its table from global memory: it has to wait)
             continue
         addr_index = {a: i for i, (a, _, _) in enumerate(ins)}
         loops = [(addr_index[t], i) for i, (a, _, t) in enumerate(ins) if t is not None and t < a and t in addr_index]
@@ -107,4 +107,4 @@ def test_decode_loops_do_not_drain_the_memory_queue(tmp_path):
             head = [s for _, s, _ in ins[lo:lo + 8]]
             assert not any(s.startswith("s_waitcnt") and "vmcnt" in s for s in head), (name, hex(ins[lo][0]), head)
             checked += 1
-    assert checked >= 12, checked
+    assert checked >= 14, checked
