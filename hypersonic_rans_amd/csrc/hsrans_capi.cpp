@@ -270,6 +270,7 @@ const char *hsrans_ctx_device_name(const hsrans_ctx *ctx) { return ctx ? ctx->na
 // (Re)fills a device plan from a validated host plan blob: uploads it and prepares whatever the launch of this plan's
 // kind needs (persistent arguments + host-built table, or the group list).  Device buffers are kept and grown, so a plan
 // object can be refilled per call without allocations (the host-pointer entries do that).  The device must be current.
+
 static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, const PlanHeader &h, hipStream_t s)
 {
   hsrans_ctx *ctx = d->ctx;
@@ -392,7 +393,7 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
         else if (!fill && !(g.flags & kGroupFill) && g.hist_off == p.hist_off)
         {
           joins = true;
-          if (!(cf[ch] - cf[ch - 1] == 1 && q.tail == 0 && q.out_off + (uint64_t)q.steps * h.states == p.out_off && q.words_off <= p.words_off))
+          if (!(cf[ch] - cf[ch - 1] == 1 && q.tail == 0 && q.out_off + (uint64_t)q.steps * h.states == p.out_off && q.words_off <= p.words_off && p.state_idx == ch))
             g.flags &= ~kGroupMergeable;
         }
       }
@@ -403,7 +404,8 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
         Group g{};
         g.begin = ch;
         g.count = 1;
-        g.flags = fill ? kGroupFill : (single ? kGroupMergeable : 0);
+        g.flags = fill ? kGroupFill : (single && p.state_idx == ch ? kGroupMergeable : 0);
+        g.piece0 = cf[ch];
         g.hist_off = fill ? 0 : p.hist_off;
         g.words_end = h.stream_len;
         // the previous rANS group's words end no later than this group's histogram / header
@@ -435,6 +437,7 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
           Group q = g;
           const uint32_t lo = (uint32_t)((uint64_t)g.count * part / k), hi = (uint32_t)((uint64_t)g.count * (part + 1) / k);
           q.begin = g.begin + lo;
+          q.piece0 = g.piece0 + lo;
           q.count = hi - lo;
           if (part + 1 < k)
             q.words_end = pc[cf[g.begin + hi]].words_off;

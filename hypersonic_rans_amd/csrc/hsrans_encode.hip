@@ -732,12 +732,14 @@ __global__ void __launch_bounds__(64) k_plan_blocks(EncParams ep)
     {
       const uint32_t lo = (uint32_t)((uint64_t)count * lane / k), hi = (uint32_t)((uint64_t)count * (lane + 1) / k);
       g.begin = c0 + lo;
+      g.piece0 = c0 + lo; // (k_plan_blocks: chain c is piece c, state set c)
       g.count = hi - lo;
       g.words_end = hi < count ? at + bytes - ep.ck_pos[(uint64_t)b * ep.max_ck + (hi - 1)] : at + bytes;
     }
     else
     {
       g.begin = c0;
+      g.piece0 = c0;
       g.count = 0;
       g.flags = kGroupFill;
       g.words_end = at + bytes;

@@ -44,7 +44,7 @@ struct Group
 {
   uint32_t begin, count;
   uint32_t flags; // 1: chains are single back-to-back rANS pieces (mergeable); 2: fill chains only (no table)
-  uint32_t reserved;
+  uint32_t piece0; // mergeable groups: index of chain `begin`'s piece (chain begin + i is piece piece0 + i, its states are states[begin + i])
   uint64_t hist_off;
   uint64_t words_end; // first stream byte after the group's words (next group's first header) or the stream length
 };

@@ -1585,14 +1585,45 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
 template <int MODE, bool FAST = false> // FAST: the hand-scheduled 32-state pair loop too (measured in a kernel of its own: 71 VGPRs, 7 waves per SIMD — not used)
 __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams &kp, uint32_t waves, uint32_t wave)
 {
+  // HSRANS_DEBUG_STAMPS: where a wave's time goes, summed over its rounds (tools/stamps_grouped.py): [0] first entry, [1] waiting
+  // at the round's barrier, [2] table build, [3] plan records + first chunks (until the decode loop starts), [4] decode, [5] rounds,
+  // [6] last exit
+  uint64_t t_first = 0, acc_wait = 0, acc_build = 0, acc_meta = 0, acc_dec = 0, rounds = 0;
+  if (kp.stamps)
+    t_first = __builtin_amdgcn_s_memrealtime();
+  // (Drawing the next group from a ticket counter instead of gi += gridDim.x was built and measured: the workgroups then finish
+  // together — lifetimes 482..515 us instead of 427..497 — but the launch takes as long: the CU decodes at its full rate either
+  // way, what a round loses is the 8 us of table build + plan records + first chunks at its start.  Left static.)
   for (uint32_t gi = blockIdx.x; gi < kp.n_groups; gi += gridDim.x)
   {
     const Group *G = kp.groups + gi;
     const uint32_t begin = uni(G->begin), count = uni(G->count), flags = uni(G->flags);
+    // mergeable groups: chain `begin + i` is piece `piece0 + i` and its start states are states[begin + i] (the host checks this
+    // when it marks a group mergeable), so a wave's records come straight from the group record: one level of loads, not three
+    const uint32_t piece0 = uni(G->piece0);
+    const uint64_t t0 = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no stream request of the previous group may still land in the scratch slot
     __syncthreads();                                    // every wave is done with the previous group's table and rings
+    const uint64_t t1 = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     if (!(flags & kGroupFill))
       build_table<MODE, true>(c, uni64(G->hist_off), threadIdx.x, blockDim.x);
+    const uint64_t t2 = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+    acc_wait += t1 - t0;
+    acc_build += t2 - t1;
+    rounds++;
+    auto stamp_out = [&]() {
+      if (kp.stamps && c.lane == 0)
+      {
+        uint64_t *st = kp.stamps + (uint64_t)(blockIdx.x * waves + wave) * 8;
+        st[0] = t_first;
+        st[1] = acc_wait;
+        st[2] = acc_build;
+        st[3] = acc_meta;
+        st[4] = acc_dec;
+        st[5] = rounds;
+        st[6] = __builtin_amdgcn_s_memrealtime();
+      }
+    };
     const uint32_t half = blockIdx.x >= (gridDim.x + 1) / 2 ? 1 : 0;
     // age-class weights only where a wave gets enough chains for them to mean something (else an even split)
     const bool weighted = count >= 8 * waves;
@@ -1607,11 +1638,11 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
       // lanes 32..63 (group_step_pair), like run_persistent_pair; whatever the pair loop leaves is finished one run at a time
       const uint32_t mid = first + (last - first + 1) / 2;
       const bool have_b = mid < last;
-      const Piece *a0 = pv.pieces + uni(pv.chain_first[first]);
-      const Piece *a1 = pv.pieces + uni(pv.chain_first[mid - 1]);
-      const Piece *b0 = pv.pieces + uni(pv.chain_first[have_b ? mid : first]);
-      const Piece *b1 = pv.pieces + uni(pv.chain_first[last - 1]);
-      const uint64_t limit = last < begin + count ? uni64(pv.pieces[uni(pv.chain_first[last])].words_off) : uni64(G->words_end);
+      const Piece *a0 = pv.pieces + (piece0 + (first - begin));
+      const Piece *a1 = pv.pieces + (piece0 + (mid - 1 - begin));
+      const Piece *b0 = pv.pieces + (piece0 + ((have_b ? mid : first) - begin));
+      const Piece *b1 = pv.pieces + (piece0 + (last - 1 - begin));
+      const uint64_t limit = last < begin + count ? uni64(pv.pieces[piece0 + (last - begin)].words_off) : uni64(G->words_end);
       StreamWin sw;
       Ring ra, rb;
       pair_bind<MODE>(ra, rb, c);
@@ -1619,7 +1650,7 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
       ring_begin(sw, ra, c, uni64(a0->words_off));
       if (have_b)
         ring_begin(sw, rb, c, uni64(b0->words_off));
-      const uint32_t src = (c.lane < 32 || !have_b) ? uni(a0->state_idx) : uni(b0->state_idx);
+      const uint32_t src = (c.lane < 32 || !have_b) ? first : mid;
       uint32_t x = pv.states[(uint64_t)src * 32 + (c.lane & 31)];
       uint64_t oa = uni64(a0->out_off), ob = have_b ? uni64(b0->out_off) : 0;
       uint32_t sa = (uint32_t)((uni64(a1->out_off) - oa) / 32) + uni(a1->steps);
@@ -1640,10 +1671,10 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
     }
     else if (flags & kGroupMergeable)
     {
-      const Piece *p0 = pv.pieces + uni(pv.chain_first[first]);
-      const Piece *p1 = pv.pieces + uni(pv.chain_first[last - 1]);
-      const uint64_t limit = last < begin + count ? uni64(pv.pieces[uni(pv.chain_first[last])].words_off) : uni64(G->words_end);
-      uint32_t x = c.lane < c.S ? pv.states[(uint64_t)uni(p0->state_idx) * c.S + c.lane] : 0;
+      const Piece *p0 = pv.pieces + (piece0 + (first - begin));
+      const Piece *p1 = pv.pieces + (piece0 + (last - 1 - begin));
+      const uint64_t limit = last < begin + count ? uni64(pv.pieces[piece0 + (last - begin)].words_off) : uni64(G->words_end);
+      uint32_t x = c.lane < c.S ? pv.states[(uint64_t)first * c.S + c.lane] : 0;
       StreamWin sw;
       Ring r;
       ring_bind(r, c.rings, 9, MODE == kModePack64);
@@ -1652,12 +1683,19 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
       uint64_t o = uni64(p0->out_off);
       const uint64_t steps = (uni64(p1->out_off) - o) / c.S + uni(p1->steps);
       ring_ready(x);
+      const uint64_t t3 = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
       run_groups<MODE, true>(x, sw, r, c, o, (uint32_t)steps);
       run_tail<MODE>(x, r, c, o, uni(p1->tail));
+      if (kp.stamps)
+      {
+        acc_meta += t3 - t2;
+        acc_dec += __builtin_amdgcn_s_memrealtime() - t3;
+      }
     }
     else
       for (uint32_t ch = first; ch < last; ch++)
         run_planned_chain<MODE, true>(c, pv, ch, kp);
+    stamp_out();
   }
 }
 
