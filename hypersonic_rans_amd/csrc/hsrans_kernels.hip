@@ -1591,9 +1591,11 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
   uint64_t t_first = 0, acc_wait = 0, acc_build = 0, acc_meta = 0, acc_dec = 0, rounds = 0;
   if (kp.stamps)
     t_first = __builtin_amdgcn_s_memrealtime();
-  // (Drawing the next group from a ticket counter instead of gi += gridDim.x was built and measured: the workgroups then finish
-  // together — lifetimes 482..515 us instead of 427..497 — but the launch takes as long: the CU decodes at its full rate either
-  // way, what a round loses is the 8 us of table build + plan records + first chunks at its start.  Left static.)
+  // (Built, measured on the 1 GiB mt_ workload and left out, separately and together: drawing the next group from a ticket counter
+  // instead of gi += gridDim.x — the workgroups then finish together, lifetimes 482..515 us instead of 427..497 — and checkpoints
+  // placed by wave class inside the blocks so that a block's 16 waves finish together (tools/stamps_grouped.py --weights).  Over
+  // 10-launch averages neither moves the launch: the CU decodes at its full rate either way; what a round loses is the ~8 us of
+  // table build + plan records + first chunks at its start.)
   for (uint32_t gi = blockIdx.x; gi < kp.n_groups; gi += gridDim.x)
   {
     const Group *G = kp.groups + gi;

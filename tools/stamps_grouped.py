@@ -16,11 +16,22 @@ ap.add_argument("--size", type=int, default=1 << 30)
 ap.add_argument("--block", type=int, default=1 << 18)
 ap.add_argument("--interval", type=int, default=256)
 ap.add_argument("--bits", type=int, default=11)
+ap.add_argument("--weights", default="", help="4 per-mille chain lengths by wave class (wave/4 in its workgroup): 16 checkpoints per block at weighted positions instead of --interval")
 a = ap.parse_args()
 base = synth.enwik8_shaped(1 << 26)
 data = np.tile(base, (a.size + base.size - 1) // base.size)[: a.size]
 ctx = H.Context(0)
-s, plan = H.encode(H.MT, 64, a.bits, data, block_size=a.block, index_interval=a.interval, independent_blocks=True)
+if a.weights:
+    w = np.repeat(np.array([float(x) for x in a.weights.split(",")]), 4)
+    gpb = a.block // 64  # groups per block
+    cum = np.cumsum(w) / w.sum()
+    inner = (np.round(cum[:-1] * gpb / 4) * 4).astype(np.uint64)  # 15 cuts inside a block, multiples of 4 groups
+    nblocks = (a.size + a.block - 1) // a.block
+    cuts = (np.arange(nblocks, dtype=np.uint64)[:, None] * np.uint64(gpb) + inner[None, :]).ravel()
+    cuts = cuts[cuts < np.uint64((a.size - 63) // 64)]
+    s, plan = H.encode(H.MT, 64, a.bits, data, block_size=a.block, index_groups=cuts, independent_blocks=True)
+else:
+    s, plan = H.encode(H.MT, 64, a.bits, data, block_size=a.block, index_interval=a.interval, independent_blocks=True)
 d_in = torch.from_numpy(np.concatenate([s, np.zeros((-s.size) % 16, np.uint8)])).cuda()
 d_out = torch.zeros(a.size, dtype=torch.uint8, device="cuda")
 dp = ctx.make_device_plan(plan)
