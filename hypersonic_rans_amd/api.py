@@ -39,7 +39,14 @@ class LaunchInfo(ctypes.Structure):
 
 def lib_path() -> str:
     # HSRANS_LIB: A/B a differently built libhsrans_hip.so in one process environment (kernel tuning only)
-    return os.environ.get("HSRANS_LIB") or os.path.join(_HERE, "lib", "libhsrans_hip.so")
+    if os.environ.get("HSRANS_LIB"):
+        return os.environ["HSRANS_LIB"]
+    if os.environ.get("HSRANS_DEBUG_STAMPS"):  # the per-wave stamps only exist in the diagnostic build (make -C csrc stamps)
+        stamps = os.path.join(_HERE, "lib", "libhsrans_hip_stamps.so")
+        if not os.path.exists(stamps):
+            raise HsransError("HSRANS_DEBUG_STAMPS needs the diagnostic library: make -C hypersonic_rans_amd/csrc stamps")
+        return stamps
+    return os.path.join(_HERE, "lib", "libhsrans_hip.so")
 
 
 _LIB = None

@@ -41,6 +41,14 @@ constexpr uint32_t kWaveRingBytes = kRingBytes + 256;     // per wave (ring + mi
 // re-based every 4 groups, so it can run up to one chunk past the ring's end: the mirror there is a whole chunk
 constexpr uint32_t kFastRingBytes = kRingBytes + kChunkBytes;
 constexpr uint32_t kConsume = 1u << 15; // rans.h:8 DecodeConsumePoint16
+// Per-wave time stamps (tools/stamps.py, tools/stamps_grouped.py, tools/tune_weights.py) exist only in the diagnostic build
+// (`make stamps` -> lib/libhsrans_hip_stamps.so: -DHSRANS_HAVE_STAMPS=1 -DHSRANS_GROUP_STAMPS=1; the Python layer loads it when
+// HSRANS_DEBUG_STAMPS=1).  Compiled in but switched off, their bookkeeping (five 64-bit time values kept across the decode loop)
+// cost the shipped kernels 3-4 %: 39.9 -> 38.1 us for the replayed 100 MB decode, 61.9 -> 59.4 us at 15 bits, 8 % in run_grouped.
+#ifndef HSRANS_HAVE_STAMPS
+#define HSRANS_HAVE_STAMPS 0
+#endif
+#define HSRANS_STAMPS(kp) (HSRANS_HAVE_STAMPS && (kp).stamps != nullptr)
 constexpr uint32_t kSingleMirror = 256;  // k_decode_single: ring entries mirrored behind the ring's end (4 groups x 64 words)
 
 // decode-table layouts
@@ -1130,7 +1138,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
 {
   const PersistentArgs &pa = kp.pa;
   const uint32_t W = gridDim.x * waves;
-  const uint64_t t_entry = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  const uint64_t t_entry = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;
   uint64_t t_table = 0, t_ready = 0;
 
   uint32_t x = 0;
@@ -1174,17 +1182,17 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
     }
     __syncthreads();
   }
-  if (kp.stamps)
+  if (HSRANS_STAMPS(kp))
     t_table = __builtin_amdgcn_s_memrealtime();
   if (q0 != 0)
   {
     ring_ready(x);
-    if (kp.stamps)
+    if (HSRANS_STAMPS(kp))
       t_ready = __builtin_amdgcn_s_memrealtime();
     run_groups<MODE, true>(x, sw, r, c, g.o, g.steps);
     run_tail<MODE>(x, r, c, g.o, g.tail);
   }
-  const uint64_t t_static = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  const uint64_t t_static = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;
 
   // Dynamic part: queue k hands out chains [lo, hi) in order.  Its 64-bit head is never reset: every launch draws
   // exactly H = (hi - lo) + (waves on this queue) tickets from it (each wave fails exactly once), and launches on one
@@ -1210,7 +1218,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
     run_tail<MODE>(x, r, c, g.o, g.tail);
   }
 
-  if (kp.stamps && c.lane == 0)
+  if (HSRANS_STAMPS(kp) && c.lane == 0)
   {
     uint64_t *st = kp.stamps + (uint64_t)w * 8;
     st[0] = t_entry;
@@ -1253,8 +1261,8 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
 {
   const PersistentArgs &pa = kp.pa;
   const uint32_t W = gridDim.x * waves;
-  const uint64_t t_entry = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
-  const uint64_t c_entry = kp.stamps ? __builtin_amdgcn_s_memtime() : 0; // shader clock (diagnostics: what does the chip run at under this load?)
+  const uint64_t t_entry = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;
+  const uint64_t c_entry = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memtime() : 0; // shader clock (diagnostics: what does the chip run at under this load?)
   uint64_t t_table = 0, t_ready = 0, t_static = 0;
   const bool host_table = (MODE == kModePack64 || MODE == kModeCoarse || MODE == kModeSpill) && pa.table != nullptr;
   if (!host_table) // the in-kernel build borrows ring space: it has to come before the first stream request
@@ -1287,7 +1295,7 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
     }
     if (MODE != kModeSpill)
       __syncthreads();
-    if (kp.stamps)
+    if (HSRANS_STAMPS(kp))
       t_table = __builtin_amdgcn_s_memrealtime();
   };
   // static part: chain w belongs to wave w (hsrans_index_boundaries sized it for this wave's scheduling class); dynamic
@@ -1319,14 +1327,14 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
         table_pending = false;
       }
       ring_ready(x);
-      if (kp.stamps && t_ready == 0)
+      if (HSRANS_STAMPS(kp) && t_ready == 0)
         t_ready = __builtin_amdgcn_s_memrealtime();
       uint64_t o = d.out;
       uint32_t steps = d.steps;
       run_groups<MODE, true>(x, sw, r, c, o, steps);
       run_tail<MODE>(x, r, c, o, d.tail);
     }
-    if (kp.stamps && t_static == 0)
+    if (HSRANS_STAMPS(kp) && t_static == 0)
       t_static = __builtin_amdgcn_s_memrealtime();
     if (!have_dynamic)
       break;
@@ -1341,7 +1349,7 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
   }
   if (table_pending) // a wave without a chain still takes part in the workgroup's table copy
     fetch_table();
-  if (kp.stamps && c.lane == 0)
+  if (HSRANS_STAMPS(kp) && c.lane == 0)
   {
     uint64_t *st = kp.stamps + (uint64_t)w * 8;
     st[0] = t_entry;
@@ -1364,7 +1372,7 @@ __device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t wa
 {
   const PersistentArgs &pa = kp.pa;
   const uint32_t W = gridDim.x * waves;
-  const uint64_t t_entry = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  const uint64_t t_entry = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;
   uint64_t t_ready = 0, t_static = 0;
   StreamWin sw;
   Ring ra, rb;
@@ -1422,7 +1430,7 @@ __device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t wa
         table_pending = false;
       }
       ring_ready(x);
-      if (kp.stamps && t_ready == 0)
+      if (HSRANS_STAMPS(kp) && t_ready == 0)
         t_ready = __builtin_amdgcn_s_memrealtime();
       uint64_t oa = da.out, ob = db.out;
       uint32_t sa = da.steps, sb = have_b ? db.steps : 0;
@@ -1436,7 +1444,7 @@ __device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t wa
       run_groups<MODE>(x, sw, ra, c, oa, sa);
       run_tail<MODE>(x, ra, c, oa, da.tail);
     }
-    if (kp.stamps && t_static == 0)
+    if (HSRANS_STAMPS(kp) && t_static == 0)
       t_static = __builtin_amdgcn_s_memrealtime();
     if (!have_dynamic)
       break;
@@ -1452,7 +1460,7 @@ __device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t wa
   }
   if (table_pending) // a wave without chains still takes part in the workgroup's table copy
     copy_table();
-  if (kp.stamps && c.lane == 0) // (tools/stamps.py, tools/tune_weights.py --states 32)
+  if (HSRANS_STAMPS(kp) && c.lane == 0) // (tools/stamps.py, tools/tune_weights.py --states 32)
   {
     uint64_t *st = kp.stamps + (uint64_t)w * 8;
     st[0] = t_entry;
@@ -1585,12 +1593,16 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
 template <int MODE, bool FAST = false> // FAST: the hand-scheduled 32-state pair loop too (measured in a kernel of its own: 71 VGPRs, 7 waves per SIMD — not used)
 __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams &kp, uint32_t waves, uint32_t wave)
 {
-  // HSRANS_DEBUG_STAMPS: where a wave's time goes, summed over its rounds (tools/stamps_grouped.py): [0] first entry, [1] waiting
-  // at the round's barrier, [2] table build, [3] plan records + first chunks (until the decode loop starts), [4] decode, [5] rounds,
-  // [6] last exit
-  uint64_t t_first = 0, acc_wait = 0, acc_build = 0, acc_meta = 0, acc_dec = 0, rounds = 0;
-  if (kp.stamps)
-    t_first = __builtin_amdgcn_s_memrealtime();
+  // -DHSRANS_GROUP_STAMPS=1 builds (tools/stamps_grouped.py; needs HSRANS_DEBUG_STAMPS=1 at run time): where a wave's time goes,
+  // summed over its rounds: [0] first entry, [1] waiting at the round's barrier, [2] table build, [3] plan records + first chunks
+  // (until the decode loop starts), [4] decode, [5] rounds, [6] last exit.  Compile-time because even switched off the extra
+  // bookkeeping cost this kernel 8 % (0.405 -> 0.44 of 8 TB/s on the 1 GiB mt_ workload without it).
+#if defined(HSRANS_GROUP_STAMPS) && HSRANS_GROUP_STAMPS
+#define HSRANS_GS(...) __VA_ARGS__
+#else
+#define HSRANS_GS(...)
+#endif
+  HSRANS_GS(uint64_t t_first = 0, acc_wait = 0, acc_build = 0, acc_meta = 0, acc_dec = 0, rounds = 0; if (HSRANS_STAMPS(kp)) t_first = __builtin_amdgcn_s_memrealtime();)
   // (Built, measured on the 1 GiB mt_ workload and left out, separately and together: drawing the next group from a ticket counter
   // instead of gi += gridDim.x — the workgroups then finish together, lifetimes 482..515 us instead of 427..497 — and checkpoints
   // placed by wave class inside the blocks so that a block's 16 waves finish together (tools/stamps_grouped.py --weights).  Over
@@ -1603,18 +1615,19 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
     // mergeable groups: chain `begin + i` is piece `piece0 + i` and its start states are states[begin + i] (the host checks this
     // when it marks a group mergeable), so a wave's records come straight from the group record: one level of loads, not three
     const uint32_t piece0 = uni(G->piece0);
-    const uint64_t t0 = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+    HSRANS_GS(const uint64_t t0 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no stream request of the previous group may still land in the scratch slot
     __syncthreads();                                    // every wave is done with the previous group's table and rings
-    const uint64_t t1 = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+    HSRANS_GS(const uint64_t t1 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;)
     if (!(flags & kGroupFill))
       build_table<MODE, true>(c, uni64(G->hist_off), threadIdx.x, blockDim.x);
-    const uint64_t t2 = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+#if defined(HSRANS_GROUP_STAMPS) && HSRANS_GROUP_STAMPS
+    const uint64_t t2 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;
     acc_wait += t1 - t0;
     acc_build += t2 - t1;
     rounds++;
     auto stamp_out = [&]() {
-      if (kp.stamps && c.lane == 0)
+      if (HSRANS_STAMPS(kp) && c.lane == 0)
       {
         uint64_t *st = kp.stamps + (uint64_t)(blockIdx.x * waves + wave) * 8;
         st[0] = t_first;
@@ -1626,6 +1639,7 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
         st[6] = __builtin_amdgcn_s_memrealtime();
       }
     };
+#endif
     const uint32_t half = blockIdx.x >= (gridDim.x + 1) / 2 ? 1 : 0;
     // age-class weights only where a wave gets enough chains for them to mean something (else an even split)
     const bool weighted = count >= 8 * waves;
@@ -1685,19 +1699,18 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
       uint64_t o = uni64(p0->out_off);
       const uint64_t steps = (uni64(p1->out_off) - o) / c.S + uni(p1->steps);
       ring_ready(x);
-      const uint64_t t3 = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+      HSRANS_GS(const uint64_t t3 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;)
       run_groups<MODE, true>(x, sw, r, c, o, (uint32_t)steps);
       run_tail<MODE>(x, r, c, o, uni(p1->tail));
-      if (kp.stamps)
-      {
+      HSRANS_GS(if (HSRANS_STAMPS(kp)) {
         acc_meta += t3 - t2;
         acc_dec += __builtin_amdgcn_s_memrealtime() - t3;
-      }
+      })
     }
     else
       for (uint32_t ch = first; ch < last; ch++)
         run_planned_chain<MODE, true>(c, pv, ch, kp);
-    stamp_out();
+    HSRANS_GS(stamp_out();)
   }
 }
 
@@ -2407,7 +2420,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
   c.scratch_cum = (uint16_t *)(smem + 512);
   const uint32_t W = gridDim.x * waves;
   const uint32_t w = blockIdx.x * waves + wave;
-  const uint64_t t_entry = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  const uint64_t t_entry = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;
   uint64_t t_table = 0, t_ready = 0;
 
   // the host-built table (always: the launcher only picks this kernel for plans that carry their histogram)
@@ -2431,7 +2444,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
         atomicOr(c.status, kStatusBadHist);
     }
     __syncthreads();
-    if (kp.stamps)
+    if (HSRANS_STAMPS(kp))
       t_table = __builtin_amdgcn_s_memrealtime();
   };
 
@@ -2465,7 +2478,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa), "+v"(xb)::"memory"); // start of a chain pair: states, table and the first chunks of both rings
     vm = 0;
     ra.seq1 = ra.seq2 = ra.seq3 = rb.seq1 = rb.seq2 = rb.seq3 = 0;
-    if (kp.stamps && t_ready == 0)
+    if (HSRANS_STAMPS(kp) && t_ready == 0)
       t_ready = __builtin_amdgcn_s_memrealtime();
     uint64_t oa = da.out, ob = db.out;
     uint32_t sa = da.steps, sb = have_b ? db.steps : 0;
@@ -2503,7 +2516,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
   }
   if (table_pending)
     fetch_table();
-  if (kp.stamps && c.lane == 0)
+  if (HSRANS_STAMPS(kp) && c.lane == 0)
   {
     uint64_t *st = kp.stamps + (uint64_t)w * 8;
     st[0] = t_entry;
@@ -2645,8 +2658,8 @@ __global__ void __launch_bounds__(128) k_decode_single(KParams kp)
   const OutLanes ol = out_lanes(lane, S);
   uint32_t cur = 0, produced_seen = 0; // words
   uint32_t refreshes = 0, starved = 0;  // diagnostics (HSRANS_DEBUG_STAMPS): reads of the producer's count / of those, how many found the ring short
-  const uint64_t t_begin = kp.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
-  const uint64_t c_begin = kp.stamps ? __builtin_amdgcn_s_memtime() : 0; // shader clock: what does a lone wave run at?
+  const uint64_t t_begin = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;
+  const uint64_t c_begin = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memtime() : 0; // shader clock: what does a lone wave run at?
   uint64_t o = uni64(a.out_off);
   uint32_t v_mask, v_bits;
   asm volatile("v_mov_b32 %0, %1" : "=v"(v_mask) : "s"(mask));
@@ -2752,7 +2765,7 @@ __global__ void __launch_bounds__(128) k_decode_single(KParams kp)
   }
   if (lane == 0)
     flags[2] = 1;
-  if (kp.stamps && lane == 0)
+  if (HSRANS_STAMPS(kp) && lane == 0)
   {
     kp.stamps[0] = t_begin;
     kp.stamps[1] = refreshes;

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Everything DESIGN.md §8 quotes, in one go on the GPU box:  bash tools/round_measure.sh <tag>   (outputs under gpurun_out/<tag>/)
+# (the two stamps files need the diagnostic library: make -C hypersonic_rans_amd/csrc stamps, before gpurun)
 set -u
 TAG=${1:-r02}
 OUT=gpurun_out/$TAG
