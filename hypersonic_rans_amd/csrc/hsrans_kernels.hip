@@ -49,6 +49,12 @@ constexpr uint32_t kConsume = 1u << 15; // rans.h:8 DecodeConsumePoint16
 #define HSRANS_HAVE_STAMPS 0
 #endif
 #define HSRANS_STAMPS(kp) (HSRANS_HAVE_STAMPS && (kp).stamps != nullptr)
+// The dynamic tail of the one-chain-per-wave launches (chains behind the first W go to whoever is done, through ticket queues):
+// measured slower than none (HSRANS_DIRECT_DYN_PERMILLE, default 0), so the default build leaves its code out of the kernels
+// as well; -DHSRANS_DIRECT_DYN=1 brings it back.  Plans with more chains than waves still decode: wave w takes chains w, w + W, ...
+#ifndef HSRANS_DIRECT_DYN
+#define HSRANS_DIRECT_DYN 0
+#endif
 constexpr uint32_t kSingleMirror = 256;  // k_decode_single: ring entries mirrored behind the ring's end (4 groups x 64 words)
 
 // decode-table layouts
@@ -1302,7 +1308,7 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
   // part: the chains behind the first W (short ones at the end of the stream, there to even out the finish) go to whoever
   // is done, through the same never-reset ticket queues as run_persistent (this launch's own set of heads).
   // (One loop, one call site of the decode body: a second copy of it pushes the kernel over the inliner's budget.)
-  const bool have_dynamic = pa.n_chains > W && pa.counters != nullptr;
+  const bool have_dynamic = HSRANS_DIRECT_DYN && pa.n_chains > W && pa.counters != nullptr;
   const uint64_t D = have_dynamic ? pa.n_chains - W : 0;
   const uint32_t nq = W < kDynQueues ? W : kDynQueues; // queues in use: every one of them needs a wave
   const uint32_t k = w % nq;
@@ -1337,7 +1343,14 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
     if (HSRANS_STAMPS(kp) && t_static == 0)
       t_static = __builtin_amdgcn_s_memrealtime();
     if (!have_dynamic)
-      break;
+    {
+      // more chains than waves (an index made for a bigger device, explicit checkpoints): wave w goes on with chain w + W, ...
+      ch += W;
+      have = ch < pa.n_chains;
+      if (!have)
+        break;
+      continue;
+    }
     unsigned long long t = 0;
     if (c.lane == 0)
       t = atomicAdd(pa.counters + k * kDynQueueStride, 1ull);
@@ -1403,7 +1416,7 @@ __device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t wa
   };
   // static pair (2w, 2w + 1), then dynamic pairs of adjacent chains behind the first 2W (see run_direct); one loop, one
   // call site of the decode body
-  const bool have_dynamic = pa.n_chains > 2 * W && pa.counters != nullptr;
+  const bool have_dynamic = HSRANS_DIRECT_DYN && pa.n_chains > 2 * W && pa.counters != nullptr;
   const uint64_t D = have_dynamic ? pa.n_chains - 2 * W : 0;
   const uint32_t nq = W < kDynQueues ? W : kDynQueues;
   const uint32_t k = w % nq;
@@ -1447,7 +1460,13 @@ __device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t wa
     if (HSRANS_STAMPS(kp) && t_static == 0)
       t_static = __builtin_amdgcn_s_memrealtime();
     if (!have_dynamic)
-      break;
+    {
+      a += 2 * W; // more chain pairs than waves: wave w goes on with chains 2 (w + W), ...
+      have = a < pa.n_chains;
+      if (!have)
+        break;
+      continue;
+    }
     unsigned long long t = 0;
     if (c.lane == 0)
       t = atomicAdd(pa.counters + k * kDynQueueStride, 1ull);

@@ -63,6 +63,8 @@ def test_raw_one_chain_per_wave_odd_shapes(gpu_ctx, oracle, nonstat, states, bit
                 cuts = (np.unique(rng.integers(1, groups_total // 4 - 1, size=k)) * 4).astype(np.uint64)
                 cases.append(cuts)
         cases.append((np.arange(1, min(64, groups_total // 8)) * 8).astype(np.uint64))  # many tiny chains at the front, one long one behind
+        if n == 3_000_000:
+            cases.append((np.arange(1, groups_total // 4) * 4).astype(np.uint64))  # more chains than the device has waves: every wave takes several
         for g in cases:
             if g.size == 0:
                 continue
