@@ -280,7 +280,7 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
         "config": {
             "workload": f"rANS32x{S} 16w {bits}-bit (raw + sidecar index) decode, {n} B enwik8-shaped synthetic (Zipf1.2/205 symbols, seed 20241008+rank), "
                         f"{P} distinct streams per GPU rotated through the timed loop ({P * (alg_bytes) / 2**20:.0f} MiB of stream + output: beyond the Infinity Cache), "
-                        + ("index with one chain per resident wavefront + a dynamic tail" if args.index == "wave" else f"index with a checkpoint every {args.index} groups")
+                        + ("index with one chain per resident wavefront" if args.index == "wave" else f"index with a checkpoint every {args.index} groups")
                         + f" ({chains} chains)",
             "container": "raw", "states": S, "bits": bits, "decoded_bytes": n, "compressed_bytes": int(stream.size),
             "ratio": stream.size / n, "index": args.index, "plan_bytes": int(plan.size), "plan_over_compressed": plan.size / stream.size,
