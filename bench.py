@@ -154,7 +154,7 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
     # BASELINE config 2's generator for the 100 MB workload; multi-GiB runs (tools/profile.sh) tile it (the generator makes ~7 MB/s)
     base = synth.enwik8_shaped(n, seed=20241008 + rank) if n <= (1 << 28) else _tiled(n, seed=20241008 + rank)
     pairs = []
-    t_enc = 0.0
+    t_enc = t_setup = 0.0
     groups = None if args.index != "wave" else H.index_boundaries(S, bits, n, ctx)
     for k in range(max(1, args.pairs)):
         data = _permuted(base, k)
@@ -165,9 +165,12 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
             stream, plan = H.encode(H.RAW, S, bits, data, index_interval=int(args.index))
         t_enc += time.perf_counter() - t0
         pad = (-stream.size) % 16
+        t0 = time.perf_counter()
+        dplan = ctx.make_device_plan(plan)  # hsrans_dplan_create: plan validation, host-built decode table, upload (synchronous)
+        t_setup += time.perf_counter() - t0
         p = {"data": data, "stream": stream, "plan": plan,
              "d_in": torch.from_numpy(np.concatenate([stream, np.zeros(pad, np.uint8)])).to(dev),
-             "d_out": torch.zeros(n, dtype=torch.uint8, device=dev), "dplan": ctx.make_device_plan(plan)}
+             "d_out": torch.zeros(n, dtype=torch.uint8, device=dev), "dplan": dplan}
         pairs.append(p)
     P = len(pairs)
     chains = H.plan_chain_count(pairs[0]["plan"])
@@ -286,12 +289,16 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
             "ratio": stream.size / n, "index": args.index, "plan_bytes": int(plan.size), "plan_over_compressed": plan.size / stream.size,
             "effective_ratio_with_index": (stream.size + plan.size) / n, "chains": chains, "pairs": P,
             "launch": info, "bit_exact": True, "sha256": shas[0], "host_encode_s": t_enc / P,
+            # once per (stream, plan), outside the timed region: hsrans_dplan_create = plan validation + host-built table + upload of the index
+            "plan_setup_ms": t_setup / P * 1e3,
         },
         # the reference harness prints min/mean throughput per decoder (src/main.cpp:72-118): same two numbers here
         "mib_s": {"mean_over_timed_region": world * n / 2**20 / elapsed * args.steps, "best_single_launch": n / 2**20 / (float(np.min(kernel_ms)) * 1e-3),
                   "warm_one_pair_replayed": n / 2**20 / (warm_ms * 1e-3), "launches_in_timed_region": args.steps},
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            # the same fraction from the wall clock of the timed region (B_alg / ms_per_step): what the driver's number implies
+            "frac_wall": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": (traffic_source + " (rocprofv3 --pmc run of this workload, not this process)") if traffic_source else None,
             "algorithmic_bytes_per_launch": alg_bytes, "index_bytes_read_per_launch": int(plan.size),
             "kernel_ms_avg": k_avg, "kernel_ms_single_launch_min": float(np.min(kernel_ms)),
@@ -357,9 +364,50 @@ def _tiled(n: int, seed: int) -> np.ndarray:
     return out
 
 
-def sharded_workload(args, world, rank, dev, dev_index, ctx, dist):
-    """ONE stream over all ranks (strong scaling): decode of this rank's chains + the exchange of the decoded ranges, both inside
-    the timed region; device plans, window uploads and buffers outside it."""
+class _Dev:
+    """What a rank's legs need from its device: the real one (HIP: torch.cuda + hsrans_ctx) or, for --rehearse only, none at
+    all (CPU tensors; the decode is the library's host SIMD decoder, the exchange runs over gloo)."""
+
+    def __init__(self, rehearse: bool, dev_index: int):
+        self.rehearse = rehearse
+        if rehearse:
+            self.dev, self.ctx = torch.device("cpu"), None
+        else:
+            self.dev = torch.device("cuda", dev_index)
+            torch.cuda.set_device(self.dev)
+            self.ctx = H.Context(dev_index)
+
+    def sync(self):
+        if not self.rehearse:
+            torch.cuda.synchronize()
+
+    def mark(self):
+        if self.rehearse:
+            return time.perf_counter()
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def ms(self, a, b) -> float:
+        return (b - a) * 1e3 if self.rehearse else a.elapsed_time(b)
+
+
+def _reduce_max(dist, dv: _Dev, x: float) -> float:
+    t = torch.tensor([x], dtype=torch.float64, device=dv.dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sharded_workload(args, world, rank, dv: _Dev, dist):
+    """ONE stream over all ranks (strong scaling, BASELINE config 4): every rank decodes its chains from its window of the stream;
+    the decoded ranges are exchanged INSIDE the timed region, pipelined behind the decode.  Device plans, window uploads and
+    buffers are made once, outside it.  Legs (all in this one run, each validated bit-exact before it is timed):
+        none   every rank keeps its range (the consumer is sharded too): decode only
+        all    every rank ends with the whole output; pipelined over --parts sub-runs, and unpipelined beside it
+        root   rank 0 ends with the whole output; its share of the chains is balanced against its inbound links
+               (measured by an unweighted, unpipelined step first); pipelined  — this is `value` for N > 1
+        one    rank 0 decodes the whole stream alone (the N = 1 figure of the same workload, same run)
+    and, beside them, `replicas`: every rank decoding its own 100 MB raw streams (the N = 1 headline workload, weak scaling)."""
     from hypersonic_rans_amd import sharded
 
     n, S, bits = args.size, args.states, args.bits
@@ -367,78 +415,177 @@ def sharded_workload(args, world, rank, dev, dev_index, ctx, dist):
     t0 = time.perf_counter()
     stream, plan = H.encode(H.MT, S, bits, data, block_size=args.block, index_interval=args.interval)
     t_enc = time.perf_counter() - t0
-    dec = sharded.ShardedDecoder(ctx, plan)
-    d_window = dec.upload_window(stream, dev)
-    out = torch.zeros(n, dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()
-    root = None if args.gather == "all" else 0
+    d_ref = torch.from_numpy(data).to(dv.dev)
+    alg = stream.size + n
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    def make(parts=1, weights=None, root=None):
+        if dv.rehearse:
+            return sharded.HostRehearsalDecoder(plan, H.MT, S, bits, parts=parts, weights=weights, root=root)
+        return sharded.ShardedDecoder(dv.ctx, plan, parts=parts, weights=weights, root=root)
 
-    def step(timed=False):
-        if timed:
-            ev[0].record()
-        dec.decode_window(d_window, out, gather=False)
-        if timed:
-            ev[1].record()
-        sharded.gather_ranges(out, dec.ranges, root=root)
-        if timed:
-            ev[2].record()
+    def check(dec, out, gathered: bool):
+        """bit-exact: the bytes this rank must hold after a step (everything, or its own range)"""
+        assert dec.global_status() == 0, "a rank's kernel reported a malformed stream"
+        if gathered and (dec.root is None or rank == dec.root):
+            ok = torch.equal(out[:n], d_ref)
+        else:
+            b, e = dec.ranges[rank]
+            ok = torch.equal(out[b - dec.out_base:e - dec.out_base], d_ref[b:e])
+        t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dv.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert int(t.item()) == 0, "sharded decode is not bit-exact"
 
-    step()
-    torch.cuda.synchronize()
-    assert dec.global_status() == 0
-    if root is None or rank == 0:
-        assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == hashlib.sha256(data.tobytes()).hexdigest(), "sharded decode is not bit-exact"
-    for _ in range(args.warmup):
-        step()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    dec_ms = gat_ms = 0.0
-    for _ in range(args.steps):
-        step(timed=True)
-        # the per-leg times need the events resolved; the synchronisation is part of a step (a consumer would wait for the output too)
-        torch.cuda.synchronize()
-        dec_ms += ev[0].elapsed_time(ev[1])
-        gat_ms += ev[1].elapsed_time(ev[2])
-    dist.barrier()
-    elapsed = time.perf_counter() - t0
-    ok = dec.global_status() == 0
-    if root is None or rank == 0:
-        ok = ok and hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == hashlib.sha256(data.tobytes()).hexdigest()
-    assert ok, "sharded decode is not bit-exact after the timed region"
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    seen = torch.ones(1, dtype=torch.int32, device=dev)
+    def leg(name, parts=1, weights=None, root=None, gather=True, split_legs=False, steps=None):
+        """Times `steps` steps of one configuration; max over ranks.  split_legs: decode and exchange timed separately
+        (unpipelined, one synchronisation per step) — used for calibration and for the per-leg figures."""
+        steps = steps or args.steps
+        dec = make(parts, weights, root)
+        d_window = dec.upload_window(stream, dv.dev)
+        out = dec.alloc_out(dv.dev)
+        dv.sync()
+        dec.step(d_window, out, gather=gather)
+        dv.sync()
+        check(dec, out, gather)
+        for _ in range(args.warmup):
+            dec.step(d_window, out, gather=gather)
+        dist.barrier()
+        dv.sync()
+        t0 = time.perf_counter()
+        dec_ms = gat_ms = 0.0
+        if split_legs:
+            for _ in range(steps):
+                a = dv.mark()
+                dec.step(d_window, out, gather=False)
+                b = dv.mark()
+                if gather:
+                    sharded.gather_ranges(out, dec.ranges, None, dec.root, dec.out_base)
+                c = dv.mark()
+                dv.sync()
+                dec_ms += dv.ms(a, b) / steps
+                gat_ms += dv.ms(b, c) / steps
+        else:
+            a = dv.mark()
+            for _ in range(steps):
+                dec.step(d_window, out, gather=gather)
+            b = dv.mark()
+            dv.sync()
+            dec_ms = dv.ms(a, b) / steps
+        dist.barrier()
+        elapsed = _reduce_max(dist, dv, time.perf_counter() - t0)
+        check(dec, out, gather)
+        mine = {"rank": rank, "chains": dec.count, "range": list(dec.ranges[rank]), "window_bytes": dec.window[1] - dec.window[0],
+                "out_bytes_held": dec.out_len, "stream_ms" if not split_legs else "decode_ms": dec_ms}
+        if split_legs:
+            mine["gather_ms"] = gat_ms
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        ms = elapsed * 1e3 / steps
+        return {"leg": name, "ms_per_step": ms, "MiB_s": n / 2**20 / (ms * 1e-3), "parts": parts, "gather": ("none" if not gather else "all" if root is None else f"root={root}"),
+                "shares": [r[1] - r[0] for r in dec.ranges], "pipelined": bool(gather and parts > 1), "per_rank": per_rank}
+
+    legs = {}
+    legs["none"] = leg("none", gather=False, split_legs=True)
+    decode_ms = max(r["decode_ms"] for r in legs["none"]["per_rank"])
+    root_share = 1.0
+    if world > 1:
+        legs["all_unpipelined"] = leg("all_unpipelined", gather=True, split_legs=True)
+        legs["all"] = leg("all", parts=args.parts, gather=True)
+        # calibration of the root's share: an unweighted, unpipelined gather to rank 0 gives one GPU's decode rate D (decoded bytes
+        # per second of the slowest rank) and the root's inbound rate B (the other ranks' bytes over the root's exchange time)
+        cal = leg("root_unweighted_unpipelined", root=0, gather=True, split_legs=True)
+        legs["root_unweighted_unpipelined"] = cal
+        r0 = cal["per_rank"][0]
+        share = cal["shares"]
+        D = max(share) / (max(r["decode_ms"] for r in cal["per_rank"]) * 1e-3)
+        B = (n - share[0]) / max(r0["gather_ms"] * 1e-3, 1e-9)
+        root_share = args.root_share if args.root_share else sharded.balanced_root_share(world, D, B)
+        # every rank must cut the chains identically: rank 0's measurement decides
+        t = torch.tensor([root_share], dtype=torch.float64, device=dv.dev)
+        dist.broadcast(t, 0)
+        root_share = float(t.item())
+        legs["root"] = leg("root", parts=args.parts, weights=sharded.root_weights(world, 0, root_share), root=0, gather=True)
+        legs["root"].update({"root_share": root_share, "decode_bytes_per_s": D, "root_inbound_bytes_per_s": B})
+        legs["one"] = leg("one", weights=sharded.root_weights(world, 0, 1.0), root=0, gather=True)
+    else:
+        legs["one"] = leg("one", gather=False)  # back-to-back launches, no per-step synchronisation
+    main = legs["root"] if world > 1 else legs["one"]
+
+    replicas = None
+    if world > 1 and not args.no_replicas and not dv.rehearse:
+        import copy
+
+        a2 = copy.copy(args)
+        a2.size, a2.no_single, a2.no_cpu, a2.timed_only = 100_000_000 if args.size >= (1 << 28) else args.size, True, True, True
+        r = headline(a2, world, rank, dv.dev, dv.dev.index, dv.ctx, dist)
+        if r is not None:
+            replicas = {"value": r["value"], "unit": "MiB/s", "ms_per_step": r["ms_per_step"], "scaling": "weak", "roofline_frac_per_gpu": r["roofline"]["frac"],
+                        "workload": r["config"]["workload"]}
+
+    seen = torch.ones(1, dtype=torch.int32, device=dv.dev)
     dist.all_reduce(seen)
-    legs = [None] * world
-    dist.all_gather_object(legs, {"rank": rank, "decode_ms": dec_ms / args.steps, "gather_ms": gat_ms / args.steps, "chains": dec.count,
-                                  "range": list(dec.ranges[rank]), "window_bytes": dec.window[1] - dec.window[0]})
     if rank != 0:
         return None
-    ms = elapsed * 1e3 / args.steps
-    worst_dec = max(l["decode_ms"] for l in legs)
-    alg = stream.size + n
-    cpu = _mt_cpu_baseline(stream, data, S, bits) if (world == 1 and not args.no_cpu) else None
-    return {
-        "cpu_baseline": cpu,
-        "metric": "decode MiB/s (bit-exact), one stream sharded over the GPUs, exchange of the decoded ranges included",
-        "value": n / 2**20 / (elapsed / args.steps), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+    cpu = _mt_cpu_baseline(stream, data, S, bits) if (world == 1 and not args.no_cpu and not dv.rehearse) else None
+    one_ms = legs["one"]["ms_per_step"] if world > 1 else main["ms_per_step"]
+    result = {
+        "metric": "decode MiB/s (bit-exact), one stream sharded over the GPUs, decoded ranges gathered to rank 0" if world > 1 else
+                  "decode MiB/s (bit-exact), one mt_ stream, one GPU",
+        "value": main["MiB_s"], "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main["ms_per_step"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 state / u16 word / u8 symbol (integer)", "data": "synthetic",
         "config": {"workload": f"mt_rANS32x{S} 16w {bits}-bit, ONE {n}-byte stream in {args.block}-byte blocks + index every {args.interval} groups, chains sharded "
-                               f"over {world} rank(s) by hsrans_plan_slice, decoded ranges exchanged point-to-point over RCCL ({args.gather})",
+                               f"over {world} rank(s) by hsrans_plan_slice, decoded ranges gathered to rank 0 point-to-point over "
+                               f"{'RCCL' if not dv.rehearse else 'gloo'}, exchange pipelined behind the decode in {args.parts} sub-runs, root share {root_share:.3f}",
                    "container": "mt_", "states": S, "bits": bits, "decoded_bytes": n, "compressed_bytes": int(stream.size), "ratio": stream.size / n,
                    "plan_bytes": int(plan.size), "plan_over_compressed": plan.size / stream.size, "chains": H.plan_chain_count(plan), "block": args.block,
-                   "index_interval_groups": args.interval, "gather": args.gather, "backend": dist.get_backend(), "n_ranks_seen": int(seen.item()),
-                   "host_encode_s": t_enc, "bit_exact": True},
-        "per_rank": legs,
-        "decode_only_MiB_s": n / 2**20 / (worst_dec * 1e-3),
-        "roofline": {"bound": "hbm", "achieved": alg / (worst_dec * 1e-3) / 1e9 / 1.0, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                     "frac": alg / (worst_dec * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
-                     "note": "decode kernels only (slowest rank), against the HBM peak of all ranks; the exchange is xGMI-bound, see per_rank.gather_ms"},
+                   "index_interval_groups": args.interval, "gather": "root" if world > 1 else "none", "parts": args.parts, "root_share": root_share,
+                   "backend": dist.get_backend(), "n_ranks_seen": int(seen.item()), "host_encode_s": t_enc, "bit_exact": True},
+        "gather": legs,
+        "decode_only_MiB_s": legs["none"]["MiB_s"],
+        "one_gpu_same_stream": {"ms_per_step": one_ms, "MiB_s": n / 2**20 / (one_ms * 1e-3)},
+        "speedup_vs_one_gpu": {k: one_ms / v["ms_per_step"] for k, v in legs.items() if k != "one"},
+        "replicas": replicas,
+        "per_rank": main["per_rank"],
+        "cpu_baseline": cpu,
+        "roofline": {"bound": "hbm", "achieved": alg / (decode_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                     "frac": alg / (decode_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), "traffic": None, "algorithmic_bytes_per_launch": alg,
+                     "frac_wall": alg / (legs["none"]["ms_per_step"] * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
+                     "note": "decode kernels of the `none` leg (slowest rank, HIP events on the launch stream), against the HBM peak of all ranks; "
+                             "the exchange is xGMI-bound: gather.*"},
     }
+    if dv.rehearse:
+        result["rehearsal"] = "host SIMD decoder over gloo: exercises rank spawn, sharding and the pipelined exchange; NOT a measurement of the product"
+    return result
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv: list[str], result_fd: int) -> int:
+    """`python bench.py --gpus N` without a launcher: this process becomes the launcher.  It starts N ranks (one per GPU) through
+    `python -m torch.distributed.run` — exactly the command line the driver uses — BEFORE anything here has touched the GPU
+    (a process that has initialised HIP must not fork/exec GPU children), relays rank 0's single JSON line and passes a
+    failure of any rank on as its own exit code."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT)
+    out, _ = p.communicate()
+    lines = [l for l in out.decode(errors="replace").splitlines() if l.startswith("{")]
+    if p.returncode != 0 or len(lines) != 1:
+        print(f"bench.py: the {n}-rank launch failed (exit code {p.returncode}, {len(lines)} result lines)", file=sys.stderr)
+        return p.returncode or 1
+    json.loads(lines[0])
+    os.write(result_fd, (lines[0] + "\n").encode())
+    return 0
 
 
 def main() -> None:
@@ -450,7 +597,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=("headline", "sharded"), default="headline")
+    ap.add_argument("--workload", choices=("headline", "sharded"), default=None,
+                    help="default: headline (100 MB raw stream per GPU) on one GPU, sharded (ONE 2^30-byte mt_ stream over all GPUs) on several")
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--bits", type=int, default=11)
     ap.add_argument("--states", type=int, default=64)
@@ -458,42 +606,60 @@ def main() -> None:
     ap.add_argument("--pairs", type=int, default=4, help="distinct (stream, output) pairs rotated through the timed loop")
     ap.add_argument("--block", type=int, default=1 << 18, help="sharded: mt_ block size in bytes")
     ap.add_argument("--interval", type=int, default=256, help="sharded: checkpoint interval inside the blocks, in groups")
-    ap.add_argument("--gather", choices=("all", "root"), default="all", help="sharded: every rank gets the whole output, or rank 0 only")
+    ap.add_argument("--parts", type=int, default=4, help="sharded: sub-runs per rank; sub-run k's exchange overlaps sub-run k+1's decode")
+    ap.add_argument("--root-share", type=float, default=0.0, help="sharded: the root's share of the decoded bytes (0 = balance it against the measured inbound rate)")
+    ap.add_argument("--no-replicas", action="store_true", help="sharded, N > 1: skip the weak-scaling replicas leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-single", action="store_true", help="skip the un-indexed single-wavefront and GPU-encoder legs")
     ap.add_argument("--timed-only", action="store_true", help="launch nothing but validation, warm-up and the timed rotation (profiling runs)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="NO GPU: ranks over gloo, sub-runs decoded by the library's host decoder — rehearses rank spawn, sharding and the pipelined "
+                         "exchange where there is no GPU (tests); the line is marked as not a measurement")
     args = ap.parse_args()
-    if args.steps is None:
-        args.steps = 50 if args.workload == "headline" else 20
-    if args.size is None:
-        args.size = 100_000_000 if args.workload == "headline" else 1 << 30
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher above us: be the launcher (nothing in this process has touched the GPU yet)
+        rc = spawn_ranks(args.gpus, sys.argv[1:], result_fd)
+        os.close(result_fd)
+        sys.exit(rc)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.workload is None:
+        args.workload = "headline" if world == 1 else "sharded"
+    if args.steps is None:
+        args.steps = 50 if args.workload == "headline" else 20
+    if args.size is None:
+        args.size = 100_000_000 if args.workload == "headline" else 1 << 30
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
     distributed = world > 1 or args.workload == "sharded"
     # one process per GPU; if the launcher narrowed each rank's view to its own GPU (HIP_VISIBLE_DEVICES), index 0 is that GPU
     n_visible = torch.cuda.device_count()
     dev_index = local_rank % n_visible if n_visible else 0
-    if not torch.cuda.is_available():
+    if args.rehearse:
+        if args.workload != "sharded":
+            raise SystemExit("--rehearse exists for the sharded workload only")
+    elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU decode path")
+    dv = _Dev(args.rehearse, dev_index)
     dist = None
     if distributed:
         import torch.distributed as dist
 
-        torch.cuda.set_device(dev_index)
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-    if args.gpus != world and rank == 0 and distributed:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    dev = torch.device("cuda", dev_index)
-    torch.cuda.set_device(dev)
-    ctx = H.Context(dev_index)
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dv.dev)
 
-    fn = headline if args.workload == "headline" else sharded_workload
-    result = fn(args, world, rank, dev, dev_index, ctx, dist)
+    if args.workload == "headline":
+        result = headline(args, world, rank, dv.dev, dev_index, dv.ctx, dist)
+    else:
+        result = sharded_workload(args, world, rank, dv, dist)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

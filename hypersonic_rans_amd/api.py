@@ -105,6 +105,8 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_decode_device.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp]
     L.hsrans_decode_device_window.restype = _i
     L.hsrans_decode_device_window.argtypes = [_vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp]
+    L.hsrans_decode_device_ranges.restype = _i
+    L.hsrans_decode_device_ranges.argtypes = [_vp, _vp, _vp, _sz, _sz, _vp, _sz, _sz, _vp]
     L.hsrans_dplan_status.restype = _i
     L.hsrans_dplan_status.argtypes = [_vp, _vp, _vp]
     L.hsrans_dplan_launch_info.restype = _i
@@ -456,6 +458,17 @@ class Context:
                                                 ctypes.c_void_p(s.cuda_stream))
         if rc != 0:
             raise HsransError(f"hsrans_decode_device_window failed with code {rc}")
+
+    def decode_device_ranges(self, dplan: DevicePlan, d_window: torch.Tensor, window_offset: int, window_length: int, d_out_window: torch.Tensor,
+                             out_offset: int, out_length: int, stream: torch.cuda.Stream | None = None):
+        """As decode_device_window for a caller that also holds only output bytes [out_offset, out_offset + out_length)
+        (hsrans_decode_device_ranges): one rank's share of a sharded decode."""
+        s = stream if stream is not None else torch.cuda.current_stream(d_window.device)
+        assert d_out_window.numel() >= out_length
+        rc = self.L.hsrans_decode_device_ranges(self.handle, dplan.handle, d_window.data_ptr(), window_offset, window_length, d_out_window.data_ptr(),
+                                                out_offset, out_length, ctypes.c_void_p(s.cuda_stream))
+        if rc != 0:
+            raise HsransError(f"hsrans_decode_device_ranges failed with code {rc}")
 
     def status(self, dplan: DevicePlan, stream: torch.cuda.Stream | None = None) -> int:
         s = stream if stream is not None else torch.cuda.current_stream()

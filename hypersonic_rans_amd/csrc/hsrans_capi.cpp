@@ -67,6 +67,9 @@ struct hsrans_dplan
   PersistentArgs pa{};
   SingleArgs single{};
   LaunchInfo info{};
+  // what the plan's chains touch, recorded by dplan_fill: the lowest stream byte any of them reads (its own words, its
+  // histogram / header, the shared histogram when the plan carries no copy of it) and the output bytes they write
+  uint64_t body_lo = 0, out_lo = 0, out_hi = 0;
 };
 
 namespace
@@ -279,6 +282,31 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
   d->pa = PersistentArgs{};
   d->single = SingleArgs{};
   d->n_groups = 0;
+  {
+    d->body_lo = 0;
+    d->out_lo = 0;
+    d->out_hi = h.decoded_len;
+    if (!(h.flags & kPlanWalk)) // (a walk plan starts from the states at stream + 16: body_lo stays 0)
+    {
+      const Piece *pc = (const Piece *)(plan + plan_pieces_off(h.n_chains));
+      uint64_t lo = h.stream_len, olo = h.decoded_len, ohi = 0;
+      for (uint32_t i = 0; i < h.n_pieces; i++)
+      {
+        const Piece &p = pc[i];
+        const uint64_t len = (p.flags & kPieceFill) ? p.fill_len : (uint64_t)p.steps * h.states + p.tail;
+        olo = std::min(olo, p.out_off);
+        ohi = std::max(ohi, p.out_off + len);
+        if (p.flags & kPieceFill)
+          continue;
+        lo = std::min(lo, p.words_off);
+        if (!h.shared_hist || !(h.flags & kPlanHasHist)) // the kernel reads this histogram from the stream
+          lo = std::min(lo, p.hist_off);
+      }
+      d->body_lo = lo;
+      d->out_lo = std::min(olo, ohi);
+      d->out_hi = ohi;
+    }
+  }
   if (!grow(&d->d_plan, &d->d_plan_cap, plan_size) || hipMemcpyAsync(d->d_plan, plan, plan_size, hipMemcpyHostToDevice, s) != hipSuccess)
     return HSRANS_E_HIP;
   if (d->d_status == nullptr && (hipMalloc((void **)&d->d_status, 64) != hipSuccess || hipMemsetAsync(d->d_status, 0, 64, s) != hipSuccess))
@@ -355,6 +383,8 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
       }
     }
   }
+  if (h.shared_hist && d->pa.table == nullptr) // no host-built table: the kernel builds its own from the histogram in the stream
+    d->body_lo = std::min(d->body_lo, h.aux_off);
   if (h.container == HSRANS_RAW && h.n_chains == 1 && h.n_pieces == 1 && !(h.flags & kPlanWalk) && h.bits <= 14)
   {
     // a raw stream without an index: one chain — the two-wave latency kernel (k_decode_single) instead of one wave of k_decode
@@ -656,6 +686,7 @@ int hsrans_dplan_create_from_device_stream(hsrans_ctx *ctx, int container, int s
     }
     d->hdr = h;
     d->plan_bytes = bytes;
+    d->out_hi = h.decoded_len; // a plan written on the device covers the whole stream and the whole output
     rc = HSRANS_OK;
   } while (false);
   if (d_res)
@@ -712,21 +743,41 @@ int hsrans_decode_device(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_stream,
   return dplan_launch(d, d_stream, stream_length, d_out, out_capacity, (hipStream_t)hip_stream);
 }
 
-int hsrans_decode_device_window(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_window, size_t window_offset, size_t window_length, void *d_out,
-                                size_t out_capacity, void *hip_stream)
+// the general launch: stream bytes [window_offset, +window_length) at d_window, output bytes [out_offset, +out_length) at d_out
+static int launch_ranges(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_window, size_t window_offset, size_t window_length, void *d_out, size_t out_offset,
+                         size_t out_length, void *hip_stream)
 {
   if (ctx == nullptr || d == nullptr || d_window == nullptr || d_out == nullptr || d->ctx != ctx)
     return HSRANS_E_ARG;
-  if (((uintptr_t)d_window & 15) != 0 || (window_offset & 15) != 0 || ((uintptr_t)d_out & 3) != 0 || (uintptr_t)d_window < window_offset)
+  if (((uintptr_t)d_window & 15) != 0 || (window_offset & 15) != 0 || ((uintptr_t)d_out & 3) != 0 || (out_offset & 3) != 0 ||
+      (uintptr_t)d_window < window_offset || (uintptr_t)d_out < out_offset)
     return HSRANS_E_ARG;
-  if (out_capacity < d->hdr.decoded_len || window_offset > d->hdr.stream_len)
+  if (window_offset > d->hdr.stream_len || out_offset > d->hdr.decoded_len)
     return HSRANS_E_FORMAT;
-  // every stream byte the plan's chains can read must be inside the window: [body_begin, body_end) of hsrans_plan_stream_ranges
-  // (checked here from the device plan's header only for the end; the begin is the caller's contract, documented in the header)
+  // Every byte the plan's chains read or write must be inside what the caller holds.  Lower edges: from the plan (dplan_fill
+  // recorded them).  Upper edge of the stream: the kernels' buffer descriptors end at min(window end, chain's last word), so a
+  // request past the window is dropped by the hardware; upper edge of the output: checked here.
+  if (window_offset > d->body_lo || d->out_lo < out_offset || d->out_hi - out_offset > out_length)
+    return HSRANS_E_FORMAT;
   if (hipSetDevice(ctx->device) != hipSuccess)
     return HSRANS_E_HIP;
-  const uint64_t end = std::min<uint64_t>(window_offset + window_length, d->hdr.stream_len);
-  return dplan_launch(d, (const uint8_t *)d_window - window_offset, (size_t)end, d_out, out_capacity, (hipStream_t)hip_stream, window_offset);
+  const uint64_t end = std::min<uint64_t>((uint64_t)window_offset + window_length, d->hdr.stream_len);
+  return dplan_launch(d, (const uint8_t *)d_window - window_offset, (size_t)end, (uint8_t *)d_out - out_offset, (size_t)d->hdr.decoded_len, (hipStream_t)hip_stream,
+                      window_offset);
+}
+
+int hsrans_decode_device_window(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_window, size_t window_offset, size_t window_length, void *d_out,
+                                size_t out_capacity, void *hip_stream)
+{
+  if (d == nullptr || out_capacity < d->hdr.decoded_len)
+    return d == nullptr ? HSRANS_E_ARG : HSRANS_E_FORMAT;
+  return launch_ranges(ctx, d, d_window, window_offset, window_length, d_out, 0, out_capacity, hip_stream);
+}
+
+int hsrans_decode_device_ranges(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_window, size_t window_offset, size_t window_length, void *d_out_window,
+                                size_t out_offset, size_t out_length, void *hip_stream)
+{
+  return launch_ranges(ctx, d, d_window, window_offset, window_length, d_out_window, out_offset, out_length, hip_stream);
 }
 
 int hsrans_dplan_status(hsrans_ctx *ctx, hsrans_dplan *d, void *hip_stream)
@@ -880,6 +931,7 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   }
   d->hdr = h;
   d->plan_bytes = bytes;
+  d->out_hi = h.decoded_len;
   d->n_groups = grouped ? ep.n_blocks * ep.group_split : 0;
   *out_dplan = d;
   return total;

@@ -223,7 +223,9 @@ __device__ __forceinline__ void win_open(StreamWin &sw, const WaveCtx &c, uint64
   const uint64_t a0 = pos & ~(uint64_t)15;
   // range in whole 16-byte lanes: a dwordx4 that straddles num_records is dropped as a whole, and a0 is 16-aligned
   // inside a 16-aligned allocation, so rounding up never leaves the page the last stream byte is on
-  const uint64_t left = a0 < limit ? (limit - a0 + 15) & ~(uint64_t)15 : 0;
+  // (a window launch holds nothing below stream_lo: the host entry refuses plans that read there, and a descriptor that would
+  // start below it is left empty, so every request through it is dropped)
+  const uint64_t left = a0 < limit && a0 >= c.stream_lo ? (limit - a0 + 15) & ~(uint64_t)15 : 0;
   const uint64_t addr = (uint64_t)(uintptr_t)c.stream + a0;
   sw.rs.x = uni((uint32_t)addr);
   sw.rs.y = uni((uint32_t)(addr >> 32) & 0xFFFF); // stride 0

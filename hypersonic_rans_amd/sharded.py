@@ -2,15 +2,21 @@
 
 The reference fans independent mt_ blocks out to a thread pool (src/mt_rANS32x64_16w_decode.cpp:182-224).  Here the unit
 is a *chain* of the decode plan (an mt_ block, or a checkpoint interval of a raw / block_ stream): the chains are split
-into `world_size` contiguous runs balanced by decoded bytes, every rank decodes its run into the same output offsets of
-its own buffer, and the disjoint byte ranges are then exchanged — the only collective, and only when the caller wants
-the output in one place.
+into `world_size` contiguous runs balanced by decoded bytes (or by given weights), every rank decodes its run into the
+same output offsets of its own buffer, and the disjoint byte ranges are then exchanged — the only collective, and only
+when the caller wants the output in one place.
 
 The exchange is point-to-point, like the hardware: on an MI355X node every GPU has a direct xGMI link to each of the
 other seven, so rank r sends its range to every peer that wants it with one grouped batch of sends/receives (RCCL
 ncclGroupStart{ncclSend/ncclRecv} under torch's batch_isend_irecv): all seven links of a GPU carry data at once and
 every byte crosses exactly one link, straight from the decoder's output buffer into the receiver's output buffer — no
 staging copy, no padding, no ring.  (A ring all-gather would push 7/8 of the output through each GPU's two ring links.)
+
+Two things keep the links from being the whole story (a GPU decodes 2 TB/s, its seven links take in about half of that):
+  * the exchange is PIPELINED behind the decode: every rank's run is cut into `parts` sub-runs; sub-run k's ranges are
+    on the links (RCCL's own stream) while sub-run k+1 decodes, so a step costs max(decode, exchange), not the sum;
+  * a gather to ONE rank is WEIGHTED: the root does not send, so it takes the share of the chains that makes its own
+    decode end together with its last receive (`root_share`); the other ranks split the rest.
 """
 from __future__ import annotations
 
@@ -21,36 +27,91 @@ import torch.distributed as dist
 from . import api
 
 
-def shard_chains(plan, world_size: int) -> list[tuple[int, int]]:
-    """Splits the plan's chains into `world_size` contiguous runs [(first, count), ...] of (nearly) equal decoded bytes.
-    Runs may be empty (count == 0) when there are fewer chains than ranks."""
+def _chain_ends(plan) -> tuple[np.ndarray, int]:
+    """decoded bytes up to and including chain c (chains are in output order in every plan this library builds)"""
     hdr, cf, pieces = api.plan_tables(plan)
     n, S = hdr["n_chains"], hdr["states"]
     size = np.where(pieces["flags"] & 2, pieces["fill_len"], pieces["steps"].astype(np.uint64) * S + pieces["tail"]).astype(np.uint64)
     per_piece_end = np.cumsum(size)
-    chain_end = per_piece_end[cf[1:].astype(np.int64) - 1]  # decoded bytes up to and including chain c (chains are in output order)
-    total = int(chain_end[-1]) if n else 0
-    bounds = [0]
-    for r in range(1, world_size):
-        target = total * r // world_size
-        bounds.append(max(bounds[-1], int(np.searchsorted(chain_end, target, side="right"))))
-    bounds.append(n)
-    return [(bounds[r], bounds[r + 1] - bounds[r]) for r in range(world_size)]
+    return per_piece_end[cf[1:].astype(np.int64) - 1], n
+
+
+def _cut(chain_end: np.ndarray, first: int, count: int, shares) -> list[tuple[int, int]]:
+    """Cuts chains [first, first+count) into len(shares) contiguous runs whose decoded bytes follow `shares` (any positive
+    numbers).  Runs may be empty when there are fewer chains than runs."""
+    shares = np.asarray(shares, dtype=np.float64)
+    assert shares.ndim == 1 and shares.size >= 1 and (shares >= 0).all() and shares.sum() > 0
+    lo = int(chain_end[first - 1]) if first > 0 else 0
+    hi = int(chain_end[first + count - 1]) if count else lo
+    cum = np.cumsum(shares) / shares.sum()
+    bounds = [first]
+    for r in range(shares.size - 1):
+        target = lo + int((hi - lo) * cum[r])
+        b = first + int(np.searchsorted(chain_end[first:first + count], target, side="right"))
+        bounds.append(min(max(bounds[-1], b), first + count))
+    bounds.append(first + count)
+    return [(bounds[r], bounds[r + 1] - bounds[r]) for r in range(shares.size)]
+
+
+def shard_chains(plan, world_size: int, weights=None) -> list[tuple[int, int]]:
+    """Splits the plan's chains into `world_size` contiguous runs [(first, count), ...] of (nearly) equal decoded bytes, or
+    of decoded bytes proportional to `weights[r]`.  Runs may be empty (count == 0) when there are fewer chains than ranks."""
+    chain_end, n = _chain_ends(plan)
+    return _cut(chain_end, 0, n, np.ones(world_size) if weights is None else weights)
 
 
 def local_range(plan, first: int, count: int) -> tuple[int, int]:
     return api.plan_chain_range(plan, first, count) if count else (0, 0)
 
 
-def gather_ranges(out: torch.Tensor, ranges: list[tuple[int, int]], group=None, root: int | None = None) -> torch.Tensor:
-    """`out` holds this rank's decoded bytes at their final offsets; `ranges[r]` = [begin, end) owned by rank r.
-    After the call `out` is complete on every rank (root None) or on rank `root` only.  In place: every transfer reads
-    the owner's slice of its `out` and lands in the same slice of the receiver's `out`; one grouped batch of
-    point-to-point operations (see the module docstring)."""
+def root_weights(world_size: int, root: int, root_share: float) -> list[float]:
+    """Shares for a gather to `root`: the root decodes `root_share` of the bytes (it sends nothing), the others split the rest."""
+    root_share = min(max(root_share, 1.0 / world_size), 1.0)
+    rest = (1.0 - root_share) / max(world_size - 1, 1)
+    return [root_share if r == root else rest for r in range(world_size)]
+
+
+def balanced_root_share(world_size: int, decode_bytes_per_s: float, inbound_bytes_per_s: float) -> float:
+    """The root's share a of the decoded bytes for which its own decode (a / D) takes as long as receiving the rest
+    ((1 - a) / B): a = D / (D + B).  D = one GPU's decode rate, B = the root's aggregate inbound rate, both in decoded
+    bytes per second (measured: bench.py times an unweighted step first).  Never below the equal share."""
+    if world_size <= 1:
+        return 1.0
+    a = decode_bytes_per_s / (decode_bytes_per_s + inbound_bytes_per_s)
+    return min(max(a, 1.0 / world_size), 1.0)
+
+
+class ShardLayout:
+    """Pure host arithmetic, identical on every rank: which chains / output bytes / stream bytes each rank owns and how each
+    rank's run is cut into `parts` sub-runs for the pipelined exchange."""
+
+    def __init__(self, plan, world_size: int, parts: int = 1, weights=None):
+        self.world, self.parts = world_size, max(1, parts)
+        chain_end, n = _chain_ends(plan)
+        self.runs = _cut(chain_end, 0, n, np.ones(world_size) if weights is None else weights)
+        self.ranges = [local_range(plan, f, c) for f, c in self.runs]
+        self.sub_runs = [_cut(chain_end, f, c, np.ones(self.parts)) for f, c in self.runs]
+        self.sub_ranges = [[local_range(plan, f, c) for f, c in subs] for subs in self.sub_runs]
+        self.total = api.plan_decoded_length(plan)
+        hdr, _, _ = api.plan_tables(plan)
+        self.stream_len = int(hdr["stream_len"])
+        self.windows = []
+        for f, c in self.runs:
+            if c:
+                (_hb, _he), (bb, be) = api.plan_stream_ranges(plan, f, c)
+                self.windows.append((bb & ~15, be))  # 16-byte aligned start: hsrans_decode_device_window
+            else:
+                self.windows.append((0, 0))
+
+
+def post_exchange(out: torch.Tensor, ranges: list[tuple[int, int]], group=None, root: int | None = None, out_base: int = 0) -> list:
+    """Posts (does not wait for) the point-to-point transfers of one set of ranges: `ranges[r]` = [begin, end) owned by rank r,
+    `out[i]` holds output byte out_base + i.  Every rank that owns bytes sends them to every peer that wants them (all peers,
+    or `root` only); one grouped batch.  Returns the requests."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1:
-        return out
+        return []
     ops = []
     b, e = ranges[rank]
     for peer in range(world):
@@ -58,38 +119,82 @@ def gather_ranges(out: torch.Tensor, ranges: list[tuple[int, int]], group=None, 
             continue
         g_peer = dist.get_global_rank(group, peer) if group is not None else peer
         if e > b and (root is None or root == peer):
-            ops.append(dist.P2POp(dist.isend, out[b:e], g_peer, group))
+            ops.append(dist.P2POp(dist.isend, out[b - out_base:e - out_base], g_peer, group))
         pb, pe = ranges[peer]
         if pe > pb and (root is None or root == rank):
-            ops.append(dist.P2POp(dist.irecv, out[pb:pe], g_peer, group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+            ops.append(dist.P2POp(dist.irecv, out[pb - out_base:pe - out_base], g_peer, group))
+    return list(dist.batch_isend_irecv(ops)) if ops else []
+
+
+def gather_ranges(out: torch.Tensor, ranges: list[tuple[int, int]], group=None, root: int | None = None, out_base: int = 0) -> torch.Tensor:
+    """`out` holds this rank's decoded bytes at their final offsets; `ranges[r]` = [begin, end) owned by rank r.
+    After the call `out` is complete on every rank (root None) or on rank `root` only.  In place: every transfer reads
+    the owner's slice of its `out` and lands in the same slice of the receiver's `out`; one grouped batch of
+    point-to-point operations (see the module docstring)."""
+    for req in post_exchange(out, ranges, group, root, out_base):
+        req.wait()
+    return out
+
+
+def pipelined_gather(out: torch.Tensor, layout: ShardLayout, decode_part, group=None, root: int | None = None, out_base: int = 0) -> torch.Tensor:
+    """One sharded decode step with the exchange pipelined behind the decode.  `decode_part(k)` launches (GPU: asynchronously
+    on the current stream) the decode of this rank's sub-run k into `out`.  Sub-run k's ranges go onto the links as soon as
+    its decode is done — the backend's own stream waits for exactly the work queued before the post — while sub-run k+1
+    decodes; the requests are waited for together at the end (GPU: the current stream then waits for the transfers).
+    A receiving root posts all its receives first: none of them depends on its own decode."""
+    rank = dist.get_rank(group)
+    reqs = []
+    if root is not None and rank == root:
+        for k in range(layout.parts):
+            reqs += post_exchange(out, [sr[k] for sr in layout.sub_ranges], group, root, out_base)
+        for k in range(layout.parts):
+            decode_part(k)
+    else:
+        for k in range(layout.parts):
+            decode_part(k)
+            reqs += post_exchange(out, [sr[k] for sr in layout.sub_ranges], group, root, out_base)
+    for req in reqs:
+        req.wait()
     return out
 
 
 class ShardedDecoder:
     """Everything that does not change between decodes of one (plan, world) pair, prepared once: this rank's chain run, its
-    output range, the stream bytes it needs and its device plan.  `decode` is then one kernel launch + the exchange."""
+    sub-runs and their device plans, its output range and the stream bytes it needs.  A step is then `parts` kernel launches
+    + the exchange.
 
-    def __init__(self, ctx: "api.Context", plan, group=None):
-        self.ctx, self.group = ctx, group
+    `parts`   sub-runs per rank for the pipelined exchange (1 = decode, then exchange).
+    `weights` decoded-byte shares of the ranks (None = equal; root_weights() for a gather to one rank).
+    `root`    the rank the output is gathered to (None = every rank): a rank that is not the root then needs only ITS OWN
+              range of the output in HBM (`alloc_out`), decoded through hsrans_decode_device_ranges."""
+
+    def __init__(self, ctx: "api.Context", plan, group=None, parts: int = 1, weights=None, root: int | None = None):
+        self.ctx, self.group, self.root = ctx, group, root
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.runs = shard_chains(plan, self.world)
-        self.ranges = [local_range(plan, f, c) for f, c in self.runs]
-        self.total = api.plan_decoded_length(plan)
-        hdr, _, _ = api.plan_tables(plan)
-        self.stream_len = int(hdr["stream_len"])
+        self.layout = ShardLayout(plan, self.world, parts, weights)
+        self.runs, self.ranges = self.layout.runs, self.layout.ranges
+        self.total, self.stream_len = self.layout.total, self.layout.stream_len
         self.first, self.count = self.runs[self.rank]
+        self.window = self.layout.windows[self.rank]
         self.dplan = None
-        self.window = (0, 0)
-        self.head = (0, 0)
+        self.part_dplans = []
         if self.count:
             self.dplan = ctx.make_device_plan(api.plan_slice(plan, self.first, self.count))
-            (hb, he), (bb, be) = api.plan_stream_ranges(plan, self.first, self.count)
-            self.head = (hb, he)
-            self.window = (bb & ~15, be)  # 16-byte aligned start: hsrans_decode_device_window
+            if self.layout.parts > 1:
+                self.part_dplans = [ctx.make_device_plan(api.plan_slice(plan, f, c)) if c else None for f, c in self.layout.sub_runs[self.rank]]
+            else:
+                self.part_dplans = [self.dplan]
+        else:
+            self.part_dplans = [None] * self.layout.parts
+        # the output bytes this rank has to hold: everything, or (root gathers, this rank is not the root) its own range
+        self.out_base, self.out_len = 0, self.total
+        if root is not None and self.rank != root:
+            b, e = self.ranges[self.rank]
+            self.out_base, self.out_len = b, e - b
+
+    def alloc_out(self, device) -> torch.Tensor:
+        return torch.zeros(max(self.out_len, 4), dtype=torch.uint8, device=device)
 
     # -- the stream is already in this rank's HBM, whole --------------------------------------------------------------
     def decode(self, d_stream: torch.Tensor, out: torch.Tensor, gather: bool = True, root: int | None = None) -> torch.Tensor:
@@ -118,18 +223,98 @@ class ShardedDecoder:
             self.ctx.decode_device_window(self.dplan, d_window, lo, hi - lo, out)
         return gather_ranges(out, self.ranges, self.group, root) if gather else out
 
+    def launch_part(self, k: int, d_window: torch.Tensor, out: torch.Tensor) -> None:
+        """Sub-run k of this rank, asynchronous on the current stream; `out` = alloc_out()'s buffer (output bytes
+        [out_base, out_base + out_len))."""
+        dp = self.part_dplans[k]
+        if dp is not None:
+            lo, hi = self.window
+            self.ctx.decode_device_ranges(dp, d_window, lo, hi - lo, out, self.out_base, self.out_len)
+
+    def step(self, d_window: torch.Tensor, out: torch.Tensor, gather: bool = True) -> torch.Tensor:
+        """One decode of the stream: this rank's sub-runs, their ranges exchanged (to `root`, or to everyone) behind the
+        decode of the next sub-run."""
+        if not gather:
+            for k in range(self.layout.parts):
+                self.launch_part(k, d_window, out)
+            return out
+        return pipelined_gather(out, self.layout, lambda k: self.launch_part(k, d_window, out), self.group, self.root, self.out_base)
+
+    def status_tensor(self, device) -> torch.Tensor:
+        """This rank's device status words OR-ed into one int32 tensor on `device` (no host round trip beyond the per-plan reads)."""
+        st = 0
+        for dp in {id(p): p for p in [self.dplan, *self.part_dplans] if p is not None}.values():
+            st |= 1 if self.ctx.status(dp) else 0
+        return torch.tensor([st], dtype=torch.int32, device=device)
+
     def global_status(self) -> int:
-        """This launch's device status OR-ed over all ranks (one small all-reduce): every rank learns whether any rank's kernel
-        met a malformed histogram / block header."""
-        st = self.ctx.status(self.dplan) if self.dplan is not None else 0
+        """The launches' device status OR-ed over all ranks (one small all-reduce): every rank learns whether any rank's kernel
+        met a malformed histogram / block header.  Synchronises; call it once after a batch of steps, not per step."""
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
-        t = torch.tensor([1 if st else 0], dtype=torch.int32, device=dev)
+        t = self.status_tensor(dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
 
     def check(self) -> None:
-        if self.dplan is not None and self.ctx.status(self.dplan) != 0:
-            raise api.HsransError("device reported a malformed histogram / block header")
+        for dp in [self.dplan, *self.part_dplans]:
+            if dp is not None and self.ctx.status(dp) != 0:
+                raise api.HsransError("device reported a malformed histogram / block header")
+
+
+class HostRehearsalDecoder:
+    """The same layout, sub-runs and pipelined exchange with NO GPU: every sub-run is decoded by the library's host SIMD
+    decoder (hsrans_decode_cpu on the sub-run's plan slice) into CPU tensors, the exchange runs over whatever backend the
+    process group has (gloo).  For rehearsing the multi-rank logic where there is no GPU — tests/ and `bench.py --rehearse` —
+    and never selected by anything on its own: the product's decode entries are the GPU ones."""
+
+    def __init__(self, plan, container: int, states: int, bits: int, group=None, parts: int = 1, weights=None, root: int | None = None):
+        self.group, self.root = group, root
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.codec = (container, states, bits)
+        self.layout = ShardLayout(plan, self.world, parts, weights)
+        self.runs, self.ranges, self.total = self.layout.runs, self.layout.ranges, self.layout.total
+        self.first, self.count = self.runs[self.rank]
+        self.window = self.layout.windows[self.rank]
+        self.part_plans = [api.plan_slice(plan, f, c) if c else None for f, c in self.layout.sub_runs[self.rank]]
+        self.out_base, self.out_len = 0, self.total
+        if root is not None and self.rank != root:
+            b, e = self.ranges[self.rank]
+            self.out_base, self.out_len = b, e - b
+        self._scratch = np.zeros(self.total + 64, np.uint8)
+
+    def alloc_out(self, device=None) -> torch.Tensor:
+        return torch.zeros(max(self.out_len, 4), dtype=torch.uint8)
+
+    def upload_window(self, host_stream, device=None, side_stream=None) -> np.ndarray:
+        """The rank's 'upload': a copy of the stream that is junk outside the bytes its chains may read."""
+        stream = api._u8(host_stream)
+        masked = np.full_like(stream, 0xEE)
+        lo, hi = self.window
+        masked[lo:hi] = stream[lo:hi]
+        return masked
+
+    def launch_part(self, k: int, window: np.ndarray, out: torch.Tensor) -> None:
+        plan = self.part_plans[k]
+        if plan is None:
+            return
+        container, states, bits = self.codec
+        r = api.load_library().hsrans_decode_cpu(-1, 1, container, states, bits, api._p(window), window.size, api._p(self._scratch), self.total, api._p(plan), plan.size)
+        if r != self.total:
+            raise api.HsransError("hsrans_decode_cpu failed on a plan slice")
+        b, e = self.layout.sub_ranges[self.rank][k]
+        out[b - self.out_base:e - self.out_base] = torch.from_numpy(self._scratch[b:e])
+
+    def step(self, window: np.ndarray, out: torch.Tensor, gather: bool = True) -> torch.Tensor:
+        if not gather:
+            for k in range(self.layout.parts):
+                self.launch_part(k, window, out)
+            return out
+        return pipelined_gather(out, self.layout, lambda k: self.launch_part(k, window, out), self.group, self.root, self.out_base)
+
+    def global_status(self) -> int:
+        t = torch.zeros(1, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
 
 
 def decode_sharded(ctx: "api.Context", d_stream: torch.Tensor, stream_length: int, plan, gather: bool = True, group=None) -> torch.Tensor:
@@ -143,15 +328,17 @@ def decode_sharded(ctx: "api.Context", d_stream: torch.Tensor, stream_length: in
     return out
 
 
-def decode_sharded_from_host(ctx: "api.Context", host_stream, plan, gather: bool = True, group=None) -> torch.Tensor:
+def decode_sharded_from_host(ctx: "api.Context", host_stream, plan, gather: bool = True, group=None, parts: int = 1, root: int | None = None,
+                             weights=None) -> torch.Tensor:
     """BASELINE config 4/5 shape: the stream lives in host memory on every rank, each rank uploads only the window its chains
-    read (on a side stream), decodes its chains, and the decoded ranges are exchanged."""
-    dec = ShardedDecoder(ctx, plan, group)
+    read (on a side stream), decodes its chains, and the decoded ranges are exchanged (pipelined over `parts` sub-runs).
+    Returns the rank's output buffer: the whole output, or — a root gather on a rank that is not the root — its own range."""
+    dec = ShardedDecoder(ctx, plan, group, parts=parts, weights=weights, root=root)
     dev = torch.device("cuda", torch.cuda.current_device())
     side = torch.cuda.Stream(device=dev)
     d_window = dec.upload_window(host_stream, dev, side)
-    out = torch.empty(dec.total, dtype=torch.uint8, device=dev)
+    out = dec.alloc_out(dev)
     torch.cuda.current_stream(dev).wait_stream(side)
-    dec.decode_window(d_window, out, gather=gather)
+    dec.step(d_window, out, gather=gather)
     dec.check()
     return out

@@ -171,10 +171,17 @@ int hsrans_decode_device(hsrans_ctx *ctx, hsrans_dplan *dplan, const void *d_str
 /* The same launch for a caller that holds only a WINDOW of the stream in device memory — the bytes
  * [window_offset, window_offset + window_length) at d_window — e.g. one GPU's share of a stream sharded with
  * hsrans_plan_slice: the window must cover the body range hsrans_plan_stream_ranges reports for the plan's chains
- * (window_offset a multiple of 16, at or below body_begin); a raw stream's shared histogram need not be in it when the plan
- * carries its copy.  Requests outside the window are dropped by the kernel's bounds check, never issued. */
+ * (window_offset a multiple of 16, at or below body_begin: HSRANS_E_FORMAT otherwise — the lowest stream byte the plan's
+ * chains read is recorded when the device plan is made); a raw stream's shared histogram need not be in it when the plan
+ * carries its copy.  Requests beyond the window's end are dropped by the kernel's bounds check, never issued. */
 int hsrans_decode_device_window(hsrans_ctx *ctx, hsrans_dplan *dplan, const void *d_window, size_t window_offset, size_t window_length, void *d_out,
                                 size_t out_capacity, void *hip_stream);
+/* ... and only a WINDOW of the output: d_out_window receives the decoded bytes [out_offset, out_offset + out_length)
+ * (out_offset a multiple of 4; the plan's chains must write inside it, hsrans_plan_chain_range: HSRANS_E_FORMAT
+ * otherwise).  A rank of a sharded decode then needs neither the whole stream nor the whole output in its HBM: the
+ * sender side of the gather in src/mt_rANS32x64_16w_decode.cpp:217-220's fan-out, one GPU per run of blocks. */
+int hsrans_decode_device_ranges(hsrans_ctx *ctx, hsrans_dplan *dplan, const void *d_window, size_t window_offset, size_t window_length, void *d_out_window,
+                                size_t out_offset, size_t out_length, void *hip_stream);
 /* Plan an mt_ stream that only exists in device memory: the header chain (src/mt_rANS32x64_16w_decode.cpp:166-227) is
  * followed by a device kernel; synchronises `hip_stream` twice (chain count, then the finished plan). HSRANS_MT only. */
 int hsrans_dplan_create_from_device_stream(hsrans_ctx *ctx, int container, int states, uint32_t bits, const void *d_stream, size_t stream_length,

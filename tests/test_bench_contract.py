@@ -28,3 +28,35 @@ def test_bench_line_has_the_contract_keys():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["value"] > 0 and d["ms_per_step"] > 0
+
+
+@pytest.mark.parametrize("n", (2, 4, 8))
+def test_bench_spawns_its_own_ranks(n):
+    """`python bench.py --gpus N` with no launcher above it starts N ranks itself and relays exactly ONE line (rehearsal mode: gloo
+    ranks, sub-runs decoded by the library's host decoder — the spawn, sharding and pipelined-exchange logic without a GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--rehearse", "--size", "2500000", "--block", "65536", "--interval", "32",
+                        "--steps", "2", "--warmup", "1", "--parts", "3"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{")
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["config"]["n_ranks_seen"] == n and d["config"]["backend"] == "gloo" and d["scaling"] == "strong"
+    assert "rehearsal" in d  # never mistaken for a measurement
+    for k in ("none", "all", "all_unpipelined", "root", "root_unweighted_unpipelined", "one"):
+        assert k in d["gather"], k
+        assert len(d["gather"][k]["per_rank"]) == n
+    assert d["gather"]["all"]["pipelined"] and d["gather"]["root"]["pipelined"] and not d["gather"]["all_unpipelined"]["pipelined"]
+    assert sum(d["gather"]["root"]["shares"]) == 2500000 and d["gather"]["one"]["shares"][0] == 2500000
+    assert 1 / n - 1e-9 <= d["config"]["root_share"] <= 1.0
+    # a rank that is not the root of a root gather holds only its own range
+    for pr in d["gather"]["root"]["per_rank"][1:]:
+        assert pr["out_bytes_held"] == pr["range"][1] - pr["range"][0]
+
+
+def test_bench_passes_a_rank_failure_on():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    # --rehearse with the headline workload is refused by every rank: the launcher must exit non-zero and print no result line
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--workload", "headline"], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

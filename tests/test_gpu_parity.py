@@ -210,6 +210,49 @@ def test_slice_upload_is_enough_for_a_slice(gpu_ctx, zipf, nonstat):
         assert uploaded < 1.1 * stream.size
 
 
+def test_output_window_and_window_lower_edge(gpu_ctx, nonstat):
+    """hsrans_decode_device_ranges: a rank holds only ITS range of the output (and its window of the stream); a window that starts
+    above the lowest byte the plan's chains read, or an output range the chains do not fit in, is refused (HSRANS_E_FORMAT = 3)."""
+    import torch
+    from hypersonic_rans_amd import sharded
+    d = nonstat[:1_200_000]
+    stream, plan = H.encode(H.MT, 64, 11, d, index_interval=32, block_size=65536)
+    layout = sharded.ShardLayout(plan, 3, parts=2)
+    for rank in range(3):
+        b, e = layout.ranges[rank]
+        lo, hi = layout.windows[rank]
+        window = torch.full((hi - lo + 16,), 0xEE, dtype=torch.uint8, device="cuda")
+        window[:hi - lo] = torch.from_numpy(stream[lo:hi]).cuda()
+        out = torch.full((e - b,), 0xCC, dtype=torch.uint8, device="cuda")
+        for f, c in layout.sub_runs[rank]:
+            dplan = gpu_ctx.make_device_plan(H.plan_slice(plan, f, c))
+            gpu_ctx.decode_device_ranges(dplan, window, lo, hi - lo, out, b, e - b)
+            assert gpu_ctx.status(dplan) == 0
+        assert torch.equal(out.cpu(), torch.from_numpy(d[b:e])), rank
+    # refusals: rank 1's plan with a window that begins 16 bytes too late / an output range that begins too late or is too short
+    f, c = layout.runs[1]
+    b, e = layout.ranges[1]
+    lo, hi = layout.windows[1]
+    dplan = gpu_ctx.make_device_plan(H.plan_slice(plan, f, c))
+    window = torch.zeros(hi - lo + 64, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(e - b + 64, dtype=torch.uint8, device="cuda")
+    (_hb, _he), (bb, _be) = H.plan_stream_ranges(plan, f, c)
+    too_late = (bb & ~15) + 16
+    L = gpu_ctx.L
+    s = torch.cuda.current_stream().cuda_stream
+    import ctypes
+    rc = L.hsrans_decode_device_ranges(gpu_ctx.handle, dplan.handle, window.data_ptr(), too_late, hi - too_late, out.data_ptr(), b, e - b, ctypes.c_void_p(s))
+    assert rc == 3
+    rc = L.hsrans_decode_device_window(gpu_ctx.handle, dplan.handle, window.data_ptr(), too_late, hi - too_late, torch.zeros(d.size, dtype=torch.uint8, device="cuda").data_ptr(),
+                                       d.size, ctypes.c_void_p(s))
+    assert rc == 3
+    rc = L.hsrans_decode_device_ranges(gpu_ctx.handle, dplan.handle, window.data_ptr(), lo, hi - lo, out.data_ptr(), b + 64, e - b, ctypes.c_void_p(s))
+    assert rc == 3
+    rc = L.hsrans_decode_device_ranges(gpu_ctx.handle, dplan.handle, window.data_ptr(), lo, hi - lo, out.data_ptr(), b, e - b - 64, ctypes.c_void_p(s))
+    assert rc == 3
+    torch.cuda.synchronize()
+
+
 def test_pipelined_host_decode(gpu_ctx, nonstat, zipf):
     """Upload / decode / download overlapped over slices of the plan (pinned host buffers): same bytes as one decode."""
     import torch
