@@ -497,7 +497,7 @@ class Context:
             raise HsransError("hsrans_index_build_at failed")
         return plan[:n].copy()
 
-    def decode_host_pipelined(self, container: int, states: int, bits: int, stream: torch.Tensor, out: torch.Tensor, plan, n_slices: int = 8) -> int:
+    def decode_host_pipelined(self, container: int, states: int, bits: int, stream: torch.Tensor, out: torch.Tensor, plan, n_slices: int = 0) -> int:
         """Host tensors (ideally pinned); returns the decoded length (0 = failure).  hsrans_decode_host_pipelined."""
         plan = _u8(plan)
         return self.L.hsrans_decode_host_pipelined(self.handle, container, states, bits, stream.data_ptr(), stream.numel(), out.data_ptr(), out.numel(),

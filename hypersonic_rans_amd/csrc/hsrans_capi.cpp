@@ -346,7 +346,15 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
     {
       const uint16_t *counts = (const uint16_t *)(plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
       std::vector<uint2> tab;
-      const TableChoice tc = choose_table(h.bits, h.states, h.interval == 0);
+      TableChoice tc = choose_table(h.bits, h.states, h.interval == 0);
+      if (tc.dual)
+      {
+        // k_decode_dual reads the two neighbouring chains of a wave through ONE 32-bit window of the stream: a pair whose words
+        // could span 4 GiB (a multi-GiB stream indexed for very few chains, e.g. by hsrans_plan_thin) goes one chain per wave
+        for (uint32_t a = 0; a < h.n_chains && tc.dual; a += 2)
+          if ((a + 2 < h.n_chains ? pc[a + 2].words_off : h.stream_len) - pc[a].words_off >= 0xFFFF0000ull)
+            tc = choose_table(h.bits, h.states, false);
+      }
       uint32_t mode = tc.mode;
       if (mode == 3 || mode == 5)
       {
@@ -487,6 +495,24 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
   return HSRANS_OK;
 }
 
+// A page-locked, device-mapped host range (hipHostMalloc / hipHostRegister): the address the GPU reaches it at, else null.
+static uint8_t *device_view_of_host(const void *ptr, size_t bytes)
+{
+  if (ptr == nullptr || bytes == 0)
+    return nullptr;
+  hipPointerAttribute_t a{}, b{};
+  if (hipPointerGetAttributes(&a, ptr) != hipSuccess || hipPointerGetAttributes(&b, (const uint8_t *)ptr + bytes - 1) != hipSuccess)
+  {
+    (void)hipGetLastError(); // pageable memory: not an error of ours
+    return nullptr;
+  }
+  if (a.type != hipMemoryTypeHost || b.type != hipMemoryTypeHost || a.devicePointer == nullptr || b.devicePointer == nullptr)
+    return nullptr;
+  if ((const uint8_t *)b.devicePointer - (const uint8_t *)a.devicePointer != (ptrdiff_t)(bytes - 1)) // one mapping, end to end
+    return nullptr;
+  return (uint8_t *)a.devicePointer;
+}
+
 // one launch of a filled device plan (asynchronous on s; the device must be current)
 static int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity, hipStream_t s, uint64_t stream_lo = 0)
 {
@@ -545,7 +571,9 @@ size_t hsrans_decode_host(hsrans_ctx *ctx, int container, int states, uint32_t b
   if (hipSetDevice(ctx->device) != hipSuccess)
     return 0;
   const size_t in_pad = (in_length + 15) / 16 * 16;
-  if (!grow(&ctx->d_in, &ctx->d_in_cap, in_pad) || !grow(&ctx->d_out, &ctx->d_out_cap, (size_t)h.decoded_len + 16))
+  // a page-locked `out` receives the kernel's stores directly (see hsrans_hpipe_decode); otherwise the output is staged and copied down
+  uint8_t *out_view = ((uintptr_t)out & 3) == 0 ? device_view_of_host(out, (size_t)h.decoded_len) : nullptr;
+  if (!grow(&ctx->d_in, &ctx->d_in_cap, in_pad) || (out_view == nullptr && !grow(&ctx->d_out, &ctx->d_out_cap, (size_t)h.decoded_len + 16)))
     return 0;
   hipStream_t s = ctx->stream;
   if (ctx->host_dplan == nullptr)
@@ -557,16 +585,16 @@ size_t hsrans_decode_host(hsrans_ctx *ctx, int container, int states, uint32_t b
   }
   hsrans_dplan *d = ctx->host_dplan;
   // the same launch the device entry gets for this plan (persistent / direct / grouped), on the context's staging buffers
-  if (hipMemcpyAsync(ctx->d_in, in, in_length, hipMemcpyHostToDevice, s) != hipSuccess || dplan_fill(d, plan, plan_size, h, s) != HSRANS_OK ||
-      hipMemsetAsync(d->d_status, 0, 4, s) != hipSuccess)
-    return 0;
-  if (dplan_launch(d, ctx->d_in, in_length, ctx->d_out, (size_t)h.decoded_len, s) != HSRANS_OK)
-    return 0;
   uint32_t status = 0xFFFFFFFF;
-  if (hipMemcpyAsync(out, ctx->d_out, (size_t)h.decoded_len, hipMemcpyDeviceToHost, s) != hipSuccess ||
-      hipMemcpyAsync(&status, d->d_status, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-    return 0;
-  return status == 0 ? (size_t)h.decoded_len : 0;
+  bool ok = hipMemcpyAsync(ctx->d_in, in, in_length, hipMemcpyHostToDevice, s) == hipSuccess && dplan_fill(d, plan, plan_size, h, s) == HSRANS_OK &&
+            hipMemsetAsync(d->d_status, 0, 4, s) == hipSuccess;
+  ok = ok && dplan_launch(d, ctx->d_in, in_length, out_view ? out_view : ctx->d_out, (size_t)h.decoded_len, s) == HSRANS_OK;
+  if (ok && out_view == nullptr)
+    ok = hipMemcpyAsync(out, ctx->d_out, (size_t)h.decoded_len, hipMemcpyDeviceToHost, s) == hipSuccess;
+  ok = ok && hipMemcpyAsync(&status, d->d_status, 4, hipMemcpyDeviceToHost, s) == hipSuccess;
+  // nothing queued may still read `in` / `own_plan` or write `out` when this returns, whether or not a call above failed
+  ok = (hipStreamSynchronize(s) == hipSuccess) && ok;
+  return ok && status == 0 ? (size_t)h.decoded_len : 0;
 }
 
 int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, hsrans_dplan **out_dplan)
@@ -1214,6 +1242,7 @@ struct hsrans_hpipe
   uint8_t *d_stream = nullptr, *d_out = nullptr;
   hipStream_t up = nullptr, dec = nullptr, down = nullptr;
   uint32_t *h_status = nullptr; // pinned, one word per slice
+  std::mutex lock;              // one decode at a time per pipe: its buffers, streams and events are shared
 };
 
 void hsrans_hpipe_destroy(hsrans_hpipe *p)
@@ -1254,8 +1283,8 @@ int hsrans_hpipe_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
   PlanHeader h;
   if (!read_header(plan, plan_size, &h) || !plan_validate(plan, plan_size, h.stream_len, h.decoded_len) || (h.flags & kPlanWalk))
     return HSRANS_E_FORMAT;
-  if (n_slices == 0) // auto: slices of >= 256 MiB of output (measured at 2^30 B: 4 slices 45.6 GB/s, 8 slices 34.7, 16 slices 34.3), 2..8
-    n_slices = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(2, h.decoded_len >> 28));
+  if (n_slices == 0) // auto: slices of >= 32 MiB of output, 2..16 (the first slice's upload is the only leg nothing overlaps with)
+    n_slices = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(2, h.decoded_len >> 25));
   if (n_slices > h.n_chains)
     n_slices = h.n_chains;
   if (hipSetDevice(ctx->device) != hipSuccess)
@@ -1271,7 +1300,8 @@ int hsrans_hpipe_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
     if (hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p->dec, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking) != hipSuccess)
       break;
-    if (hipMalloc((void **)&p->d_stream, (h.stream_len + 15) / 16 * 16 + 16) != hipSuccess || hipMalloc((void **)&p->d_out, h.decoded_len + 16) != hipSuccess ||
+    // (d_out, the staging buffer of the output, is allocated by the first decode that needs it: a page-locked `out` does not)
+    if (hipMalloc((void **)&p->d_stream, (h.stream_len + 15) / 16 * 16 + 16) != hipSuccess ||
         hipHostMalloc((void **)&p->h_status, n_slices * 4, hipHostMallocDefault) != hipSuccess)
       break;
     // chains -> n_slices contiguous runs of (nearly) equal decoded bytes (chains are in output order)
@@ -1333,8 +1363,19 @@ size_t hsrans_hpipe_decode(hsrans_hpipe *p, const uint8_t *in, size_t in_length,
 {
   if (p == nullptr || in == nullptr || out == nullptr || in_length < p->hdr.stream_len || out_capacity < p->hdr.decoded_len)
     return 0;
+  std::lock_guard<std::mutex> guard(p->lock); // a pipe's device buffers, streams and events serve one decode at a time
   if (hipSetDevice(p->ctx->device) != hipSuccess)
     return 0;
+  // Output leg.  Page-locked `out` (the documented way to call this): the decode kernels store STRAIGHT into it — every
+  // wavefront's 256-byte streaming stores cross PCIe themselves, so there is no device-side output buffer pass, no download
+  // copies and nothing for the copy engines to interleave badly (measured at 2^30 bytes: kernel with its output in host memory
+  // 19.6 ms against 18.8 ms for the plain download of the same bytes; staged through d_out with >= 8 slices the two copy
+  // directions serialised: 31 ms).  Pageable or unaligned `out`: staged through d_out and copied down slice by slice.
+  uint8_t *out_view = getenv("HSRANS_HPIPE_STAGED") == nullptr && ((uintptr_t)out & 3) == 0 ? device_view_of_host(out, (size_t)p->hdr.decoded_len) : nullptr;
+  const bool direct = out_view != nullptr;
+  if (!direct && p->d_out == nullptr && hipMalloc((void **)&p->d_out, p->hdr.decoded_len + 16) != hipSuccess)
+    return 0;
+  bool ok = true;
   // leg 1: every slice's stream bytes, in order, on the upload stream (a raw stream's shared histogram goes up once)
   bool head_done = false;
   for (auto &sl : p->slices)
@@ -1342,30 +1383,32 @@ size_t hsrans_hpipe_decode(hsrans_hpipe *p, const uint8_t *in, size_t in_length,
     const uint64_t *r = sl.in_ranges;
     if (r[1] > r[0] && !head_done)
     {
-      if (hipMemcpyAsync(p->d_stream + r[0], in + r[0], r[1] - r[0], hipMemcpyHostToDevice, p->up) != hipSuccess)
-        return 0;
+      ok = ok && hipMemcpyAsync(p->d_stream + r[0], in + r[0], r[1] - r[0], hipMemcpyHostToDevice, p->up) == hipSuccess;
       head_done = true;
     }
-    if (r[3] > r[2] && hipMemcpyAsync(p->d_stream + r[2], in + r[2], r[3] - r[2], hipMemcpyHostToDevice, p->up) != hipSuccess)
-      return 0;
-    if (hipEventRecord(sl.up_done, p->up) != hipSuccess)
-      return 0;
+    if (r[3] > r[2])
+      ok = ok && hipMemcpyAsync(p->d_stream + r[2], in + r[2], r[3] - r[2], hipMemcpyHostToDevice, p->up) == hipSuccess;
+    ok = ok && hipEventRecord(sl.up_done, p->up) == hipSuccess;
+    if (!ok)
+      break;
   }
-  // legs 2 and 3: slice k decodes as soon as its bytes are up; its output comes down as soon as it is decoded
-  for (size_t k = 0; k < p->slices.size(); k++)
+  // leg 2: slice k decodes as soon as its bytes are up (leg 3, staged mode only: its output comes down as soon as it is decoded)
+  for (size_t k = 0; ok && k < p->slices.size(); k++)
   {
     auto &sl = p->slices[k];
-    if (hipStreamWaitEvent(p->dec, sl.up_done, 0) != hipSuccess ||
-        dplan_launch(sl.dplan, p->d_stream, (size_t)p->hdr.stream_len, p->d_out, (size_t)p->hdr.decoded_len, p->dec) != HSRANS_OK ||
-        hipEventRecord(sl.dec_done, p->dec) != hipSuccess || hipStreamWaitEvent(p->down, sl.dec_done, 0) != hipSuccess)
-      return 0;
-    if (sl.out_end > sl.out_begin &&
-        hipMemcpyAsync(out + sl.out_begin, p->d_out + sl.out_begin, sl.out_end - sl.out_begin, hipMemcpyDeviceToHost, p->down) != hipSuccess)
-      return 0;
-    if (hipMemcpyAsync(p->h_status + k, sl.dplan->d_status, 4, hipMemcpyDeviceToHost, p->down) != hipSuccess)
-      return 0;
+    ok = hipStreamWaitEvent(p->dec, sl.up_done, 0) == hipSuccess &&
+         dplan_launch(sl.dplan, p->d_stream, (size_t)p->hdr.stream_len, direct ? out_view : p->d_out, (size_t)p->hdr.decoded_len, p->dec) == HSRANS_OK;
+    if (ok && !direct)
+    {
+      ok = hipEventRecord(sl.dec_done, p->dec) == hipSuccess && hipStreamWaitEvent(p->down, sl.dec_done, 0) == hipSuccess;
+      if (ok && sl.out_end > sl.out_begin)
+        ok = hipMemcpyAsync(out + sl.out_begin, p->d_out + sl.out_begin, sl.out_end - sl.out_begin, hipMemcpyDeviceToHost, p->down) == hipSuccess;
+    }
+    ok = ok && hipMemcpyAsync(p->h_status + k, sl.dplan->d_status, 4, hipMemcpyDeviceToHost, direct ? p->dec : p->down) == hipSuccess;
   }
-  if (hipStreamSynchronize(p->down) != hipSuccess)
+  // whatever happened, nothing that was queued may still be reading `in` or writing `out` when this returns
+  const bool s1 = hipStreamSynchronize(p->up) == hipSuccess, s2 = hipStreamSynchronize(p->dec) == hipSuccess, s3 = hipStreamSynchronize(p->down) == hipSuccess;
+  if (!ok || !s1 || !s2 || !s3)
     return 0;
   bool good = true;
   for (size_t k = 0; k < p->slices.size(); k++)

@@ -53,12 +53,21 @@ struct Table
 {
   uint32_t bits = 0;
   std::vector<uint32_t> slot;
+  bool freq_by_slot = false;
+  std::vector<uint16_t> slot_freq; // bits >= 13: freq per SLOT, so that the SIMD paths gather it beside `slot`, not after it
   alignas(64) uint32_t freq[256];
-  bool build(const uint8_t *counts_le16, uint32_t b)
+  // by_slot: also fill slot_freq (32-state chains, bits >= 13: their SIMD loop is bound by the latency of the dependent chain
+  // gather -> multiply -> renormalise, and a second gather BESIDE the first one is shorter than one behind it; 64-state chains
+  // are bound by throughput, where the larger table costs more in cache misses than the shorter chain gains — measured both ways)
+  bool build(const uint8_t *counts_le16, uint32_t b, bool by_slot)
   {
     bits = b;
+    by_slot = by_slot && b > 12;
+    freq_by_slot = by_slot;
     const uint32_t total = 1u << b;
     slot.resize(total + 16); // (+16: gathers never leave the allocation even with junk indices in dead lanes)
+    if (by_slot)
+      slot_freq.resize(total + 16);
     uint32_t cum = 0;
     for (uint32_t s = 0; s < 256; s++)
     {
@@ -68,6 +77,9 @@ struct Table
         return false;
       for (uint32_t k = 0; k < f; k++)
         slot[cum + k] = b <= 12 ? (s | ((f - 1) << 8) | (k << 20)) : (s | (k << 8));
+      if (by_slot)
+        for (uint32_t k = 0; k < f; k++)
+          slot_freq[cum + k] = (uint16_t)(f - 1); // (f - 1: 2^15 must fit; the dword gather at scale 2 reads two entries, the low one counts)
       cum += f;
     }
     return cum == total; // inplace_complete_hist (hist.cpp:308-324): the decoder returns 0 otherwise
@@ -121,6 +133,7 @@ void groups_scalar(uint32_t *x, const Table &t, Cursor &c, uint8_t *out, uint64_
 // ---------------------------------------------------------------------------------------------------------------
 alignas(32) uint32_t g_expand8[256][8]; // [mask][lane] = index of the word lane takes (rank of the lane among the set bits)
 alignas(64) uint32_t g_out_perm16[16];  // AVX-512: dword order after the two packs -> output order
+alignas(64) uint32_t g_out_perm16_s32[16]; // 32 states: the same (the low 8 dwords are stored)
 std::once_flag g_luts_once;
 
 void init_luts()
@@ -138,9 +151,16 @@ void init_luts()
   for (uint32_t q = 0; q < 4; q++)
     for (uint32_t v = 0; v < 4; v++)
       g_out_perm16[4 * (q & 1) + (q >> 1) + 2 * (v & 1) + 8 * (v >> 1)] = 4 * q + v;
+  // 32 states: state j = 16 v + 4 q + r -> byte r | (q >> 1) << 2 | v << 3 | (q & 1) << 4: output dword (q >> 1) | v << 1 | (q & 1) << 2
+  // comes from packed dword 4 q + v (lane q, dword v); output dwords 8..15 are not stored
+  for (uint32_t d = 0; d < 16; d++)
+    g_out_perm16_s32[d] = 0;
+  for (uint32_t q = 0; q < 4; q++)
+    for (uint32_t v = 0; v < 2; v++)
+      g_out_perm16_s32[(q >> 1) | (v << 1) | ((q & 1) << 2)] = 4 * q + v;
 }
 
-template <bool PACKED>
+template <int PACKED> // 1: bits <= 12 (one packed gather); 0: freq gathered by symbol after the slot entry; 2: freq gathered by slot beside it
 __attribute__((target("avx2,bmi2,popcnt"))) void groups_avx2(uint32_t *xs, const Table &t, Cursor &c, uint8_t *out, uint64_t steps, uint32_t S)
 {
   const uint32_t V = S / 8;
@@ -150,7 +170,7 @@ __attribute__((target("avx2,bmi2,popcnt"))) void groups_avx2(uint32_t *xs, const
   const __m256i vmask = _mm256_set1_epi32((int)((1u << t.bits) - 1));
   const __m128i vbits = _mm_cvtsi32_si128((int)t.bits);
   const __m256i lim = _mm256_set1_epi32((int)kConsumePoint16);
-  const __m256i m12 = _mm256_set1_epi32(0xFFF), mff = _mm256_set1_epi32(0xFF), one = _mm256_set1_epi32(1);
+  const __m256i m12 = _mm256_set1_epi32(0xFFF), mff = _mm256_set1_epi32(0xFF), one = _mm256_set1_epi32(1), mffff = _mm256_set1_epi32(0xFFFF);
   const int *tab = (const int *)t.slot.data();
   uint64_t g = 0;
   // a group reads at most S words + one 16-byte load at the last position: stay that far from the end, the rest goes scalar
@@ -163,14 +183,15 @@ __attribute__((target("avx2,bmi2,popcnt"))) void groups_avx2(uint32_t *xs, const
       const __m256i e = _mm256_i32gather_epi32(tab, slot, 4);
       const __m256i q = _mm256_srl_epi32(x[v], vbits);
       __m256i nx;
-      if (PACKED)
+      if (PACKED == 1)
       {
         const __m256i f = _mm256_add_epi32(_mm256_and_si256(_mm256_srli_epi32(e, 8), m12), one);
         nx = _mm256_add_epi32(_mm256_mullo_epi32(q, f), _mm256_srli_epi32(e, 20));
       }
       else
       {
-        const __m256i f = _mm256_i32gather_epi32((const int *)t.freq, _mm256_and_si256(e, mff), 4);
+        const __m256i f = PACKED == 2 ? _mm256_add_epi32(_mm256_and_si256(_mm256_i32gather_epi32((const int *)t.slot_freq.data(), slot, 2), mffff), one)
+                                      : _mm256_i32gather_epi32((const int *)t.freq, _mm256_and_si256(e, mff), 4);
         nx = _mm256_add_epi32(_mm256_mullo_epi32(q, f), _mm256_srli_epi32(e, 8));
       }
       sym[v] = _mm256_and_si256(e, mff);
@@ -204,38 +225,42 @@ __attribute__((target("avx2,bmi2,popcnt"))) void groups_avx2(uint32_t *xs, const
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// AVX-512 (F + BW + DQ + VL), 64 states = 4 vectors of 16
+// AVX-512 (F + BW + DQ + VL): 64 states = 4 vectors of 16, 32 states = 2 (the reference has AVX-512 decoders for both state
+// counts too: rANS32x64_16w.cpp:2108-4187, rANS32x32_16w.cpp:3032,3387)
 // ---------------------------------------------------------------------------------------------------------------
-template <bool PACKED>
+
+template <int PACKED, uint32_t V>
 __attribute__((target("avx512f,avx512bw,avx512dq,avx512vl,popcnt"))) void groups_avx512(uint32_t *xs, const Table &t, Cursor &c, uint8_t *out, uint64_t steps)
 {
-  __m512i x[4];
-  for (uint32_t v = 0; v < 4; v++)
+  constexpr uint32_t S = 16 * V;
+  __m512i x[V];
+  for (uint32_t v = 0; v < V; v++)
     x[v] = _mm512_loadu_si512(xs + 16 * v);
   const __m512i vmask = _mm512_set1_epi32((int)((1u << t.bits) - 1));
   const __m128i vbits = _mm_cvtsi32_si128((int)t.bits);
   const __m512i lim = _mm512_set1_epi32((int)kConsumePoint16);
-  const __m512i m12 = _mm512_set1_epi32(0xFFF), mff = _mm512_set1_epi32(0xFF), one = _mm512_set1_epi32(1);
-  const __m512i order = _mm512_load_si512(g_out_perm16);
+  const __m512i m12 = _mm512_set1_epi32(0xFFF), mff = _mm512_set1_epi32(0xFF), one = _mm512_set1_epi32(1), mffff = _mm512_set1_epi32(0xFFFF);
+  const __m512i order = _mm512_load_si512(V == 4 ? g_out_perm16 : g_out_perm16_s32);
   const int *tab = (const int *)t.slot.data();
   uint64_t g = 0;
-  while (g < steps && c.p + 2 * 64 + 32 <= c.end)
+  while (g < steps && c.p + 2 * S + 32 <= c.end)
   {
-    __m512i sym[4];
-    for (uint32_t v = 0; v < 4; v++)
+    __m512i sym[V];
+    for (uint32_t v = 0; v < V; v++)
     {
       const __m512i slot = _mm512_and_si512(x[v], vmask);
       const __m512i e = _mm512_i32gather_epi32(slot, tab, 4);
       const __m512i q = _mm512_srl_epi32(x[v], vbits);
       __m512i nx;
-      if (PACKED)
+      if (PACKED == 1)
       {
         const __m512i f = _mm512_add_epi32(_mm512_and_si512(_mm512_srli_epi32(e, 8), m12), one);
         nx = _mm512_add_epi32(_mm512_mullo_epi32(q, f), _mm512_srli_epi32(e, 20));
       }
       else
       {
-        const __m512i f = _mm512_i32gather_epi32(_mm512_and_si512(e, mff), (const int *)t.freq, 4);
+        const __m512i f = PACKED == 2 ? _mm512_add_epi32(_mm512_and_si512(_mm512_i32gather_epi32(slot, t.slot_freq.data(), 2), mffff), one)
+                                      : _mm512_i32gather_epi32(_mm512_and_si512(e, mff), (const int *)t.freq, 4);
         nx = _mm512_add_epi32(_mm512_mullo_epi32(q, f), _mm512_srli_epi32(e, 8));
       }
       sym[v] = _mm512_and_si512(e, mff);
@@ -245,14 +270,24 @@ __attribute__((target("avx512f,avx512bw,avx512dq,avx512vl,popcnt"))) void groups
       x[v] = _mm512_mask_or_epi32(nx, low, _mm512_slli_epi32(nx, 16), mine);
       c.p += 2 * (uint32_t)_mm_popcnt_u32((uint32_t)low);
     }
-    const __m512i packed = _mm512_packus_epi16(_mm512_packus_epi32(sym[0], sym[1]), _mm512_packus_epi32(sym[2], sym[3]));
-    _mm512_storeu_si512(out, _mm512_permutexvar_epi32(order, packed));
-    out += 64;
+    if constexpr (V == 4)
+    {
+      const __m512i packed = _mm512_packus_epi16(_mm512_packus_epi32(sym[0], sym[1]), _mm512_packus_epi32(sym[2], sym[3]));
+      _mm512_storeu_si512(out, _mm512_permutexvar_epi32(order, packed));
+    }
+    else
+    {
+      // per 128-bit lane q (states 4q..4q+3 of both vectors): bytes 0..3 = vector 0, bytes 4..7 = vector 1; the rest is padding
+      const __m512i pk = _mm512_packus_epi32(sym[0], sym[V - 1]);
+      const __m512i packed = _mm512_packus_epi16(pk, pk);
+      _mm256_storeu_si256((__m256i *)out, _mm512_castsi512_si256(_mm512_permutexvar_epi32(order, packed)));
+    }
+    out += S;
     g++;
   }
-  for (uint32_t v = 0; v < 4; v++)
+  for (uint32_t v = 0; v < V; v++)
     _mm512_storeu_si512(xs + 16 * v, x[v]);
-  groups_scalar(xs, t, c, out, steps - g, 64);
+  groups_scalar(xs, t, c, out, steps - g, S);
 }
 
 int detect_level()
@@ -281,11 +316,13 @@ static void decode_groups(int level, uint32_t *x, const Table &t, Cursor &c, uin
   std::call_once(g_luts_once, init_luts);
   if (level > best_level())
     level = best_level();
-  const bool packed = t.bits <= 12;
+  const int mode = t.bits <= 12 ? 1 : t.freq_by_slot ? 2 : 0;
   if (level == kLevelAvx512 && S == 64)
-    packed ? groups_avx512<true>(x, t, c, out, steps) : groups_avx512<false>(x, t, c, out, steps);
+    mode == 1 ? groups_avx512<1, 4>(x, t, c, out, steps) : mode == 2 ? groups_avx512<2, 4>(x, t, c, out, steps) : groups_avx512<0, 4>(x, t, c, out, steps);
+  else if (level == kLevelAvx512 && S == 32)
+    mode == 1 ? groups_avx512<1, 2>(x, t, c, out, steps) : mode == 2 ? groups_avx512<2, 2>(x, t, c, out, steps) : groups_avx512<0, 2>(x, t, c, out, steps);
   else if (level >= kLevelAvx2)
-    packed ? groups_avx2<true>(x, t, c, out, steps, S) : groups_avx2<false>(x, t, c, out, steps, S);
+    mode == 1 ? groups_avx2<1>(x, t, c, out, steps, S) : mode == 2 ? groups_avx2<2>(x, t, c, out, steps, S) : groups_avx2<0>(x, t, c, out, steps, S);
   else
     groups_scalar(x, t, c, out, steps, S);
 }
@@ -323,7 +360,7 @@ bool run_chain(int level, const PlanHeader &h, const uint32_t *cf, const Piece *
     }
     if (p.hist_off != have_hist)
     {
-      if (!t.build(stream + p.hist_off, h.bits))
+      if (!t.build(stream + p.hist_off, h.bits, S == 32))
         return false;
       have_hist = p.hist_off;
     }
@@ -389,7 +426,7 @@ bool run_block_walk(int level, const PlanHeader &h, const uint32_t *st, const ui
     }
     else
     {
-      if (hdr == 0 || pos + 512 > stream_len || !t.build(stream + pos, h.bits))
+      if (hdr == 0 || pos + 512 > stream_len || !t.build(stream + pos, h.bits, h.states == 32))
         return false;
       have_table = true;
       pos += 512;

@@ -24,6 +24,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "hsrans_kernels.h"
 #include "hsrans_plan.h"
 
@@ -3100,12 +3102,14 @@ size_t build_coarse_table(const uint16_t counts[256], uint32_t bits, uint2 *out,
   return coarse_table_entries(bits);
 }
 
-static void read_tuning_once()
+static void read_tuning_impl();
+static void read_tuning_once() // contexts may be created from several threads
 {
-  static bool done = false;
-  if (done)
-    return;
-  done = true;
+  static std::once_flag once;
+  std::call_once(once, read_tuning_impl);
+}
+static void read_tuning_impl()
+{
   if (const char *e = getenv("HSRANS_STATIC_PERCENT"))
     g_static_percent = (uint32_t)atoi(e) > 100 ? 100 : (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_PACK64_MAX_BITS"))
@@ -3151,8 +3155,8 @@ static void read_tuning_once()
     g_persist_kernel = (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_SINGLE_FAST"))
     g_single_fast = (uint32_t)atoi(e);
-  read_weights("HSRANS_DUAL_WEIGHTS", g_dual_weights);
-  read_weights("HSRANS_DUAL_WEIGHTS", g_dual_weights_coarse);
+  read_weights("HSRANS_DUAL_WEIGHTS", g_dual_weights);               // 13 bits (8-byte table)
+  read_weights("HSRANS_DUAL_WEIGHTS_COARSE", g_dual_weights_coarse); // 14 / 15 bits (coarse + fine tables)
   if (const char *e = getenv("HSRANS_DIRECT_DYN_PERMILLE"))
     g_direct_dyn_permille = (uint32_t)atoi(e) > 500 ? 500 : (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_DIRECT_DYN_GROUPS"))

@@ -23,7 +23,7 @@ class PipelinedHostDecoder:
     plan's layout (in practice: the same stream).  `host_stream` and `host_out` should be pinned (torch `pin_memory()`,
     or hsrans_host_register): with pageable memory the runtime stages the copies itself and the legs no longer overlap."""
 
-    def __init__(self, ctx: "api.Context", plan, n_slices: int = 8, device: "torch.device | None" = None):
+    def __init__(self, ctx: "api.Context", plan, n_slices: int = 0, device: "torch.device | None" = None):
         self.ctx = ctx
         self.L = api.load_library()
         plan = api._u8(plan)

@@ -114,7 +114,7 @@ def test_config5_eight_gib_of_mt_streams_through_the_pipelined_host_path(gpu_ctx
         host_stream = torch.empty(m, dtype=torch.uint8).pin_memory()
         host_stream.copy_(d_enc[:m])
         torch.cuda.synchronize()
-        dec = pipeline.PipelinedHostDecoder(gpu_ctx, plan, n_slices=8)
+        dec = pipeline.PipelinedHostDecoder(gpu_ctx, plan)  # default slicing (hsrans_hpipe_create n_slices = 0: by size)
         host_out.fill_(0xCC)
         t0 = time.perf_counter()
         dec.decode(host_stream, host_out)

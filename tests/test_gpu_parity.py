@@ -270,6 +270,15 @@ def test_pipelined_host_decode(gpu_ctx, nonstat, zipf):
             assert np.array_equal(host_out.numpy(), d), (container, k)
             dec.decode(host_stream, host_out)  # reusable
             assert np.array_equal(host_out.numpy(), d), (container, k)
+            # pageable output (and stream): the staged path — device-side output buffer, copied down slice by slice
+            pageable = torch.full((d.size,), 0xCC, dtype=torch.uint8)
+            dec.decode(torch.from_numpy(stream.copy()), pageable)
+            assert np.array_equal(pageable.numpy(), d), (container, k, "pageable")
+        # the one-call host entry with a page-locked output: the kernel stores straight into it
+        host_out.fill_(0xCC)
+        r = gpu_ctx.L.hsrans_decode_host(gpu_ctx.handle, container, 64, 11, host_stream.data_ptr(), host_stream.numel(), host_out.data_ptr(), host_out.numel(),
+                                         H.api._p(plan), plan.size)
+        assert r == d.size and np.array_equal(host_out.numpy(), d)
         host_out.fill_(0xCC)
         pipeline.decode_from_host_unpipelined(gpu_ctx, plan, host_stream, host_out)
         assert np.array_equal(host_out.numpy(), d)

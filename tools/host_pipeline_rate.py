@@ -50,12 +50,12 @@ assert torch.equal(host_out, host_ref)
 best, mean = timed(lambda: pipeline.decode_from_host_unpipelined(ctx, plan, host_stream, host_out))
 print(json.dumps({"mode": "upload, decode, download one after the other", "size": n, "compressed": m, "ms_best": round(best * 1e3, 2), "ms_mean": round(mean * 1e3, 2),
                   "decoded_GB_s": round(n / best / 1e9, 1)}), flush=True)
-for k in (4, 8, 16, 32):
+for k in (0, 2, 4, 8, 16, 32):  # 0 = the library's default slicing
     dec = pipeline.PipelinedHostDecoder(ctx, plan, n_slices=k)
     host_out.zero_()
     dec.decode(host_stream, host_out)
     ok = bool(torch.equal(host_out, host_ref))
     best, mean = timed(lambda: dec.decode(host_stream, host_out))
-    print(json.dumps({"mode": f"pipelined, {k} slices", "size": n, "compressed": m, "ms_best": round(best * 1e3, 2),
+    print(json.dumps({"mode": f"pipelined, {k} slices" + (" (staged output)" if os.environ.get("HSRANS_HPIPE_STAGED") else ""), "size": n, "compressed": m, "ms_best": round(best * 1e3, 2),
                       "ms_mean": round(mean * 1e3, 2), "decoded_GB_s": round(n / best / 1e9, 1), "bit_exact": ok}), flush=True)
     del dec
