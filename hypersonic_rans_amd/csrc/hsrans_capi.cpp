@@ -64,6 +64,7 @@ struct hsrans_dplan
   uint8_t *d_groups = nullptr;              // grouped launches (block_/mt_ plans with checkpoints)
   size_t d_groups_cap = 0;
   uint32_t n_groups = 0;
+  bool groups_lean = false; // 64 states, every group a mergeable run or fills only
   PersistentArgs pa{};
   SingleArgs single{};
   LaunchInfo info{};
@@ -282,6 +283,7 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
   d->pa = PersistentArgs{};
   d->single = SingleArgs{};
   d->n_groups = 0;
+  d->groups_lean = false;
   {
     d->body_lo = 0;
     d->out_lo = 0;
@@ -486,10 +488,21 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
     }
     if (groups.size() < h.n_chains)
     {
+      // ticket counters of the dynamic group order (monotonic: zeroed here once, never again)
+      const size_t cbytes = (size_t)kCounterSets * kDynQueues * kDynQueueStride * 8;
+      if (d->d_counters == nullptr && hipMalloc((void **)&d->d_counters, cbytes) != hipSuccess)
+        return HSRANS_E_HIP;
+      if (hipMemsetAsync(d->d_counters, 0, cbytes, s) != hipSuccess)
+        return HSRANS_E_HIP;
+      d->epoch.store(0, std::memory_order_relaxed);
       if (!grow(&d->d_groups, &d->d_groups_cap, groups.size() * sizeof(Group)) ||
           hipMemcpyAsync(d->d_groups, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
         return HSRANS_E_HIP;
       d->n_groups = (uint32_t)groups.size();
+      d->groups_lean = h.states == 64;
+      for (const Group &g : groups)
+        if (!(g.flags & (kGroupMergeable | kGroupFill)))
+          d->groups_lean = false;
     }
   }
   return HSRANS_OK;
@@ -534,6 +547,11 @@ static int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_len
   {
     kp.groups = (const Group *)d->d_groups;
     kp.n_groups = d->n_groups;
+    kp.groups_lean = d->groups_lean ? 1 : 0;
+    kp.group_overlap = getenv("HSRANS_GROUP_OVERLAP") != nullptr ? (uint32_t)atoi(getenv("HSRANS_GROUP_OVERLAP")) : 1;
+    // dynamic group order: this launch's own ticket counter (the counter sets of the persistent launches, one head of each used)
+    if (d->d_counters != nullptr && getenv("HSRANS_GROUP_STATIC") == nullptr)
+      kp.group_tickets = d->d_counters + (size_t)(d->epoch.fetch_add(1, std::memory_order_relaxed) % kCounterSets) * kDynQueues * kDynQueueStride;
   }
   return launch_decode(kp, d->hdr, d->ctx->geom, s, &d->info) == hipSuccess ? HSRANS_OK : HSRANS_E_HIP;
 }
@@ -961,6 +979,17 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   d->plan_bytes = bytes;
   d->out_hi = h.decoded_len;
   d->n_groups = grouped ? ep.n_blocks * ep.group_split : 0;
+  d->groups_lean = grouped && h.states == 64; // k_plan_blocks writes mergeable runs and fill groups only
+  if (grouped)
+  {
+    // ticket counters of the dynamic group order (as dplan_fill); without them the launch falls back to the static order
+    const size_t cbytes = (size_t)kCounterSets * kDynQueues * kDynQueueStride * 8;
+    if (hipMalloc((void **)&d->d_counters, cbytes) == hipSuccess && (hipMemsetAsync(d->d_counters, 0, cbytes, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess))
+    {
+      (void)hipFree(d->d_counters);
+      d->d_counters = nullptr;
+    }
+  }
   *out_dplan = d;
   return total;
 }

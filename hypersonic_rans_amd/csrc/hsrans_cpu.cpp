@@ -23,6 +23,7 @@
 #include "hsrans_cpu.h"
 
 #include <immintrin.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -45,41 +46,67 @@ inline uint16_t rd16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v;
 inline uint32_t lane_to_byte(uint32_t j) { return (j & 0x23u) | ((j & 0x04u) << 2) | ((j & 0x18u) >> 1); }
 
 // ---------------------------------------------------------------------------------------------------------------
-// decode table: one uint32 per slot.
-//   bits <= 12:  sym | (freq - 1) << 8 | (slot - cumul) << 20     (freq - 1 so that freq == 4096 fits; one gather per vector)
-//   bits >= 13:  sym | (slot - cumul) << 8, and freq[256] gathered by symbol (two gathers, like the reference's dec2 layout)
+// decode tables (chosen per histogram width and state count; `mode` tells the loops which one was built)
+//   kPacked    bits <= 11:  uint32 per slot = sym | (slot - cumul) << 8 | freq << 20: freq is one shift away from the gather
+//   kPackedM1  bits == 12:  the same with freq - 1 (4096 must fit 12 bits)
+//   kCompact   bits >= 13:  uint8 sym[2^bits] + uint32 {freq | cumul << 16}[256] — the reference's dec2 layout (hist.h:42-47):
+//                           two dependent gathers, both from tables that stay in L1 (8..32 KiB + 1 KiB)
+//   kBySlot    bits >= 13, 32-state chains: uint32 per slot = sym | (slot - cumul) << 8 and uint16 (freq - 1) per slot, gathered
+//                           side by side: a 32-state loop is bound by the latency of gather -> multiply -> renormalise, and a
+//                           second gather BESIDE the first is shorter than one behind it (64 states are throughput-bound: there
+//                           the bigger tables cost more in cache misses than the shorter chain gains — measured both ways)
 // ---------------------------------------------------------------------------------------------------------------
+enum TableMode { kPacked = 1, kPackedM1 = 3, kCompact = 0, kBySlot = 2 };
+
+inline int wide_mode_override() // HSRANS_CPU_WIDE_MODE=0|2: force kCompact / kBySlot for bits >= 13 (A/B runs)
+{
+  static const int v = [] { const char *e = getenv("HSRANS_CPU_WIDE_MODE"); return e ? atoi(e) : -1; }();
+  return v;
+}
+
 struct Table
 {
   uint32_t bits = 0;
-  std::vector<uint32_t> slot;
-  bool freq_by_slot = false;
-  std::vector<uint16_t> slot_freq; // bits >= 13: freq per SLOT, so that the SIMD paths gather it beside `slot`, not after it
-  alignas(64) uint32_t freq[256];
-  // by_slot: also fill slot_freq (32-state chains, bits >= 13: their SIMD loop is bound by the latency of the dependent chain
-  // gather -> multiply -> renormalise, and a second gather BESIDE the first one is shorter than one behind it; 64-state chains
-  // are bound by throughput, where the larger table costs more in cache misses than the shorter chain gains — measured both ways)
-  bool build(const uint8_t *counts_le16, uint32_t b, bool by_slot)
+  int mode = kPacked;
+  std::vector<uint32_t> slot;      // kPacked / kPackedM1 / kBySlot
+  std::vector<uint16_t> slot_freq; // kBySlot
+  std::vector<uint8_t> sym8;       // bits >= 13 (the scalar loop uses the compact pair at every such width)
+  alignas(64) uint32_t fc[256];    // freq | cumul << 16
+  bool build(const uint8_t *counts_le16, uint32_t b, uint32_t S)
   {
     bits = b;
-    by_slot = by_slot && b > 12;
-    freq_by_slot = by_slot;
+    mode = b <= 11 ? kPacked : b == 12 ? kPackedM1 : (S == 32 && b <= 14) ? kBySlot : kCompact;
+    if (b >= 13 && (wide_mode_override() == kCompact || wide_mode_override() == kBySlot))
+      mode = wide_mode_override();
     const uint32_t total = 1u << b;
-    slot.resize(total + 16); // (+16: gathers never leave the allocation even with junk indices in dead lanes)
-    if (by_slot)
+    // (+16: gathers never leave the allocation even with junk indices in dead lanes)
+    if (mode != kCompact)
+      slot.resize(total + 16);
+    if (mode == kBySlot)
       slot_freq.resize(total + 16);
+    if (b >= 13)
+      sym8.resize(total + 16);
     uint32_t cum = 0;
     for (uint32_t s = 0; s < 256; s++)
     {
       const uint32_t f = rd16(counts_le16 + 2 * s);
-      freq[s] = f;
+      fc[s] = f | (cum << 16);
       if (cum + f > total)
         return false;
-      for (uint32_t k = 0; k < f; k++)
-        slot[cum + k] = b <= 12 ? (s | ((f - 1) << 8) | (k << 20)) : (s | (k << 8));
-      if (by_slot)
+      if (mode == kPacked)
         for (uint32_t k = 0; k < f; k++)
+          slot[cum + k] = s | (k << 8) | (f << 20);
+      else if (mode == kPackedM1)
+        for (uint32_t k = 0; k < f; k++)
+          slot[cum + k] = s | (k << 8) | ((f - 1) << 20);
+      else if (mode == kBySlot)
+        for (uint32_t k = 0; k < f; k++)
+        {
+          slot[cum + k] = s | (k << 8);
           slot_freq[cum + k] = (uint16_t)(f - 1); // (f - 1: 2^15 must fit; the dword gather at scale 2 reads two entries, the low one counts)
+        }
+      if (b >= 13)
+        memset(sym8.data() + cum, (int)s, f);
       cum += f;
     }
     return cum == total; // inplace_complete_hist (hist.cpp:308-324): the decoder returns 0 otherwise
@@ -109,12 +136,18 @@ inline void group_scalar(uint32_t *x, const Table &t, Cursor &c, uint8_t *out, u
     const uint32_t p = lane_to_byte(j);
     if (p >= limit)
       continue;
-    const uint32_t v = x[j], e = t.slot[v & mask];
-    uint32_t nx;
+    const uint32_t v = x[j], sl = v & mask;
+    uint32_t nx, e;
     if (t.bits <= 12)
-      nx = (v >> t.bits) * (((e >> 8) & 0xFFF) + 1) + (e >> 20);
+    {
+      e = t.slot[sl];
+      nx = (v >> t.bits) * ((e >> 20) + (t.bits == 12 ? 1 : 0)) + ((e >> 8) & 0xFFF);
+    }
     else
-      nx = (v >> t.bits) * t.freq[e & 0xFF] + (e >> 8);
+    {
+      e = t.sym8[sl];
+      nx = (v >> t.bits) * (t.fc[e] & 0xFFFF) + sl - (t.fc[e] >> 16);
+    }
     out[p] = (uint8_t)e;
     if (nx < kConsumePoint16)
       nx = (nx << 16) | c.next();
@@ -160,7 +193,7 @@ void init_luts()
       g_out_perm16_s32[(q >> 1) | (v << 1) | ((q & 1) << 2)] = 4 * q + v;
 }
 
-template <int PACKED> // 1: bits <= 12 (one packed gather); 0: freq gathered by symbol after the slot entry; 2: freq gathered by slot beside it
+template <int PACKED> // = Table::mode
 __attribute__((target("avx2,bmi2,popcnt"))) void groups_avx2(uint32_t *xs, const Table &t, Cursor &c, uint8_t *out, uint64_t steps, uint32_t S)
 {
   const uint32_t V = S / 8;
@@ -169,7 +202,7 @@ __attribute__((target("avx2,bmi2,popcnt"))) void groups_avx2(uint32_t *xs, const
     x[v] = _mm256_loadu_si256((const __m256i *)(xs + 8 * v));
   const __m256i vmask = _mm256_set1_epi32((int)((1u << t.bits) - 1));
   const __m128i vbits = _mm_cvtsi32_si128((int)t.bits);
-  const __m256i lim = _mm256_set1_epi32((int)kConsumePoint16);
+  const __m256i lim_m1 = _mm256_set1_epi32((int)kConsumePoint16 - 1);
   const __m256i m12 = _mm256_set1_epi32(0xFFF), mff = _mm256_set1_epi32(0xFF), one = _mm256_set1_epi32(1), mffff = _mm256_set1_epi32(0xFFFF);
   const int *tab = (const int *)t.slot.data();
   uint64_t g = 0;
@@ -180,22 +213,30 @@ __attribute__((target("avx2,bmi2,popcnt"))) void groups_avx2(uint32_t *xs, const
     for (uint32_t v = 0; v < V; v++)
     {
       const __m256i slot = _mm256_and_si256(x[v], vmask);
-      const __m256i e = _mm256_i32gather_epi32(tab, slot, 4);
       const __m256i q = _mm256_srl_epi32(x[v], vbits);
-      __m256i nx;
-      if (PACKED == 1)
+      __m256i nx, e;
+      if (PACKED == kPacked || PACKED == kPackedM1)
       {
-        const __m256i f = _mm256_add_epi32(_mm256_and_si256(_mm256_srli_epi32(e, 8), m12), one);
-        nx = _mm256_add_epi32(_mm256_mullo_epi32(q, f), _mm256_srli_epi32(e, 20));
+        e = _mm256_i32gather_epi32(tab, slot, 4);
+        const __m256i f = PACKED == kPacked ? _mm256_srli_epi32(e, 20) : _mm256_add_epi32(_mm256_srli_epi32(e, 20), one);
+        nx = _mm256_add_epi32(_mm256_mullo_epi32(q, f), _mm256_and_si256(_mm256_srli_epi32(e, 8), m12));
+      }
+      else if (PACKED == kBySlot)
+      {
+        e = _mm256_i32gather_epi32(tab, slot, 4);
+        const __m256i f = _mm256_add_epi32(_mm256_and_si256(_mm256_i32gather_epi32((const int *)t.slot_freq.data(), slot, 2), mffff), one);
+        nx = _mm256_add_epi32(_mm256_mullo_epi32(q, f), _mm256_srli_epi32(e, 8));
       }
       else
       {
-        const __m256i f = PACKED == 2 ? _mm256_add_epi32(_mm256_and_si256(_mm256_i32gather_epi32((const int *)t.slot_freq.data(), slot, 2), mffff), one)
-                                      : _mm256_i32gather_epi32((const int *)t.freq, _mm256_and_si256(e, mff), 4);
-        nx = _mm256_add_epi32(_mm256_mullo_epi32(q, f), _mm256_srli_epi32(e, 8));
+        e = _mm256_and_si256(_mm256_i32gather_epi32((const int *)t.sym8.data(), slot, 1), mff);
+        const __m256i fc = _mm256_i32gather_epi32((const int *)t.fc, e, 4);
+        nx = _mm256_add_epi32(_mm256_mullo_epi32(q, _mm256_and_si256(fc, mffff)), _mm256_sub_epi32(slot, _mm256_srli_epi32(fc, 16)));
       }
       sym[v] = _mm256_and_si256(e, mff);
-      const __m256i low = _mm256_cmpgt_epi32(lim, nx); // nx < 2^15 (both < 2^31: signed compare is fine)
+      // nx < 2^15, UNSIGNED like every other level and the GPU (start states come from plan blobs: a state >= 2^31 must not
+      // renormalise here and nowhere else): min(nx, 2^15 - 1) == nx
+      const __m256i low = _mm256_cmpeq_epi32(_mm256_min_epu32(nx, lim_m1), nx);
       const uint32_t m = (uint32_t)_mm256_movemask_ps(_mm256_castsi256_ps(low));
       const __m256i words = _mm256_cvtepu16_epi32(_mm_loadu_si128((const __m128i *)c.p));
       const __m256i mine = _mm256_permutevar8x32_epi32(words, _mm256_load_si256((const __m256i *)g_expand8[m]));
@@ -249,19 +290,25 @@ __attribute__((target("avx512f,avx512bw,avx512dq,avx512vl,popcnt"))) void groups
     for (uint32_t v = 0; v < V; v++)
     {
       const __m512i slot = _mm512_and_si512(x[v], vmask);
-      const __m512i e = _mm512_i32gather_epi32(slot, tab, 4);
       const __m512i q = _mm512_srl_epi32(x[v], vbits);
-      __m512i nx;
-      if (PACKED == 1)
+      __m512i nx, e;
+      if (PACKED == kPacked || PACKED == kPackedM1)
       {
-        const __m512i f = _mm512_add_epi32(_mm512_and_si512(_mm512_srli_epi32(e, 8), m12), one);
-        nx = _mm512_add_epi32(_mm512_mullo_epi32(q, f), _mm512_srli_epi32(e, 20));
+        e = _mm512_i32gather_epi32(slot, tab, 4);
+        const __m512i f = PACKED == kPacked ? _mm512_srli_epi32(e, 20) : _mm512_add_epi32(_mm512_srli_epi32(e, 20), one);
+        nx = _mm512_add_epi32(_mm512_mullo_epi32(q, f), _mm512_and_si512(_mm512_srli_epi32(e, 8), m12));
+      }
+      else if (PACKED == kBySlot)
+      {
+        e = _mm512_i32gather_epi32(slot, tab, 4);
+        const __m512i f = _mm512_add_epi32(_mm512_and_si512(_mm512_i32gather_epi32(slot, t.slot_freq.data(), 2), mffff), one);
+        nx = _mm512_add_epi32(_mm512_mullo_epi32(q, f), _mm512_srli_epi32(e, 8));
       }
       else
       {
-        const __m512i f = PACKED == 2 ? _mm512_add_epi32(_mm512_and_si512(_mm512_i32gather_epi32(slot, t.slot_freq.data(), 2), mffff), one)
-                                      : _mm512_i32gather_epi32(_mm512_and_si512(e, mff), (const int *)t.freq, 4);
-        nx = _mm512_add_epi32(_mm512_mullo_epi32(q, f), _mm512_srli_epi32(e, 8));
+        e = _mm512_and_si512(_mm512_i32gather_epi32(slot, t.sym8.data(), 1), mff);
+        const __m512i fc = _mm512_i32gather_epi32(e, t.fc, 4);
+        nx = _mm512_add_epi32(_mm512_mullo_epi32(q, _mm512_and_si512(fc, mffff)), _mm512_sub_epi32(slot, _mm512_srli_epi32(fc, 16)));
       }
       sym[v] = _mm512_and_si512(e, mff);
       const __mmask16 low = _mm512_cmplt_epu32_mask(nx, lim);
@@ -316,13 +363,16 @@ static void decode_groups(int level, uint32_t *x, const Table &t, Cursor &c, uin
   std::call_once(g_luts_once, init_luts);
   if (level > best_level())
     level = best_level();
-  const int mode = t.bits <= 12 ? 1 : t.freq_by_slot ? 2 : 0;
+  const int mode = t.mode;
+#define HSRANS_CPU_BY_MODE(fn, ...) \
+  (mode == kPacked ? fn<kPacked __VA_ARGS__> : mode == kPackedM1 ? fn<kPackedM1 __VA_ARGS__> : mode == kBySlot ? fn<kBySlot __VA_ARGS__> : fn<kCompact __VA_ARGS__>)
   if (level == kLevelAvx512 && S == 64)
-    mode == 1 ? groups_avx512<1, 4>(x, t, c, out, steps) : mode == 2 ? groups_avx512<2, 4>(x, t, c, out, steps) : groups_avx512<0, 4>(x, t, c, out, steps);
+    HSRANS_CPU_BY_MODE(groups_avx512, , 4)(x, t, c, out, steps);
   else if (level == kLevelAvx512 && S == 32)
-    mode == 1 ? groups_avx512<1, 2>(x, t, c, out, steps) : mode == 2 ? groups_avx512<2, 2>(x, t, c, out, steps) : groups_avx512<0, 2>(x, t, c, out, steps);
+    HSRANS_CPU_BY_MODE(groups_avx512, , 2)(x, t, c, out, steps);
   else if (level >= kLevelAvx2)
-    mode == 1 ? groups_avx2<1>(x, t, c, out, steps, S) : mode == 2 ? groups_avx2<2>(x, t, c, out, steps, S) : groups_avx2<0>(x, t, c, out, steps, S);
+    HSRANS_CPU_BY_MODE(groups_avx2)(x, t, c, out, steps, S);
+#undef HSRANS_CPU_BY_MODE
   else
     groups_scalar(x, t, c, out, steps, S);
 }
@@ -360,7 +410,7 @@ bool run_chain(int level, const PlanHeader &h, const uint32_t *cf, const Piece *
     }
     if (p.hist_off != have_hist)
     {
-      if (!t.build(stream + p.hist_off, h.bits, S == 32))
+      if (!t.build(stream + p.hist_off, h.bits, S))
         return false;
       have_hist = p.hist_off;
     }
@@ -426,7 +476,7 @@ bool run_block_walk(int level, const PlanHeader &h, const uint32_t *st, const ui
     }
     else
     {
-      if (hdr == 0 || pos + 512 > stream_len || !t.build(stream + pos, h.bits, h.states == 32))
+      if (hdr == 0 || pos + 512 > stream_len || !t.build(stream + pos, h.bits, h.states))
         return false;
       have_table = true;
       pos += 512;

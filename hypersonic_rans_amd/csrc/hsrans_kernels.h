@@ -87,6 +87,11 @@ struct KParams
   PersistentArgs pa;
   const Group *groups; // null = not a grouped launch
   uint32_t n_groups;
+  // grouped launches with more groups than workgroups: the groups behind the first gridDim.x are handed out by a ticket counter
+  // (monotonic, this launch's own: never reset — every launch draws exactly n_groups tickets — see run_grouped); null = static
+  unsigned long long *group_tickets;
+  uint32_t groups_lean;   // 64-state plan, every group a mergeable run or fills only: the lean instantiation of k_decode_grouped
+  uint32_t group_overlap; // grouped launches: request piece records, states and first chunks before the table build (run_grouped)
   // grouped launches: wave k of a workgroup in grid half h takes chains [count * cum[h][k] / cum[h][waves], count * cum[h][k+1] / cum[h][waves])
   // of its group (the same age-class weights as PersistentArgs::run_len)
   uint16_t group_cum[2][17];

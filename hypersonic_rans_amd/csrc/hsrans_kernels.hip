@@ -246,7 +246,9 @@ __device__ __forceinline__ void win_open(StreamWin &sw, const WaveCtx &c, uint64
 static_assert(HSRANS_RING_AHEAD == 2 || HSRANS_RING_AHEAD == 3, "the ring has 4 slots: the cursor's chunk + 2 or 3 requested ones");
 
 // start streaming a chain whose first word is at absolute stream byte `pos` (>= sw.base, < sw.base + 4 GiB)
-__device__ __forceinline__ void ring_begin(const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t pos)
+// (`issue` false: the requests of exactly this call were issued earlier — run_grouped asks for a round's first chunks before
+// the round's table build — and only the ring's bookkeeping is set up)
+__device__ __forceinline__ void ring_begin(const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t pos, bool issue = true)
 {
   pos = uni64(pos);
   const uint32_t rel = (uint32_t)(pos - sw.base);
@@ -255,15 +257,20 @@ __device__ __forceinline__ void ring_begin(const StreamWin &sw, Ring &r, const W
   r.k = 0;
   // every lane is done with the ring's previous contents (its ds_reads returned before their results were used)
   r.vm = 0;
-  ring_request(sw, r, c, 0);
-  ring_request(sw, r, c, 1);
+  if (issue)
+  {
+    ring_request(sw, r, c, 0);
+    ring_request(sw, r, c, 1);
+  }
   r.vm += 3; // chunk 0, its mirror, chunk 1
   r.seq1 = r.vm;
-  ring_request(sw, r, c, 2);
+  if (issue)
+    ring_request(sw, r, c, 2);
   r.seq2 = ++r.vm;
   if (HSRANS_RING_AHEAD == 3)
   {
-    ring_request(sw, r, c, 3);
+    if (issue)
+      ring_request(sw, r, c, 3);
     r.vm++;
   }
   r.seq3 = r.vm;
@@ -1613,7 +1620,10 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
 
 // Grouped launch: workgroup b walks groups b, b + gridDim.x, ...; per group one table build, then every wave decodes an
 // equal contiguous share of the group's chains.
-template <int MODE, bool FAST = false> // FAST: the hand-scheduled 32-state pair loop too (measured in a kernel of its own: 71 VGPRs, 7 waves per SIMD — not used)
+// LEAN: the host promises a 64-state plan whose groups are all mergeable runs or fills (every block_/mt_ stream with checkpoints
+// this library's encoders or index builders make): the 32-state pair path and the general chain runner are left out of the
+// kernel, which is what keeps it at 8 waves per SIMD
+template <int MODE, bool LEAN = false, bool FAST = false> // FAST: the hand-scheduled 32-state pair loop too (measured in a kernel of its own: 71 VGPRs, 7 waves per SIMD — not used)
 __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams &kp, uint32_t waves, uint32_t wave)
 {
   // -DHSRANS_GROUP_STAMPS=1 builds (tools/stamps_grouped.py; needs HSRANS_DEBUG_STAMPS=1 at run time): where a wave's time goes,
@@ -1631,19 +1641,51 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
   // placed by wave class inside the blocks so that a block's 16 waves finish together (tools/stamps_grouped.py --weights).  Over
   // 10-launch averages neither moves the launch: the CU decodes at its full rate either way; what a round loses is the ~8 us of
   // table build + plan records + first chunks at its start.)
-  for (uint32_t gi = blockIdx.x; gi < kp.n_groups; gi += gridDim.x)
+  // Which group next.  Static: b, b + gridDim.x, ...  Dynamic (kp.group_tickets): round 0 is static, every later group comes from
+  // a ticket counter.  The draw is made by WAVE 0 alone, at the end of its share of the round, and waited for on the spot: wave 0
+  // is the oldest wave of the workgroup, the SIMDs serve it first, it finishes first and would spend the round trip (and several
+  // microseconds more) at the round's barrier anyway — so the draw costs the workgroup nothing, the decision is made as late as
+  // it can be, and no register carries a ticket across the decode loop.  (Drawn after the barrier by everyone it cost ~2 us per
+  // round and made the launch slower than the static order it was meant to beat.)  The group goes through one of two LDS words,
+  // alternating by round: round r's word is written before barrier r and read behind it; the next write to it comes behind
+  // barrier r + 1.  Every workgroup draws once at the end of every round it runs, the launch as a whole exactly n_groups times:
+  // ticket mod n_groups is the launch-local order whatever the counter has seen before (it is never reset).
+  const bool dynamic = kp.group_tickets != nullptr && kp.n_groups > gridDim.x;
+  volatile uint32_t *lds_next = (volatile uint32_t *)(c.table + table_bytes_for(MODE, c.bits)); // 2 words: launch_shape reserves 64 bytes behind the table
+  uint32_t gi = blockIdx.x;
+  for (uint32_t round = 0;; round++)
   {
+    if (!(dynamic && round >= 1) && gi >= kp.n_groups) // (dynamic rounds: decided below, from the published group)
+      break;
+    // `advance` runs at the end of the round (every path of the loop body ends in it)
+    auto advance = [&]() {
+      if (!dynamic)
+        gi += gridDim.x;
+      else if (wave == 0 && c.lane == 0)
+      {
+        const uint32_t j = (uint32_t)(atomicAdd(kp.group_tickets, 1ull) % kp.n_groups);
+        lds_next[(round + 1) & 1] = j < kp.n_groups - gridDim.x ? gridDim.x + j : 0xFFFFFFFFu;
+      }
+    };
+    HSRANS_GS(const uint64_t t0 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no stream request of the previous group may still land in the scratch slot
+    __syncthreads();                                    // every wave is done with the previous group's table and rings
+    if (dynamic && round >= 1)
+    {
+      gi = uni(lds_next[round & 1]);
+      if (gi >= kp.n_groups) // (the same in every wave)
+        break;
+    }
     const Group *G = kp.groups + gi;
     const uint32_t begin = uni(G->begin), count = uni(G->count), flags = uni(G->flags);
     // mergeable groups: chain `begin + i` is piece `piece0 + i` and its start states are states[begin + i] (the host checks this
     // when it marks a group mergeable), so a wave's records come straight from the group record: one level of loads, not three
     const uint32_t piece0 = uni(G->piece0);
-    HSRANS_GS(const uint64_t t0 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no stream request of the previous group may still land in the scratch slot
-    __syncthreads();                                    // every wave is done with the previous group's table and rings
     HSRANS_GS(const uint64_t t1 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;)
-    if (!(flags & kGroupFill))
-      build_table<MODE, true>(c, uni64(G->hist_off), threadIdx.x, blockDim.x);
+    // kp.group_overlap (64-state mergeable groups): the wave's piece records, start states and first stream chunks are requested
+    // BEFORE the table build and land while it runs (the build's scratch then has an LDS area of its own: launch_shape) — the
+    // ~4.5 us of dependent round trips a round used to spend after the build overlap its ~3 us instead
+    const bool overlap = LEAN && kp.group_overlap != 0 && (flags & kGroupMergeable); // (the general instantiation has no registers to spare for it)
 #if defined(HSRANS_GROUP_STAMPS) && HSRANS_GROUP_STAMPS
     const uint64_t t2 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;
     acc_wait += t1 - t0;
@@ -1669,9 +1711,38 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
     const uint32_t cum_all = weighted ? kp.group_cum[half][waves] : waves;
     const uint32_t first = begin + (uint32_t)((uint64_t)(weighted ? kp.group_cum[half][wave] : wave) * count / cum_all);
     const uint32_t last = begin + (uint32_t)((uint64_t)(weighted ? kp.group_cum[half][wave + 1] : wave + 1) * count / cum_all);
+    // the wave's run of a mergeable 64-state group: chains [first, last) as one chain.  With `early` it is opened twice: before
+    // the table build for the sake of its requests (start states, first stream chunks: in flight during the build), and again
+    // after it without them — the records come from the caches then — so that only the state register lives across the build
+    // (the window, the ring and the run's geometry are 20 scalar registers the builder has no room for: they spilled).
+    StreamWin sw;
+    Ring r;
+    uint32_t x = 0, run_tail_syms = 0;
+    uint64_t o = 0, run_steps = 0;
+    auto open_run = [&](bool issue) {
+      const Piece *p0 = pv.pieces + (piece0 + (first - begin));
+      const Piece *p1 = pv.pieces + (piece0 + (last - 1 - begin));
+      const uint64_t limit = last < begin + count ? uni64(pv.pieces[piece0 + (last - begin)].words_off) : uni64(G->words_end);
+      if (issue)
+        x = c.lane < c.S ? pv.states[(uint64_t)first * c.S + c.lane] : 0;
+      ring_bind(r, c.rings, 9, MODE == kModePack64);
+      win_open(sw, c, uni64(p0->words_off), limit);
+      ring_begin(sw, r, c, uni64(p0->words_off), issue);
+      o = uni64(p0->out_off);
+      run_steps = (uni64(p1->out_off) - o) / c.S + uni(p1->steps);
+      run_tail_syms = uni(p1->tail);
+    };
+    const bool early = overlap && first < last;
+    if (early)
+      open_run(true);
+    if (!(flags & kGroupFill)) // (one call site: every inlined copy of the builder costs the kernel registers)
+      build_table<MODE, true>(c, uni64(G->hist_off), threadIdx.x, blockDim.x);
     if (first >= last)
+    {
+      advance();
       continue;
-    if ((flags & kGroupMergeable) && c.S == 32)
+    }
+    if (!LEAN && (flags & kGroupMergeable) && c.S == 32)
     {
       // 32-state chains: the wave's share is cut in two runs that are decoded side by side, A on lanes 0..31 and B on
       // lanes 32..63 (group_step_pair), like run_persistent_pair; whatever the pair loop leaves is finished one run at a time
@@ -1710,30 +1781,27 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
     }
     else if (flags & kGroupMergeable)
     {
-      const Piece *p0 = pv.pieces + (piece0 + (first - begin));
-      const Piece *p1 = pv.pieces + (piece0 + (last - 1 - begin));
-      const uint64_t limit = last < begin + count ? uni64(pv.pieces[piece0 + (last - begin)].words_off) : uni64(G->words_end);
-      uint32_t x = c.lane < c.S ? pv.states[(uint64_t)first * c.S + c.lane] : 0;
-      StreamWin sw;
-      Ring r;
-      ring_bind(r, c.rings, 9, MODE == kModePack64);
-      win_open(sw, c, uni64(p0->words_off), limit);
-      ring_begin(sw, r, c, uni64(p0->words_off));
-      uint64_t o = uni64(p0->out_off);
-      const uint64_t steps = (uni64(p1->out_off) - o) / c.S + uni(p1->steps);
+      open_run(!early);
       ring_ready(x);
       HSRANS_GS(const uint64_t t3 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;)
-      run_groups<MODE, true>(x, sw, r, c, o, (uint32_t)steps);
-      run_tail<MODE>(x, r, c, o, uni(p1->tail));
+      run_groups<MODE, true>(x, sw, r, c, o, (uint32_t)run_steps);
+      run_tail<MODE>(x, r, c, o, run_tail_syms);
       HSRANS_GS(if (HSRANS_STAMPS(kp)) {
         acc_meta += t3 - t2;
         acc_dec += __builtin_amdgcn_s_memrealtime() - t3;
       })
     }
+    else if (LEAN) // fill chains (single-symbol blocks): one fill piece each
+      for (uint32_t ch = first; ch < last; ch++)
+      {
+        const Piece *pc = pv.pieces + uni(pv.chain_first[ch]);
+        wave_fill(c, uni64(pc->out_off), uni64(pc->fill_len), (uint32_t)uni64(pc->hist_off) & 0xFF);
+      }
     else
       for (uint32_t ch = first; ch < last; ch++)
         run_planned_chain<MODE, true>(c, pv, ch, kp);
     HSRANS_GS(stamp_out();)
+    advance();
   }
 }
 
@@ -1970,11 +2038,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
         run_persistent<MODE>(c, kp, waves, chain);
       return;
     }
-    if (kp.groups != nullptr)
-    {
-      run_grouped<MODE>(c, pv, kp, waves, wave);
-      return;
-    }
+    // (grouped launches have a kernel of their own: k_decode_grouped)
     build_table<MODE, true>(c, hist_off, threadIdx.x, blockDim.x);
     if (chain < pv.hdr->n_chains)
       run_planned_chain<MODE, true>(c, pv, chain, kp);
@@ -2041,6 +2105,43 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
     run_direct_pair<MODE>(c, kp, waves, chain);
   else
     run_direct<MODE>(c, kp, waves, chain);
+}
+
+// The kernel of the grouped launches (block_/mt_ plans with checkpoints: one workgroup per block, run_grouped) — BASELINE config 4's
+// kernel.  A kernel of its own for the same reason as k_decode_direct: inside k_decode<MODE, true> it shared one register
+// allocation with five other launch shapes (two more VGPRs there are the difference between 8 and 7 waves per SIMD).
+// LDS: [waves x ring][table][2 next-group words, 64 B][table-build scratch, 1 KiB].
+template <int MODE, bool LEAN>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_decode_grouped(KParams kp)
+{
+  extern __shared__ u32x4 smem_v[];
+  uint8_t *smem = (uint8_t *)smem_v;
+  const PlanView pv = plan_view(kp.plan);
+  const uint32_t waves = blockDim.x >> 6;
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  WaveCtx c;
+  c.stream = kp.stream;
+  c.stream_len = kp.stream_len;
+  c.stream_lo = kp.stream_lo;
+  c.out = kp.out;
+  c.out_cap = kp.out_cap;
+  c.status = kp.status;
+  c.bits = pv.hdr->bits;
+  c.S = pv.hdr->states;
+  c.lane = threadIdx.x & 63;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gshift) : "s"(c.bits > 12 ? c.bits - 12 : 0));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gmask) : "s"(c.bits > 12 ? (1u << (c.bits - 12)) - 1 : 0));
+  const uint32_t ring_stride = MODE == kModePack64 ? kFastRingBytes : kWaveRingBytes; // (launch_shape sizes the LDS the same way)
+  c.rings = smem + wave * ring_stride;
+  c.table = smem + waves * ring_stride;
+  c.table_b = c.table;
+  c.gtable = nullptr;
+  // the table build's scratch has an area of its own: a round's first stream chunks are requested before its table is built
+  c.scratch_cnt = (uint16_t *)(c.table + table_bytes_for(MODE, c.bits) + 64);
+  c.scratch_cum = c.scratch_cnt + 256;
+  run_grouped<MODE, LEAN>(c, pv, kp, waves, wave);
 }
 
 // The same for uniform-interval raw plans with the 8-byte table (run_persistent / run_persistent_pair): in a kernel of their own
@@ -3181,7 +3282,9 @@ hipError_t prepare_kernels(DeviceGeom *geom)
         return e;
     }
   for (KernelFn fn : {(KernelFn)k_decode_single, (KernelFn)k_decode_persist, (KernelFn)k_decode_dual<kModePack64>, (KernelFn)k_decode_dual<kModeCoarse>, (KernelFn)k_decode_direct<kModePack>, (KernelFn)k_decode_direct<kModePackM1>,
-                      (KernelFn)k_decode_direct<kModeTwoLevel>, (KernelFn)k_decode_direct<kModePack64>, (KernelFn)k_decode_direct<kModeCoarse>, (KernelFn)k_decode_direct<kModeSpill>})
+                      (KernelFn)k_decode_direct<kModeTwoLevel>, (KernelFn)k_decode_direct<kModePack64>, (KernelFn)k_decode_direct<kModeCoarse>, (KernelFn)k_decode_direct<kModeSpill>,
+                      (KernelFn)k_decode_grouped<kModePack, false>, (KernelFn)k_decode_grouped<kModePackM1, false>, (KernelFn)k_decode_grouped<kModeTwoLevel, false>,
+                      (KernelFn)k_decode_grouped<kModePack64, false>, (KernelFn)k_decode_grouped<kModeTwoLevel, true>, (KernelFn)k_decode_grouped<kModePack64, true>})
   {
     const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
     if (e != hipSuccess)
@@ -3241,7 +3344,7 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
       waves = (dg.max_lds - table_bytes) / ring / 4 * 4; // a big table: as many waves as still fit (multiple of 4: one per SIMD)
     while (waves > 1 && (waves / 2 >= h.n_chains || waves * ring + table_bytes > dg.max_lds))
       waves /= 2;
-    lds = waves * ring + table_bytes;
+    lds = waves * ring + table_bytes + (grouped ? 64 + 1024 : 0); // (run_grouped's two next-group words and its table-build scratch)
     grid = (h.n_chains + waves - 1) / waves;
     if (grouped)
       grid = n_groups;
@@ -3421,6 +3524,14 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
   else if (persistent && kp.pa.interval != 0 && L.shared && L.mode == kModePack64 && !index_pass && g_persist_kernel)
     fn = k_decode_persist;
 
+  else if (grouped && L.shared)
+    switch (L.mode)
+    {
+    case kModePack: fn = k_decode_grouped<kModePack, false>; break;
+    case kModePackM1: fn = k_decode_grouped<kModePackM1, false>; break;
+    case kModeTwoLevel: fn = kp.groups_lean ? k_decode_grouped<kModeTwoLevel, true> : k_decode_grouped<kModeTwoLevel, false>; break;
+    default: fn = kp.groups_lean ? k_decode_grouped<kModePack64, true> : k_decode_grouped<kModePack64, false>; break;
+    }
   else if (persistent && kp.pa.interval == 0 && L.shared)
     switch (L.mode)
     {

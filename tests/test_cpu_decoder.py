@@ -109,3 +109,24 @@ def test_host_index_builder_matches_the_encoders_plan(oracle, zipf, nonstat):
     r, got = oracle.exec_plan(built, s, nonstat.size)
     assert r == nonstat.size and np.array_equal(got, nonstat)
     assert H.plan_chain_count(built) > H.plan_chain_count(H.plan_build(MT, 64, 11, s))
+
+
+@pytest.mark.parametrize("states", (32, 64))
+def test_hostile_start_states_decode_the_same_at_every_level(states):
+    """start states come from the (untrusted) plan blob.  A state >= 2^31 must renormalise the same way — never — at
+    every dispatch level (the AVX2 level used a signed compare): same bytes, whatever they are, from scalar, AVX2 and AVX-512."""
+    data = synth.enwik8_shaped(200_000, seed=33)
+    stream, plan = H.encode(H.RAW, states, 11, data, index_interval=64)
+    hdr, cf, pieces = api.plan_tables(plan)
+    so = 64 + ((hdr["n_chains"] + 1) * 4 + 15) // 16 * 16 + 48 * hdr["n_pieces"]
+    bad = plan.copy()
+    st = bad[so:so + 4 * states * hdr["n_chains"]].view("<u4")
+    st[3 * states + 5] = 0x80001234          # chain 3, state 5: above 2^31
+    st[7 * states + states - 1] = 0xFFFFFFFF
+    outs = []
+    for level in range(api.cpu_level() + 1):
+        r, out = api.decode_cpu(H.RAW, states, 11, stream, data.size, plan=bad, level=level)
+        assert r == data.size
+        outs.append(out.copy())
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
