@@ -34,7 +34,8 @@ class EncodeOpts(ctypes.Structure):
 
 
 class LaunchInfo(ctypes.Structure):
-    _fields_ = [(n, _u32) for n in ("grid", "block", "lds_bytes", "waves_per_block", "chains", "shared_table", "walk", "two_level", "table_mode", "chains_per_wave")]
+    _fields_ = [(n, _u32) for n in ("grid", "block", "lds_bytes", "waves_per_block", "chains", "shared_table", "walk", "two_level", "table_mode", "chains_per_wave")] + \
+               [("class_weights", _u32 * 8), ("dynamic_groups", _u32)]
 
 
 def lib_path() -> str:
@@ -352,7 +353,7 @@ class DevicePlan:
     def launch_info(self) -> dict:
         info = LaunchInfo()
         load_library().hsrans_dplan_launch_info(self.handle, ctypes.byref(info))
-        return {n: getattr(info, n) for n, _ in LaunchInfo._fields_}
+        return {n: (list(getattr(info, n)) if n == "class_weights" else getattr(info, n)) for n, _ in LaunchInfo._fields_}
 
     def close(self):
         if self.handle:

@@ -459,7 +459,7 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
     // >= 128 chains (8 per wave: below that the per-part prologue costs more than the idle slots) while there are fewer
     // groups than resident workgroups.  A part is a group of its own: same histogram, a sub-range of the chains, and its
     // words end where the next part's first chain starts reading.  Measured: 382 groups of 128 chains are best left alone.
-    const size_t want = (size_t)2 * ctx->geom.num_cus;
+    const size_t want = launch_shape(h, ctx->geom, false, 0, (uint32_t)groups.size(), false, false, false).resident;
     if (groups.size() < h.n_chains && groups.size() < want)
     {
       const uint32_t k_max = (uint32_t)((want + groups.size() - 1) / groups.size());
@@ -485,6 +485,45 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
         }
       }
       groups.swap(parts);
+    }
+    // Dynamic group order (run_grouped): the groups are handed out in list order, so the END of the list decides how evenly the
+    // launch finishes — a workgroup that draws a whole block last is still busy a round after the others are done (measured at
+    // 2^30 bytes: lifetimes p50 360, max 403 us).  The last eighth of the list is therefore cut into half-blocks (parts like
+    // the ones above: same histogram, half the chains, >= one chain per wave).  HSRANS_GROUP_TAIL_PERMILLE / _PARTS override.
+    {
+      const LaunchShape ls = launch_shape(h, ctx->geom, false, 0, (uint32_t)groups.size(), false, false, false);
+      uint32_t permille = 125, tail_parts = 2;
+      if (const char *e = getenv("HSRANS_GROUP_TAIL_PERMILLE"))
+        permille = (uint32_t)atoi(e) > 1000 ? 1000 : (uint32_t)atoi(e);
+      if (const char *e = getenv("HSRANS_GROUP_TAIL_PARTS"))
+        tail_parts = (uint32_t)atoi(e) >= 1 && atoi(e) <= 16 ? (uint32_t)atoi(e) : 2;
+      if (groups.size() < h.n_chains && groups.size() >= (size_t)2 * ls.grid && permille != 0 && tail_parts > 1)
+      {
+        const size_t first_cut = groups.size() - groups.size() * permille / 1000;
+        std::vector<Group> cut(groups.begin(), groups.begin() + first_cut);
+        for (size_t i = first_cut; i < groups.size(); i++)
+        {
+          const Group &g = groups[i];
+          const uint32_t k = (g.flags & kGroupMergeable) ? std::min(tail_parts, g.count / ls.waves) : 1;
+          if (k < 2)
+          {
+            cut.push_back(g);
+            continue;
+          }
+          for (uint32_t part = 0; part < k; part++)
+          {
+            Group q = g;
+            const uint32_t lo = (uint32_t)((uint64_t)g.count * part / k), hi = (uint32_t)((uint64_t)g.count * (part + 1) / k);
+            q.begin = g.begin + lo;
+            q.piece0 = g.piece0 + lo;
+            q.count = hi - lo;
+            if (part + 1 < k)
+              q.words_end = pc[cf[g.begin + hi]].words_off;
+            cut.push_back(q);
+          }
+        }
+        groups.swap(cut);
+      }
     }
     if (groups.size() < h.n_chains)
     {
@@ -548,7 +587,9 @@ static int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_len
     kp.groups = (const Group *)d->d_groups;
     kp.n_groups = d->n_groups;
     kp.groups_lean = d->groups_lean ? 1 : 0;
-    kp.group_overlap = getenv("HSRANS_GROUP_OVERLAP") != nullptr ? (uint32_t)atoi(getenv("HSRANS_GROUP_OVERLAP")) : 1;
+    // (requesting a round's records and first chunks before its table build: measured, no gain — the other workgroups of the CU
+    // fill the gap either way — so off unless asked for)
+    kp.group_overlap = getenv("HSRANS_GROUP_OVERLAP") != nullptr ? (uint32_t)atoi(getenv("HSRANS_GROUP_OVERLAP")) : 0;
     // dynamic group order: this launch's own ticket counter (the counter sets of the persistent launches, one head of each used)
     if (d->d_counters != nullptr && getenv("HSRANS_GROUP_STATIC") == nullptr)
       kp.group_tickets = d->d_counters + (size_t)(d->epoch.fetch_add(1, std::memory_order_relaxed) % kCounterSets) * kDynQueues * kDynQueueStride;
@@ -855,6 +896,9 @@ int hsrans_dplan_launch_info(const hsrans_dplan *d, hsrans_launch_info *info)
   info->two_level = d->info.two_level;
   info->table_mode = d->info.table_mode;
   info->chains_per_wave = d->info.chains_per_wave;
+  for (int k = 0; k < 8; k++)
+    info->class_weights[k] = d->info.class_weights[k];
+  info->dynamic_groups = d->info.dynamic_groups;
   return HSRANS_OK;
 }
 

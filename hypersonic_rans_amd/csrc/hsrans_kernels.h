@@ -105,6 +105,8 @@ struct KParams
 struct LaunchInfo
 {
   uint32_t grid, block, lds_bytes, waves_per_block, chains, shared_table, walk, two_level, table_mode, chains_per_wave;
+  uint32_t class_weights[8]; // the per-mille run lengths of the 8 wave classes this launch was shaped with (LaunchShape::weights)
+  uint32_t dynamic_groups;   // grouped launches: groups handed out by the ticket counter (1) or in static order (0)
 };
 
 // what the launcher needs to know about the device a context lives on

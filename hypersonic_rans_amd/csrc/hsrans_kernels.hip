@@ -3338,6 +3338,14 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
     // (k_decode_direct's hand-scheduled loop wants a whole-chunk mirror behind every ring)
     const uint32_t ring = L.mode == kModePack64 ? kFastRingBytes : kWaveRingBytes;
     waves = g_waves_per_wg;
+    // Grouped launches (one workgroup per block, round after round): FOUR workgroups of 8 waves per CU instead of two of 16
+    // wherever four fit the LDS.  A round is table build + records + first chunks (~12 us in which the workgroup decodes
+    // nothing) and then the decode; with two workgroups per CU the other one is alone on the CU meanwhile, 4 waves per SIMD,
+    // which is too few to hide the loop's LDS latency.  With four, three are decoding while one is between rounds, and a round
+    // is twice as long for the same fixed cost.  Measured at 2^30 bytes: 256 KiB blocks 0.461 -> 0.492 of 8 TB/s, 64 KiB blocks
+    // 0.358 -> 0.427 (1 MiB blocks: unchanged).  HSRANS_WAVES_PER_WG still overrides.
+    if (grouped && getenv("HSRANS_WAVES_PER_WG") == nullptr && 4 * (8 * ring + table_bytes + 64 + 1024) <= dg.max_lds)
+      waves = 8;
     if (L.mode == kModeCoarse && waves * ring + table_bytes > dg.max_lds / 2)
       waves = 12; // 15 bits: 48 KiB of tables + 12 rings = 75 KiB, two workgroups per CU
     if (waves * ring + table_bytes > dg.max_lds && table_bytes + 4 * ring <= dg.max_lds)
@@ -3554,6 +3562,9 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
     info->two_level = L.mode == kModeTwoLevel;
     info->table_mode = (uint32_t)L.mode;
     info->chains_per_wave = L.dual ? 2 : 1;
+    for (uint32_t k = 0; k < 8; k++)
+      info->class_weights[k] = L.weights[k];
+    info->dynamic_groups = grouped && kp.group_tickets != nullptr && kp.n_groups > grid ? 1 : 0;
   }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), L.lds, stream, kp);
   return hipGetLastError();

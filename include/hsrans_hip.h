@@ -241,6 +241,9 @@ typedef struct hsrans_launch_info
   uint32_t grid, block, lds_bytes, waves_per_block, chains, shared_table, walk, two_level;
   uint32_t table_mode; /* decode-table layout: 0/1 packed u32, 2 two-level, 3 8-byte per slot, 4 coarse + fine, 5 8-byte in global memory */
   uint32_t chains_per_wave; /* 2: the two-chains-per-wave kernel (13..15 bits with a one-chain-per-wave index) */
+  uint32_t class_weights[8]; /* per-mille chain / run lengths of the 8 wave scheduling classes the launch was shaped with (fitted
+                              * constants, HSRANS_*_WEIGHTS override them): which table a measurement used */
+  uint32_t dynamic_groups;   /* block_/mt_ plans with checkpoints: blocks handed to workgroups by a ticket counter (1) or statically (0) */
 } hsrans_launch_info;
 int hsrans_dplan_launch_info(const hsrans_dplan *dplan, hsrans_launch_info *info);
 
