@@ -459,7 +459,7 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
     // >= 128 chains (8 per wave: below that the per-part prologue costs more than the idle slots) while there are fewer
     // groups than resident workgroups.  A part is a group of its own: same histogram, a sub-range of the chains, and its
     // words end where the next part's first chain starts reading.  Measured: 382 groups of 128 chains are best left alone.
-    const size_t want = launch_shape(h, ctx->geom, false, 0, (uint32_t)groups.size(), false, false, false).resident;
+    const size_t want = (size_t)2 * ctx->geom.num_cus; // (two 16-wave workgroups per CU: with this few groups launch_shape stays with those)
     if (groups.size() < h.n_chains && groups.size() < want)
     {
       const uint32_t k_max = (uint32_t)((want + groups.size() - 1) / groups.size());
@@ -487,12 +487,14 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
       groups.swap(parts);
     }
     // Dynamic group order (run_grouped): the groups are handed out in list order, so the END of the list decides how evenly the
-    // launch finishes — a workgroup that draws a whole block last is still busy a round after the others are done (measured at
-    // 2^30 bytes: lifetimes p50 360, max 403 us).  The last eighth of the list is therefore cut into half-blocks (parts like
-    // the ones above: same histogram, half the chains, >= one chain per wave).  HSRANS_GROUP_TAIL_PERMILLE / _PARTS override.
+    // launch finishes — a workgroup that draws a whole block last is still busy a round after the others are done (at 2^30
+    // bytes: lifetimes p50 360, max 403 us).  Cutting the last part of the list into half-blocks (parts like the ones above:
+    // same histogram, half the chains, >= one chain per wave) was built and measured: 0.454-0.458 ms with the last eighth in
+    // halves, 0.451-0.456 without, 0.455-0.458 with a quarter — the extra table builds cost what the evener finish gains — so
+    // it is off unless HSRANS_GROUP_TAIL_PERMILLE (and _PARTS) ask for it.
     {
       const LaunchShape ls = launch_shape(h, ctx->geom, false, 0, (uint32_t)groups.size(), false, false, false);
-      uint32_t permille = 125, tail_parts = 2;
+      uint32_t permille = 0, tail_parts = 2;
       if (const char *e = getenv("HSRANS_GROUP_TAIL_PERMILLE"))
         permille = (uint32_t)atoi(e) > 1000 ? 1000 : (uint32_t)atoi(e);
       if (const char *e = getenv("HSRANS_GROUP_TAIL_PARTS"))

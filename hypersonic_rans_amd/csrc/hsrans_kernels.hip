@@ -3344,7 +3344,8 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
     // which is too few to hide the loop's LDS latency.  With four, three are decoding while one is between rounds, and a round
     // is twice as long for the same fixed cost.  Measured at 2^30 bytes: 256 KiB blocks 0.461 -> 0.492 of 8 TB/s, 64 KiB blocks
     // 0.358 -> 0.427 (1 MiB blocks: unchanged).  HSRANS_WAVES_PER_WG still overrides.
-    if (grouped && getenv("HSRANS_WAVES_PER_WG") == nullptr && 4 * (8 * ring + table_bytes + 64 + 1024) <= dg.max_lds)
+    // (only with at least four groups per CU: fewer, e.g. a 100 MB stream in 256 KiB blocks, fill more wave slots as 16-wave workgroups)
+    if (grouped && getenv("HSRANS_WAVES_PER_WG") == nullptr && 4 * (8 * ring + table_bytes + 64 + 1024) <= dg.max_lds && n_groups >= 4 * dg.num_cus)
       waves = 8;
     if (L.mode == kModeCoarse && waves * ring + table_bytes > dg.max_lds / 2)
       waves = 12; // 15 bits: 48 KiB of tables + 12 rings = 75 KiB, two workgroups per CU

@@ -4,6 +4,9 @@ under the driver's multi-GPU run; their host logic runs under gloo in tests/test
 Full-size checks compare SHA-256 of the GPU output with the scalar CPU oracle's output for the same stream (not with the input:
 the oracle is the contract), plus the size-independent property decode(encode(x)) == x."""
 import hashlib
+import os
+import subprocess
+import sys
 import time
 
 import numpy as np
@@ -14,6 +17,7 @@ from hypersonic_rans_amd import synth
 from oracle_lib import BLOCK, MT, RAW
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _sha(a):
@@ -91,6 +95,63 @@ def test_config4_block_1gib_in_256k_blocks_on_one_gpu(gpu_ctx, oracle):
     del want
     got, info = _device_decode(gpu_ctx, stream, plan, n)
     assert _sha(got) == want_sha, info
+
+
+def test_dynamic_block_order_with_many_small_blocks(gpu_ctx, oracle):
+    """More blocks than resident workgroups: the grouped launch hands the blocks behind the first round out through its ticket
+    counter (k_decode_grouped, launch info `dynamic_groups`).  Non-stationary data so that single-symbol (fill) blocks are in the
+    list; several launches of one plan back to back (the counter is never reset: ticket mod n_groups); the same through a device
+    plan written by the GPU encoder; bit-exact against the oracle."""
+    import torch
+    n = 40 << 20
+    data = synth.nonstationary(n, seed=77)
+    stream, plan = H.encode(MT, 64, 11, data, block_size=1 << 14, index_interval=16)  # 2,560 blocks of 16 chains
+    r, want = oracle.decode(MT, 64, 11, stream, n)
+    assert r == n and np.array_equal(want, data)
+    d_in = torch.from_numpy(np.concatenate([stream, np.zeros((-stream.size) % 16, np.uint8)])).cuda()
+    d_out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    dplan = gpu_ctx.make_device_plan(plan)
+    for launch in range(5):
+        d_out.zero_()
+        gpu_ctx.decode_device(dplan, d_in, d_out, stream_length=stream.size)
+        assert gpu_ctx.status(dplan) == 0
+        assert torch.equal(d_out.cpu(), torch.from_numpy(data)), launch
+    info = dplan.launch_info()
+    assert info["dynamic_groups"] == 1 and info["waves_per_block"] == 8 and info["grid"] < 2560, info
+    # the encoder's device-built plan (its group list is written on the device) takes the same path
+    d_src = torch.from_numpy(data).cuda()
+    d_enc = torch.empty(H.capacity(MT, 64, n), dtype=torch.uint8, device="cuda")
+    m, dplan2 = gpu_ctx.encode_device(MT, 64, 11, d_src, d_enc, block_size=1 << 14, index_interval=16, want_plan=True)
+    for launch in range(3):
+        d_out.zero_()
+        gpu_ctx.decode_device(dplan2, d_enc, d_out, stream_length=m)
+        assert gpu_ctx.status(dplan2) == 0 and torch.equal(d_out, d_src), launch
+    assert dplan2.launch_info()["dynamic_groups"] == 1
+
+
+def test_dynamic_block_order_variants_in_a_subprocess():
+    """The A/B switches of the grouped launch (static order, half-block tail, records requested before the table build, 16-wave
+    workgroups) all decode the same bytes: each is an environment variable read when a plan is made / launched, so each runs in
+    its own process."""
+    code = (
+        "import numpy as np, torch, hashlib\n"
+        "import hypersonic_rans_amd as H\n"
+        "from hypersonic_rans_amd import synth\n"
+        "n = 24 << 20\n"
+        "data = synth.nonstationary(n, seed=78)\n"
+        "stream, plan = H.encode(H.MT, 64, 11, data, block_size=1 << 13, index_interval=8)\n"
+        "ctx = H.Context(0)\n"
+        "d_in = torch.from_numpy(np.concatenate([stream, np.zeros((-stream.size) % 16, np.uint8)])).cuda()\n"
+        "d_out = torch.zeros(n, dtype=torch.uint8, device='cuda')\n"
+        "dp = ctx.make_device_plan(plan)\n"
+        "for _ in range(3):\n"
+        "    ctx.decode_device(dp, d_in, d_out, stream_length=stream.size)\n"
+        "assert ctx.status(dp) == 0 and np.array_equal(d_out.cpu().numpy(), data)\n"
+        "print('ok', dp.launch_info()['dynamic_groups'], dp.launch_info()['waves_per_block'])\n")
+    for env, want in (({"HSRANS_GROUP_STATIC": "1"}, "ok 0 8"), ({"HSRANS_GROUP_TAIL_PERMILLE": "250"}, "ok 1 8"), ({"HSRANS_GROUP_OVERLAP": "1"}, "ok 1 8"),
+                      ({"HSRANS_WAVES_PER_WG": "16"}, "ok 1 16"), ({"HSRANS_GROUP_TAIL_PERMILLE": "1000", "HSRANS_GROUP_TAIL_PARTS": "4"}, "ok 1 8")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **env))
+        assert r.returncode == 0 and want in r.stdout, (env, r.stdout[-500:], r.stderr[-2000:])
 
 
 def test_config5_eight_gib_of_mt_streams_through_the_pipelined_host_path(gpu_ctx):

@@ -2,11 +2,12 @@
 # Everything DESIGN.md §8 quotes, in one go on the GPU box:  bash tools/round_measure.sh <tag>   (outputs under gpurun_out/<tag>/)
 # (the two stamps files need the diagnostic library: make -C hypersonic_rans_amd/csrc stamps, before gpurun)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
-python bench.py --workload sharded --steps 10 > $OUT/bench_sharded_line.json 2> $OUT/bench_sharded.err
+python bench.py --workload sharded > $OUT/bench_sharded_line.json 2> $OUT/bench_sharded.err
+python bench.py --workload sharded --no-cpu --block 65536 --interval 64 > $OUT/bench_sharded_64k_line.json 2> $OUT/bench_sharded_64k.err
 python tools/sweep_configs.py > $OUT/config_sweep.jsonl 2> $OUT/sweep.err
 HSRANS_TABLE_SPILL=1 python tools/sweep_configs.py --only-raw --tag "HSRANS_TABLE_SPILL=1 (tables left in global memory)" >> $OUT/config_sweep.jsonl 2>> $OUT/sweep.err
 HSRANS_DUAL=0 python tools/sweep_configs.py --only-raw --tag "HSRANS_DUAL=0 (one chain per wave at 13-15 bits)" >> $OUT/config_sweep.jsonl 2>> $OUT/sweep.err
@@ -18,6 +19,9 @@ PY
 hypersonic_rans_amd/bin/hsrans_harness /tmp/zipf100.bin --bits 11 --runs 2 --decode-runs 8 --test > $OUT/harness_100mb_11bit.txt 2>&1
 hypersonic_rans_amd/bin/hsrans_harness /tmp/zipf100.bin --bits 14 --only "(raw)" --runs 1 --decode-runs 8 --test > $OUT/harness_100mb_14bit_raw.txt 2>&1
 python tools/host_pipeline_rate.py > $OUT/host_pipeline_1gib.jsonl 2> $OUT/pipeline.err
+HSRANS_HPIPE_STAGED=1 python tools/host_pipeline_rate.py >> $OUT/host_pipeline_1gib.jsonl 2>> $OUT/pipeline.err
+python tools/host_decoder_vs_reference.py --size 100000000 --budget 2.0 --cases 32:11,32:12,32:13,32:14,32:15,64:11,64:12,64:13,64:14,64:15 > $OUT/host_decoder_vs_reference.jsonl 2> $OUT/host_decoder.err
+python tools/stamps_grouped.py 2>/dev/null | grep -v amdgpu > $OUT/stamps_grouped_1gib.txt
 python tools/encode_rate.py > $OUT/encode_rate_100mb.jsonl 2> $OUT/encode.err
 python tools/cold_cache.py > $OUT/cold_cache.jsonl 2> $OUT/cold.err
 timeout 300 tools/microbench/stream_pattern > $OUT/stream_pattern.txt 2>&1
