@@ -155,6 +155,14 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
     base = synth.enwik8_shaped(n, seed=20241008 + rank) if n <= (1 << 28) else _tiled(n, seed=20241008 + rank)
     pairs = []
     t_enc = t_setup = 0.0
+    # the one-chain-per-wave index is shaped for THIS device: hsrans_ctx_calibrate fits the chain lengths of the 8 wave classes
+    # (about half a second, outside the timed region; the lengths used are in config.launch.class_weights either way)
+    calibration = None
+    if args.index == "wave" and S == 64 and bits <= 12 and not args.no_calibrate:
+        try:
+            calibration = ctx.calibrate(bits=bits)
+        except H.HsransError as e:  # not the launch shape the classes are defined for (another device geometry): compiled-in lengths
+            calibration = {"skipped": str(e)}
     groups = None if args.index != "wave" else H.index_boundaries(S, bits, n, ctx)
     for k in range(max(1, args.pairs)):
         data = _permuted(base, k)
@@ -291,6 +299,7 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
             "launch": info, "bit_exact": True, "sha256": shas[0], "host_encode_s": t_enc / P,
             # once per (stream, plan), outside the timed region: hsrans_dplan_create = plan validation + host-built table + upload of the index
             "plan_setup_ms": t_setup / P * 1e3,
+            "calibration": calibration,
         },
         # the reference harness prints min/mean throughput per decoder (src/main.cpp:72-118): same two numbers here
         "mib_s": {"mean_over_timed_region": world * n / 2**20 / elapsed * args.steps, "best_single_launch": n / 2**20 / (float(np.min(kernel_ms)) * 1e-3),
@@ -611,6 +620,7 @@ def main() -> None:
     ap.add_argument("--parts", type=int, default=4, help="sharded: sub-runs per rank; sub-run k's exchange overlaps sub-run k+1's decode")
     ap.add_argument("--root-share", type=float, default=0.0, help="sharded: the root's share of the decoded bytes (0 = balance it against the measured inbound rate)")
     ap.add_argument("--no-replicas", action="store_true", help="sharded, N > 1: skip the weak-scaling replicas leg")
+    ap.add_argument("--no-calibrate", action="store_true", help="headline: shape the index with the compiled-in class lengths instead of fitting them to this device")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-single", action="store_true", help="skip the un-indexed single-wavefront and GPU-encoder legs")
     ap.add_argument("--timed-only", action="store_true", help="launch nothing but validation, warm-up and the timed rotation (profiling runs)")

@@ -33,6 +33,12 @@ class EncodeOpts(ctypes.Structure):
                 ("reserved", _u32), ("index_groups", _vp), ("n_index_groups", _sz)]
 
 
+class Calibration(ctypes.Structure):
+    _fields_ = [("class_weights", _u32 * 8), ("class_finish_us_last_iteration", ctypes.c_double * 8), ("last_wave_us_before", ctypes.c_double),
+                ("last_wave_us_after", ctypes.c_double), ("class_spread_us_before", ctypes.c_double), ("class_spread_us_after", ctypes.c_double),
+                ("iterations", _u32), ("reserved", _u32), ("bytes", ctypes.c_uint64)]
+
+
 class LaunchInfo(ctypes.Structure):
     _fields_ = [(n, _u32) for n in ("grid", "block", "lds_bytes", "waves_per_block", "chains", "shared_table", "walk", "two_level", "table_mode", "chains_per_wave")] + \
                [("class_weights", _u32 * 8), ("dynamic_groups", _u32)]
@@ -108,6 +114,8 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_decode_device_window.argtypes = [_vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp]
     L.hsrans_decode_device_ranges.restype = _i
     L.hsrans_decode_device_ranges.argtypes = [_vp, _vp, _vp, _sz, _sz, _vp, _sz, _sz, _vp]
+    L.hsrans_ctx_calibrate.restype = _i
+    L.hsrans_ctx_calibrate.argtypes = [_vp, _u32, _u32, ctypes.POINTER(Calibration)]
     L.hsrans_dplan_status.restype = _i
     L.hsrans_dplan_status.argtypes = [_vp, _vp, _vp]
     L.hsrans_dplan_launch_info.restype = _i
@@ -393,6 +401,17 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def calibrate(self, bits: int = 11, iterations: int = 0) -> dict:
+        """hsrans_ctx_calibrate: fits the one-chain-per-wave index's class lengths to this device; returns the report."""
+        rep = Calibration()
+        rc = self.L.hsrans_ctx_calibrate(self.handle, bits, iterations, ctypes.byref(rep))
+        if rc != 0:
+            raise HsransError(f"hsrans_ctx_calibrate failed with code {rc}")
+        return {"class_weights": list(rep.class_weights), "class_finish_us_last_iteration": [round(v, 3) for v in rep.class_finish_us_last_iteration],
+                "last_wave_us_before": rep.last_wave_us_before, "last_wave_us_after": rep.last_wave_us_after,
+                "class_spread_us_before": rep.class_spread_us_before, "class_spread_us_after": rep.class_spread_us_after,
+                "iterations": rep.iterations, "bytes": rep.bytes}
 
     # -- host-pointer drop-in: decodeFunc(pInData, inLength, pOutData, outCapacity) ------------------------------
     def decode_host(self, container: int, states: int, bits: int, stream, out_capacity: int, plan=None, in_length: int | None = None):

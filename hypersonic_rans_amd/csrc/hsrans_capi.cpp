@@ -1,6 +1,7 @@
 // C ABI of libhsrans_hip.so (declared in include/hsrans_hip.h).  Nothing here decodes on the CPU: every decode entry
 // ends in a launch of the gfx950 kernels in hsrans_kernels.hip and fails when no usable device exists.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -57,6 +58,7 @@ struct hsrans_dplan
   uint32_t *d_status = nullptr;
   size_t plan_bytes = 0;
   uint64_t *d_stamps = nullptr; // diagnostics (HSRANS_DEBUG_STAMPS=1)
+  uint64_t *d_finish = nullptr; // hsrans_ctx_calibrate: per-wave finish times of the plan's launches (owned by the calibration)
   unsigned long long *d_counters = nullptr; // uniform persistent launches: kCounterSets sets of monotonic queue heads
   std::atomic<uint32_t> epoch{0};           // launches so far: launch k uses counter set k % kCounterSets
   uint8_t *d_table = nullptr;               // host-built decode table (plans that carry their histogram)
@@ -579,6 +581,7 @@ static int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_len
   kp.plan = d->d_plan;
   kp.status = d->d_status;
   kp.stamps = d->d_stamps;
+  kp.finish = d->d_finish;
   kp.pa = d->pa;
   kp.single = d->single;
   kp.single_states = (const uint32_t *)(d->d_plan + plan_states_off(d->hdr.n_chains, d->hdr.n_pieces));
@@ -632,8 +635,10 @@ size_t hsrans_decode_host(hsrans_ctx *ctx, int container, int states, uint32_t b
   if (hipSetDevice(ctx->device) != hipSuccess)
     return 0;
   const size_t in_pad = (in_length + 15) / 16 * 16;
-  // a page-locked `out` receives the kernel's stores directly (see hsrans_hpipe_decode); otherwise the output is staged and copied down
-  uint8_t *out_view = ((uintptr_t)out & 3) == 0 ? device_view_of_host(out, (size_t)h.decoded_len) : nullptr;
+  // (Storing straight into a page-locked `out`, as hsrans_hpipe_decode does, was measured here too: with nothing to overlap it
+  // only replaces a download copy at 55 GB/s by the kernel's own PCIe writes at 47 — 100 MB: 3.58 instead of 3.26 ms — so this
+  // one-shot entry stages its output and copies it down; HSRANS_HOST_DIRECT=1 switches the direct stores on.)
+  uint8_t *out_view = getenv("HSRANS_HOST_DIRECT") != nullptr && ((uintptr_t)out & 3) == 0 ? device_view_of_host(out, (size_t)h.decoded_len) : nullptr;
   if (!grow(&ctx->d_in, &ctx->d_in_cap, in_pad) || (out_view == nullptr && !grow(&ctx->d_out, &ctx->d_out_cap, (size_t)h.decoded_len + 16)))
     return 0;
   hipStream_t s = ctx->stream;
@@ -1358,8 +1363,8 @@ int hsrans_hpipe_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
   PlanHeader h;
   if (!read_header(plan, plan_size, &h) || !plan_validate(plan, plan_size, h.stream_len, h.decoded_len) || (h.flags & kPlanWalk))
     return HSRANS_E_FORMAT;
-  if (n_slices == 0) // auto: slices of >= 32 MiB of output, 2..16 (the first slice's upload is the only leg nothing overlaps with)
-    n_slices = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(2, h.decoded_len >> 25));
+  if (n_slices == 0) // auto: slices of >= 16 MiB of output, 2..16 (the first slice's upload is the only leg nothing overlaps with)
+    n_slices = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(2, h.decoded_len >> 24));
   if (n_slices > h.n_chains)
     n_slices = h.n_chains;
   if (hipSetDevice(ctx->device) != hipSuccess)
@@ -1451,6 +1456,20 @@ size_t hsrans_hpipe_decode(hsrans_hpipe *p, const uint8_t *in, size_t in_length,
   if (!direct && p->d_out == nullptr && hipMalloc((void **)&p->d_out, p->hdr.decoded_len + 16) != hipSuccess)
     return 0;
   bool ok = true;
+  // HSRANS_HPIPE_TRACE=1: per-slice timeline on stderr (timing events around every leg; diagnostics only)
+  const bool trace = getenv("HSRANS_HPIPE_TRACE") != nullptr;
+  std::vector<hipEvent_t> tev;
+  auto mark = [&](hipStream_t st) {
+    if (!trace)
+      return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) == hipSuccess)
+    {
+      (void)hipEventRecord(e, st);
+      tev.push_back(e);
+    }
+  };
+  mark(p->up);
   // leg 1: every slice's stream bytes, in order, on the upload stream (a raw stream's shared histogram goes up once)
   bool head_done = false;
   for (auto &sl : p->slices)
@@ -1464,6 +1483,7 @@ size_t hsrans_hpipe_decode(hsrans_hpipe *p, const uint8_t *in, size_t in_length,
     if (r[3] > r[2])
       ok = ok && hipMemcpyAsync(p->d_stream + r[2], in + r[2], r[3] - r[2], hipMemcpyHostToDevice, p->up) == hipSuccess;
     ok = ok && hipEventRecord(sl.up_done, p->up) == hipSuccess;
+    mark(p->up);
     if (!ok)
       break;
   }
@@ -1471,8 +1491,10 @@ size_t hsrans_hpipe_decode(hsrans_hpipe *p, const uint8_t *in, size_t in_length,
   for (size_t k = 0; ok && k < p->slices.size(); k++)
   {
     auto &sl = p->slices[k];
-    ok = hipStreamWaitEvent(p->dec, sl.up_done, 0) == hipSuccess &&
-         dplan_launch(sl.dplan, p->d_stream, (size_t)p->hdr.stream_len, direct ? out_view : p->d_out, (size_t)p->hdr.decoded_len, p->dec) == HSRANS_OK;
+    ok = hipStreamWaitEvent(p->dec, sl.up_done, 0) == hipSuccess;
+    mark(p->dec);
+    ok = ok && dplan_launch(sl.dplan, p->d_stream, (size_t)p->hdr.stream_len, direct ? out_view : p->d_out, (size_t)p->hdr.decoded_len, p->dec) == HSRANS_OK;
+    mark(p->dec);
     if (ok && !direct)
     {
       ok = hipEventRecord(sl.dec_done, p->dec) == hipSuccess && hipStreamWaitEvent(p->down, sl.dec_done, 0) == hipSuccess;
@@ -1483,6 +1505,22 @@ size_t hsrans_hpipe_decode(hsrans_hpipe *p, const uint8_t *in, size_t in_length,
   }
   // whatever happened, nothing that was queued may still be reading `in` or writing `out` when this returns
   const bool s1 = hipStreamSynchronize(p->up) == hipSuccess, s2 = hipStreamSynchronize(p->dec) == hipSuccess, s3 = hipStreamSynchronize(p->down) == hipSuccess;
+  if (trace && tev.size() == 1 + 3 * p->slices.size())
+  {
+    const size_t K = p->slices.size();
+    fprintf(stderr, "hpipe %s, %zu slices (ms from the first upload's start): ", direct ? "direct" : "staged", K);
+    for (size_t k = 0; k < K; k++)
+    {
+      float up = 0, k0 = 0, k1 = 0;
+      (void)hipEventElapsedTime(&up, tev[0], tev[1 + k]);
+      (void)hipEventElapsedTime(&k0, tev[0], tev[1 + K + 2 * k]);
+      (void)hipEventElapsedTime(&k1, tev[0], tev[2 + K + 2 * k]);
+      fprintf(stderr, "[up %.3f kernel %.3f..%.3f] ", up, k0, k1);
+    }
+    fprintf(stderr, "\n");
+  }
+  for (hipEvent_t e : tev)
+    (void)hipEventDestroy(e);
   if (!ok || !s1 || !s2 || !s3)
     return 0;
   bool good = true;
@@ -1506,14 +1544,22 @@ size_t hsrans_decode_host_pipelined(hsrans_ctx *ctx, int container, int states, 
   if (!read_header(plan, plan_size, &h) || (int)h.container != container || (int)h.states != states || h.bits != bits || h.stream_len > in_length ||
       h.decoded_len > out_capacity)
     return 0;
-  // the pipeline (slice plans on the device, streams, buffers) is kept for the plan seen last
+  // The pipeline (slice plans on the device, streams, buffers) is kept for the plan seen last, recognised by address, size and
+  // a checksum over the header, 64 bytes of every 4 KiB and the last 64 bytes (a whole-plan checksum cost more than the decode
+  // it guards: 2.5 ms for the 12.9 MB index of a 100 MB stream).  A different plan of the same size at the same address differs
+  // in its start states (random 32-bit words) at every sample; whatever plan a pipe holds was validated when the pipe was made.
   uint64_t sum = 0x9E3779B97F4A7C15ull ^ n_slices;
-  for (size_t i = 0; i + 8 <= plan_size; i += 8)
-  {
-    uint64_t v;
-    memcpy(&v, plan + i, 8);
-    sum = (sum ^ v) * 0x100000001B3ull + (sum >> 29);
-  }
+  auto mix = [&](size_t from, size_t to) {
+    for (size_t i = from; i + 8 <= to; i += 8)
+    {
+      uint64_t v;
+      memcpy(&v, plan + i, 8);
+      sum = (sum ^ v) * 0x100000001B3ull + (sum >> 29);
+    }
+  };
+  for (size_t at = 0; at < plan_size; at += 4096)
+    mix(at, std::min(at + 64, plan_size));
+  mix(plan_size >= 64 ? plan_size - 64 : 0, plan_size);
   std::lock_guard<std::mutex> guard(ctx->lock);
   const uint64_t key[3] = {(uint64_t)(uintptr_t)plan, (uint64_t)plan_size, sum};
   if (ctx->cached_pipe == nullptr || memcmp(key, ctx->cached_pipe_key, sizeof(key)) != 0)
@@ -1526,6 +1572,191 @@ size_t hsrans_decode_host_pipelined(hsrans_ctx *ctx, int container, int states, 
     memcpy(ctx->cached_pipe_key, key, sizeof(key));
   }
   return hsrans_hpipe_decode(ctx->cached_pipe, in, in_length, out, out_capacity);
+}
+
+// ---- per-device fit of the one-chain-per-wave index ----------------------------------------------------------------
+// The SIMDs serve their oldest wave first and the decode loop is issue-bound, so the 8 wave classes of the one-chain-per-wave
+// launch (workgroup in the grid's first / second half x wave / 4) decode at different rates and the index gives them chains of
+// different lengths (hsrans_index_boundaries).  The lengths compiled in were fitted on one box; how early the second workgroup
+// of a CU becomes resident, and with it the right lengths, differs from box to box by a few per cent (r03: classes of the
+// second half done 2 us before the first half's on another box).  This fits them to the context's own device: synthetic
+// enwik8-shaped bytes, encoded once on the host; per iteration an index at the current lengths (one host decode pass that
+// records the checkpoints), a few launches whose waves leave their finish time, and every class length moved towards
+// length x (mean finish / class finish) ^ 0.8.  The best lengths seen stay in the context: hsrans_index_boundaries(ctx, ...)
+// and the launch info (class_weights) use them from then on.
+int hsrans_ctx_calibrate(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, hsrans_calibration *report)
+{
+  if (ctx == nullptr || bits < 10 || bits > 12) // (the fitted kernel is k_decode_direct<3>: 64 states, 8-byte table, one chain per wave)
+    return HSRANS_E_ARG;
+  if (iterations == 0)
+    iterations = 4;
+  if (iterations > 16)
+    iterations = 16;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return HSRANS_E_HIP;
+  const size_t n = (size_t)48 << 20;
+  std::vector<uint8_t> data(n), stream(capacity(HSRANS_RAW, 64, n));
+  {
+    // Zipf(1.2) over 205 symbols through a 65,536-entry inverse-CDF table, xorshift64* indices: the shape of the benchmark's data
+    std::vector<uint8_t> inv(65536);
+    double w[205], sum = 0;
+    for (int r = 0; r < 205; r++)
+      sum += (w[r] = 1.0 / pow((double)(r + 1), 1.2));
+    double acc = 0;
+    size_t at = 0;
+    for (int r = 0; r < 205; r++)
+    {
+      acc += w[r] / sum;
+      const size_t end = r == 204 ? 65536 : (size_t)(acc * 65536.0);
+      for (; at < end && at < 65536; at++)
+        inv[at] = (uint8_t)((r * 37 + 11) & 0xFF); // (any fixed symbol -> byte map)
+    }
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    for (size_t i = 0; i < n; i += 4)
+    {
+      x ^= x >> 12, x ^= x << 25, x ^= x >> 27;
+      const uint64_t v = x * 0x2545F4914F6CDD1Dull;
+      data[i] = inv[v & 0xFFFF], data[i + 1] = inv[(v >> 16) & 0xFFFF], data[i + 2] = inv[(v >> 32) & 0xFFFF], data[i + 3] = inv[v >> 48];
+    }
+  }
+  const size_t stream_len = encode(HSRANS_RAW, 64, bits, data.data(), n, stream.data(), stream.size(), nullptr, nullptr);
+  if (stream_len == 0)
+    return HSRANS_E_FORMAT;
+  uint8_t *d_stream = nullptr, *d_out = nullptr;
+  uint64_t *d_finish = nullptr;
+  std::vector<uint64_t> groups(1 << 16), finish;
+  std::vector<uint8_t> plan(plan_capacity_chains(HSRANS_RAW, 64, n, 1 << 14, 0));
+  uint32_t best_w[8] = {}, cur_w[8];
+  double best_last = 1e30, first_last = 0, first_spread = 0, best_spread = 0;
+  int rc = HSRANS_E_HIP;
+  const DeviceGeom saved = ctx->geom;
+  do
+  {
+    if (hipMalloc((void **)&d_stream, (stream_len + 15) / 16 * 16 + 16) != hipSuccess || hipMalloc((void **)&d_out, n) != hipSuccess ||
+        hipMemcpy(d_stream, stream.data(), stream_len, hipMemcpyHostToDevice) != hipSuccess)
+      break;
+    // start from the lengths in use (the compiled-in fit, or an earlier calibration)
+    {
+      PlanHeader h{};
+      h.states = 64, h.bits = bits, h.shared_hist = 1, h.n_chains = 1u << 30;
+      const TableChoice tc = choose_table(bits, 64, true);
+      const LaunchShape L = launch_shape(h, ctx->geom, true, tc.mode, 0, false, true, tc.dual);
+      if (L.dual || L.waves != 16 || L.grid <= ctx->geom.num_cus) // not the launch shape the classes are defined for: nothing to fit
+      {
+        rc = HSRANS_E_ARG;
+        break;
+      }
+      for (int k = 0; k < 8; k++)
+        cur_w[k] = L.weights[k];
+    }
+    bool failed = false;
+    for (uint32_t it = 0; it < iterations && !failed; it++)
+    {
+      ctx->geom.have_direct_weights = 1;
+      for (int k = 0; k < 8; k++)
+        ctx->geom.direct_weights[k] = cur_w[k];
+      const uint64_t T = (n - 63) / 64; // whole groups (hsrans_index_boundaries)
+      const size_t chains = direct_boundaries(ctx->geom, 64, bits, T, groups.data(), groups.size());
+      if (chains < 2)
+      {
+        failed = true;
+        break;
+      }
+      const size_t plan_len = cpu::index_build(cpu::best_level(), 1, HSRANS_RAW, 64, bits, stream.data(), stream_len, groups.data(), chains - 1, plan.data(), plan.size());
+      hsrans_dplan *dp = nullptr;
+      if (plan_len == 0 || hsrans_dplan_create(ctx, plan.data(), plan_len, &dp) != HSRANS_OK)
+      {
+        failed = true;
+        break;
+      }
+      const uint32_t W = (uint32_t)chains; // one chain per wave
+      if (d_finish == nullptr && hipMalloc((void **)&d_finish, ((size_t)1 << 14) * 8 + 8) != hipSuccess)
+        failed = true;
+      double cls_t[8] = {}, cls_n[8] = {}, last = 0;
+      const int launches = 4;
+      for (int l = 0; l < launches + 1 && !failed; l++) // (the first one warms caches and clocks and is not counted)
+      {
+        dp->d_finish = d_finish;
+        failed = hipMemset(d_finish, 0, ((size_t)W + 1) * 8) != hipSuccess || dplan_launch(dp, d_stream, stream_len, d_out, n, nullptr) != HSRANS_OK ||
+                 hipDeviceSynchronize() != hipSuccess;
+        finish.resize((size_t)W + 1);
+        failed = failed || hipMemcpy(finish.data(), d_finish, ((size_t)W + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess;
+        if (failed || l == 0)
+          continue;
+        const uint32_t waves = dp->info.waves_per_block, grid = dp->info.grid, first_half = (grid + 1) / 2;
+        if (waves != 16 || (uint64_t)grid * waves != W)
+        {
+          failed = true;
+          break;
+        }
+        for (uint32_t w = 0; w < W; w++)
+        {
+          const double t = (double)(finish[w] - finish[W]) / 100.0; // us
+          const uint32_t cls = (w / waves >= first_half ? 4 : 0) + (w % waves) / 4;
+          cls_t[cls] += t, cls_n[cls] += 1;
+          last = t > last ? t : last;
+        }
+      }
+      dp->d_finish = nullptr;
+      uint32_t status_ok = hsrans_dplan_status(ctx, dp, nullptr) == HSRANS_OK;
+      hsrans_dplan_destroy(dp);
+      if (failed || !status_ok)
+      {
+        failed = true;
+        break;
+      }
+      last /= 1.0; // (the latest wave of any counted launch)
+      double mean = 0, lo = 1e30, hi = 0;
+      for (int k = 0; k < 8; k++)
+      {
+        cls_t[k] /= cls_n[k] > 0 ? cls_n[k] : 1;
+        mean += cls_t[k] / 8;
+        lo = cls_t[k] < lo ? cls_t[k] : lo, hi = cls_t[k] > hi ? cls_t[k] : hi;
+      }
+      if (it == 0)
+        first_last = last, first_spread = hi - lo;
+      if (last < best_last)
+      {
+        best_last = last, best_spread = hi - lo;
+        for (int k = 0; k < 8; k++)
+          best_w[k] = cur_w[k];
+      }
+      if (report)
+        for (int k = 0; k < 8; k++)
+          report->class_finish_us_last_iteration[k] = cls_t[k];
+      double nw[8], s = 0;
+      for (int k = 0; k < 8; k++)
+        s += (nw[k] = (double)cur_w[k] * pow(mean / cls_t[k], 0.8));
+      for (int k = 0; k < 8; k++)
+        cur_w[k] = (uint32_t)(nw[k] * 8000.0 / s + 0.5);
+    }
+    if (failed)
+      break;
+    rc = HSRANS_OK;
+  } while (false);
+  if (d_stream)
+    (void)hipFree(d_stream);
+  if (d_out)
+    (void)hipFree(d_out);
+  if (d_finish)
+    (void)hipFree(d_finish);
+  ctx->geom = saved;
+  if (rc == HSRANS_OK)
+  {
+    ctx->geom.have_direct_weights = 1;
+    for (int k = 0; k < 8; k++)
+      ctx->geom.direct_weights[k] = best_w[k];
+    if (report)
+    {
+      for (int k = 0; k < 8; k++)
+        report->class_weights[k] = best_w[k];
+      report->last_wave_us_before = first_last, report->last_wave_us_after = best_last;
+      report->class_spread_us_before = first_spread, report->class_spread_us_after = best_spread;
+      report->iterations = iterations;
+      report->bytes = n;
+    }
+  }
+  return rc;
 }
 
 int hsrans_host_register(hsrans_ctx *ctx, void *ptr, size_t bytes)

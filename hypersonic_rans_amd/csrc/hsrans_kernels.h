@@ -90,6 +90,9 @@ struct KParams
   // grouped launches with more groups than workgroups: the groups behind the first gridDim.x are handed out by a ticket counter
   // (monotonic, this launch's own: never reset — every launch draws exactly n_groups tickets — see run_grouped); null = static
   unsigned long long *group_tickets;
+  // calibration launches only (hsrans_ctx_calibrate): wave w of a one-chain-per-wave launch leaves its finish time (s_memrealtime,
+  // 100 MHz) in finish[w]; finish[gridDim.x * waves] = the first wave's entry time
+  uint64_t *finish;
   uint32_t groups_lean;   // 64-state plan, every group a mergeable run or fills only: the lean instantiation of k_decode_grouped
   uint32_t group_overlap; // grouped launches: request piece records, states and first chunks before the table build (run_grouped)
   // grouped launches: wave k of a workgroup in grid half h takes chains [count * cum[h][k] / cum[h][waves], count * cum[h][k+1] / cum[h][waves])
@@ -113,6 +116,10 @@ struct LaunchInfo
 struct DeviceGeom
 {
   uint32_t num_cus, max_lds;
+  // per-mille chain lengths of the 8 wave classes of the 64-state one-chain-per-wave launch, fitted to THIS device by
+  // hsrans_ctx_calibrate (0 = not calibrated: the constants fitted on the development box, g_direct_weights)
+  uint32_t have_direct_weights;
+  uint32_t direct_weights[8];
 };
 
 // a launch's shape as it follows from plan header + device (launch_shape)

@@ -1282,6 +1282,8 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
   const uint64_t c_entry = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memtime() : 0; // shader clock (diagnostics: what does the chip run at under this load?)
   uint64_t t_table = 0, t_ready = 0, t_static = 0;
   const bool host_table = (MODE == kModePack64 || MODE == kModeCoarse || MODE == kModeSpill) && pa.table != nullptr;
+  if (kp.finish != nullptr && w == 0 && c.lane == 0) // calibration launches: the launch's time zero
+    kp.finish[W] = __builtin_amdgcn_s_memrealtime();
   if (!host_table) // the in-kernel build borrows ring space: it has to come before the first stream request
     build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
   bool table_pending = host_table;
@@ -1373,6 +1375,8 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
   }
   if (table_pending) // a wave without a chain still takes part in the workgroup's table copy
     fetch_table();
+  if (kp.finish != nullptr && c.lane == 0) // calibration launches (hsrans_ctx_calibrate): when this wave was done
+    kp.finish[w] = __builtin_amdgcn_s_memrealtime();
   if (HSRANS_STAMPS(kp) && c.lane == 0)
   {
     uint64_t *st = kp.stamps + (uint64_t)w * 8;
@@ -3296,7 +3300,7 @@ hipError_t prepare_kernels(DeviceGeom *geom)
 DeviceGeom default_geom()
 {
   read_tuning_once();
-  DeviceGeom g;
+  DeviceGeom g{};
   g.max_lds = 160 * 1024;
   g.num_cus = 256; // MI355X
   return g;
@@ -3385,7 +3389,7 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
   for (uint32_t k = 0; k < 8; k++)
     L.weights[k] = !weighted ? 1000
                    : L.dual   ? (L.mode == kModeCoarse ? g_dual_weights_coarse : g_dual_weights)[k]
-                   : direct   ? (L.grid > dg.num_cus ? (waves == 16 ? (h.states == 32 ? g_direct_weights_pair : g_direct_weights) : g_direct_weights6) : (waves == 16 ? g_direct_weights4 : g_direct_weights3))[k]
+                   : direct   ? (L.grid > dg.num_cus ? (waves == 16 ? (h.states == 32 ? g_direct_weights_pair : dg.have_direct_weights ? dg.direct_weights : g_direct_weights) : g_direct_weights6) : (waves == 16 ? g_direct_weights4 : g_direct_weights3))[k]
                               : (L.grid > dg.num_cus ? (persistent && !grouped && h.states == 32 ? g_direct_weights_pair : g_slot_weights) : g_slot_weights4)[k];
   return L;
 }

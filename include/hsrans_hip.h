@@ -159,11 +159,12 @@ size_t hsrans_decode_host(hsrans_ctx *ctx, int container, int states, uint32_t b
 /* Device-resident entry: everything asynchronous on `hip_stream` (a hipStream_t of the context's device; NULL = default
  * stream), graph-capturable (no allocation, no synchronisation).  `d_stream` must be 16-byte aligned, `d_out` 4-byte aligned.
  * Overlapping launches of ONE device plan (several streams, double-buffered outputs) are fine: plans with one chain per
- * wave (hsrans_index_boundaries) and block_/mt_ plans keep no per-launch state on the device; uniform-interval raw plans
- * draw work from atomic queues and own 32 sets of queue heads, used round robin, so up to 32 of their launches may be in
- * flight at once — a captured graph node keeps the set it was captured with, so replays of one captured graph must not
- * overlap each other (HIP does not allow a hipGraphExec to run concurrently with itself anyway).  The status word of a
- * plan is shared by all its launches (error bits are only ever OR-ed in; hsrans_dplan_status clears them). */
+ * wave (hsrans_index_boundaries) and mt_ plans without checkpoints keep no per-launch state on the device; uniform-interval
+ * raw plans and block_/mt_ plans with checkpoints draw work from atomic ticket counters and own 32 sets of them, used round
+ * robin, so up to 32 of their launches may be in flight at once — a captured graph node keeps the set it was captured with,
+ * so replays of one captured graph must not overlap each other (HIP does not allow a hipGraphExec to run concurrently with
+ * itself anyway).  The status word of a plan is shared by all its launches (error bits are only ever OR-ed in;
+ * hsrans_dplan_status clears them). */
 int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, hsrans_dplan **out_dplan);
 void hsrans_dplan_destroy(hsrans_dplan *dplan);
 int hsrans_decode_device(hsrans_ctx *ctx, hsrans_dplan *dplan, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity,
@@ -219,14 +220,16 @@ size_t hsrans_index_build_at(hsrans_ctx *ctx, int container, int states, uint32_
 /* ------------------------------------------------------------------------------------------------------------
  * Host buffers, PCIe legs overlapped (BASELINE config 5 shape; the GPU counterpart of the reference's thread-pool fan-out,
  * src/mt_rANS32x64_16w_decode.cpp:137-265): the plan's chains are cut into `n_slices` runs; slice k's compressed bytes go
- * up on one HIP stream while slice k-1 decodes on a second and slice k-2's output comes down on a third.  The slice
- * plans live on the device for the lifetime of the pipeline object.  Host buffers should be page-locked
- * (hipHostMalloc / hipHostRegister / hsrans_host_register) — with pageable memory the runtime stages every copy and the
- * legs serialise.  hsrans_decode_host_pipelined is the one-call form: it keeps the pipeline of the plan it saw last
- * inside the context (keyed by the plan's address, size and checksum).
+ * up on one HIP stream while slice k-1 decodes on a second — and, when `out` is page-locked (hipHostMalloc / hipHostRegister /
+ * hsrans_host_register), the decode kernels store STRAIGHT into it: there is no device-side output buffer and no download
+ * copy (2^30 bytes: 22.6 ms end to end against 30.7 ms staged).  Pageable or unaligned `out`: staged in device memory and
+ * copied down slice by slice on a third stream; pageable `in`: the runtime stages the uploads and the legs serialise.
+ * The slice plans live on the device for the lifetime of the pipeline object; a pipe serves one decode at a time (calls
+ * serialise on it).  hsrans_decode_host_pipelined is the one-call form: it keeps the pipeline of the plan it saw last inside
+ * the context (keyed by the plan's address, size and a sampled checksum).  On any failure every entry returns only after all work it queued has drained.
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct hsrans_hpipe hsrans_hpipe;
-int hsrans_hpipe_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, uint32_t n_slices /* 0 = by size: 2..8 slices of >= 256 MiB */, hsrans_hpipe **out_pipe);
+int hsrans_hpipe_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, uint32_t n_slices /* 0 = by size: 2..16 slices of >= 16 MiB of output */, hsrans_hpipe **out_pipe);
 size_t hsrans_hpipe_decode(hsrans_hpipe *pipe, const uint8_t *in, size_t in_length, uint8_t *out, size_t out_capacity);
 void hsrans_hpipe_destroy(hsrans_hpipe *pipe);
 size_t hsrans_decode_host_pipelined(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out,
@@ -234,6 +237,23 @@ size_t hsrans_decode_host_pipelined(hsrans_ctx *ctx, int container, int states, 
 /* page-lock / release a caller-owned host buffer (hipHostRegister on the context's device); 0 on success */
 int hsrans_host_register(hsrans_ctx *ctx, void *ptr, size_t bytes);
 int hsrans_host_unregister(hsrans_ctx *ctx, void *ptr);
+
+/* Per-device fit of the one-chain-per-wave index (hsrans_index_boundaries): the SIMDs serve their oldest wave first, so the 8
+ * scheduling classes of waves decode at different rates and get chains of different lengths; the lengths compiled in were fitted
+ * on one box and are a few per cent off on others.  This measures the classes' finish times on the context's own device (48 MiB
+ * of synthetic enwik8-shaped bytes, encoded once on the host; `iterations` (0 = 4) rounds of index -> launches -> adjust; about
+ * half a second) and keeps the best lengths in the context: hsrans_index_boundaries(ctx, ...) and the launch info use them from
+ * then on.  64 states, bits 10..12 (the 8-byte-table kernel).  Returns HSRANS_OK; `report` may be NULL. */
+typedef struct hsrans_calibration
+{
+  uint32_t class_weights[8];                 /* per-mille chain lengths kept */
+  double class_finish_us_last_iteration[8];  /* mean finish time of each class in the last iteration measured */
+  double last_wave_us_before, last_wave_us_after;       /* when the launch's last wave was done: first iteration / best iteration */
+  double class_spread_us_before, class_spread_us_after; /* latest minus earliest class mean */
+  uint32_t iterations, reserved;
+  uint64_t bytes;
+} hsrans_calibration;
+int hsrans_ctx_calibrate(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, hsrans_calibration *report);
 
 /* kernel launch geometry of the last hsrans_decode_device call on this plan (for benchmarks / DESIGN.md tables) */
 typedef struct hsrans_launch_info
