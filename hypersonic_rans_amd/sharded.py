@@ -168,10 +168,12 @@ class ShardedDecoder:
     `root`    the rank the output is gathered to (None = every rank): a rank that is not the root then needs only ITS OWN
               range of the output in HBM (`alloc_out`), decoded through hsrans_decode_device_ranges."""
 
-    def __init__(self, ctx: "api.Context", plan, group=None, parts: int = 1, weights=None, root: int | None = None):
+    def __init__(self, ctx: "api.Context", plan, group=None, parts: int = 1, weights=None, root: int | None = None, world: int | None = None,
+                 rank: int | None = None):
+        # (world / rank given explicitly: one rank's share without a process group — tests run every rank's GPU side on one GPU)
         self.ctx, self.group, self.root = ctx, group, root
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group) if world is None else world
+        self.rank = dist.get_rank(group) if rank is None else rank
         self.layout = ShardLayout(plan, self.world, parts, weights)
         self.runs, self.ranges = self.layout.runs, self.layout.ranges
         self.total, self.stream_len = self.layout.total, self.layout.stream_len

@@ -243,7 +243,9 @@ int hsrans_host_unregister(hsrans_ctx *ctx, void *ptr);
  * on one box and are a few per cent off on others.  This measures the classes' finish times on the context's own device (48 MiB
  * of synthetic enwik8-shaped bytes, encoded once on the host; `iterations` (0 = 4) rounds of index -> launches -> adjust; about
  * half a second) and keeps the best lengths in the context: hsrans_index_boundaries(ctx, ...) and the launch info use them from
- * then on.  64 states, bits 10..12 (the 8-byte-table kernel).  Returns HSRANS_OK; `report` may be NULL. */
+ * then on.  64 states, bits 10..12 (the 8-byte-table kernel).  Returns HSRANS_OK; `report` may be NULL.  Synchronises the
+ * device; call it before the context is shared between threads (it rewrites the context's geometry while it runs).  Indexes made
+ * before and after stay valid on any device: the lengths only decide how evenly a launch finishes. */
 typedef struct hsrans_calibration
 {
   uint32_t class_weights[8];                 /* per-mille chain lengths kept */

@@ -284,6 +284,45 @@ def test_pipelined_host_decode(gpu_ctx, nonstat, zipf):
         assert np.array_equal(host_out.numpy(), d)
 
 
+@pytest.mark.parametrize("world,root,parts,root_share", ((2, None, 3, 0.0), (8, 0, 4, 0.66), (4, 2, 2, 0.0), (8, None, 1, 0.0)))
+def test_every_ranks_gpu_side_of_a_sharded_decode_on_one_gpu(gpu_ctx, nonstat, world, root, parts, root_share):
+    """No multi-GPU node here, so the N > 1 path is checked in two halves: the exchange logic on gloo (tests/test_sharded_gloo.py,
+    test_bench_contract.py) and — this test — the GPU side of EVERY rank on the one GPU: each rank's slice plans, stream window,
+    output window (a rank that is not the root of a gather holds only its own range), sub-runs and weighted shares, launched
+    through hsrans_decode_device_ranges exactly as ShardedDecoder.step does; the exchange is replaced by copies of the ranks'
+    sub-ranges into the root's buffer, in the order pipelined_gather posts them."""
+    import torch
+    from hypersonic_rans_amd import sharded
+    d = nonstat[:3_000_000]
+    stream, plan = H.encode(H.MT, 64, 11, d, index_interval=32, block_size=65536)
+    weights = sharded.root_weights(world, root, root_share) if (root is not None and root_share) else None
+    decs = [sharded.ShardedDecoder(gpu_ctx, plan, parts=parts, weights=weights, root=root, world=world, rank=r) for r in range(world)]
+    outs = []
+    for dec in decs:
+        d_window = dec.upload_window(stream, "cuda")
+        out = dec.alloc_out("cuda")
+        if root is not None and dec.rank != root:
+            assert out.numel() == max(dec.out_len, 4) and dec.out_len == dec.ranges[dec.rank][1] - dec.ranges[dec.rank][0] < d.size
+        dec.step(d_window, out, gather=False)  # the rank's sub-runs, no exchange
+        dec.check()
+        outs.append(out)
+    torch.cuda.synchronize()
+    receivers = range(world) if root is None else (root,)
+    for recv in receivers:
+        full = outs[recv].clone()
+        for k in range(parts):
+            for src in range(world):
+                if src == recv:
+                    continue
+                b, e = decs[src].layout.sub_ranges[src][k]
+                if e > b:
+                    full[b - decs[recv].out_base:e - decs[recv].out_base] = outs[src][b - decs[src].out_base:e - decs[src].out_base]
+        assert torch.equal(full[:d.size].cpu(), torch.from_numpy(d)), (world, root, recv)
+    if root_share:
+        share = (decs[root].ranges[root][1] - decs[root].ranges[root][0]) / d.size
+        assert abs(share - root_share) < 0.05
+
+
 def test_sharded_decode_single_rank_over_rccl(gpu_ctx, zipf):
     """decode_sharded on the `nccl` backend (= RCCL) with a world of one rank: the communicator is created on the GPU and the
     status all-reduce runs through RCCL (the N>1 exchange logic runs on CPU under gloo in tests/test_sharded_gloo.py)."""
