@@ -2111,6 +2111,38 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
     run_direct<MODE>(c, kp, waves, chain);
 }
 
+// hsrans_ctx_calibrate's launches: k_decode_direct<kModePack64> under a name of its own, so that a profile of a run that
+// calibrates first (bench.py does) lists the calibration's launches — a 48 MiB stream, finish stamps on — apart from the decodes
+// it is there to measure (rocprofv3 --stats averages per kernel name).
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_calibrate(KParams kp)
+{
+  constexpr int MODE = kModePack64;
+  extern __shared__ u32x4 smem_v[];
+  uint8_t *smem = (uint8_t *)smem_v;
+  const uint32_t waves = blockDim.x >> 6;
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  WaveCtx c;
+  c.stream = kp.stream;
+  c.stream_len = kp.stream_len;
+  c.stream_lo = kp.stream_lo;
+  c.out = kp.out;
+  c.out_cap = kp.out_cap;
+  c.status = kp.status;
+  c.bits = kp.pa.bits;
+  c.S = kp.pa.S;
+  c.lane = threadIdx.x & 63;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
+  c.v_gshift = c.v_gmask = 0;
+  c.rings = smem + wave * kFastRingBytes;
+  c.table = smem + waves * kFastRingBytes;
+  c.table_b = c.table;
+  c.gtable = kp.pa.table;
+  c.scratch_cnt = (uint16_t *)smem;
+  c.scratch_cum = (uint16_t *)(smem + 512);
+  run_direct<MODE>(c, kp, waves, blockIdx.x * waves + wave);
+}
+
 // The kernel of the grouped launches (block_/mt_ plans with checkpoints: one workgroup per block, run_grouped) — BASELINE config 4's
 // kernel.  A kernel of its own for the same reason as k_decode_direct: inside k_decode<MODE, true> it shared one register
 // allocation with five other launch shapes (two more VGPRs there are the difference between 8 and 7 waves per SIMD).
@@ -3285,7 +3317,7 @@ hipError_t prepare_kernels(DeviceGeom *geom)
       if (e != hipSuccess)
         return e;
     }
-  for (KernelFn fn : {(KernelFn)k_decode_single, (KernelFn)k_decode_persist, (KernelFn)k_decode_dual<kModePack64>, (KernelFn)k_decode_dual<kModeCoarse>, (KernelFn)k_decode_direct<kModePack>, (KernelFn)k_decode_direct<kModePackM1>,
+  for (KernelFn fn : {(KernelFn)k_decode_single, (KernelFn)k_decode_persist, (KernelFn)k_calibrate, (KernelFn)k_decode_dual<kModePack64>, (KernelFn)k_decode_dual<kModeCoarse>, (KernelFn)k_decode_direct<kModePack>, (KernelFn)k_decode_direct<kModePackM1>,
                       (KernelFn)k_decode_direct<kModeTwoLevel>, (KernelFn)k_decode_direct<kModePack64>, (KernelFn)k_decode_direct<kModeCoarse>, (KernelFn)k_decode_direct<kModeSpill>,
                       (KernelFn)k_decode_grouped<kModePack, false>, (KernelFn)k_decode_grouped<kModePackM1, false>, (KernelFn)k_decode_grouped<kModeTwoLevel, false>,
                       (KernelFn)k_decode_grouped<kModePack64, false>, (KernelFn)k_decode_grouped<kModeTwoLevel, true>, (KernelFn)k_decode_grouped<kModePack64, true>})
@@ -3553,7 +3585,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
     case kModeTwoLevel: fn = k_decode_direct<kModeTwoLevel>; break;
     case kModeCoarse: fn = k_decode_direct<kModeCoarse>; break;
     case kModeSpill: fn = k_decode_direct<kModeSpill>; break;
-    default: fn = k_decode_direct<kModePack64>; break;
+    default: fn = kp.finish != nullptr && h.states == 64 ? (KernelFn)k_calibrate : (KernelFn)k_decode_direct<kModePack64>; break;
     }
   if (info)
   {
