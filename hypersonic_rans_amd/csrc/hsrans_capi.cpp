@@ -1689,13 +1689,15 @@ int hsrans_ctx_calibrate(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, hs
           failed = true;
           break;
         }
+        double launch_last = 0;
         for (uint32_t w = 0; w < W; w++)
         {
           const double t = (double)(finish[w] - finish[W]) / 100.0; // us
           const uint32_t cls = (w / waves >= first_half ? 4 : 0) + (w % waves) / 4;
           cls_t[cls] += t, cls_n[cls] += 1;
-          last = t > last ? t : last;
+          launch_last = t > launch_last ? t : launch_last;
         }
+        last += launch_last / launches; // (mean over the launches of each launch's last wave: one late wave in one launch does not decide)
       }
       dp->d_finish = nullptr;
       uint32_t status_ok = hsrans_dplan_status(ctx, dp, nullptr) == HSRANS_OK;
@@ -1705,7 +1707,6 @@ int hsrans_ctx_calibrate(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, hs
         failed = true;
         break;
       }
-      last /= 1.0; // (the latest wave of any counted launch)
       double mean = 0, lo = 1e30, hi = 0;
       for (int k = 0; k < 8; k++)
       {

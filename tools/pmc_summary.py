@@ -19,11 +19,17 @@ src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+# (a directory that was profiled more than once holds every run's files: the newest of each kind counts)
+stats = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 counters = {}
+newest = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+    key = f.split(os.sep + "pmc_")[1].split(os.sep)[0]
+    if key not in newest or os.path.getmtime(f) > os.path.getmtime(newest[key]):
+        newest[key] = f
+for f in newest.values():
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "k_decode" in r["Kernel_Name"]:

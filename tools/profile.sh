@@ -9,6 +9,7 @@ TAG=${1:-r02}; shift || true
 export TMPDIR=/tmp
 BARGS="$*"
 OUT=$PWD/gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 # STEPS=<n> overrides the step count; ONLY_TRACE=1 skips the counter passes (multi-GiB runs: the host encode dominates every pass)
 # (every rocprofv3 run sits under a timeout: a counter set the hardware cannot collect makes it abort and then hang in its signal handler)
