@@ -94,6 +94,7 @@ struct KParams
   // 100 MHz) in finish[w]; finish[gridDim.x * waves] = the first wave's entry time
   uint64_t *finish;
   uint32_t groups_lean;   // 64-state plan, every group a mergeable run or fills only: the lean instantiation of k_decode_grouped
+  uint32_t group_prio;    // grouped launches: per mille of its run the younger half of a workgroup's waves decodes at raised priority (s_setprio)
   uint32_t group_overlap; // grouped launches: request piece records, states and first chunks before the table build (run_grouped)
   // grouped launches: wave k of a workgroup in grid half h takes chains [count * cum[h][k] / cum[h][waves], count * cum[h][k+1] / cum[h][waves])
   // of its group (the same age-class weights as PersistentArgs::run_len)

@@ -1788,7 +1788,19 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
       open_run(!early);
       ring_ready(x);
       HSRANS_GS(const uint64_t t3 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;)
-      run_groups<MODE, true>(x, sw, r, c, o, (uint32_t)run_steps);
+      // kp.group_prio (per mille; 350 by default): the younger half of the workgroup's waves decodes that share of its run at
+      // raised instruction priority (s_setprio) — the SIMD otherwise serves its oldest wave first, the older half of the waves is
+      // done 8 us before the younger one and waits at the round's barrier.  Unlike the one-chain-per-wave launch, whose index
+      // gives the classes chains of different lengths, a block's checkpoints are where the encoder put them.
+      // (not where the wave's share was already sized by its age class: 100 MB in 256 KiB blocks + G=32: 0.359 -> 0.340 with both)
+      const uint32_t prio_steps = kp.group_prio != 0 && !weighted && wave >= waves / 2 ? (uint32_t)(run_steps * kp.group_prio / 1000) & ~3u : 0;
+      if (prio_steps != 0)
+      {
+        __builtin_amdgcn_s_setprio(1);
+        run_groups<MODE, true>(x, sw, r, c, o, prio_steps);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      run_groups<MODE, true>(x, sw, r, c, o, (uint32_t)run_steps - prio_steps);
       run_tail<MODE>(x, r, c, o, run_tail_syms);
       HSRANS_GS(if (HSRANS_STAMPS(kp)) {
         acc_meta += t3 - t2;
