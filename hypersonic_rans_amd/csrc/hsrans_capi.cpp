@@ -57,6 +57,11 @@ struct hsrans_dplan
   size_t d_plan_cap = 0;
   uint32_t *d_status = nullptr;
   size_t plan_bytes = 0;
+  // dplan_fill puts status word, ticket counters, plan blob, host-built table and group list into ONE device allocation (a
+  // device plan used to cost up to five hipMalloc calls and three synchronisations: 3.2 ms for a 2.5 MB index): the pointers
+  // below then point into d_arena and are not freed one by one.  Plans written on the device (K2, the GPU encoder) still own theirs.
+  uint8_t *d_arena = nullptr;
+  size_t d_arena_cap = 0, arena_used = 0;
   uint64_t *d_stamps = nullptr; // diagnostics (HSRANS_DEBUG_STAMPS=1)
   uint64_t *d_finish = nullptr; // hsrans_ctx_calibrate: per-wave finish times of the plan's launches (owned by the calibration)
   unsigned long long *d_counters = nullptr; // uniform persistent launches: kCounterSets sets of monotonic queue heads
@@ -311,11 +316,43 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
       d->out_hi = ohi;
     }
   }
-  if (!grow(&d->d_plan, &d->d_plan_cap, plan_size) || hipMemcpyAsync(d->d_plan, plan, plan_size, hipMemcpyHostToDevice, s) != hipSuccess)
+  // one allocation for everything this function uploads (sizes: upper bounds known from the header alone)
+  const bool mergeable_raw = (h.flags & kPlanMergeable) && h.container == HSRANS_RAW;
+  const bool may_group = !(h.flags & (kPlanWalk | kPlanMergeable)) && h.n_chains > 1;
+  const size_t counter_bytes = (size_t)kCounterSets * kDynQueues * kDynQueueStride * 8;
+  const bool need_counters = (mergeable_raw && h.interval != 0) || may_group; // (one-chain-per-wave plans draw nothing)
+  auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t table_bound = mergeable_raw && (h.flags & kPlanHasHist) ? up256(std::max<size_t>((size_t)8 << h.bits, coarse_table_entries(h.bits >= 13 ? h.bits : 13) * 8)) : 0;
+  const size_t group_bound = may_group ? up256(((size_t)h.n_chains + 16) * sizeof(Group)) : 0;
+  const size_t arena_need = 256 + (need_counters ? up256(counter_bytes) : 0) + up256(plan_size) + table_bound + group_bound;
+  if (!grow(&d->d_arena, &d->d_arena_cap, arena_need))
     return HSRANS_E_HIP;
-  if (d->d_status == nullptr && (hipMalloc((void **)&d->d_status, 64) != hipSuccess || hipMemsetAsync(d->d_status, 0, 64, s) != hipSuccess))
+  d->arena_used = 0;
+  auto carve = [&](size_t bytes) -> uint8_t * {
+    uint8_t *ptr = d->d_arena + d->arena_used;
+    d->arena_used += up256(bytes);
+    return d->arena_used <= d->d_arena_cap ? ptr : nullptr;
+  };
+  d->d_status = (uint32_t *)carve(64);
+  d->d_counters = need_counters ? (unsigned long long *)carve(counter_bytes) : nullptr;
+  // status word and ticket counters start from zero on every (re)fill: "ticket mod draws-per-launch" only works while every
+  // launch on a set of heads draws the same number of tickets, i.e. for ONE plan
+  if (hipMemsetAsync(d->d_arena, 0, d->arena_used, s) != hipSuccess)
     return HSRANS_E_HIP;
-  if ((h.flags & kPlanMergeable) && h.container == HSRANS_RAW)
+  d->epoch.store(0, std::memory_order_relaxed);
+  d->d_plan = carve(plan_size);
+  d->d_plan_cap = plan_size;
+  d->d_table = nullptr, d->d_table_cap = 0;
+  d->d_groups = nullptr, d->d_groups_cap = 0;
+  if (d->d_plan == nullptr || hipMemcpyAsync(d->d_plan, plan, plan_size, hipMemcpyHostToDevice, s) != hipSuccess)
+    return HSRANS_E_HIP;
+  std::vector<uint2> tab;     // (host copies of what is uploaded asynchronously: alive until the one synchronisation at the end)
+  std::vector<Group> groups;
+  auto fail = [&](int rc) { // (nothing queued above may still be reading `plan`, `tab` or `groups` when the caller sees the failure)
+    (void)hipStreamSynchronize(s);
+    return rc;
+  };
+  if (mergeable_raw)
   {
     // persistent launch arguments, taken from the plan once (hsrans_kernels.h PersistentArgs).  plan_validate has
     // re-derived what the flag promises: single-piece chains, back to back in output and stream, tail on the last only,
@@ -324,17 +361,7 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
     const Piece &first = pc[0], &last = pc[h.n_pieces - 1];
     const uint64_t steps_total = (last.out_off - first.out_off) / h.states + last.steps;
     if (first.out_off > h.decoded_len || steps_total * h.states + last.tail > h.decoded_len - first.out_off)
-      return HSRANS_E_FORMAT;
-    {
-      // queue heads: zeroed on every (re)fill — "ticket mod draws-per-launch" only works while every launch on a set of
-      // heads draws the same number of tickets, i.e. for ONE plan; a refilled plan object starts from zero again
-      const size_t bytes = (size_t)kCounterSets * kDynQueues * kDynQueueStride * 8;
-      if (d->d_counters == nullptr && hipMalloc((void **)&d->d_counters, bytes) != hipSuccess)
-        return HSRANS_E_HIP;
-      if (hipMemsetAsync(d->d_counters, 0, bytes, s) != hipSuccess)
-        return HSRANS_E_HIP;
-      d->epoch.store(0, std::memory_order_relaxed);
-    }
+      return fail(HSRANS_E_FORMAT);
     d->pa.pieces = (const Piece *)(d->d_plan + plan_pieces_off(h.n_chains));
     d->pa.states = (const uint32_t *)(d->d_plan + plan_states_off(h.n_chains, h.n_pieces));
     d->pa.n_chains = h.n_chains;
@@ -349,7 +376,6 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
     if (h.flags & kPlanHasHist)
     {
       const uint16_t *counts = (const uint16_t *)(plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
-      std::vector<uint2> tab;
       TableChoice tc = choose_table(h.bits, h.states, h.interval == 0);
       if (tc.dual)
       {
@@ -374,21 +400,22 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
           cum += counts[sy];
         }
         if (cum != total)
-          return HSRANS_E_FORMAT;
+          return fail(HSRANS_E_FORMAT);
       }
       else if (mode == 4)
       {
         // wider histograms: the coarse + fine table pair (kModeCoarse), 36 / 40 / 48 KiB instead of 64 / 128 / 256 KiB
         tab.resize(coarse_table_entries(h.bits));
         if (build_coarse_table(counts, h.bits, tab.data(), tab.size()) == 0)
-          return HSRANS_E_FORMAT;
+          return fail(HSRANS_E_FORMAT);
       }
       d->pa.dual = tc.dual ? 1 : 0;
       if (mode != 0)
       {
-        if (!grow(&d->d_table, &d->d_table_cap, tab.size() * sizeof(uint2)) ||
-            hipMemcpyAsync(d->d_table, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-          return HSRANS_E_HIP; // (synchronised: `tab` is about to go away)
+        d->d_table = carve(tab.size() * sizeof(uint2));
+        d->d_table_cap = tab.size() * sizeof(uint2);
+        if (d->d_table == nullptr || hipMemcpyAsync(d->d_table, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice, s) != hipSuccess)
+          return fail(HSRANS_E_HIP);
         d->pa.table = (const uint2 *)d->d_table;
         d->pa.table_mode = mode;
         d->pa.hist_copy = (const uint16_t *)(d->d_plan + plan_hist_off(h.n_chains, h.n_pieces, h.states));
@@ -419,7 +446,6 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
     // group consecutive chains that decode with the same histogram (= the chains of one block_/mt_ block)
     const uint32_t *cf = (const uint32_t *)(plan + plan_chain_first_off());
     const Piece *pc = (const Piece *)(plan + plan_pieces_off(h.n_chains));
-    std::vector<Group> groups;
     for (uint32_t ch = 0; ch < h.n_chains; ch++)
     {
       const Piece &p = pc[cf[ch]];
@@ -531,16 +557,10 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
     }
     if (groups.size() < h.n_chains)
     {
-      // ticket counters of the dynamic group order (monotonic: zeroed here once, never again)
-      const size_t cbytes = (size_t)kCounterSets * kDynQueues * kDynQueueStride * 8;
-      if (d->d_counters == nullptr && hipMalloc((void **)&d->d_counters, cbytes) != hipSuccess)
-        return HSRANS_E_HIP;
-      if (hipMemsetAsync(d->d_counters, 0, cbytes, s) != hipSuccess)
-        return HSRANS_E_HIP;
-      d->epoch.store(0, std::memory_order_relaxed);
-      if (!grow(&d->d_groups, &d->d_groups_cap, groups.size() * sizeof(Group)) ||
-          hipMemcpyAsync(d->d_groups, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-        return HSRANS_E_HIP;
+      d->d_groups = carve(groups.size() * sizeof(Group)); // (the dynamic group order's ticket counters: d_counters, zeroed above)
+      d->d_groups_cap = groups.size() * sizeof(Group);
+      if (d->d_groups == nullptr || hipMemcpyAsync(d->d_groups, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice, s) != hipSuccess)
+        return fail(HSRANS_E_HIP);
       d->n_groups = (uint32_t)groups.size();
       d->groups_lean = h.states == 64;
       for (const Group &g : groups)
@@ -548,6 +568,9 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
           d->groups_lean = false;
     }
   }
+  // `tab` and `groups` are about to go away: everything queued above has to have left them
+  if (hipStreamSynchronize(s) != hipSuccess)
+    return HSRANS_E_HIP;
   return HSRANS_OK;
 }
 
@@ -811,16 +834,21 @@ void hsrans_dplan_destroy(hsrans_dplan *d)
     return;
   if (d->d_stamps)
     (void)hipFree(d->d_stamps);
-  if (d->d_counters)
-    (void)hipFree(d->d_counters);
-  if (d->d_table)
-    (void)hipFree(d->d_table);
-  if (d->d_groups)
-    (void)hipFree(d->d_groups);
-  if (d->d_plan)
-    (void)hipFree(d->d_plan);
-  if (d->d_status)
-    (void)hipFree(d->d_status);
+  if (d->d_arena) // (status, counters, plan, table and groups live inside it)
+    (void)hipFree(d->d_arena);
+  else
+  {
+    if (d->d_counters)
+      (void)hipFree(d->d_counters);
+    if (d->d_table)
+      (void)hipFree(d->d_table);
+    if (d->d_groups)
+      (void)hipFree(d->d_groups);
+    if (d->d_plan)
+      (void)hipFree(d->d_plan);
+    if (d->d_status)
+      (void)hipFree(d->d_status);
+  }
   delete d;
 }
 
