@@ -1640,11 +1640,9 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
 #define HSRANS_GS(...)
 #endif
   HSRANS_GS(uint64_t t_first = 0, acc_wait = 0, acc_build = 0, acc_meta = 0, acc_dec = 0, rounds = 0; if (HSRANS_STAMPS(kp)) t_first = __builtin_amdgcn_s_memrealtime();)
-  // (Built, measured on the 1 GiB mt_ workload and left out, separately and together: drawing the next group from a ticket counter
-  // instead of gi += gridDim.x — the workgroups then finish together, lifetimes 482..515 us instead of 427..497 — and checkpoints
-  // placed by wave class inside the blocks so that a block's 16 waves finish together (tools/stamps_grouped.py --weights).  Over
-  // 10-launch averages neither moves the launch: the CU decodes at its full rate either way; what a round loses is the ~8 us of
-  // table build + plan records + first chunks at its start.)
+  // (Round 2 had measured a ticket counter — drawn by everyone after the round's barrier — and checkpoints placed by wave class
+  // inside the blocks, and found neither worth it; what changed the picture in round 3 is below: the draw hidden in wave 0's
+  // barrier wait, four 8-wave workgroups per CU (launch_shape) and the younger waves' raised priority.)
   // Which group next.  Static: b, b + gridDim.x, ...  Dynamic (kp.group_tickets): round 0 is static, every later group comes from
   // a ticket counter.  The draw is made by WAVE 0 alone, at the end of its share of the round, and waited for on the spot: wave 0
   // is the oldest wave of the workgroup, the SIMDs serve it first, it finishes first and would spend the round trip (and several
