@@ -568,6 +568,64 @@ def sharded_workload(args, world, rank, dv: _Dev, dist):
     return result
 
 
+def host_workload(args, world, rank, dv: _Dev, dist):
+    """BASELINE config 5's shape: every rank decodes its OWN mt_ stream from page-locked host memory into page-locked host memory
+    (upload overlapped with decode kernels that store straight into the host buffer: hsrans_hpipe) — independent
+    streams, no data-path collective, weak scaling.  PCIe-inclusive by construction, so this is never the headline `value`: it is
+    its own workload with its own metric.  The stream is written by the GPU encoder (the scalar host encoder would take minutes)."""
+    from hypersonic_rans_amd import pipeline
+
+    n, S, bits = args.size, args.states, args.bits
+    ctx = dv.ctx
+    g = torch.Generator(device=dv.dev).manual_seed(11 + rank)
+    d_in = torch.rand(n, device=dv.dev, generator=g).pow_(6).mul_(205).to(torch.uint8)
+    d_enc = torch.empty(H.capacity(H.MT, S, n), dtype=torch.uint8, device=dv.dev)
+    m, dplan = ctx.encode_device(H.MT, S, bits, d_in, d_enc, block_size=args.block, index_interval=args.interval, want_plan=True)
+    plan = ctx.read_device_plan(dplan, capacity=1 << 30)
+    host_stream = torch.empty(m, dtype=torch.uint8).pin_memory()
+    host_stream.copy_(d_enc[:m])
+    host_ref = d_in.cpu()
+    del d_enc, dplan, d_in
+    host_out = torch.empty(n, dtype=torch.uint8).pin_memory()
+    dec = pipeline.PipelinedHostDecoder(ctx, plan)
+    dec.decode(host_stream, host_out)
+    assert torch.equal(host_out, host_ref), "pipelined host decode is not bit-exact"
+    for _ in range(args.warmup):
+        dec.decode(host_stream, host_out)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dec.decode(host_stream, host_out)  # synchronous: the decoded bytes are in host memory on return
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    assert torch.equal(host_out, host_ref), "pipelined host decode is not bit-exact after the timed region"
+    if dist is not None:
+        elapsed = _reduce_max(dist, dv, elapsed)
+    if rank != 0:
+        return None
+    ms = elapsed * 1e3 / args.steps
+    link = 63.0  # PCIe Gen5 x16, GB/s per direction (MI355X_MICROARCH.md): the output leg is the longer one
+    return {
+        "metric": "decode MiB/s (bit-exact), stream and output in page-locked HOST memory (PCIe-inclusive), one mt_ stream per GPU",
+        "value": world * n / 2**20 / (elapsed / args.steps), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 state / u16 word / u8 symbol (integer)", "data": "synthetic",
+        "config": {"workload": f"mt_rANS32x{S} 16w {bits}-bit, one {n}-byte stream per GPU in {args.block}-byte blocks + index every {args.interval} groups, "
+                               "compressed stream and decoded output in page-locked host memory, hsrans_hpipe (upload slices overlapped with decode kernels "
+                               "that store straight into the host buffer)",
+                   "container": "mt_", "states": S, "bits": bits, "decoded_bytes": n, "compressed_bytes": int(m), "ratio": m / n, "plan_bytes": int(plan.size),
+                   "block": args.block, "index_interval_groups": args.interval, "bit_exact": True},
+        "decoded_GB_s": world * n / (elapsed / args.steps) / 1e9,
+        "roofline": {"bound": "pcie", "achieved": n / (ms * 1e-3) / 1e9, "peak": link, "unit": "GB/s", "frac": n / (ms * 1e-3) / 1e9 / link, "traffic": None,
+                     "note": "per GPU: decoded bytes written to host memory over the link's device-to-host direction (63 GB/s spec); the kernels are PCIe-bound "
+                             "here, not HBM-bound: this line never stands in for the headline"},
+        "cpu_baseline": None,
+    }
+
+
 def _free_port() -> int:
     import socket
 
@@ -608,8 +666,9 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=("headline", "sharded"), default=None,
-                    help="default: headline (100 MB raw stream per GPU) on one GPU, sharded (ONE 2^30-byte mt_ stream over all GPUs) on several")
+    ap.add_argument("--workload", choices=("headline", "sharded", "host"), default=None,
+                    help="default: headline (100 MB raw stream per GPU) on one GPU, sharded (ONE 2^30-byte mt_ stream over all GPUs) on several; "
+                         "host: one 2^30-byte mt_ stream per GPU from / to page-locked host memory (BASELINE config 5's shape, PCIe-inclusive)")
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--bits", type=int, default=11)
     ap.add_argument("--states", type=int, default=64)
@@ -641,7 +700,7 @@ def main() -> None:
     if args.workload is None:
         args.workload = "headline" if world == 1 else "sharded"
     if args.steps is None:
-        args.steps = 50 if args.workload == "headline" else 20
+        args.steps = 50 if args.workload == "headline" else 20 if args.workload == "sharded" else 8
     if args.size is None:
         args.size = 100_000_000 if args.workload == "headline" else 1 << 30
     if args.gpus != world and rank == 0:
@@ -670,6 +729,8 @@ def main() -> None:
 
     if args.workload == "headline":
         result = headline(args, world, rank, dv.dev, dev_index, dv.ctx, dist)
+    elif args.workload == "host":
+        result = host_workload(args, world, rank, dv, dist)
     else:
         result = sharded_workload(args, world, rank, dv, dist)
     if dist is not None:

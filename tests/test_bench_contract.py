@@ -60,3 +60,16 @@ def test_bench_passes_a_rank_failure_on():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--workload", "headline"], capture_output=True, text=True,
                        timeout=600, cwd=ROOT, env=env)
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_host_workload_line():
+    """`--workload host` (BASELINE config 5's shape on one GPU): its own metric, PCIe roofline, bit-exact."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "host", "--size", str(64 << 20), "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["bit_exact"] is True and d["roofline"]["bound"] == "pcie"
+    assert "host memory" in d["metric"].lower() and d["value"] > 0
