@@ -487,8 +487,43 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
     // >= 128 chains (8 per wave: below that the per-part prologue costs more than the idle slots) while there are fewer
     // groups than resident workgroups.  A part is a group of its own: same histogram, a sub-range of the chains, and its
     // words end where the next part's first chain starts reading.  Measured: 382 groups of 128 chains are best left alone.
+    // Round 3, measured and left off (HSRANS_GROUP_FINE_SPLIT=1): cutting finer instead — parts of >= 32 chains until there are
+    // four per CU, so that launch_shape runs four 8-wave workgroups per CU and hands the parts out by ticket (382 blocks on 256
+    // CUs otherwise leave half the CUs with two blocks and half with one).  100 MB in 256 KiB blocks + G=32: 0.319 of 8 TB/s
+    // against 0.356 as it is: a part of 85 KiB is 11 us of decode behind 11 us of table build and records, three times per block.
+    const size_t want8 = (size_t)4 * ctx->geom.num_cus;
+    bool fine_split = false;
+    if (groups.size() < h.n_chains && groups.size() < want8 && getenv("HSRANS_GROUP_FINE_SPLIT") && atoi(getenv("HSRANS_GROUP_FINE_SPLIT")) == 1)
+    {
+      const uint32_t k_max = (uint32_t)((want8 + groups.size() - 1) / groups.size());
+      size_t total = 0;
+      for (const Group &g : groups)
+        total += (g.flags & kGroupMergeable) ? std::max<uint32_t>(1, std::min(k_max, g.count / 32)) : 1;
+      if (total >= want8)
+      {
+        std::vector<Group> parts;
+        parts.reserve(total);
+        for (const Group &g : groups)
+        {
+          const uint32_t k = (g.flags & kGroupMergeable) ? std::max<uint32_t>(1, std::min(k_max, g.count / 32)) : 1;
+          for (uint32_t part = 0; part < k; part++)
+          {
+            Group q = g;
+            const uint32_t lo = (uint32_t)((uint64_t)g.count * part / k), hi = (uint32_t)((uint64_t)g.count * (part + 1) / k);
+            q.begin = g.begin + lo;
+            q.piece0 = g.piece0 + lo;
+            q.count = hi - lo;
+            if (part + 1 < k)
+              q.words_end = pc[cf[g.begin + hi]].words_off;
+            parts.push_back(q);
+          }
+        }
+        groups.swap(parts);
+        fine_split = true;
+      }
+    }
     const size_t want = (size_t)2 * ctx->geom.num_cus; // (two 16-wave workgroups per CU: with this few groups launch_shape stays with those)
-    if (groups.size() < h.n_chains && groups.size() < want)
+    if (!fine_split && groups.size() < h.n_chains && groups.size() < want)
     {
       const uint32_t k_max = (uint32_t)((want + groups.size() - 1) / groups.size());
       std::vector<Group> parts;
