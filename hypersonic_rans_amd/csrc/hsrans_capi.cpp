@@ -1735,6 +1735,12 @@ int hsrans_ctx_calibrate(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, hs
         break;
       }
       const uint32_t W = (uint32_t)chains; // one chain per wave
+      if (W > (1u << 14)) // (the finish-time buffer below is sized for 16,384 waves: twice an MI355X)
+      {
+        hsrans_dplan_destroy(dp);
+        failed = true;
+        break;
+      }
       if (d_finish == nullptr && hipMalloc((void **)&d_finish, ((size_t)1 << 14) * 8 + 8) != hipSuccess)
         failed = true;
       double cls_t[8] = {}, cls_n[8] = {}, last = 0;
