@@ -164,3 +164,52 @@ def test_shard_weights_and_balance_formula():
     assert sharded.balanced_root_share(8, 1.0, 1e9) == 1 / 8
     assert sharded.balanced_root_share(1, 1.0, 1.0) == 1.0
     assert sharded.root_weights(4, 2, 0.7)[2] == 0.7 and abs(sum(sharded.root_weights(4, 2, 0.7)) - 1) < 1e-12
+
+
+# ---- ShardLayout is pure host arithmetic: property test over containers, world sizes, sub-run counts and weights -------------
+from hypothesis import given, settings, strategies as st
+
+
+@settings(max_examples=40, deadline=None)
+@given(container=st.sampled_from((H.RAW, H.MT, H.BLOCK)), n=st.integers(70_000, 400_000), world=st.integers(1, 9), parts=st.integers(1, 5),
+       interval=st.sampled_from((4, 16, 64)), heavy=st.integers(0, 8), seed=st.integers(0, 1000))
+def test_shard_layout_tiles_output_and_stream(container, n, world, parts, interval, heavy, seed):
+    """Whatever the plan and the split: the ranks' ranges tile the output in order, a rank's sub-runs tile its run and its range,
+    the window of a rank covers what its chains read (hsrans_plan_stream_ranges of its run and of every sub-run), and weights move
+    bytes towards the heavy rank."""
+    data = synth.nonstationary(n, seed=seed)
+    stream, plan = H.encode(container, 64, 11, data, index_interval=interval, block_size=0 if container == H.RAW else 32768)
+    weights = None
+    if heavy and world > 1:
+        weights = [1.0] * world
+        weights[heavy % world] = 3.0
+    lay = sharded.ShardLayout(plan, world, parts, weights)
+    n_chains = H.plan_chain_count(plan)
+    assert sum(c for _f, c in lay.runs) == n_chains and lay.runs[0][0] == 0
+    pos = 0
+    for r in range(world):
+        f, c = lay.runs[r]
+        assert f == (lay.runs[r - 1][0] + lay.runs[r - 1][1] if r else 0)
+        if c == 0:
+            continue
+        b, e = lay.ranges[r]
+        assert b == pos and e > b
+        pos = e
+        subs = [(sf, sc) for sf, sc in lay.sub_runs[r] if sc]
+        assert subs[0][0] == f and sum(sc for _sf, sc in subs) == c
+        sub_pos = b
+        lo, hi = lay.windows[r]
+        assert lo % 16 == 0
+        for (sf, sc), (sb, se) in zip(lay.sub_runs[r], lay.sub_ranges[r]):
+            if sc == 0:
+                continue
+            assert sb == sub_pos and se > sb
+            sub_pos = se
+            (_hb, _he), (bb, be) = H.plan_stream_ranges(plan, sf, sc)
+            assert lo <= bb and be <= hi, "a sub-run reads outside its rank's window"
+        assert sub_pos == e
+    assert pos == n
+    if weights is not None and n_chains >= 8 * world:
+        hv = heavy % world
+        sizes = [e - b for b, e in lay.ranges]
+        assert sizes[hv] >= max(s for i, s in enumerate(sizes) if i != hv)
