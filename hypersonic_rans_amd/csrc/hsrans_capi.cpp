@@ -128,16 +128,26 @@ void hsrans_make_hist(hsrans_hist *hist, const uint8_t *data, size_t size, uint3
 }
 
 size_t hsrans_encode(int container, int states, uint32_t bits, const uint8_t *in, size_t length, uint8_t *out, size_t out_capacity, const hsrans_hist *hist)
+try
 {
   return encode(container, states, bits, in, length, out, out_capacity, hist, nullptr);
+}
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return 0;
 }
 
 size_t hsrans_encode_ex(int container, int states, uint32_t bits, const uint8_t *in, size_t length, uint8_t *out, size_t out_capacity,
                         const hsrans_hist *hist, hsrans_encode_opts *opts)
+try
 {
   if (opts)
     opts->plan_size = 0;
   return encode(container, states, bits, in, length, out, out_capacity, hist, opts);
+}
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return 0;
 }
 
 size_t hsrans_plan_capacity(int container, int states, size_t decoded_size, uint32_t index_interval, uint32_t block_size)
@@ -149,10 +159,15 @@ size_t hsrans_plan_capacity(int container, int states, size_t decoded_size, uint
 
 size_t hsrans_plan_build(int container, int states, uint32_t bits, const uint8_t *stream, size_t stream_length, size_t out_capacity, uint8_t *plan_out,
                          size_t plan_capacity)
+try
 {
   if (plan_out == nullptr)
     return 0;
   return plan_build(container, states, bits, stream, stream_length, out_capacity, plan_out, plan_capacity);
+}
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return 0;
 }
 
 uint32_t hsrans_plan_chain_count(const uint8_t *plan, size_t plan_size)
@@ -168,10 +183,15 @@ uint64_t hsrans_plan_decoded_length(const uint8_t *plan, size_t plan_size)
 }
 
 size_t hsrans_plan_slice(const uint8_t *plan, size_t plan_size, uint32_t first_chain, uint32_t chain_count, uint8_t *out, size_t out_capacity)
+try
 {
   if (out == nullptr)
     return 0;
   return plan_slice(plan, plan_size, first_chain, chain_count, out, out_capacity);
+}
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return 0;
 }
 
 int hsrans_plan_chain_range(const uint8_t *plan, size_t plan_size, uint32_t first_chain, uint32_t chain_count, uint64_t *begin, uint64_t *end)
@@ -193,6 +213,7 @@ int hsrans_cpu_level(void) { return cpu::best_level(); }
 
 size_t hsrans_decode_cpu(int level, uint32_t threads, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out,
                          size_t out_capacity, const uint8_t *plan, size_t plan_size)
+try
 {
   if (in == nullptr || out == nullptr || !valid_codec(container, states, bits))
     return 0;
@@ -207,13 +228,22 @@ size_t hsrans_decode_cpu(int level, uint32_t threads, int container, int states,
     return 0;
   return cpu::exec_plan(level, threads, plan, plan_size, in, in_length, out, out_capacity);
 }
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return 0;
+}
 
 size_t hsrans_index_build_host(int level, uint32_t threads, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length,
                                const uint64_t *groups, size_t n_groups, uint8_t *plan_out, size_t plan_capacity)
+try
 {
   if (level < 0)
     level = cpu::best_level();
   return cpu::index_build(level, threads ? threads : 1, container, states, bits, in, in_length, groups, n_groups, plan_out, plan_capacity);
+}
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return 0;
 }
 
 // ---- GPU side ---------------------------------------------------------------------------------------------------
@@ -664,6 +694,7 @@ static int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_len
 
 size_t hsrans_decode_host(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out, size_t out_capacity,
                           const uint8_t *plan, size_t plan_size)
+try
 {
   if (ctx == nullptr || in == nullptr || out == nullptr || !valid_codec(container, states, bits))
     return 0;
@@ -722,8 +753,13 @@ size_t hsrans_decode_host(hsrans_ctx *ctx, int container, int states, uint32_t b
   ok = (hipStreamSynchronize(s) == hipSuccess) && ok;
   return ok && status == 0 ? (size_t)h.decoded_len : 0;
 }
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return 0;
+}
 
 int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, hsrans_dplan **out_dplan)
+try
 {
   if (ctx == nullptr || out_dplan == nullptr)
     return HSRANS_E_ARG;
@@ -749,6 +785,10 @@ int hsrans_dplan_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
     (void)hipMemset(d->d_stamps, 0, kStampWaves * 8 * 8);
   *out_dplan = d;
   return HSRANS_OK;
+}
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return HSRANS_E_HIP;
 }
 
 size_t hsrans_debug_read_stamps(hsrans_dplan *d, uint64_t *out, size_t capacity_u64)
@@ -1136,7 +1176,10 @@ static size_t index_build_impl(hsrans_ctx *ctx, int container, int states, uint3
   }
   uint64_t out_len;
   memcpy(&out_len, in, 8);
-  std::vector<uint8_t> base(hsrans::plan_capacity(container, states, (size_t)out_len, 0, 0));
+  // (the header's decoded length is untrusted: the base plan of a valid stream is at most ~40x the stream, see cpu::index_build)
+  const size_t base_cap = (size_t)std::min<uint64_t>(hsrans::plan_capacity(container, states, (size_t)std::min<uint64_t>(out_len, (uint64_t)1 << 56), 0, 0), (uint64_t)in_length * 40 + (1 << 20));
+  std::vector<uint8_t> base;
+  base.resize(base_cap);
   const size_t base_size = plan_build(container, states, bits, in, in_length, (size_t)out_len, base.data(), base.size());
   if (base_size == 0)
     return 0;
@@ -1359,16 +1402,26 @@ static size_t index_build_impl(hsrans_ctx *ctx, int container, int states, uint3
 
 size_t hsrans_index_build(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint32_t index_interval,
                           uint8_t *plan_out, size_t plan_capacity)
+try
 {
   return index_build_impl(ctx, container, states, bits, in, in_length, index_interval, nullptr, 0, plan_out, plan_capacity);
+}
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return 0;
 }
 
 size_t hsrans_index_build_at(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, const uint64_t *groups,
                              size_t n_groups, uint8_t *plan_out, size_t plan_capacity)
+try
 {
   if (groups == nullptr)
     return 0;
   return index_build_impl(ctx, container, states, bits, in, in_length, 0, groups, n_groups, plan_out, plan_capacity);
+}
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return 0;
 }
 
 // ---- host buffers, PCIe legs overlapped ---------------------------------------------------------------------------
@@ -1421,6 +1474,7 @@ void hsrans_hpipe_destroy(hsrans_hpipe *p)
 }
 
 int hsrans_hpipe_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, uint32_t n_slices, hsrans_hpipe **out_pipe)
+try
 {
   if (ctx == nullptr || out_pipe == nullptr)
     return HSRANS_E_ARG;
@@ -1502,6 +1556,10 @@ int hsrans_hpipe_create(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, 
   }
   *out_pipe = p;
   return HSRANS_OK;
+}
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return HSRANS_E_HIP;
 }
 
 size_t hsrans_hpipe_decode(hsrans_hpipe *p, const uint8_t *in, size_t in_length, uint8_t *out, size_t out_capacity)
@@ -1650,6 +1708,7 @@ size_t hsrans_decode_host_pipelined(hsrans_ctx *ctx, int container, int states, 
 // length x (mean finish / class finish) ^ 0.8.  The best lengths seen stay in the context: hsrans_index_boundaries(ctx, ...)
 // and the launch info (class_weights) use them from then on.
 int hsrans_ctx_calibrate(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, hsrans_calibration *report)
+try
 {
   if (ctx == nullptr || bits < 10 || bits > 12) // (the fitted kernel is k_decode_direct<3>: 64 states, 8-byte table, one chain per wave)
     return HSRANS_E_ARG;
@@ -1830,6 +1889,10 @@ int hsrans_ctx_calibrate(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, hs
   }
   return rc;
 }
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return HSRANS_E_HIP;
+}
 
 int hsrans_host_register(hsrans_ctx *ctx, void *ptr, size_t bytes)
 {
@@ -1861,8 +1924,13 @@ size_t hsrans_index_boundaries(const hsrans_ctx *ctx, int states, uint32_t bits,
 }
 
 size_t hsrans_plan_thin(const uint8_t *plan, size_t plan_size, const uint64_t *groups, size_t n_groups, uint8_t *out, size_t out_capacity)
+try
 {
   return plan_thin(plan, plan_size, groups, n_groups, out, out_capacity);
+}
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return 0;
 }
 
 size_t hsrans_plan_capacity_chains(int container, int states, size_t decoded_size, size_t extra_chains, uint32_t block_size)

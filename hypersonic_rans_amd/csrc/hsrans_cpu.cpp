@@ -28,7 +28,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -468,7 +470,11 @@ struct CheckpointSink
   size_t n = 0;
   uint32_t *states = nullptr; // [n * S]
   uint64_t *words = nullptr;  // [n] absolute stream offset of the read cursor
+  // index builds want the states, not the bytes: the decoded symbols then go to a 32 KiB scratch that is written over and over
+  // (`out` may be null), so the pass needs no buffer of the stream's CLAIMED decoded length — a header is untrusted input
+  bool discard = false;
 };
+constexpr uint64_t kDiscardGroups = 512;
 
 bool run_chain(int level, const PlanHeader &h, const uint32_t *cf, const Piece *pc, const uint32_t *st, uint32_t chain, const uint8_t *stream, uint64_t stream_len,
                uint8_t *out, const CheckpointSink *sink)
@@ -477,6 +483,8 @@ bool run_chain(int level, const PlanHeader &h, const uint32_t *cf, const Piece *
   uint32_t x[64] = {};
   Table t;
   uint64_t have_hist = ~(uint64_t)0;
+  const bool discard = sink != nullptr && sink->discard;
+  alignas(64) uint8_t scratch[kDiscardGroups * 64 + 64];
   for (uint32_t pi = cf[chain]; pi < cf[chain + 1]; pi++)
   {
     const Piece &p = pc[pi];
@@ -484,7 +492,8 @@ bool run_chain(int level, const PlanHeader &h, const uint32_t *cf, const Piece *
       memcpy(x, st + (size_t)p.state_idx * S, 4 * (size_t)S);
     if (p.flags & kPieceFill)
     {
-      memset(out + p.out_off, (int)(p.hist_off & 0xFF), (size_t)p.fill_len);
+      if (!discard)
+        memset(out + p.out_off, (int)(p.hist_off & 0xFF), (size_t)p.fill_len);
       continue;
     }
     if (p.hist_off != have_hist)
@@ -494,7 +503,7 @@ bool run_chain(int level, const PlanHeader &h, const uint32_t *cf, const Piece *
       have_hist = p.hist_off;
     }
     Cursor c{stream + p.words_off, stream + stream_len};
-    uint8_t *o = out + p.out_off;
+    uint8_t *o = discard ? scratch : out + p.out_off;
     uint64_t steps = p.steps;
     if (sink != nullptr && sink->n != 0)
     {
@@ -503,7 +512,23 @@ bool run_chain(int level, const PlanHeader &h, const uint32_t *cf, const Piece *
       while (steps > 0)
       {
         const uint64_t next = k < sink->n ? sink->groups[k] : ~(uint64_t)0;
-        const uint64_t n = std::min<uint64_t>(steps, next - g_abs);
+        uint64_t n = std::min<uint64_t>(steps, next - g_abs);
+        if (discard)
+        {
+          n = std::min<uint64_t>(n, kDiscardGroups); // the scratch holds this many groups
+          decode_groups(level, x, t, c, scratch, n, S);
+          if (c.p > c.end) // the stream ran out long before its header's claim: no point in "decoding" zeros for hours
+            return false;
+          steps -= n;
+          g_abs += n;
+          if (steps > 0 && g_abs == next)
+          {
+            memcpy(sink->states + k * S, x, 4 * (size_t)S);
+            sink->words[k] = (uint64_t)(c.p - stream);
+            k++;
+          }
+          continue;
+        }
         decode_groups(level, x, t, c, o, n, S);
         o += n * S;
         steps -= n;
@@ -522,7 +547,7 @@ bool run_chain(int level, const PlanHeader &h, const uint32_t *cf, const Piece *
       o += steps * S;
     }
     if (p.tail)
-      group_scalar(x, t, c, o, S, p.tail);
+      group_scalar(x, t, c, discard ? scratch : o, S, p.tail);
   }
   return true;
 }
@@ -662,15 +687,21 @@ size_t index_build(int level, uint32_t threads, int container, int states, uint3
       return 0;
   const uint64_t out_len = rd64(in);
   const uint32_t S = (uint32_t)states;
-  std::vector<uint8_t> base(plan_capacity(container, states, (size_t)out_len, 0, 0));
-  const size_t base_size = plan_build(container, states, bits, in, in_len, (size_t)out_len, base.data(), base.size());
+  // The decoded length in the header is untrusted: nothing here is sized by it alone.  The base plan (one chain per block) of a
+  // VALID stream is at most ~40x the stream (a block header is >= 8 bytes, a chain of the plan ~308), so that bounds the buffer,
+  // which is not initialised either (pages it never uses are never touched); the decode pass keeps no output (sink.discard).
+  const size_t base_cap = (size_t)std::min<uint64_t>(plan_capacity(container, states, (size_t)std::min<uint64_t>(out_len, (uint64_t)1 << 56), 0, 0), (uint64_t)in_len * 40 + (1 << 20));
+  std::unique_ptr<uint8_t[]> base_mem(new (std::nothrow) uint8_t[base_cap]);
+  if (!base_mem)
+    return 0;
+  struct { uint8_t *p; uint8_t *data() const { return p; } } base{base_mem.get()};
+  const size_t base_size = plan_build(container, states, bits, in, in_len, (size_t)out_len, base.data(), base_cap);
   if (base_size == 0)
     return 0;
   PlanHeader h;
   memcpy(&h, base.data(), sizeof(h));
   if (h.n_pieces != h.n_chains)
     return 0;
-  std::vector<uint8_t> scratch((size_t)out_len + 64);
   std::vector<uint32_t> ck_states(n_groups * S);
   std::vector<uint64_t> ck_words(n_groups, 0);
   CheckpointSink sink;
@@ -678,7 +709,8 @@ size_t index_build(int level, uint32_t threads, int container, int states, uint3
   sink.n = n_groups;
   sink.states = ck_states.data();
   sink.words = ck_words.data();
-  if (exec_plan_impl(level, threads, base.data(), base_size, in, in_len, scratch.data(), (size_t)out_len, &sink) == 0)
+  sink.discard = true;
+  if (exec_plan_impl(level, threads, base.data(), base_size, in, in_len, nullptr, (size_t)out_len, &sink) == 0)
     return 0;
   const uint32_t *cf0 = (const uint32_t *)(base.data() + plan_chain_first_off());
   const Piece *pc0 = (const Piece *)(base.data() + plan_pieces_off(h.n_chains));
