@@ -274,6 +274,11 @@ int hsrans_ctx_create(int device, hsrans_ctx **out_ctx)
     hsrans_ctx_destroy(ctx);
     return HSRANS_E_HIP;
   }
+  // HSRANS_CALIBRATE=1: fit the one-chain-per-wave index's class lengths to this device right away (~0.5 s; for callers that cannot
+  // call hsrans_ctx_calibrate themselves, e.g. the drop-in entries, which create their one context on first use)
+  if (const char *e = getenv("HSRANS_CALIBRATE"))
+    if (atoi(e) != 0)
+      (void)hsrans_ctx_calibrate(ctx, 11, 0, nullptr);
   *out_ctx = ctx;
   return HSRANS_OK;
 }
