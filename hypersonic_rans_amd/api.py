@@ -250,6 +250,12 @@ def plan_build(container: int, states: int, bits: int, stream, out_capacity: int
     pcap = L.hsrans_plan_capacity(container, states, min(out_len, 1 << 40), 0, 0)
     plan = np.zeros(pcap, np.uint8)
     n = L.hsrans_plan_build(container, states, bits, _p(stream), stream.size, out_capacity, _p(plan), pcap)
+    if n == 0 and container != RAW:
+        # blocks below the 32 KiB hsrans_plan_capacity assumes for foreign streams (encode(block_size=...)): one chain per
+        # block header of the stream at most
+        pcap = min(L.hsrans_plan_capacity(container, states, min(out_len, 1 << 40), 0, 64), stream.size * 40 + (1 << 20))
+        plan = np.zeros(pcap, np.uint8)
+        n = L.hsrans_plan_build(container, states, bits, _p(stream), stream.size, out_capacity, _p(plan), pcap)
     if n == 0:
         raise HsransError("malformed stream (plan_build returned 0)")
     return plan[:n].copy()

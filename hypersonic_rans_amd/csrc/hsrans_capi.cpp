@@ -94,7 +94,10 @@ bool grow(uint8_t **p, size_t *cap, size_t need)
   *cap = 0;
   const size_t want = need + need / 8 + 4096;
   if (hipMalloc((void **)p, want) != hipSuccess)
+  {
+    (void)hipGetLastError(); // (consumed here: the runtime's last error is sticky per thread and would surface at an unrelated launch)
     return false;
+  }
   *cap = want;
   return true;
 }
@@ -714,12 +717,10 @@ try
     memcpy(&out_len, in, 8);
     if (out_len > out_capacity)
       return 0;
-    own_plan.resize(plan_capacity(container, states, (size_t)out_len, 0, 0));
-    const size_t n = plan_build(container, states, bits, in, in_length, out_capacity, own_plan.data(), own_plan.size());
-    if (n == 0)
+    if (!plan_build_vec(container, states, bits, in, in_length, out_capacity, &own_plan)) // sized by the stream's own chain count
       return 0;
     plan = own_plan.data();
-    plan_size = n;
+    plan_size = own_plan.size();
   }
   PlanHeader h;
   if (!read_header(plan, plan_size, &h) || (int)h.container != container || (int)h.states != states || h.bits != bits)
@@ -1181,13 +1182,11 @@ static size_t index_build_impl(hsrans_ctx *ctx, int container, int states, uint3
   }
   uint64_t out_len;
   memcpy(&out_len, in, 8);
-  // (the header's decoded length is untrusted: the base plan of a valid stream is at most ~40x the stream, see cpu::index_build)
-  const size_t base_cap = (size_t)std::min<uint64_t>(hsrans::plan_capacity(container, states, (size_t)std::min<uint64_t>(out_len, (uint64_t)1 << 56), 0, 0), (uint64_t)in_length * 40 + (1 << 20));
+  // (the header's decoded length is untrusted: the base plan is sized by the chains the stream really holds, at most ~40x the stream)
   std::vector<uint8_t> base;
-  base.resize(base_cap);
-  const size_t base_size = plan_build(container, states, bits, in, in_length, (size_t)out_len, base.data(), base.size());
-  if (base_size == 0)
+  if (!plan_build_vec(container, states, bits, in, in_length, (size_t)out_len, &base))
     return 0;
+  const size_t base_size = base.size();
   PlanHeader h;
   memcpy(&h, base.data(), sizeof(h));
   const uint32_t *cf0 = (const uint32_t *)(base.data() + plan_chain_first_off());

@@ -668,11 +668,10 @@ size_t decode(int level, uint32_t threads, int container, int states, uint32_t b
   const uint64_t out_len = rd64(in);
   if (out_len > out_cap)
     return 0;
-  std::vector<uint8_t> plan(plan_capacity(container, states, (size_t)out_len, 0, 0));
-  const size_t n = plan_build(container, states, bits, in, in_len, out_cap, plan.data(), plan.size());
-  if (n == 0)
+  std::vector<uint8_t> plan;
+  if (!plan_build_vec(container, states, bits, in, in_len, out_cap, &plan))
     return 0;
-  return exec_plan(level, threads, plan.data(), n, in, in_len, out, out_cap);
+  return exec_plan(level, threads, plan.data(), plan.size(), in, in_len, out, out_cap);
 }
 
 // Index of an existing raw / mt_ stream with checkpoints at the given groups: one sequential host decode that records
@@ -687,17 +686,13 @@ size_t index_build(int level, uint32_t threads, int container, int states, uint3
       return 0;
   const uint64_t out_len = rd64(in);
   const uint32_t S = (uint32_t)states;
-  // The decoded length in the header is untrusted: nothing here is sized by it alone.  The base plan (one chain per block) of a
-  // VALID stream is at most ~40x the stream (a block header is >= 8 bytes, a chain of the plan ~308), so that bounds the buffer,
-  // which is not initialised either (pages it never uses are never touched); the decode pass keeps no output (sink.discard).
-  const size_t base_cap = (size_t)std::min<uint64_t>(plan_capacity(container, states, (size_t)std::min<uint64_t>(out_len, (uint64_t)1 << 56), 0, 0), (uint64_t)in_len * 40 + (1 << 20));
-  std::unique_ptr<uint8_t[]> base_mem(new (std::nothrow) uint8_t[base_cap]);
-  if (!base_mem)
+  // The decoded length in the header is untrusted: nothing here is sized by it alone.  The base plan (one chain per block) is
+  // sized by the chains the stream really holds (a block header is >= 8 bytes, a chain of the plan ~308: at most ~40x the
+  // stream); the decode pass keeps no output (sink.discard).
+  std::vector<uint8_t> base;
+  if (!plan_build_vec(container, states, bits, in, in_len, (size_t)out_len, &base))
     return 0;
-  struct { uint8_t *p; uint8_t *data() const { return p; } } base{base_mem.get()};
-  const size_t base_size = plan_build(container, states, bits, in, in_len, (size_t)out_len, base.data(), base_cap);
-  if (base_size == 0)
-    return 0;
+  const size_t base_size = base.size();
   PlanHeader h;
   memcpy(&h, base.data(), sizeof(h));
   if (h.n_pieces != h.n_chains)

@@ -811,6 +811,7 @@ hipError_t launch_encode(const EncParams &ep, hipStream_t stream, bool *prepared
     prepared = true;
   }
   const uint32_t grid = (ep.n_blocks + kWavesPerWG - 1) / kWavesPerWG;
+  (void)hipGetLastError(); // (sticky per thread)
   if (ep.S == 64)
     hipLaunchKernelGGL(k_encode_blocks<64>, dim3(grid), dim3(64 * kWavesPerWG), lds, stream, ep);
   else
@@ -822,6 +823,7 @@ hipError_t launch_encode(const EncParams &ep, hipStream_t stream, bool *prepared
 
 hipError_t launch_encode_plan(const EncParams &ep, hipStream_t stream)
 {
+  (void)hipGetLastError();
   hipLaunchKernelGGL(k_plan_blocks, dim3(ep.n_blocks), dim3(64), 0, stream, ep);
   return hipGetLastError();
 }

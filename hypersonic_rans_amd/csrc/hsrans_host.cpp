@@ -779,24 +779,23 @@ size_t plan_capacity(int container, int states, size_t decoded_size, uint32_t in
 // ---------------------------------------------------------------------------------------------------------------
 // planner: derive the chains from the stream alone
 // ---------------------------------------------------------------------------------------------------------------
-size_t plan_build(int container, int states, uint32_t bits, const uint8_t *in, size_t in_len, size_t out_cap, uint8_t *plan_out, size_t plan_cap)
+static bool plan_collect(int container, int states, uint32_t bits, const uint8_t *in, size_t in_len, size_t out_cap, PlanBuilder &pb)
 {
   if (!valid_codec(container, states, bits) || in == nullptr)
-    return 0;
+    return false;
   const uint32_t S = (uint32_t)states;
   // the checks every reference decoder opens with (rANS32x64_16w.cpp:171-187, block_…decode.cpp:15-32, mt_…decode.cpp:15-32)
   if (in_len < 16 + 4 * (size_t)S + 512)
-    return 0;
+    return false;
   const uint64_t out_len = rd64(in);
   if (out_len > out_cap)
-    return 0;
+    return false;
   const uint64_t stored = rd64(in + 8);
   if (in_len < stored)
-    return 0;
+    return false;
   if (out_len == 0)
-    return 0;
+    return false;
 
-  PlanBuilder pb;
   pb.begin(container, states, bits, out_len, in_len);
   uint32_t st[64];
 
@@ -811,18 +810,18 @@ size_t plan_build(int container, int states, uint32_t bits, const uint8_t *in, s
     p.out_off = 0;
     const uint64_t T = out_len + 1 >= S ? (out_len - S + 1 + S - 1) / S : 0; // trip count of the loop at :223
     if (T > 0xFFFFFFFFull)
-      return 0;
+      return false;
     p.steps = (uint32_t)T;
     p.tail = (uint16_t)(out_len - T * S);
     pb.add_chain(p, st);
     uint16_t counts[256];
     memcpy(counts, in + 16, 512);
     pb.set_hist(counts);
-    return pb.serialize(plan_out, plan_cap);
+    return true;
   }
 
   if (out_len + 1 < S) // `outLen - StateCount + 1` underflows in the reference (block_…decode.cpp:43): undefined there, rejected here
-    return 0;
+    return false;
   const uint64_t whole = out_len - S + 1;
 
   if (container == HSRANS_BLOCK)
@@ -834,7 +833,7 @@ size_t plan_build(int container, int states, uint32_t bits, const uint8_t *in, s
     pb.hdr.aux_off = 16 + 4 * (uint64_t)S;
     Piece p{};
     pb.add_chain(p, st);
-    return pb.serialize(plan_out, plan_cap);
+    return true;
   }
 
   // mt_: follow the header chain exactly like mt_rANS32x64_16w_decode.cpp:41-96
@@ -843,14 +842,14 @@ size_t plan_build(int container, int states, uint32_t bits, const uint8_t *in, s
   do
   {
     if (pos + 8 > in_len)
-      return 0;
+      return false;
     const uint64_t size_val = rd64(in + pos);
     pos += 8;
     if (size_val >> 63)
     {
       const uint64_t len = size_val & (((uint64_t)1 << 54) - 1);
       if (len == 0 || len > out_len - std::min(i, out_len) || i > out_len)
-        return 0;
+        return false;
       Piece p{};
       p.flags = kPieceFill;
       p.out_off = i;
@@ -863,11 +862,11 @@ size_t plan_build(int container, int states, uint32_t bits, const uint8_t *in, s
     else
     {
       if (pos + 8 + 4 * (uint64_t)S + 512 > in_len)
-        return 0;
+        return false;
       const uint64_t skip = rd64(in + pos);
       pos += 8;
       if (skip > in_len) // keeps `after` from wrapping
-        return 0;
+        return false;
       const uint64_t after = pos + 2 * (skip + 1);
       for (uint32_t j = 0; j < S; j++)
         st[j] = rd32(in + pos + 4 * j);
@@ -876,7 +875,7 @@ size_t plan_build(int container, int states, uint32_t bits, const uint8_t *in, s
       for (uint32_t s = 0; s < 256; s++)
         sum += rd16(in + pos + 2 * s);
       if (sum != (1u << bits)) // inplace_complete_hist, hist.cpp:308-324
-        return 0;
+        return false;
       Piece p{};
       p.hist_off = pos;
       pos += 512;
@@ -886,10 +885,10 @@ size_t plan_build(int container, int states, uint32_t bits, const uint8_t *in, s
       if (end > whole || end < i)
         end = whole;
       else if (end & (S - 1))
-        return 0;
+        return false;
       const uint64_t steps = end > i ? (end - i + S - 1) / S : 0; // decode_section: `for (; i < end; i += S)`
       if (steps > 0xFFFFFFFFull || size_val == 0)
-        return 0;
+        return false;
       p.steps = (uint32_t)steps;
       pb.add_chain(p, st);
       i += steps * S;
@@ -906,10 +905,32 @@ size_t plan_build(int container, int states, uint32_t bits, const uint8_t *in, s
     // (mt_…decode.cpp:99-130) == a tail on the last chain.  A trailing single-symbol block followed by a partial group
     // cannot be produced by the encoder ("unreachable", :102) and is rejected.
     if (!last_is_rans || out_len - i >= S)
-      return 0;
+      return false;
     pb.pieces.back().tail = (uint16_t)(out_len - i);
   }
+  return true;
+}
+
+size_t plan_build(int container, int states, uint32_t bits, const uint8_t *in, size_t in_len, size_t out_cap, uint8_t *plan_out, size_t plan_cap)
+{
+  PlanBuilder pb;
+  if (plan_out == nullptr || !plan_collect(container, states, bits, in, in_len, out_cap, pb))
+    return 0;
   return pb.serialize(plan_out, plan_cap);
+}
+
+// Same planner into a buffer sized by what the stream turned out to hold: the one-shot decode entries use this, so that a
+// stream whose blocks are smaller than the 32 KiB plan_capacity() assumes for foreign streams (block_size option of
+// hsrans_encode) still decodes without a caller-made plan.  The chain count is bounded by the stream (>= 8 bytes per header).
+bool plan_build_vec(int container, int states, uint32_t bits, const uint8_t *in, size_t in_len, size_t out_cap, std::vector<uint8_t> *plan)
+{
+  PlanBuilder pb;
+  if (plan == nullptr || !plan_collect(container, states, bits, in, in_len, out_cap, pb))
+    return false;
+  plan->resize(pb.serialized_size());
+  const size_t n = pb.serialize(plan->data(), plan->size());
+  plan->resize(n);
+  return n != 0;
 }
 
 // Plans can come from anywhere (files, other processes): nothing a kernel derives an address from is taken on trust.

@@ -49,6 +49,7 @@ struct PlanBuilder
 
 // plan derived from the stream alone (mirrors the control flow of the reference decoders; see hsrans_host.cpp)
 size_t plan_build(int container, int states, uint32_t bits, const uint8_t *stream, size_t stream_len, size_t out_cap, uint8_t *plan_out, size_t plan_cap);
+bool plan_build_vec(int container, int states, uint32_t bits, const uint8_t *stream, size_t stream_len, size_t out_cap, std::vector<uint8_t> *plan);
 bool plan_validate(const uint8_t *plan, size_t plan_size, uint64_t stream_len, uint64_t out_cap);
 size_t plan_slice(const uint8_t *plan, size_t plan_size, uint32_t first, uint32_t count, uint8_t *out, size_t cap);
 bool plan_chain_range(const uint8_t *plan, size_t plan_size, uint32_t first, uint32_t count, uint64_t *begin, uint64_t *end);

@@ -3097,6 +3097,7 @@ __global__ void __launch_bounds__(64) k_mt_fill(const uint8_t *in, uint64_t in_l
 hipError_t launch_mt_chase(const uint8_t *d_stream, uint64_t stream_len, uint64_t out_cap, uint32_t S, uint64_t *d_blocks, uint32_t max_blocks, WalkResult *d_result,
                            hipStream_t stream)
 {
+  (void)hipGetLastError(); // (the runtime's last error is sticky per thread: an earlier failed call must not be reported as this launch's)
   hipLaunchKernelGGL(k_mt_chase, dim3(1), dim3(64), 0, stream, d_stream, stream_len, out_cap, S, d_blocks, max_blocks, d_result);
   return hipGetLastError();
 }
@@ -3104,6 +3105,7 @@ hipError_t launch_mt_chase(const uint8_t *d_stream, uint64_t stream_len, uint64_
 hipError_t launch_mt_fill(const uint8_t *d_stream, uint64_t stream_len, uint32_t S, uint32_t bits, const uint64_t *d_blocks, uint8_t *d_plan, uint32_t n_chains,
                           uint64_t out_len, WalkResult *d_result, hipStream_t stream)
 {
+  (void)hipGetLastError();
   hipLaunchKernelGGL(k_mt_fill, dim3(n_chains), dim3(64), 0, stream, d_stream, stream_len, S, bits, d_blocks, d_plan, n_chains, out_len, d_result);
   return hipGetLastError();
 }
@@ -3570,6 +3572,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
       info->table_mode = kModePack64;
       info->chains_per_wave = 1;
     }
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_decode_single, dim3(1), dim3(128), lds, stream, kp);
     return hipGetLastError();
   }
@@ -3613,6 +3616,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
       info->class_weights[k] = L.weights[k];
     info->dynamic_groups = grouped && kp.group_tickets != nullptr && kp.n_groups > grid ? 1 : 0;
   }
+  (void)hipGetLastError(); // (sticky per thread: an earlier failed call — e.g. an allocation a hostile stream asked for — is not this launch's error)
   hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), L.lds, stream, kp);
   return hipGetLastError();
 }

@@ -130,3 +130,18 @@ def test_hostile_start_states_decode_the_same_at_every_level(states):
         outs.append(out.copy())
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])
+
+
+@pytest.mark.parametrize("container", [H.BLOCK, H.MT])
+@pytest.mark.parametrize("block_size", [4096, 16384])
+def test_blocks_smaller_than_the_reference_minimum_decode_without_a_caller_plan(container, block_size):
+    """hsrans_plan_capacity assumes the reference's >= 32 KiB blocks for foreign streams; the one-shot decode entries size their
+    own plan by the chains the stream holds instead (a GPU fuzz run found the 16 KiB case returning 0)."""
+    from hypersonic_rans_amd import api
+    data = synth.nonstationary(200_000, seed=17)
+    stream = H.encode(container, 64, 11, data, block_size=block_size)
+    r, out = api.decode_cpu(container, 64, 11, stream)
+    assert r == data.size and np.array_equal(out[:r], data)
+    plan = H.plan_build(container, 64, 11, stream)
+    r, out = api.decode_cpu(container, 64, 11, stream, plan=plan)
+    assert r == data.size and np.array_equal(out[:r], data)

@@ -1,0 +1,74 @@
+"""Mutated streams through the GPU entries: whatever the bytes say, a decode returns (the decoded length, or 0 / an error code) — no
+fault, no hang, no write outside the output buffer (guard bytes behind it stay untouched).  The plans the kernels run come from the
+host planner / validator (fuzzed under sanitizers in tests/test_fuzz_host.py); what is exercised HERE are the parsers that run on
+the device: the block_ walk over inline headers (run_block_walk), the mt_ header chase (K2, hsrans_dplan_create_from_device_stream),
+the in-kernel histogram checks and the stream windows' bounds."""
+import numpy as np
+import pytest
+import torch
+
+import hypersonic_rans_amd as H
+from hypersonic_rans_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+EDGES = (0, 1, 0x7FFF, 0x8000, 0xFFFF, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF, 0xFFFFFFFF00000000, 0x7FFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF)
+
+
+def _mutate(rng, stream):
+    s = stream.copy()
+    for _ in range(int(rng.integers(1, 4))):
+        kind = int(rng.integers(0, 5))
+        at = int(rng.integers(0, s.size))
+        if kind == 0:
+            s[at] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        elif kind == 1:
+            w = 1 << int(rng.integers(1, 4))
+            a = at // w * w
+            if a + w <= s.size:
+                s[a:a + w] = np.frombuffer(np.uint64(EDGES[int(rng.integers(0, len(EDGES)))]).tobytes(), np.uint8)[:w]
+        elif kind == 2:
+            s = s[:max(at, 1)].copy()
+        elif kind == 3:
+            a = at // 8 * 8
+            if a + 8 <= s.size:
+                v = int(s[a:a + 8].view(np.uint64)[0])
+                s[a:a + 8] = np.frombuffer(np.uint64((v + (64 if rng.integers(0, 2) else -64)) % (1 << 64)).tobytes(), np.uint8)
+        else:
+            n = int(rng.integers(1, 64))
+            s[at:at + n] = rng.integers(0, 256, size=s[at:at + n].size, dtype=np.uint8)
+    return s
+
+
+@pytest.mark.parametrize("container,states,bits", ((H.BLOCK, 64, 11), (H.MT, 64, 11), (H.RAW, 64, 12), (H.BLOCK, 32, 13), (H.MT, 32, 10)))
+def test_mutated_streams_never_fault_or_write_outside(gpu_ctx, container, states, bits):
+    rng = np.random.default_rng(1234 + container * 10 + states)
+    data = synth.nonstationary(200_000, seed=17)
+    stream = H.encode(container, states, bits, data, block_size=0 if container == H.RAW else 16384)
+    n = data.size
+    L = gpu_ctx.L
+    out = np.zeros(n + 4096, np.uint8)
+    ok = bad = 0
+    for it in range(120):
+        s = _mutate(rng, stream)
+        out[:] = 0xCC
+        r = L.hsrans_decode_host(gpu_ctx.handle, container, states, bits, H.api._p(s), s.size, H.api._p(out), n, None, 0)
+        assert r in (0, n)
+        assert (out[n:] == 0xCC).all(), "a decode wrote behind its output buffer"
+        ok += r == n
+        bad += r == 0
+        if container == H.MT and it % 4 == 0:  # the device-side header chase on the same bytes
+            d = torch.from_numpy(np.concatenate([s, np.zeros((-s.size) % 16 + 16, np.uint8)])).cuda()
+            try:
+                dp = gpu_ctx.make_device_plan_from_stream(container, states, bits, d, s.size, n)
+                d_out = torch.full((n + 4096,), 0xCC, dtype=torch.uint8, device="cuda")
+                gpu_ctx.decode_device(dp, d, d_out[:n], stream_length=s.size)
+                gpu_ctx.status(dp)
+                assert bool((d_out[n:] == 0xCC).all())
+            except H.HsransError:
+                pass
+    torch.cuda.synchronize()
+    assert ok + bad == 120
+    # the unmodified stream still decodes after all that
+    r = L.hsrans_decode_host(gpu_ctx.handle, container, states, bits, H.api._p(stream), stream.size, H.api._p(out), n, None, 0)
+    assert r == n and np.array_equal(out[:n], data)
