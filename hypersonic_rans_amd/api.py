@@ -114,6 +114,8 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_decode_device_window.argtypes = [_vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp]
     L.hsrans_decode_device_ranges.restype = _i
     L.hsrans_decode_device_ranges.argtypes = [_vp, _vp, _vp, _sz, _sz, _vp, _sz, _sz, _vp]
+    L.hsrans_decode_device_indexing.restype = _i
+    L.hsrans_decode_device_indexing.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _vp, ctypes.POINTER(_vp)]
     L.hsrans_ctx_calibrate.restype = _i
     L.hsrans_ctx_calibrate.argtypes = [_vp, _u32, _u32, ctypes.POINTER(Calibration)]
     L.hsrans_dplan_status.restype = _i
@@ -475,6 +477,18 @@ class Context:
                                          d_out.data_ptr(), d_out.numel(), ctypes.c_void_p(s.cuda_stream))
         if rc != 0:
             raise HsransError(f"hsrans_decode_device failed with code {rc}")
+
+    def decode_device_indexing(self, dplan: DevicePlan, d_stream: torch.Tensor, d_out: torch.Tensor, index_interval: int,
+                               stream: torch.cuda.Stream | None = None, stream_length: int | None = None) -> DevicePlan:
+        """First decode of a stream without an index: fills ``d_out`` and returns the plan with a checkpoint every
+        ``index_interval`` groups for the later decodes (hsrans_decode_device_indexing; synchronises ``stream``)."""
+        s = stream if stream is not None else torch.cuda.current_stream(d_stream.device)
+        h = _vp()
+        rc = self.L.hsrans_decode_device_indexing(self.handle, dplan.handle, d_stream.data_ptr(), d_stream.numel() if stream_length is None else stream_length,
+                                                  d_out.data_ptr(), d_out.numel(), index_interval, ctypes.c_void_p(s.cuda_stream), ctypes.byref(h))
+        if rc != 0:
+            raise HsransError(f"hsrans_decode_device_indexing failed with code {rc}")
+        return DevicePlan(self, h)
 
     def decode_device_window(self, dplan: DevicePlan, d_window: torch.Tensor, window_offset: int, window_length: int, d_out: torch.Tensor,
                              stream: torch.cuda.Stream | None = None):

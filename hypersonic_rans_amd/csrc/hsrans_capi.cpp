@@ -47,6 +47,8 @@ struct hsrans_ctx
   size_t d_enc_meta_cap = 0;
   uint8_t *d_enc_ck = nullptr; // checkpoint states / cursors of the blocks being encoded
   size_t d_enc_ck_cap = 0;
+  uint8_t *h_pin = nullptr; // page-locked staging of hsrans_decode_device_indexing (checkpoints down, plan blob up); under `lock`
+  size_t h_pin_cap = 0;
 };
 
 struct hsrans_dplan
@@ -96,6 +98,24 @@ bool grow(uint8_t **p, size_t *cap, size_t need)
   if (hipMalloc((void **)p, want) != hipSuccess)
   {
     (void)hipGetLastError(); // (consumed here: the runtime's last error is sticky per thread and would surface at an unrelated launch)
+    return false;
+  }
+  *cap = want;
+  return true;
+}
+
+bool grow_pinned(uint8_t **p, size_t *cap, size_t need)
+{
+  if (need <= *cap)
+    return true;
+  if (*p)
+    (void)hipHostFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  const size_t want = need + need / 4 + 65536;
+  if (hipHostMalloc((void **)p, want, hipHostMallocDefault) != hipSuccess)
+  {
+    (void)hipGetLastError();
     return false;
   }
   *cap = want;
@@ -311,6 +331,8 @@ void hsrans_ctx_destroy(hsrans_ctx *ctx)
     (void)hipFree(ctx->d_enc_ck);
   if (ctx->d_status)
     (void)hipFree(ctx->d_status);
+  if (ctx->h_pin)
+    (void)hipHostFree(ctx->h_pin);
   delete ctx;
 }
 
@@ -1156,6 +1178,36 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   return total;
 }
 
+// The chains of a plan with a checkpoint every `index_interval` groups (absolute group numbers: slot = group / interval), given
+// the base plan (one single-piece chain per block) and what a recording decode pass left at the checkpoints
+static void add_interval_chains(PlanBuilder &pb, const PlanHeader &h, const uint32_t *cf0, const Piece *pc0, const uint32_t *st0, uint32_t index_interval,
+                                const uint32_t *ck_states, const uint64_t *ck_words)
+{
+  const uint32_t S = h.states;
+  for (uint32_t ch = 0; ch < h.n_chains; ch++)
+  {
+    const Piece &bp = pc0[cf0[ch]];
+    if (bp.flags & kPieceFill)
+    {
+      pb.add_chain(bp, nullptr);
+      continue;
+    }
+    const uint64_t T = bp.steps, g_abs0 = bp.out_off / S;
+    for (uint64_t g = 0; g < T || g == 0; g += index_interval)
+    {
+      Piece p{};
+      p.hist_off = bp.hist_off;
+      p.out_off = bp.out_off + g * S;
+      const uint64_t slot = (g_abs0 + g) / index_interval;
+      p.words_off = g == 0 ? bp.words_off : ck_words[slot];
+      const uint64_t steps = T - g < index_interval ? T - g : index_interval;
+      p.steps = (uint32_t)steps;
+      p.tail = (uint16_t)(g + steps == T ? bp.tail : 0);
+      pb.add_chain(p, g == 0 ? st0 + (size_t)bp.state_idx * S : &ck_states[slot * S]);
+    }
+  }
+}
+
 static size_t index_build_impl(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint32_t index_interval,
                                const uint64_t *groups, size_t n_groups, uint8_t *plan_out, size_t plan_capacity)
 {
@@ -1365,28 +1417,7 @@ static size_t index_build_impl(hsrans_ctx *ctx, int container, int states, uint3
       }
     }
     else
-    for (uint32_t ch = 0; ch < h.n_chains; ch++)
-    {
-      const Piece &bp = pc0[cf0[ch]];
-      if (bp.flags & kPieceFill)
-      {
-        pb.add_chain(bp, nullptr);
-        continue;
-      }
-      const uint64_t T = bp.steps, g_abs0 = bp.out_off / S;
-      for (uint64_t g = 0; g < T || g == 0; g += index_interval)
-      {
-        Piece p{};
-        p.hist_off = bp.hist_off;
-        p.out_off = bp.out_off + g * S;
-        const uint64_t slot = (g_abs0 + g) / index_interval;
-        p.words_off = g == 0 ? bp.words_off : ck_words[slot];
-        const uint64_t steps = T - g < index_interval ? T - g : index_interval;
-        p.steps = (uint32_t)steps;
-        p.tail = (uint16_t)(g + steps == T ? bp.tail : 0);
-        pb.add_chain(p, g == 0 ? st0 + (size_t)bp.state_idx * S : &ck_states[slot * S]);
-      }
-    }
+      add_interval_chains(pb, h, cf0, pc0, st0, index_interval, ck_states.data(), ck_words.data());
     result = pb.serialize(plan_out, plan_capacity);
   } while (false);
   if (d_ck_states)
@@ -1426,6 +1457,105 @@ try
 catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
 {
   return 0;
+}
+
+// The first decode of a stream that came without an index (a reference-emitted mt_ stream planned by hsrans_plan_build or on the
+// device by hsrans_dplan_create_from_device_stream: one chain per block, most wave slots empty) also RECORDS the coder states and
+// the read cursor every `index_interval` groups — two stores per checkpoint on a pass that is latency-bound anyway — and returns
+// the plan with those checkpoints for every later decode of the same stream.  The stream never leaves device memory; the plan
+// blob (chain table, a few MB) is assembled on the host as in hsrans_index_build, whose result it equals byte for byte.
+int hsrans_decode_device_indexing(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity,
+                                  uint32_t index_interval, void *hip_stream, hsrans_dplan **indexed)
+try
+{
+  if (ctx == nullptr || d == nullptr || d_stream == nullptr || d_out == nullptr || indexed == nullptr || d->ctx != ctx)
+    return HSRANS_E_ARG;
+  *indexed = nullptr;
+  if (((uintptr_t)d_stream & 15) != 0 || ((uintptr_t)d_out & 3) != 0 || index_interval == 0 || (index_interval % 4) != 0)
+    return HSRANS_E_ARG;
+  const PlanHeader &h = d->hdr;
+  // base plans only: one single-piece chain per block (raw: one chain), no inline-header walk (block_ streams: hsrans_index_build)
+  if ((h.flags & kPlanWalk) || h.n_pieces != h.n_chains || h.interval != 0 || d->d_plan == nullptr || d->plan_bytes == 0)
+    return HSRANS_E_ARG;
+  if (stream_length < h.stream_len || out_capacity < h.decoded_len)
+    return HSRANS_E_FORMAT;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return HSRANS_E_HIP;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const uint32_t S = h.states;
+  const uint64_t n_ck = h.decoded_len / S / index_interval + 2;
+  // page-locked staging (kept by the context): [checkpoint states | cursors | base plan] down, then the new plan blob up —
+  // from pageable memory these copies (12.5 MB of states each way for 100 MB at 32 groups) took 15 ms, the decode 0.25
+  std::lock_guard<std::mutex> guard(ctx->lock);
+  const size_t st_bytes = (size_t)n_ck * S * 4, wd_bytes = (size_t)n_ck * 8, base_bytes = (d->plan_bytes + 15) / 16 * 16;
+  const size_t new_cap = (size_t)plan_size((uint32_t)std::min<uint64_t>(h.n_chains + n_ck, 0xFFFFFFF0u), (uint32_t)std::min<uint64_t>(h.n_chains + n_ck, 0xFFFFFFF0u), S, kPlanHasHist);
+  if (!grow_pinned(&ctx->h_pin, &ctx->h_pin_cap, st_bytes + wd_bytes + base_bytes + new_cap))
+    return HSRANS_E_HIP;
+  uint32_t *ck_states = (uint32_t *)ctx->h_pin;
+  uint64_t *ck_words = (uint64_t *)(ctx->h_pin + st_bytes);
+  uint8_t *base = ctx->h_pin + st_bytes + wd_bytes;
+  uint8_t *plan = base + base_bytes;
+  size_t plan_bytes = 0;
+  // (the checkpoints land in the context's checkpoint buffer — the GPU encoder's, kept and grown — not in fresh allocations)
+  if (!grow(&ctx->d_enc_ck, &ctx->d_enc_ck_cap, st_bytes + wd_bytes))
+    return HSRANS_E_HIP;
+  uint32_t *d_ck_states = (uint32_t *)ctx->d_enc_ck;
+  uint64_t *d_ck_words = (uint64_t *)(ctx->d_enc_ck + st_bytes);
+  int rc = HSRANS_E_HIP;
+  do
+  {
+    KParams kp{};
+    kp.stream = (const uint8_t *)d_stream;
+    kp.stream_len = stream_length;
+    kp.out = (uint8_t *)d_out;
+    kp.out_cap = out_capacity;
+    kp.plan = d->d_plan;
+    kp.status = d->d_status;
+    kp.ckpt_states = d_ck_states;
+    kp.ckpt_words = d_ck_words;
+    kp.ckpt_interval = index_interval;
+    PlanHeader hl = h;
+    hl.shared_hist = 0; // private tables, as in hsrans_index_build's pass
+    uint32_t status = 0xFFFFFFFF;
+    if (launch_decode(kp, hl, ctx->geom, s, nullptr) != hipSuccess ||
+        hipMemcpyAsync(base, d->d_plan, d->plan_bytes, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(ck_states, d_ck_states, st_bytes, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(ck_words, d_ck_words, wd_bytes, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(&status, d->d_status, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      break;
+    if (status != 0) // the pass found a bad histogram / header: reported and cleared like hsrans_dplan_status does
+    {
+      rc = hipMemsetAsync(d->d_status, 0, 4, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess ? HSRANS_E_DEVICE : HSRANS_E_HIP;
+      break;
+    }
+    PlanHeader hb;
+    if (!read_header(base, d->plan_bytes, &hb) || hb.n_chains != h.n_chains || hb.n_pieces != h.n_pieces || hb.states != h.states ||
+        !plan_validate(base, d->plan_bytes, h.stream_len, h.decoded_len))
+    {
+      rc = HSRANS_E_FORMAT;
+      break;
+    }
+    PlanBuilder pb;
+    pb.begin((int)h.container, (int)S, h.bits, h.decoded_len, h.stream_len);
+    pb.hdr.interval = index_interval;
+    if (hb.flags & kPlanHasHist)
+    {
+      uint16_t counts[256];
+      memcpy(counts, base + plan_hist_off(hb.n_chains, hb.n_pieces, hb.states), 512);
+      pb.set_hist(counts);
+    }
+    add_interval_chains(pb, hb, (const uint32_t *)(base + plan_chain_first_off()), (const Piece *)(base + plan_pieces_off(hb.n_chains)),
+                        (const uint32_t *)(base + plan_states_off(hb.n_chains, hb.n_pieces)), index_interval, ck_states, ck_words);
+    plan_bytes = pb.serialize(plan, new_cap);
+    rc = plan_bytes == 0 ? HSRANS_E_FORMAT : HSRANS_OK;
+  } while (false);
+  if (rc != HSRANS_OK)
+    return rc;
+  return hsrans_dplan_create(ctx, plan, plan_bytes, indexed);
+}
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return HSRANS_E_HIP;
 }
 
 // ---- host buffers, PCIe legs overlapped ---------------------------------------------------------------------------

@@ -192,6 +192,16 @@ size_t hsrans_dplan_read_plan(hsrans_dplan *dplan, uint8_t *out, size_t capacity
 /* synchronises `hip_stream` and returns HSRANS_OK or HSRANS_E_DEVICE (kernel found a bad histogram/header) */
 int hsrans_dplan_status(hsrans_ctx *ctx, hsrans_dplan *dplan, void *hip_stream);
 
+/* First decode of a stream that came WITHOUT an index (e.g. a reference-emitted mt_ stream: one chain per block,
+ * src/mt_rANS32x64_16w_decode.cpp:137-265 decodes it with one thread per block): decodes like hsrans_decode_device with
+ * `dplan` (from hsrans_plan_build + hsrans_dplan_create, or from hsrans_dplan_create_from_device_stream; HSRANS_RAW and
+ * HSRANS_MT, no checkpoints yet) and records the coder states and read cursor every `index_interval` groups (multiple of 4)
+ * on the way.  *indexed receives a device plan with those checkpoints (the blob hsrans_index_build would return for the
+ * same stream and interval) for every later decode of the same stream.  Synchronises `hip_stream`.  d_out is complete on
+ * return.  HSRANS_E_DEVICE: the pass found a malformed stream (status cleared), *indexed is NULL. */
+int hsrans_decode_device_indexing(hsrans_ctx *ctx, hsrans_dplan *dplan, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity,
+                                  uint32_t index_interval, void *hip_stream, hsrans_dplan **indexed);
+
 /* GPU encoder: mt_ stream with fixed blocks of `block_size` symbols (multiple of 64), each block
  * encoded independently by one wavefront (HSRANS_ENC_INDEPENDENT_BLOCKS layout).  d_in / d_out are device pointers (16-byte
  * aligned); d_out needs hsrans_capacity(HSRANS_MT, states, length) bytes.  Synchronises `hip_stream`; returns the stream

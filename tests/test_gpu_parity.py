@@ -411,6 +411,54 @@ def test_index_build_for_reference_mt_streams(gpu_ctx, ref, nonstat, zipf, state
 
 
 @pytest.mark.parametrize("states", (32, 64))
+def test_first_decode_of_an_unindexed_stream_leaves_the_index_behind(gpu_ctx, ref, nonstat, zipf, states):
+    """hsrans_decode_device_indexing: a reference-emitted mt_ stream that only exists in device memory is planned on the device
+    (K2), decoded once with one chain per block — that pass records the checkpoints — and decoded again with the plan it left
+    behind, which is byte for byte the one hsrans_index_build makes from a host copy of the stream.  Raw streams likewise."""
+    import torch
+
+    for container, bits, src, n, interval in ((H.MT, 11, nonstat, 3_000_000, 32), (H.MT, 14, zipf, 1 << 20, 64), (H.MT, 11, zipf, 65560, 4),
+                                              (H.RAW, 11, zipf, 400_037, 32)):
+        d = src[:n]
+        s = ref.encode(MT if container == H.MT else RAW, states, bits, d)
+        d_in = torch.from_numpy(np.concatenate([s, np.zeros((-s.size) % 16, np.uint8)])).cuda()
+        if container == H.MT:
+            base = gpu_ctx.make_device_plan_from_stream(H.MT, states, bits, d_in, s.size, n)
+        else:
+            base = gpu_ctx.make_device_plan(H.plan_build(H.RAW, states, bits, s))
+        first = torch.full((n + 64,), 0xCC, dtype=torch.uint8, device="cuda")
+        indexed = gpu_ctx.decode_device_indexing(base, d_in, first[:n], interval, stream_length=s.size)
+        r, want = gpu_ctx.decode_host(container, states, bits, s, n)  # (65560 is a length whose last block the reference itself mis-decodes)
+        assert r == n and (n == 65560 or np.array_equal(want, d))
+        assert np.array_equal(first[:n].cpu().numpy(), want) and bool((first[n:] == 0xCC).all())
+        want_plan = gpu_ctx.index_build(container, states, bits, s, interval)
+        assert np.array_equal(gpu_ctx.read_device_plan(indexed, capacity=want_plan.size + 4096), want_plan)
+        assert H.plan_chain_count(want_plan) > H.plan_chain_count(gpu_ctx.read_device_plan(base, capacity=want_plan.size + 4096))
+        again = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        gpu_ctx.decode_device(indexed, d_in, again, stream_length=s.size)
+        assert gpu_ctx.status(indexed) == 0 and np.array_equal(again.cpu().numpy(), want)
+    # arguments: an interval that is not a multiple of 4, a plan that has checkpoints already
+    with pytest.raises(H.HsransError):
+        gpu_ctx.decode_device_indexing(base, d_in, first[:n], 6, stream_length=s.size)
+    with pytest.raises(H.HsransError):
+        gpu_ctx.decode_device_indexing(indexed, d_in, first[:n], 32, stream_length=s.size)
+    # a corrupted block: reported as a device error, no plan
+    s_mt = ref.encode(MT, states, 11, nonstat[:3_000_000])
+    host_plan = H.plan_build(H.MT, states, 11, s_mt)
+    bad = s_mt.copy()
+    _, _, pc = H.api.plan_tables(host_plan)
+    bad[int(pc[1]["hist_off"]) + 2] ^= 0x40  # a count of the second block's histogram: its sum is no longer 2^bits
+    d_bad = torch.from_numpy(np.concatenate([bad, np.zeros((-bad.size) % 16, np.uint8)])).cuda()
+    base = gpu_ctx.make_device_plan(host_plan)
+    out = torch.zeros(3_000_000, dtype=torch.uint8, device="cuda")
+    with pytest.raises(H.HsransError):
+        gpu_ctx.decode_device_indexing(base, d_bad, out, 32, stream_length=bad.size)
+    d_good = torch.from_numpy(np.concatenate([s_mt, np.zeros((-s_mt.size) % 16, np.uint8)])).cuda()
+    gpu_ctx.decode_device(base, d_good, out, stream_length=s_mt.size)
+    assert gpu_ctx.status(base) == 0 and np.array_equal(out.cpu().numpy(), nonstat[:3_000_000])  # the status word was cleared
+
+
+@pytest.mark.parametrize("states", (32, 64))
 def test_index_build_for_block_streams(gpu_ctx, oracle, ref, nonstat, zipf, states):
     """block_ streams are one chain with inline headers: the single wavefront that walks them also reports the headers it meets,
     so one pass turns a stream (ours or the real reference's) into a plan with a chain per block and per checkpoint."""
