@@ -491,6 +491,8 @@ def sharded_workload(args, world, rank, dv: _Dev, dist):
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         ms = elapsed * 1e3 / steps
+        if rank == 0:  # (stderr: if a later leg dies on hardware this run has never seen, the log still holds the legs before it)
+            print(f"bench.py sharded: leg {name}: {ms:.4f} ms per step over {world} rank(s)", file=sys.stderr, flush=True)
         return {"leg": name, "ms_per_step": ms, "MiB_s": n / 2**20 / (ms * 1e-3), "parts": parts, "gather": ("none" if not gather else "all" if root is None else f"root={root}"),
                 "shares": [r[1] - r[0] for r in dec.ranges], "pipelined": bool(gather and parts > 1), "per_rank": per_rank}
 
