@@ -382,7 +382,7 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
   const size_t counter_bytes = (size_t)kCounterSets * kDynQueues * kDynQueueStride * 8;
   const bool need_counters = (mergeable_raw && h.interval != 0) || may_group; // (one-chain-per-wave plans draw nothing)
   auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  const size_t table_bound = mergeable_raw && (h.flags & kPlanHasHist) ? up256(std::max<size_t>((size_t)8 << h.bits, coarse_table_entries(h.bits >= 13 ? h.bits : 13) * 8)) : 0;
+  const size_t table_bound = mergeable_raw && (h.flags & kPlanHasHist) ? up256(std::max<size_t>((size_t)8 << h.bits, rank_table_entries(h.bits >= 13 ? h.bits : 13) * 8)) : 0;
   const size_t group_bound = may_group ? up256(((size_t)h.n_chains + 16) * sizeof(Group)) : 0;
   const size_t arena_need = 256 + (need_counters ? up256(counter_bytes) : 0) + up256(plan_size) + table_bound + group_bound;
   if (!grow(&d->d_arena, &d->d_arena_cap, arena_need))
@@ -464,9 +464,9 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
       }
       else if (mode == 4)
       {
-        // wider histograms: the coarse + fine table pair (kModeCoarse), 36 / 40 / 48 KiB instead of 64 / 128 / 256 KiB
-        tab.resize(coarse_table_entries(h.bits));
-        if (build_coarse_table(counts, h.bits, tab.data(), tab.size()) == 0)
+        // wider histograms: the rank table (kModeRank: a byte per slot + 256 entries), 18 / 34 KiB at 14 / 15 bits instead of 128 / 256 KiB
+        tab.resize(rank_table_entries(h.bits));
+        if (build_rank_table(counts, h.bits, tab.data(), tab.size()) == 0)
           return fail(HSRANS_E_FORMAT);
       }
       d->pa.dual = tc.dual ? 1 : 0;

@@ -158,8 +158,8 @@ TableChoice choose_table(uint32_t bits, uint32_t states, bool direct);
 size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, uint64_t total_groups, uint64_t *out, size_t cap);
 bool table_spill(); // HSRANS_TABLE_SPILL: leave host-built tables in global memory (comparison only)
 // host-side builder of the bits >= 13 coarse/fine decode table (layout: kModeCoarse in hsrans_kernels.hip); returns entries written
-size_t build_coarse_table(const uint16_t counts[256], uint32_t bits, uint2 *out, size_t capacity_entries);
-size_t coarse_table_entries(uint32_t bits);
+size_t build_rank_table(const uint16_t counts[256], uint32_t bits, uint2 *out, size_t capacity_entries);
+size_t rank_table_entries(uint32_t bits);
 // widest histogram the shared 8-byte-per-slot table (MODE 3) is used for
 uint32_t pack64_max_bits();
 // per device (call with the device current): raise the dynamic-LDS limit of every kernel variant to the gfx950 maximum

@@ -66,13 +66,13 @@ constexpr int kModeTwoLevel = 2; // bits >= 13: uint8 sym[2^bits] + uint32 {freq
 constexpr int kModePack64 = 3;   // bits <= 14, table shared by a workgroup: uint2 per slot = {freq | sym << 24, slot - cumul}:
                                  // v_mad_u32_u24 takes freq (low 24 bits) and the bias operand as they are, v_perm takes byte 3
 
-// bits >= 13 with a host-built table (persistent 64-state launches): a COARSE table of 4096 granules of g = 2^(bits-12) slots,
-// uint2 {freq | sym << 24, bias of the granule's first slot} when all g slots decode to one symbol (bias = that + slot % g),
-// else {0, 1 << 31 | index} into a FINE table of ordinary per-slot entries; at most 255 granules straddle a symbol boundary,
-// so the fine table has 255 * g entries.  32 KiB + 4/8/16 KiB instead of 64/128/256 KiB: two workgroups per CU at every
-// width, one 8-byte gather per group plus a second one on the few lanes that hit a boundary granule.
-constexpr int kModeCoarse = 4;
-constexpr uint32_t kCoarseEntries = 4096;
+// bits >= 14 with a host-built table (persistent 64-state launches): uint8 rank[2^bits] — the slot's symbol as its RANK by
+// frequency — followed by 256 x uint2 {freq | sym << 24, -cumul} ordered by rank.  A byte gather (the slot is the LDS address in
+// k_decode_dual), then an 8-byte gather from a 2 KiB table in which the 32 most frequent symbols — nearly every lane of a group —
+// sit in 32 different bank pairs; x' = freq * (x >> bits) + slot - cumul.  18 / 34 KiB at 14 / 15 bits instead of 128 / 256 KiB.
+// (Round 2's layout for these widths was a coarse table of 4096 granules + a fine table for the granules that straddle a symbol
+// boundary: 16.4 vector instructions and 11.2 LDS cycles per group against 12.3 and 13.3 here — 62.2 -> 56.7 us at 15 bits.)
+constexpr int kModeRank = 4;
 // The MODE 3 entries left in global memory ("spilled" table: L1/L2-resident, gathered with global_load_dwordx2): the
 // comparison point BASELINE config 3 asks for next to the LDS-resident tables (HSRANS_TABLE_SPILL=1, host-built tables only)
 constexpr int kModeSpill = 5;
@@ -82,7 +82,7 @@ __host__ __device__ constexpr uint32_t table_bytes_for(int mode, uint32_t bits)
   return mode == kModeSpill ? 0u
          : mode == kModeTwoLevel ? (1u << bits) + 1024
          : mode == kModePack64 ? 8u << bits
-         : mode == kModeCoarse ? 8u * kCoarseEntries + 8u * 255u * (1u << (bits - 12))
+         : mode == kModeRank ? (1u << bits) + 2048u
                                : 4u << bits;
 }
 
@@ -126,7 +126,6 @@ struct WaveCtx
   uint32_t *status;
   uint32_t bits, S, lane;
   uint32_t v_mask, v_bits; // 2^bits - 1 and bits, each held in a VGPR: a VALU op with an SGPR operand issues at half rate
-  uint32_t v_gshift, v_gmask; // kModeCoarse: log2 of the granule and granule - 1, in VGPRs for the same reason
   uint8_t *rings;        // LDS, kWaveRingBytes: this wave's stream ring + mirror
   uint8_t *table;        // LDS
   uint8_t *table_b;      // LDS: the table lanes 32..63 use in the paired 32-state modes (== table unless the halves decode different blocks)
@@ -521,22 +520,12 @@ __device__ __forceinline__ uint32_t group_step(uint32_t &x, Ring &r, const WaveC
     e = e2.x;
     nx = __umul24(q, e2.x) + e2.y;
   }
-  else if (MODE == kModeCoarse)
+  else if (MODE == kModeRank)
   {
-    uint2 e2 = ((const uint2 *)c.table)[slot >> c.v_gshift];
-    const uint32_t in_granule = slot & c.v_gmask;
-    uint32_t bias = e2.y + in_granule;
-    const bool mixed = (int32_t)e2.y < 0; // the granule straddles a symbol boundary: per-slot entry from the fine table
-    if (__builtin_amdgcn_ballot_w64(mixed) != 0)
-    {
-      if (mixed)
-      {
-        e2 = ((const uint2 *)(c.table + 8 * kCoarseEntries))[(e2.y & 0x7FFFFFFFu) + in_granule];
-        bias = e2.y;
-      }
-    }
+    const uint32_t rank = c.table[slot];
+    const uint2 e2 = ((const uint2 *)(c.table + mask + 1))[rank];
     e = e2.x;
-    nx = __umul24(q, e2.x) + bias;
+    nx = __umul24(q, e2.x) + e2.y + slot;
   }
   else if (MODE == kModePack)
   {
@@ -619,7 +608,7 @@ __device__ __forceinline__ void run_groups_impl(uint32_t &x, const StreamWin &sw
   const uint32_t S = FULL ? 64 : c.S;
   const bool act = FULL || c.lane < S;
   const unsigned long long act_mask = FULL ? ~0ull : __builtin_amdgcn_ballot_w64(act);
-  constexpr uint32_t kSymByte = (MODE == kModePack64 || MODE == kModeCoarse || MODE == kModeSpill) ? 3 : 0; // where group_step's return value holds the symbol
+  constexpr uint32_t kSymByte = (MODE == kModePack64 || MODE == kModeRank || MODE == kModeSpill) ? 3 : 0; // where group_step's return value holds the symbol
   const OutLanes ol = out_lanes(c.lane, S);
 
   for (; steps >= 4; steps -= 4)
@@ -979,7 +968,7 @@ __device__ __forceinline__ void run_tail(uint32_t &x, Ring &r, const WaveCtx &c,
   const bool act = c.lane < c.S && p < tail;
   const uint32_t e = group_step<MODE, false>(x, r, c, __builtin_amdgcn_ballot_w64(act));
   if (act)
-    c.out[o + p] = (uint8_t)(e >> ((MODE == kModePack64 || MODE == kModeCoarse || MODE == kModeSpill) ? 24 : 0));
+    c.out[o + p] = (uint8_t)(e >> ((MODE == kModePack64 || MODE == kModeRank || MODE == kModeSpill) ? 24 : 0));
 }
 
 // single-symbol block (block_rANS32x64_16w_decode.cpp:52-60): wave-wide fill
@@ -1171,7 +1160,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
   const uint32_t cls = half * 4 + wave_in_wg / per_class;
   const uint32_t q0 = pa.run_len[cls];
   const uint32_t c_first = pa.half_base[half] + (blk - half * first_half) * pa.wg_chains[half] + pa.class_off[cls] + (wave_in_wg % per_class) * q0;
-  const bool host_table = (MODE == kModePack64 || MODE == kModeCoarse || MODE == kModeSpill) && pa.table != nullptr; // kModeCoarse / kModeSpill are host-built only
+  const bool host_table = (MODE == kModePack64 || MODE == kModeRank || MODE == kModeSpill) && pa.table != nullptr; // kModeRank / kModeSpill are host-built only
   if (!host_table) // the in-kernel build borrows ring space: it has to come before the first stream request
     build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
   if (q0 != 0)
@@ -1281,7 +1270,7 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
   const uint64_t t_entry = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;
   const uint64_t c_entry = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memtime() : 0; // shader clock (diagnostics: what does the chip run at under this load?)
   uint64_t t_table = 0, t_ready = 0, t_static = 0;
-  const bool host_table = (MODE == kModePack64 || MODE == kModeCoarse || MODE == kModeSpill) && pa.table != nullptr;
+  const bool host_table = (MODE == kModePack64 || MODE == kModeRank || MODE == kModeSpill) && pa.table != nullptr;
   if (kp.finish != nullptr && w == 0 && c.lane == 0) // calibration launches: the launch's time zero
     kp.finish[W] = __builtin_amdgcn_s_memrealtime();
   if (!host_table) // the in-kernel build borrows ring space: it has to come before the first stream request
@@ -2027,8 +2016,6 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.lane = threadIdx.x & 63;
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << bits) - 1));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(bits));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gshift) : "s"(bits > 12 ? bits - 12 : 0));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gmask) : "s"(bits > 12 ? (1u << (bits - 12)) - 1 : 0));
 
   const uint32_t chain = blockIdx.x * waves + wave;
 
@@ -2044,9 +2031,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
     c.gtable = kp.pa.table;
     if (kp.pa.pieces != nullptr)
     {
-      // (the coarse + fine tables are only ever used for 64-state plans: no pair variants of that mode; one-chain-per-wave
+      // (the rank table is only ever used for 64-state plans: no pair variants of that mode; one-chain-per-wave
       // plans, interval == 0, have a kernel of their own: k_decode_direct)
-      if (MODE != kModeCoarse && c.S == 32)
+      if (MODE != kModeRank && c.S == 32)
         run_persistent_pair<MODE>(c, kp, waves, chain);
       else
         run_persistent<MODE>(c, kp, waves, chain);
@@ -2105,8 +2092,6 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.lane = threadIdx.x & 63;
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gshift) : "s"(c.bits > 12 ? c.bits - 12 : 0));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gmask) : "s"(c.bits > 12 ? (1u << (c.bits - 12)) - 1 : 0));
   const uint32_t ring_stride = MODE == kModePack64 ? kFastRingBytes : kWaveRingBytes; // (launch_shape sizes the LDS the same way)
   c.rings = smem + wave * ring_stride;
   c.table = smem + waves * ring_stride;
@@ -2115,7 +2100,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.scratch_cnt = (uint16_t *)smem; // wave 0's ring (no request in flight while a table is built)
   c.scratch_cum = (uint16_t *)(smem + 512);
   const uint32_t chain = blockIdx.x * waves + wave;
-  if (MODE != kModeCoarse && c.S == 32)
+  if (MODE != kModeRank && c.S == 32)
     run_direct_pair<MODE>(c, kp, waves, chain);
   else
     run_direct<MODE>(c, kp, waves, chain);
@@ -2143,7 +2128,6 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_c
   c.lane = threadIdx.x & 63;
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
-  c.v_gshift = c.v_gmask = 0;
   c.rings = smem + wave * kFastRingBytes;
   c.table = smem + waves * kFastRingBytes;
   c.table_b = c.table;
@@ -2177,8 +2161,6 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.lane = threadIdx.x & 63;
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gshift) : "s"(c.bits > 12 ? c.bits - 12 : 0));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gmask) : "s"(c.bits > 12 ? (1u << (c.bits - 12)) - 1 : 0));
   const uint32_t ring_stride = MODE == kModePack64 ? kFastRingBytes : kWaveRingBytes; // (launch_shape sizes the LDS the same way)
   c.rings = smem + wave * ring_stride;
   c.table = smem + waves * ring_stride;
@@ -2211,7 +2193,6 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.lane = threadIdx.x & 63;
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
-  c.v_gshift = c.v_gmask = 0;
   c.rings = smem + wave * kFastRingBytes;
   c.table = smem + waves * kFastRingBytes;
   c.table_b = c.table;
@@ -2227,7 +2208,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
 
 // ---------------------------------------------------------------------------------------------------------------
 // Two 64-state chains per wave (k_decode_dual): for the table layouts that leave room for only one workgroup per CU (the
-// 8-byte-per-slot table at 13 bits: 64 KiB) or whose group step is three dependent LDS round trips (coarse + fine at 14 / 15
+// 8-byte-per-slot table at 13 bits: 64 KiB) or whose group step is three dependent LDS round trips (the rank table at 14 / 15
 // bits), a wave's single dependent chain leaves the SIMD idle most of the time (4 waves per SIMD, each waiting on LDS).
 // Wave w decodes chains 2w and 2w + 1 of a one-chain-per-wave index side by side: two independent dependency chains in one
 // instruction stream, which the scheduler interleaves.
@@ -2333,34 +2314,15 @@ __device__ __forceinline__ void group_step_dual(uint32_t &xa, uint32_t &xb, Ring
     nxa = __umul24(qa, ta.x) + ta.y;
     nxb = __umul24(qb, tb.x) + tb.y;
   }
-  else // kModeCoarse
+  else // kModeRank
   {
-    uint2 ta = ((const uint2 *)c.table)[slot_a >> c.v_gshift];
-    uint2 tb = ((const uint2 *)c.table)[slot_b >> c.v_gshift];
-    const uint32_t ga = slot_a & c.v_gmask, gb = slot_b & c.v_gmask;
-    uint32_t bias_a = ta.y + ga, bias_b = tb.y + gb;
-    const bool mixed_a = (int32_t)ta.y < 0, mixed_b = (int32_t)tb.y < 0; // the granule straddles a symbol boundary: per-slot entry from the fine table
-    if (__builtin_amdgcn_ballot_w64(mixed_a || mixed_b) != 0)
-    {
-      const uint2 *fine = (const uint2 *)(c.table + 8 * kCoarseEntries);
-      // (lanes that are not mixed read entry 0 of the fine table: harmless, and both gathers stay unconditional inside this branch)
-      const uint2 fa = fine[mixed_a ? (ta.y & 0x7FFFFFFFu) + ga : 0];
-      const uint2 fb = fine[mixed_b ? (tb.y & 0x7FFFFFFFu) + gb : 0];
-      if (mixed_a)
-      {
-        ta = fa;
-        bias_a = fa.y;
-      }
-      if (mixed_b)
-      {
-        tb = fb;
-        bias_b = fb.y;
-      }
-    }
+    const uint2 *ent = (const uint2 *)(c.table + (1u << c.bits));
+    const uint2 ta = ent[c.table[slot_a]];
+    const uint2 tb = ent[c.table[slot_b]];
     ea = ta.x;
     eb = tb.x;
-    nxa = __umul24(qa, ta.x) + bias_a;
-    nxb = __umul24(qb, tb.x) + bias_b;
+    nxa = __umul24(qa, ta.x) + ta.y + slot_a;
+    nxb = __umul24(qb, tb.x) + tb.y + slot_b;
   }
   const unsigned long long ma = __builtin_amdgcn_ballot_w64(nxa < kConsume);
   const unsigned long long mb = __builtin_amdgcn_ballot_w64(nxb < kConsume);
@@ -2437,69 +2399,58 @@ __device__ __forceinline__ void dual_groups4(uint32_t &xa, uint32_t &xb, uint32_
                : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "s92", "s93", "vcc", "scc", "memory");
 }
 
-// The step for the coarse + fine tables (kModeCoarse; 14 / 15 bits): the granule's entry, then — for the lanes whose granule
-// straddles a symbol boundary (entry.y < 0 after the slot's offset in the granule was added: ptr + g with bit 31 set) — the per-slot
-// entry from the fine table, read under EXEC = those lanes straight over the coarse one.  Masks: A's boundary lanes in s[90:91],
-// B's in VCC; the branch skips the second gather only when no lane of either chain needs it (rare at 15 bits).
-#define HSRANS_DUAL_GROUP_COARSE(A0, A1, B0, B1)                                                                                                     \
-  "v_and_b32 %[ta], %[xa], %[vmask]\n\t"                                                                                                             \
-  "v_and_b32 %[tb], %[xb], %[vmask]\n\t"                                                                                                             \
-  "v_and_b32 %[ga], %[ta], %[vgmask]\n\t"                                                                                                            \
-  "v_and_b32 %[gb], %[tb], %[vgmask]\n\t"                                                                                                            \
-  "v_lshrrev_b32 %[ta], %[vgshift], %[ta]\n\t"                                                                                                       \
-  "v_lshrrev_b32 %[tb], %[vgshift], %[tb]\n\t"                                                                                                       \
-  "v_lshl_add_u32 %[ta], %[ta], 3, %[stab]\n\t"                                                                                                      \
-  "v_lshl_add_u32 %[tb], %[tb], 3, %[stab]\n\t"                                                                                                      \
-  "ds_read_b64 v[" #A0 ":" #A1 "], %[ta]\n\t"                                                                                                        \
-  "ds_read_b64 v[" #B0 ":" #B1 "], %[tb]\n\t"                                                                                                        \
+// The step for the rank table (kModeRank; 14 / 15 bits).  The rank bytes start at LDS address 0 (k_decode_dual puts the table
+// first), so the slot is the address of the first gather; the entries follow at %[sent] = 2^bits.  Three dependent LDS reads
+// per group and chain — rank byte, entry, stream word — the two chains' reads interleaved; A's mask in s[92:93], B's in VCC.
+// Per group and chain: 10 vector instructions (+ packing), 3 LDS.  Measured (15 bits, 100 MB): 12.3 vector instructions and
+// 13.3 LDS cycles per group, 7.3 of them bank conflicts — 5 from the byte gather alone: 64 random dwords over the LDS's 32 banks
+// (with every lane reading ONE entry the conflicts fall to 5.0, with the byte read made conflict-free as well to 0.03 and the
+// LDS cycles to 6.1: tools/debug/session21.sh).
+#define HSRANS_DUAL_GROUP_RANK(A0, A1, B0, B1)                                                                                                       \
+  "v_and_b32 %[ga], %[xa], %[vmask]\n\t"                                                                                                             \
+  "v_and_b32 %[gb], %[xb], %[vmask]\n\t"                                                                                                             \
+  "ds_read_u8 v" #A0 ", %[ga]\n\t"                                                                                                                   \
+  "ds_read_u8 v" #B0 ", %[gb]\n\t"                                                                                                                   \
   "v_lshrrev_b32 %[xa], %[vbits], %[xa]\n\t"                                                                                                         \
   "v_lshrrev_b32 %[xb], %[vbits], %[xb]\n\t"                                                                                                         \
   "s_waitcnt lgkmcnt(1)\n\t"                                                                                                                        \
-  "v_add_u32 v" #A1 ", v" #A1 ", %[ga]\n\t"                                                                                                          \
-  "v_cmp_gt_i32 s[90:91], 0, v" #A1 "\n\t"                                                                                                           \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                        \
-  "v_add_u32 v" #B1 ", v" #B1 ", %[gb]\n\t"                                                                                                          \
-  "v_cmp_gt_i32 vcc, 0, v" #B1 "\n\t"                                                                                                                \
-  "s_or_b64 s[92:93], s[90:91], vcc\n\t"                                                                                                            \
-  "s_cbranch_scc0 1f\n\t"                                                                                                                           \
-  "s_mov_b64 exec, s[90:91]\n\t"                                                                                                                    \
-  "v_lshl_add_u32 %[ta], v" #A1 ", 3, %[sfine]\n\t"                                                                                                  \
+  "v_lshl_add_u32 %[ta], v" #A0 ", 3, %[sent]\n\t"                                                                                                   \
   "ds_read_b64 v[" #A0 ":" #A1 "], %[ta]\n\t"                                                                                                        \
-  "s_mov_b64 exec, vcc\n\t"                                                                                                                         \
-  "v_lshl_add_u32 %[tb], v" #B1 ", 3, %[sfine]\n\t"                                                                                                  \
+  "s_waitcnt lgkmcnt(1)\n\t"                                                                                                                        \
+  "v_lshl_add_u32 %[tb], v" #B0 ", 3, %[sent]\n\t"                                                                                                   \
   "ds_read_b64 v[" #B0 ":" #B1 "], %[tb]\n\t"                                                                                                        \
-  "s_mov_b64 exec, -1\n\t"                                                                                                                          \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                        \
-  "1:\n\t"                                                                                                                                          \
+  "s_waitcnt lgkmcnt(1)\n\t"                                                                                                                        \
   "v_mad_u32_u24 %[xa], v" #A0 ", %[xa], v" #A1 "\n\t"                                                                                               \
-  "v_cmp_gt_u32 s[88:89], %[lim], %[xa]\n\t"                                                                                                        \
+  "v_add_u32 %[xa], %[xa], %[ga]\n\t"                                                                                                                \
+  "v_cmp_gt_u32 s[92:93], %[lim], %[xa]\n\t"                                                                                                        \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                        \
   "v_mad_u32_u24 %[xb], v" #B0 ", %[xb], v" #B1 "\n\t"                                                                                               \
+  "v_add_u32 %[xb], %[xb], %[gb]\n\t"                                                                                                                \
   "v_cmp_gt_u32 vcc, %[lim], %[xb]\n\t"                                                                                                             \
-  "s_nop 0\n\t"                                                                                                                                     \
-  "v_mbcnt_lo_u32_b32 %[ta], s88, 0\n\t"                                                                                                            \
-  "v_mbcnt_hi_u32_b32 %[ta], s89, %[ta]\n\t"                                                                                                        \
+  "v_mbcnt_lo_u32_b32 %[ta], s92, 0\n\t"                                                                                                            \
+  "v_mbcnt_hi_u32_b32 %[ta], s93, %[ta]\n\t"                                                                                                        \
   "v_lshl_add_u32 %[ta], %[ta], 1, %[sa]\n\t"                                                                                                       \
   "v_mbcnt_lo_u32_b32 %[tb], vcc_lo, 0\n\t"                                                                                                         \
   "v_mbcnt_hi_u32_b32 %[tb], vcc_hi, %[tb]\n\t"                                                                                                     \
   "v_lshl_add_u32 %[tb], %[tb], 1, %[sb]\n\t"                                                                                                       \
-  "s_mov_b64 exec, s[88:89]\n\t"                                                                                                                    \
+  "s_mov_b64 exec, s[92:93]\n\t"                                                                                                                    \
   "ds_read_u16 %[ta], %[ta]\n\t"                                                                                                                    \
   "s_mov_b64 exec, vcc\n\t"                                                                                                                         \
   "ds_read_u16 %[tb], %[tb]\n\t"                                                                                                                    \
-  "s_bcnt1_i32_b64 %[st], s[88:89]\n\t"                                                                                                             \
+  "s_bcnt1_i32_b64 %[st], s[92:93]\n\t"                                                                                                             \
   "s_lshl1_add_u32 %[sa], %[st], %[sa]\n\t"                                                                                                         \
   "s_bcnt1_i32_b64 %[st], vcc\n\t"                                                                                                                  \
   "s_lshl1_add_u32 %[sb], %[st], %[sb]\n\t"                                                                                                         \
   "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                        \
   "v_lshl_or_b32 %[xb], %[xb], 16, %[tb]\n\t"                                                                                                       \
-  "s_mov_b64 exec, s[88:89]\n\t"                                                                                                                    \
+  "s_mov_b64 exec, s[92:93]\n\t"                                                                                                                    \
   "v_lshl_or_b32 %[xa], %[xa], 16, %[ta]\n\t"                                                                                                       \
   "s_mov_b64 exec, -1\n\t"
 
-__device__ __forceinline__ void dual_groups4_coarse(uint32_t &xa, uint32_t &xb, uint32_t &s_a, uint32_t &s_b, const WaveCtx &c, uint32_t s_table, uint32_t &acc_a, uint32_t &acc_b)
+__device__ __forceinline__ void dual_groups4_rank(uint32_t &xa, uint32_t &xb, uint32_t &s_a, uint32_t &s_b, const WaveCtx &c, uint32_t s_entries, uint32_t &acc_a, uint32_t &acc_b)
 {
   uint32_t ta, tb, ga, gb, st;
-  asm volatile(HSRANS_DUAL_GROUP_COARSE(64, 65, 72, 73) HSRANS_DUAL_GROUP_COARSE(66, 67, 74, 75) HSRANS_DUAL_GROUP_COARSE(68, 69, 76, 77) HSRANS_DUAL_GROUP_COARSE(70, 71, 78, 79)
+  asm volatile(HSRANS_DUAL_GROUP_RANK(64, 65, 72, 73) HSRANS_DUAL_GROUP_RANK(66, 67, 74, 75) HSRANS_DUAL_GROUP_RANK(68, 69, 76, 77) HSRANS_DUAL_GROUP_RANK(70, 71, 78, 79)
                "v_perm_b32 %[aa], v66, v64, %[selp]\n\t"
                "v_perm_b32 %[ta], v70, v68, %[selp]\n\t"
                "v_perm_b32 %[aa], %[ta], %[aa], %[selq]\n\t"
@@ -2508,10 +2459,8 @@ __device__ __forceinline__ void dual_groups4_coarse(uint32_t &xa, uint32_t &xb, 
                "v_perm_b32 %[ab], %[tb], %[ab], %[selq]"
                : [xa] "+v"(xa), [xb] "+v"(xb), [sa] "+s"(s_a), [sb] "+s"(s_b), [aa] "=&v"(acc_a), [ab] "=&v"(acc_b), [ta] "=&v"(ta), [tb] "=&v"(tb), [ga] "=&v"(ga), [gb] "=&v"(gb),
                  [st] "=&s"(st)
-               : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [vgmask] "v"(c.v_gmask), [vgshift] "v"(c.v_gshift), [stab] "s"(s_table), [sfine] "s"(s_table + 8 * kCoarseEntries),
-                 [lim] "s"(kConsume), [selp] "s"(0x0c0c0703u), [selq] "s"(0x05040100u)
-               : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "s88", "s89", "s90", "s91", "s92", "s93", "vcc", "scc",
-                 "memory");
+               : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [sent] "s"(s_entries), [lim] "s"(kConsume), [selp] "s"(0x0c0c0703u), [selq] "s"(0x05040100u)
+               : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "s92", "s93", "vcc", "scc", "memory");
 }
 
 // `both` (a multiple of 4) groups of each of the two chains
@@ -2537,8 +2486,8 @@ __device__ __forceinline__ void run_dual_fast(uint32_t &xa, uint32_t &xb, const 
   for (; both != 0; both -= 4)
   {
     uint32_t acc_a, acc_b;
-    if (MODE == kModeCoarse)
-      dual_groups4_coarse(xa, xb, fa.addr, fb.addr, c, s_table, acc_a, acc_b);
+    if (MODE == kModeRank)
+      dual_groups4_rank(xa, xb, fa.addr, fb.addr, c, 1u << c.bits, acc_a, acc_b); // (the table starts at LDS address 0: k_decode_dual)
     else
       dual_groups4(xa, xb, fa.addr, fb.addr, c, s_table, acc_a, acc_b);
     acc_a = quad_transpose(acc_a, ol.sel_a, ol.sel_b);
@@ -2579,11 +2528,18 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
   c.lane = threadIdx.x & 63;
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gshift) : "s"(c.bits > 12 ? c.bits - 12 : 0));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_gmask) : "s"(c.bits > 12 ? (1u << (c.bits - 12)) - 1 : 0));
   constexpr uint32_t kDualRing = kFastRingBytes; // whole-chunk mirrors for the hand-scheduled loop (launch_shape sizes the LDS the same way)
-  c.rings = smem + wave * 2 * kDualRing;
-  c.table = smem + waves * 2 * kDualRing;
+  if (MODE == kModeRank)
+  {
+    // the rank bytes at LDS address 0 (this kernel has no static LDS): the hand-scheduled group uses the slot as the address
+    c.table = smem;
+    c.rings = smem + table_bytes_for(MODE, c.bits) + wave * 2 * kDualRing;
+  }
+  else
+  {
+    c.rings = smem + wave * 2 * kDualRing;
+    c.table = smem + waves * 2 * kDualRing;
+  }
   c.table_b = c.table;
   c.gtable = pa.table;
   c.scratch_cnt = (uint16_t *)smem;
@@ -2677,12 +2633,11 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
     // (the single-ring wait in ring_advance is only ever stricter than needed here: the other ring's requests are older or done)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     run_groups<MODE>(xa, sw, ra.r, c, oa, sa);
+    if (have_b)
+      run_groups<MODE>(xb, sw, rb.r, c, ob, sb);
     run_tail<MODE>(xa, ra.r, c, oa, da.tail);
     if (have_b)
-    {
-      run_groups<MODE>(xb, sw, rb.r, c, ob, sb);
       run_tail<MODE>(xb, rb.r, c, ob, db.tail);
-    }
   }
   if (table_pending)
     fetch_table();
@@ -3130,7 +3085,7 @@ static uint32_t g_slot_weights4[8] = {1150, 1050, 950, 850, 1150, 1050, 950, 850
 // mean finish times goes from 19.8 us with the weights above to 0.1 us): the waves of a CU's first workgroup run ahead of
 // the second one's on every SIMD, and inside a workgroup the older waves a little ahead of the younger.
 // One set per occupancy (waves per SIMD): 8 = two 16-wave workgroups per CU (bits <= 12), 6 = two 12-wave workgroups (15 bits,
-// coarse + fine tables), 4 = one 16-wave workgroup (13 bits), 3 = one 12-wave workgroup (14 bits).
+// rank table), 4 = one 16-wave workgroup (13 bits), 3 = one 12-wave workgroup (14 bits).
 // (Re-fitted after the decode loops stopped draining the memory queue every iteration: the oldest class now runs three times as
 // many groups as the youngest in the same time.  The same fit with the buffers rotated through HBM lands within 2 % of these.)
 static uint32_t g_direct_weights[8] = {1424, 1371, 1283, 1165, 920, 768, 606, 464};
@@ -3154,11 +3109,12 @@ static uint32_t g_direct_dyn_groups = 32;   // HSRANS_DIRECT_DYN_GROUPS (multipl
 static void read_tuning_once();
 static uint32_t g_persist_kernel = 1; // HSRANS_PERSIST_KERNEL: 0 = uniform-interval plans on k_decode<3, true> (A/B)
 static uint32_t g_single_fast = 1; // HSRANS_SINGLE_FAST: 0 = un-indexed raw streams on the general kernel (one wave, two LDS round trips per group)
+static bool g_rank_table = true;      // HSRANS_NO_RANK_TABLE: the wide histograms fall back to the 8-byte-per-slot / two-level tables (comparison)
 static uint32_t g_dual_waves = 16; // HSRANS_DUAL_WAVES: waves per workgroup of k_decode_dual (12: two workgroups per CU fit beside a 16 KiB table)
 static uint32_t g_dual = 1; // HSRANS_DUAL: 0 = never run two chains per wave (k_decode_dual), 1 = where it pays (default), 2 = for every width (experiment)
 // the one-chain-per-wave weights of the dual kernel's launches (one 16-wave workgroup per CU, two chains per wave)
 static uint32_t g_dual_weights[8] = {1249, 1118, 925, 708, 1249, 1118, 925, 708};        // 13 bits (8-byte table)
-static uint32_t g_dual_weights_coarse[8] = {1239, 1102, 927, 732, 1239, 1102, 927, 732}; // 14 / 15 bits (coarse + fine tables)
+static uint32_t g_dual_weights_wide[8] = {1170, 1083, 953, 795, 1170, 1083, 953, 795}; // 14 / 15 bits (rank table; fitted with 4 pairs rotated: spread of the classes' finish 5.4 -> 0.2 us)
 
 typedef void (*KernelFn)(KParams);
 static KernelFn kernel_for(int mode, bool shared)
@@ -3171,7 +3127,7 @@ static KernelFn kernel_for(int mode, bool shared)
   case 3: return k_decode<kModePackM1, true>;
   case 4: return k_decode<kModeTwoLevel, false>;
   case 5: return k_decode<kModeTwoLevel, true>;
-  case 8: case 9: return k_decode<kModeCoarse, true>;
+  case 8: case 9: return k_decode<kModeRank, true>;
   case 10: case 11: return k_decode<kModeSpill, true>;
   default: return k_decode<kModePack64, true>;
   }
@@ -3196,59 +3152,45 @@ TableChoice choose_table(uint32_t bits, uint32_t states, bool direct)
   else if (direct && g_dual && states == 64 && bits >= 13)
   {
     // one workgroup of 16 waves per CU, two chains per wave: 13 bits keeps the 8-byte-per-slot table (64 KiB + 32 rings = 144 KiB);
-    // at 14 / 15 bits that table does not fit beside 32 rings, so coarse + fine (40 / 48 KiB).  Measured (100 MB, last wave
-    // done, fitted weights, hand-scheduled loops): 13 bits 42.7 us against 49.7 us one chain per wave; 14 bits 57.8 against 63.3
-    // (one chain per wave beside the 128 KiB one-lookup table); 15 bits 57.7 against 77.3
-    t.mode = bits == 13 ? kModePack64 : kModeCoarse;
+    // at 14 / 15 bits that table does not fit beside 32 rings, so the rank table (18 / 34 KiB).  Measured (100 MB, last wave
+    // done, fitted weights, hand-scheduled loops): 13 bits 42.7 us against 49.7 us one chain per wave; 14 / 15 bits 52.3 / 52.7 us
+    // (round 2's coarse + fine tables: 57.8 / 57.7; one chain per wave beside the 128 KiB one-lookup table at 14 bits: 63.3)
+    t.mode = bits == 13 ? kModePack64 : kModeRank;
     t.dual = true;
   }
-  else if (bits <= g_pack64_max_bits)
+  else if (bits <= g_pack64_max_bits && !(bits == 14 && states == 64 && g_rank_table))
     t.mode = kModePack64;
-  else if (bits >= 13 && states == 64 && getenv("HSRANS_NO_COARSE_TABLE") == nullptr)
-    t.mode = kModeCoarse;
+  else if (bits >= 13 && states == 64 && g_rank_table)
+    t.mode = kModeRank; // (14 bits too: beside the 128 KiB one-lookup table only 12 waves fit a CU — 0.31 against 0.37 with a checkpoint every 32 groups)
   return t;
 }
 
-size_t coarse_table_entries(uint32_t bits) { return table_bytes_for(kModeCoarse, bits) / 8; }
+size_t rank_table_entries(uint32_t bits) { return table_bytes_for(kModeRank, bits) / 8; }
 
-size_t build_coarse_table(const uint16_t counts[256], uint32_t bits, uint2 *out, size_t capacity_entries)
+size_t build_rank_table(const uint16_t counts[256], uint32_t bits, uint2 *out, size_t capacity_entries)
 {
-  if (bits < 13 || bits > 15 || capacity_entries < coarse_table_entries(bits))
+  if (bits < 13 || bits > 15 || capacity_entries < rank_table_entries(bits))
     return 0;
-  const uint32_t total = 1u << bits, g = 1u << (bits - 12);
-  // slot -> symbol by a running cursor over the cumulative counts (hist.cpp:343-351: zero-count symbols are skipped)
-  uint32_t cum[257];
-  cum[0] = 0;
+  // the 32 most frequent symbols — nearly every lane of a group — get 32 different bank pairs of the entry table (indexed by
+  // symbol value, symbols 32 apart would share banks: 8.0 instead of 7.3 bank-conflict cycles per group)
+  uint8_t *rank_of_slot = (uint8_t *)out;
+  uint2 *ent = (uint2 *)(rank_of_slot + (1u << bits));
+  uint32_t order[256];
   for (uint32_t s = 0; s < 256; s++)
-    cum[s + 1] = cum[s] + counts[s];
-  if (cum[256] != total)
-    return 0;
-  uint2 *fine = out + kCoarseEntries;
-  uint32_t n_fine = 0, s = 0;
-  for (uint32_t gi = 0; gi < kCoarseEntries; gi++)
+    order[s] = s;
+  std::stable_sort(order, order + 256, [&](uint32_t a, uint32_t b) { return counts[a] > counts[b]; });
+  uint8_t rank[256];
+  for (uint32_t r = 0; r < 256; r++)
+    rank[order[r]] = (uint8_t)r;
+  uint32_t cumul = 0;
+  for (uint32_t s = 0; s < 256; s++)
   {
-    const uint32_t first = gi * g, last = first + g - 1;
-    while (cum[s + 1] <= first)
-      s++;
-    if (cum[s + 1] > last) // the whole granule decodes to symbol s
-    {
-      out[gi] = make_uint2((uint32_t)counts[s] | (s << 24), first - cum[s]);
-      continue;
-    }
-    if (n_fine + g > 255 * g)
-      return 0; // cannot happen: at most 255 symbol boundaries
-    out[gi] = make_uint2(0, 0x80000000u | n_fine);
-    uint32_t t = s;
-    for (uint32_t slot = first; slot <= last; slot++)
-    {
-      while (cum[t + 1] <= slot)
-        t++;
-      fine[n_fine++] = make_uint2((uint32_t)counts[t] | (t << 24), slot - cum[t]);
-    }
+    ent[rank[s]] = make_uint2((uint32_t)counts[s] | (s << 24), 0u - cumul);
+    for (uint32_t k = 0; k < counts[s] && cumul + k < (1u << bits); k++)
+      rank_of_slot[cumul + k] = rank[s];
+    cumul += counts[s];
   }
-  for (uint32_t k = n_fine; k < 255 * g; k++)
-    fine[k] = make_uint2(0, 0);
-  return coarse_table_entries(bits);
+  return cumul == (1u << bits) ? rank_table_entries(bits) : 0;
 }
 
 static void read_tuning_impl();
@@ -3305,7 +3247,8 @@ static void read_tuning_impl()
   if (const char *e = getenv("HSRANS_SINGLE_FAST"))
     g_single_fast = (uint32_t)atoi(e);
   read_weights("HSRANS_DUAL_WEIGHTS", g_dual_weights);               // 13 bits (8-byte table)
-  read_weights("HSRANS_DUAL_WEIGHTS_COARSE", g_dual_weights_coarse); // 14 / 15 bits (coarse + fine tables)
+  read_weights("HSRANS_DUAL_WEIGHTS_WIDE", g_dual_weights_wide); // 14 / 15 bits (rank table)
+  g_rank_table = getenv("HSRANS_NO_RANK_TABLE") == nullptr;
   if (const char *e = getenv("HSRANS_DIRECT_DYN_PERMILLE"))
     g_direct_dyn_permille = (uint32_t)atoi(e) > 500 ? 500 : (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_DIRECT_DYN_GROUPS"))
@@ -3329,8 +3272,8 @@ hipError_t prepare_kernels(DeviceGeom *geom)
       if (e != hipSuccess)
         return e;
     }
-  for (KernelFn fn : {(KernelFn)k_decode_single, (KernelFn)k_decode_persist, (KernelFn)k_calibrate, (KernelFn)k_decode_dual<kModePack64>, (KernelFn)k_decode_dual<kModeCoarse>, (KernelFn)k_decode_direct<kModePack>, (KernelFn)k_decode_direct<kModePackM1>,
-                      (KernelFn)k_decode_direct<kModeTwoLevel>, (KernelFn)k_decode_direct<kModePack64>, (KernelFn)k_decode_direct<kModeCoarse>, (KernelFn)k_decode_direct<kModeSpill>,
+  for (KernelFn fn : {(KernelFn)k_decode_single, (KernelFn)k_decode_persist, (KernelFn)k_calibrate, (KernelFn)k_decode_dual<kModePack64>, (KernelFn)k_decode_dual<kModeRank>, (KernelFn)k_decode_direct<kModePack>, (KernelFn)k_decode_direct<kModePackM1>,
+                      (KernelFn)k_decode_direct<kModeTwoLevel>, (KernelFn)k_decode_direct<kModePack64>, (KernelFn)k_decode_direct<kModeRank>, (KernelFn)k_decode_direct<kModeSpill>,
                       (KernelFn)k_decode_grouped<kModePack, false>, (KernelFn)k_decode_grouped<kModePackM1, false>, (KernelFn)k_decode_grouped<kModeTwoLevel, false>,
                       (KernelFn)k_decode_grouped<kModePack64, false>, (KernelFn)k_decode_grouped<kModeTwoLevel, true>, (KernelFn)k_decode_grouped<kModePack64, true>})
   {
@@ -3361,15 +3304,15 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
   L.walk = walk;
   L.shared = !walk && (grouped || (h.shared_hist != 0 && h.n_chains > 1));
   // 64-bit entries only where one table serves a whole workgroup (LDS: 16 KiB table + 16 x 2.25 KiB rings, two per CU)
-  const bool coarse = L.shared && persistent && table_mode == kModeCoarse && h.states == 64;
+  const bool rank_table = L.shared && persistent && table_mode == kModeRank && h.states == 64;
   const bool spill = L.shared && persistent && table_mode == kModeSpill;
-  L.mode = spill ? kModeSpill : coarse ? kModeCoarse : L.shared && h.bits <= pack64_max_bits() ? kModePack64 : h.bits >= 13 ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : kModePack;
+  L.mode = spill ? kModeSpill : rank_table ? kModeRank : L.shared && h.bits <= pack64_max_bits() ? kModePack64 : h.bits >= 13 ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : kModePack;
   const bool two_level = L.mode == kModeTwoLevel;
   const uint32_t table_bytes = table_bytes_for(L.mode, h.bits);
   const uint32_t wave_bytes = kWaveRingBytes + ((table_bytes + 15) & ~15u); // private rings + table
   uint32_t waves, lds, grid;
   const uint32_t dual_ring = kFastRingBytes;
-  L.dual = dual && L.shared && persistent && (L.mode == kModePack64 || L.mode == kModeCoarse) && g_dual_waves * 2 * dual_ring + table_bytes <= dg.max_lds;
+  L.dual = dual && L.shared && persistent && (L.mode == kModePack64 || L.mode == kModeRank) && g_dual_waves * 2 * dual_ring + table_bytes <= dg.max_lds;
   if (L.dual)
   {
     // k_decode_dual: workgroups of 16 (or HSRANS_DUAL_WAVES) waves, two rings per wave, wave w decodes chains 2w and 2w + 1
@@ -3395,7 +3338,7 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
     // (only with at least four groups per CU: fewer, e.g. a 100 MB stream in 256 KiB blocks, fill more wave slots as 16-wave workgroups)
     if (grouped && getenv("HSRANS_WAVES_PER_WG") == nullptr && 4 * (8 * ring + table_bytes + 64 + 1024) <= dg.max_lds && n_groups >= 4 * dg.num_cus)
       waves = 8;
-    if (L.mode == kModeCoarse && waves * ring + table_bytes > dg.max_lds / 2)
+    if (L.mode == kModeRank && waves * ring + table_bytes > dg.max_lds / 2)
       waves = 12; // 15 bits: 48 KiB of tables + 12 rings = 75 KiB, two workgroups per CU
     if (waves * ring + table_bytes > dg.max_lds && table_bytes + 4 * ring <= dg.max_lds)
       waves = (dg.max_lds - table_bytes) / ring / 4 * 4; // a big table: as many waves as still fit (multiple of 4: one per SIMD)
@@ -3432,7 +3375,7 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
   const bool weighted = (waves == 16 || waves == 12) && (!two_level || g_weights_two_level);
   for (uint32_t k = 0; k < 8; k++)
     L.weights[k] = !weighted ? 1000
-                   : L.dual   ? (L.mode == kModeCoarse ? g_dual_weights_coarse : g_dual_weights)[k]
+                   : L.dual   ? (L.mode == kModeRank ? g_dual_weights_wide : g_dual_weights)[k]
                    : direct   ? (L.grid > dg.num_cus ? (waves == 16 ? (h.states == 32 ? g_direct_weights_pair : dg.have_direct_weights ? dg.direct_weights : g_direct_weights) : g_direct_weights6) : (waves == 16 ? g_direct_weights4 : g_direct_weights3))[k]
                               : (L.grid > dg.num_cus ? (persistent && !grouped && h.states == 32 ? g_direct_weights_pair : g_slot_weights) : g_slot_weights4)[k];
   return L;
@@ -3578,7 +3521,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
   }
   KernelFn fn = kernel_for(L.mode, L.shared);
   if (L.dual)
-    fn = L.mode == kModeCoarse ? (KernelFn)k_decode_dual<kModeCoarse> : (KernelFn)k_decode_dual<kModePack64>;
+    fn = L.mode == kModeRank ? (KernelFn)k_decode_dual<kModeRank> : (KernelFn)k_decode_dual<kModePack64>;
   else if (persistent && kp.pa.interval != 0 && L.shared && L.mode == kModePack64 && !index_pass && g_persist_kernel)
     fn = k_decode_persist;
 
@@ -3596,7 +3539,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
     case kModePack: fn = k_decode_direct<kModePack>; break;
     case kModePackM1: fn = k_decode_direct<kModePackM1>; break;
     case kModeTwoLevel: fn = k_decode_direct<kModeTwoLevel>; break;
-    case kModeCoarse: fn = k_decode_direct<kModeCoarse>; break;
+    case kModeRank: fn = k_decode_direct<kModeRank>; break;
     case kModeSpill: fn = k_decode_direct<kModeSpill>; break;
     default: fn = kp.finish != nullptr && h.states == 64 ? (KernelFn)k_calibrate : (KernelFn)k_decode_direct<kModePack64>; break;
     }

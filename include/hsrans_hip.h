@@ -271,7 +271,7 @@ int hsrans_ctx_calibrate(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, hs
 typedef struct hsrans_launch_info
 {
   uint32_t grid, block, lds_bytes, waves_per_block, chains, shared_table, walk, two_level;
-  uint32_t table_mode; /* decode-table layout: 0/1 packed u32, 2 two-level, 3 8-byte per slot, 4 coarse + fine, 5 8-byte in global memory */
+  uint32_t table_mode; /* decode-table layout: 0/1 packed u32, 2 two-level, 3 8-byte per slot, 4 rank byte per slot + 256 entries, 5 8-byte in global memory */
   uint32_t chains_per_wave; /* 2: the two-chains-per-wave kernel (13..15 bits with a one-chain-per-wave index) */
   uint32_t class_weights[8]; /* per-mille chain / run lengths of the 8 wave scheduling classes the launch was shaped with (fitted
                               * constants, HSRANS_*_WEIGHTS override them): which table a measurement used */
