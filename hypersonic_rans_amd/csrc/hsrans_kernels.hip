@@ -775,6 +775,12 @@ __device__ __forceinline__ uint32_t group_step_pair(uint32_t &x, Ring &ra, Ring 
     e = e2.x;
     nx = __umul24(q, e2.x) + e2.y;
   }
+  else if (MODE == kModeRank)
+  {
+    const uint2 e2 = ((const uint2 *)(tab + mask + 1))[tab[slot]];
+    e = e2.x;
+    nx = __umul24(q, e2.x) + e2.y + slot;
+  }
   else if (MODE == kModePack)
   {
     e = ((const uint32_t *)tab)[slot];
@@ -902,7 +908,7 @@ __device__ __forceinline__ void run_pair_groups(uint32_t &x, const StreamWin &sw
                                                 uint32_t steps)
 {
   const uint64_t oa = uni64(oa_ref), ob = uni64(ob_ref);
-  constexpr uint32_t kSymByte = (MODE == kModePack64 || MODE == kModeSpill) ? 3 : 0;
+  constexpr uint32_t kSymByte = (MODE == kModePack64 || MODE == kModeSpill || MODE == kModeRank) ? 3 : 0;
   const uint32_t l32 = c.lane & 31, row = l32 & 3, quad = l32 >> 2;
   const uint32_t dcol = ((quad & 1) << 2) | ((quad & 6) >> 1);
   const uint32_t sel_a = (c.lane & 1) ? 0x03070105u : 0x06020400u;
@@ -1394,7 +1400,7 @@ __device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t wa
   StreamWin sw;
   Ring ra, rb;
   pair_bind<MODE>(ra, rb, c);
-  const bool host_table = (MODE == kModePack64 || MODE == kModeSpill) && pa.table != nullptr;
+  const bool host_table = (MODE == kModePack64 || MODE == kModeRank || MODE == kModeSpill) && pa.table != nullptr;
   if (!host_table)
     build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
   bool table_pending = host_table && MODE != kModeSpill;
@@ -1413,7 +1419,7 @@ __device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t wa
       atomicOr(c.status, kStatusBadHist);
   }
   auto copy_table = [&]() {
-    const uint32_t entries = 1u << c.bits;
+    const uint32_t entries = table_bytes_for(MODE, c.bits) / 8;
     for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
       *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
     __syncthreads();
@@ -1516,7 +1522,7 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
   const uint32_t cls = half * 4 + wave_in_wg / per_class;
   const uint32_t q0 = pa.run_len[cls];
   const uint32_t c_first = pa.half_base[half] + (blk - half * first_half) * pa.wg_chains[half] + pa.class_off[cls] + (wave_in_wg % per_class) * 2 * q0;
-  const bool host_table = (MODE == kModePack64 || MODE == kModeSpill) && pa.table != nullptr;
+  const bool host_table = (MODE == kModePack64 || MODE == kModeRank || MODE == kModeSpill) && pa.table != nullptr;
   if (!host_table)
     build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
 
@@ -1546,7 +1552,7 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
     {
       // the table was built on the host from the plan's histogram copy: one coalesced 16 B load + LDS store per thread
       // (see run_persistent for the check of the copy against the stream)
-      const uint32_t entries = MODE == kModeSpill ? 0 : 1u << c.bits;
+      const uint32_t entries = table_bytes_for(MODE, c.bits) / 8; // (0 for the spilled table)
       for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
         *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
       __syncthreads();
@@ -1585,7 +1591,7 @@ __device__ void run_persistent_pair(const WaveCtx &c, const KParams &kp, uint32_
     run(c_first, c_first + q0, c_first + 2 * q0, host_table);
   else if (host_table)
   {
-    const uint32_t entries = MODE == kModeSpill ? 0 : 1u << c.bits;
+    const uint32_t entries = table_bytes_for(MODE, c.bits) / 8; // (0 for the spilled table)
     for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
       *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
     __syncthreads();
@@ -2031,9 +2037,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
     c.gtable = kp.pa.table;
     if (kp.pa.pieces != nullptr)
     {
-      // (the rank table is only ever used for 64-state plans: no pair variants of that mode; one-chain-per-wave
-      // plans, interval == 0, have a kernel of their own: k_decode_direct)
-      if (MODE != kModeRank && c.S == 32)
+      // (one-chain-per-wave plans, interval == 0, have a kernel of their own: k_decode_direct)
+      if (c.S == 32)
         run_persistent_pair<MODE>(c, kp, waves, chain);
       else
         run_persistent<MODE>(c, kp, waves, chain);
@@ -2100,7 +2105,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.scratch_cnt = (uint16_t *)smem; // wave 0's ring (no request in flight while a table is built)
   c.scratch_cum = (uint16_t *)(smem + 512);
   const uint32_t chain = blockIdx.x * waves + wave;
-  if (MODE != kModeRank && c.S == 32)
+  if (c.S == 32)
     run_direct_pair<MODE>(c, kp, waves, chain);
   else
     run_direct<MODE>(c, kp, waves, chain);
@@ -3158,9 +3163,9 @@ TableChoice choose_table(uint32_t bits, uint32_t states, bool direct)
     t.mode = bits == 13 ? kModePack64 : kModeRank;
     t.dual = true;
   }
-  else if (bits <= g_pack64_max_bits && !(bits == 14 && states == 64 && g_rank_table))
+  else if (bits <= g_pack64_max_bits && !(bits == 14 && g_rank_table))
     t.mode = kModePack64;
-  else if (bits >= 13 && states == 64 && g_rank_table)
+  else if (bits >= 13 && g_rank_table)
     t.mode = kModeRank; // (14 bits too: beside the 128 KiB one-lookup table only 12 waves fit a CU — 0.31 against 0.37 with a checkpoint every 32 groups)
   return t;
 }
@@ -3304,7 +3309,7 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
   L.walk = walk;
   L.shared = !walk && (grouped || (h.shared_hist != 0 && h.n_chains > 1));
   // 64-bit entries only where one table serves a whole workgroup (LDS: 16 KiB table + 16 x 2.25 KiB rings, two per CU)
-  const bool rank_table = L.shared && persistent && table_mode == kModeRank && h.states == 64;
+  const bool rank_table = L.shared && persistent && table_mode == kModeRank;
   const bool spill = L.shared && persistent && table_mode == kModeSpill;
   L.mode = spill ? kModeSpill : rank_table ? kModeRank : L.shared && h.bits <= pack64_max_bits() ? kModePack64 : h.bits >= 13 ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : kModePack;
   const bool two_level = L.mode == kModeTwoLevel;

@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("size", nargs="?", type=int, default=100_000_000)
 ap.add_argument("--only-raw", action="store_true", help="raw rows only (e.g. for the HSRANS_TABLE_SPILL=1 / HSRANS_DUAL=0 comparison runs)")
 ap.add_argument("--bits", default="", help="comma-separated histogram widths: raw 64-state rows of these widths only")
+ap.add_argument("--states", default="64", help="with --bits: comma-separated state counts")
 ap.add_argument("--tag", default="", help="copied into every row (which environment the library ran under)")
 args = ap.parse_args()
 n = args.size
@@ -62,8 +63,9 @@ def measure(container, S, bits, interval, block_size=0, reps=20):
 
 if args.bits:
     for bits in (int(b) for b in args.bits.split(",")):
-        measure(H.RAW, 64, bits, "wave")
-        measure(H.RAW, 64, bits, 32)
+        for S in (int(x) for x in args.states.split(",")):
+            measure(H.RAW, S, bits, "wave")
+            measure(H.RAW, S, bits, 32)
     sys.exit(0)
 for bits in (10, 11, 12, 13, 14, 15):
     measure(H.RAW, 64, bits, "wave")
