@@ -693,9 +693,44 @@ __device__ __forceinline__ uint32_t fast_groups4(uint32_t &x, uint32_t &s_addr, 
 // decode unchanged (38.2-38.9 us against 38.8-39.4), the rotated one 4-6 us slower: the loop is not bound by vector issue alone
 // — the table gather keeps the LDS busy two thirds of the time — and four times as many store instructions crowd vmcnt.)
 // `steps` whole groups (64 states, kModePack64) with the loop above; what is left over (< 4 groups) goes to the ordinary path
+// The exact wait at a chunk crossing of the hand-scheduled loops, from the loop's iteration counter alone (it runs DOWN; one
+// counted store per iteration, issued before the crossing is looked for).  The wave must know that chunk k + 1 has landed; its
+// request was made at the crossing before the previous one, when the counter stood at t2.  Issued after it: the stores of the
+// iterations since, the requests for k + 2 and k + 3 = `k3` (the latter just now) and their mirrors — and whatever else the wave
+// issued (another ring's requests), which only makes "at most n outstanding" stricter than needed.  One asm statement with
+// t1 / t2 tied to their registers: left to the compiler, the count became an induction variable of its own (a v_add and a
+// v_readfirstlane per iteration) and the rotation of the marks put register moves on the path WITHOUT a crossing.
+template <int STORES_PER_ITERATION = 1>
+__device__ __forceinline__ void wait_after_crossing(uint32_t &t1, uint32_t &t2, uint32_t iters, uint32_t k3)
+{
+  static_assert(HSRANS_RING_AHEAD == 3 || HSRANS_RING_AHEAD == 2, "");
+  const uint32_t extra = 2u + ((k3 & (kRingSlots - 1)) == 0 ? 1u : 0u) + (((k3 - 1) & (kRingSlots - 1)) == 0 ? 1u : 0u);
+  uint32_t n;
+  asm volatile("s_sub_u32 %[n], %[t2], %[it]\n\t"
+               "s_lshl_b32 %[n], %[n], %[sh]\n\t"
+               "s_add_u32 %[n], %[n], %[extra]\n\t"
+               "s_mov_b32 %[t2], %[t1]\n\t"
+               "s_mov_b32 %[t1], %[it]\n\t"
+               "s_cmp_ge_u32 %[n], 8\n\t"
+               "s_cbranch_scc1 8f\n\t"
+               "s_cmp_ge_u32 %[n], 6\n\t"
+               "s_cbranch_scc1 6f\n\t"
+               "s_waitcnt vmcnt(4)\n\t"
+               "s_branch 9f\n"
+               "6:\n\t"
+               "s_waitcnt vmcnt(6)\n\t"
+               "s_branch 9f\n"
+               "8:\n\t"
+               "s_waitcnt vmcnt(8)\n"
+               "9:"
+               : [n] "=&s"(n), [t1] "+s"(t1), [t2] "+s"(t2)
+               : [it] "s"(iters), [extra] "s"(extra), [sh] "n"(STORES_PER_ITERATION == 2 ? 1 : 0)
+               : "scc", "memory");
+}
+
+template <bool STRICT>
 __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o_ref, uint32_t &steps)
 {
-  uint64_t o = uni64(o_ref);
   const OutLanes ol = out_lanes(c.lane, 64);
   const uint32_t s_table = uni(lds_address(c.table));
   // the cursor as an LDS address, and the address at which it enters the next chunk
@@ -706,12 +741,32 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
   uint32_t words0 = r.cur; // to rebuild r.cur afterwards: words consumed = (bytes the address moved) / 2
   uint32_t moved = 0;      // bytes the address has moved, including the re-basings
   const uint32_t s_addr0 = s_addr;
-  for (; steps >= 4; steps -= 4)
+  // The loop's own bookkeeping is scalar work too, and the scalar unit is shared by the CU's four SIMDs (see above).  As the
+  // compiler had it, an iteration WITHOUT a chunk crossing spent 15 scalar instructions outside the four groups (base + offset of
+  // the output added up twice, a count of vector-memory instructions, register moves for the three request marks it rotates);
+  // now 7: the output position is ONE pointer, the iteration counter is the only count, and everything about the waits happens
+  // at the crossings.  At a crossing into chunk k the wave must know that chunk k + 1 has landed.  Issued after that chunk's
+  // request: the requests for k + 2 and k + 3 (and their mirrors) and the stores of the iterations since.
+  //   exact  (!STRICT): that number, from the iteration counter at the crossing before the previous one (t2);
+  //   STRICT: "at most 4 outstanding" — there is at least one store between any two crossings (a crossing is looked for once per
+  //           iteration, after the iteration's store), so 4 always implies it; stricter than exact by a store or two issued two
+  //           chunks ago.
+  // Measured (same box, 100 MB raw 11 bit / 2^30-byte mt_ stream in 256 KiB blocks): one pair replayed 39.1 -> 37.8 us exact,
+  // 37.5 strict; four pairs rotated 44.6 -> 45.3 exact (noise), 45.9 strict (the cold stores' acknowledgements are slow: waiting
+  // for them costs); the grouped launch 484-497 -> 494-497 us exact, 475-477 strict.  Hence exact for the one-chain-per-wave
+  // launches and strict for the grouped ones.
+  uint8_t *outp = (uint8_t *)uni64((uint64_t)(uintptr_t)(c.out + uni64(o_ref)));
+  uint32_t iters = steps >> 2;
+  steps &= 3;
+  o_ref += (uint64_t)iters * 256;
+  // iteration counts (they run down) at the last two crossings; at entry: as if both had just happened, i.e. the first two waits
+  // count no stores — stricter than needed by what was stored before this loop, never weaker
+  uint32_t t1 = iters, t2 = iters;
+  for (; iters != 0; iters--)
   {
     const uint32_t acc = quad_transpose(fast_groups4(x, s_addr, c, s_table), ol.sel_a, ol.sel_b);
-    HSRANS_STORE_U32_SADDR((uint8_t *)uni64((uint64_t)(uintptr_t)(c.out + o)), ol.store_off, acc);
-    r.vm++;
-    o += 256;
+    HSRANS_STORE_U32_SADDR((uint8_t *)uni64((uint64_t)(uintptr_t)outp), ol.store_off, acc);
+    outp += 256;
     if (s_addr >= next_cross) // entered the next chunk (at most one per 4 groups: they take <= 512 bytes)
     {
       r.k++;
@@ -723,26 +778,28 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
         moved += kRingBytes;
       }
       ring_request(sw, r, c, r.k + HSRANS_RING_AHEAD);
-      r.vm += ((r.k + HSRANS_RING_AHEAD) & (kRingSlots - 1)) == 0 ? 2 : 1;
-      r.seq1 = r.seq2;
-      r.seq2 = r.seq3;
-      r.seq3 = r.vm;
-      if (HSRANS_RING_AHEAD == 2)
-        r.seq2 = r.vm;
-      wait_vm_at_most(r.vm - r.seq1);
+      if (!STRICT && HSRANS_RING_AHEAD == 3)
+        wait_after_crossing(t1, t2, iters, r.k + HSRANS_RING_AHEAD);
+      else
+      {
+        if (HSRANS_RING_AHEAD == 3)
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); // (request k + 2 and one store)
+      }
     }
   }
   r.cur = words0 + ((s_addr + moved - s_addr0) >> 1);
-  o_ref = o;
+  r.vm = r.seq1 = r.seq2 = r.seq3 = 0; // (not kept here; zero only makes the waits of the few groups behind this loop stricter)
 }
 
 // FAST: the call sites that carry the bulk of a launch's groups (every inlined copy of the hand-scheduled loop pins v52-v59 and
 // costs the big multi-path kernel registers: with it at every call site k_decode<3, true> went to 97 VGPRs and spilled)
-template <int MODE, bool FAST = false>
+template <int MODE, bool FAST = false, bool STRICT = false> // STRICT: the constant wait of run_groups_fast (the grouped launches)
 __device__ __forceinline__ void run_groups(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps)
 {
   if (FAST && MODE == kModePack64 && c.S == 64 && r.mirror_lanes == 0xFFFFFFFFu)
-    run_groups_fast(x, sw, r, c, o, steps); // the hand-scheduled loop; leaves < 4 groups
+    run_groups_fast<STRICT>(x, sw, r, c, o, steps); // the hand-scheduled loop; leaves < 4 groups
   if (c.S == 64)
     run_groups_impl<MODE, true>(x, sw, r, c, o, steps);
   else
@@ -920,28 +977,27 @@ __device__ __forceinline__ void run_pair_groups(uint32_t &x, const StreamWin &sw
     // the hand-scheduled loop; its waits are counted from here on (everything issued before is older than anything it waits for)
     const uint32_t s_table = uni(lds_address(c.table));
     FastCursor fa = fast_cursor_open(ra), fb = fast_cursor_open(rb);
-    uint32_t vm = 0, seq_a[3] = {0, 0, 0}, seq_b[3] = {0, 0, 0};
-    auto crossed = [&](FastCursor &f, Ring &r, uint32_t(&seq)[3]) {
+    // (the loop's bookkeeping as in run_groups_fast: the iteration counter is the only count, the waits are made up at the crossings)
+    uint32_t iters = (steps - done) >> 2;
+    done += iters * 4;
+    uint32_t ta1 = iters, ta2 = iters, tb1 = iters, tb2 = iters;
+    auto crossed = [&](FastCursor &f, Ring &r, uint32_t &t1, uint32_t &t2) {
       fast_cursor_cross(f, r);
       ring_request(sw, r, c, r.k + HSRANS_RING_AHEAD);
-      vm += ((r.k + HSRANS_RING_AHEAD) & (kRingSlots - 1)) == 0 ? 2 : 1;
-      seq[0] = seq[1];
-      seq[1] = seq[2];
-      seq[2] = vm;
-      if (HSRANS_RING_AHEAD == 2)
-        seq[1] = vm;
-      wait_vm_at_most(vm - seq[0]);
+      if (HSRANS_RING_AHEAD == 3)
+        wait_after_crossing(t1, t2, iters, r.k + HSRANS_RING_AHEAD); // (the other ring's requests are not counted: stricter, never weaker)
+      else
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); // (this ring's request for k + 2 and one store)
     };
-    for (; steps - done >= 4; done += 4)
+    for (; iters != 0; iters--)
     {
       const uint32_t acc = quad_transpose(pair_groups4(x, fa.addr, fb.addr, c, s_table), sel_a, sel_b);
       asm volatile("global_store_dword %0, %1, off nt" : : "v"(vout), "v"(acc) : "memory");
-      vm++;
       vout += 128;
       if (fa.addr >= fa.next_cross)
-        crossed(fa, ra, seq_a);
+        crossed(fa, ra, ta1, ta2);
       if (fb.addr >= fb.next_cross)
-        crossed(fb, rb, seq_b);
+        crossed(fb, rb, tb1, tb2);
     }
     fast_cursor_close(fa, ra);
     fast_cursor_close(fb, rb);
@@ -1790,10 +1846,10 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
       if (prio_steps != 0)
       {
         __builtin_amdgcn_s_setprio(1);
-        run_groups<MODE, true>(x, sw, r, c, o, prio_steps);
+        run_groups<MODE, true, true>(x, sw, r, c, o, prio_steps);
         __builtin_amdgcn_s_setprio(0);
       }
-      run_groups<MODE, true>(x, sw, r, c, o, (uint32_t)run_steps - prio_steps);
+      run_groups<MODE, true, true>(x, sw, r, c, o, (uint32_t)run_steps - prio_steps);
       run_tail<MODE>(x, r, c, o, run_tail_syms);
       HSRANS_GS(if (HSRANS_STAMPS(kp)) {
         acc_meta += t3 - t2;
@@ -2477,18 +2533,22 @@ __device__ __forceinline__ void run_dual_fast(uint32_t &xa, uint32_t &xb, const 
   const OutLanes ol = out_lanes(c.lane, 64);
   const uint32_t s_table = uni(lds_address(c.table));
   FastCursor fa = fast_cursor_open(ra.r), fb = fast_cursor_open(rb.r);
-  auto crossed = [&](FastCursor &f, RingD &d) {
+  // (the loop's bookkeeping as in run_groups_fast: the iteration counter is the only count — two stores per iteration here —
+  // and the waits are made up at the crossings)
+  uint32_t iters = both >> 2;
+  uint32_t ta1 = iters, ta2 = iters, tb1 = iters, tb2 = iters;
+  uint8_t *pa = (uint8_t *)uni64((uint64_t)(uintptr_t)(c.out + oa)), *pb = (uint8_t *)uni64((uint64_t)(uintptr_t)(c.out + ob)); // one pointer per chain, not base + offset
+  oa += (uint64_t)iters * 256;
+  ob += (uint64_t)iters * 256;
+  auto crossed = [&](FastCursor &f, RingD &d, uint32_t &t1, uint32_t &t2) {
     fast_cursor_cross(f, d.r);
-    d.seq1 = d.seq2;
-    d.seq2 = d.seq3;
-    ring_request_counted(sw, d.r, c, d.r.k + HSRANS_RING_AHEAD, vm);
+    ring_request(sw, d.r, c, d.r.k + HSRANS_RING_AHEAD);
     if (HSRANS_RING_AHEAD == 3)
-      d.seq3 = vm;
+      wait_after_crossing<2>(t1, t2, iters, d.r.k + HSRANS_RING_AHEAD); // (the other ring's requests are not counted: stricter, never weaker)
     else
-      d.seq2 = d.seq3 = vm;
-    wait_vm_at_most(vm - d.seq1);
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); // (this ring's request for k + 2 and the two stores of an iteration)
   };
-  for (; both != 0; both -= 4)
+  for (; iters != 0; iters--)
   {
     uint32_t acc_a, acc_b;
     if (MODE == kModeRank)
@@ -2497,16 +2557,17 @@ __device__ __forceinline__ void run_dual_fast(uint32_t &xa, uint32_t &xb, const 
       dual_groups4(xa, xb, fa.addr, fb.addr, c, s_table, acc_a, acc_b);
     acc_a = quad_transpose(acc_a, ol.sel_a, ol.sel_b);
     acc_b = quad_transpose(acc_b, ol.sel_a, ol.sel_b);
-    HSRANS_STORE_U32_SADDR((uint8_t *)uni64((uint64_t)(uintptr_t)(c.out + oa)), ol.store_off, acc_a);
-    HSRANS_STORE_U32_SADDR((uint8_t *)uni64((uint64_t)(uintptr_t)(c.out + ob)), ol.store_off, acc_b);
-    vm += 2;
-    oa += 256;
-    ob += 256;
+    HSRANS_STORE_U32_SADDR((uint8_t *)uni64((uint64_t)(uintptr_t)pa), ol.store_off, acc_a);
+    HSRANS_STORE_U32_SADDR((uint8_t *)uni64((uint64_t)(uintptr_t)pb), ol.store_off, acc_b);
+    pa += 256;
+    pb += 256;
     if (fa.addr >= fa.next_cross)
-      crossed(fa, ra);
+      crossed(fa, ra, ta1, ta2);
     if (fb.addr >= fb.next_cross)
-      crossed(fb, rb);
+      crossed(fb, rb, tb1, tb2);
   }
+  vm = 0;
+  ra.seq1 = ra.seq2 = ra.seq3 = rb.seq1 = rb.seq2 = rb.seq3 = 0; // (not kept in the loop; the caller drains the queue behind it anyway)
   fast_cursor_close(fa, ra.r);
   fast_cursor_close(fb, rb.r);
   oa_ref = oa;
