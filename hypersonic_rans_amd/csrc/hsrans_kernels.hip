@@ -200,14 +200,15 @@ __device__ __forceinline__ void ring_request(const StreamWin &sw, const Ring &r,
   const uint32_t slot = chunk & (kRingSlots - 1);
   const uint32_t dst = uni(r.lds + (slot << r.clog));
   const uint32_t lanes = r.clog == 9 ? 0xFFFFFFFFu : 0xFFFFu; // 32 or 16 lanes x 16 B
-  asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen" HSRANS_STREAM_LOAD_FLAGS " lds\n\ts_mov_b64 exec, -1"
+  // (EXEC in one move: the 64-bit move zero-extends its 32-bit source, and these masks never reach the upper half)
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %3\n\tbuffer_load_dwordx4 %0, %2, 0 offen" HSRANS_STREAM_LOAD_FLAGS " lds\n\ts_mov_b64 exec, -1"
                :
-               : "v"(voff), "s"(dst), "s"(sw.rs), "s"(lanes)
+               : "v"(voff), "s"(dst), "s"(sw.rs), "s"((uint64_t)lanes)
                : "memory");
   if (slot == 0) // wave-uniform: the ring's first 128 (64) bytes once more, behind its end (lanes 0..7 / 0..3)
-    asm volatile("s_mov_b32 m0, %1\n\ts_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen" HSRANS_STREAM_LOAD_FLAGS " lds\n\ts_mov_b64 exec, -1"
+    asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 exec, %3\n\tbuffer_load_dwordx4 %0, %2, 0 offen" HSRANS_STREAM_LOAD_FLAGS " lds\n\ts_mov_b64 exec, -1"
                  :
-                 : "v"(voff), "s"(uni(r.lds + ring_bytes(r))), "s"(sw.rs), "s"(r.mirror_lanes)
+                 : "v"(voff), "s"(uni(r.lds + ring_bytes(r))), "s"(sw.rs), "s"((uint64_t)r.mirror_lanes)
                  : "memory");
 }
 
@@ -704,9 +705,12 @@ template <int STORES_PER_ITERATION = 1>
 __device__ __forceinline__ void wait_after_crossing(uint32_t &t1, uint32_t &t2, uint32_t iters, uint32_t k3)
 {
   static_assert(HSRANS_RING_AHEAD == 3 || HSRANS_RING_AHEAD == 2, "");
-  const uint32_t extra = 2u + ((k3 & (kRingSlots - 1)) == 0 ? 1u : 0u) + (((k3 - 1) & (kRingSlots - 1)) == 0 ? 1u : 0u);
-  uint32_t n;
-  asm volatile("s_sub_u32 %[n], %[t2], %[it]\n\t"
+  static_assert(kRingSlots == 4, "");
+  uint32_t n, extra; // extra = 2 requests + a mirror if k3 or k3 - 1 went to slot 0, i.e. slot(k3) < 2
+  asm volatile("s_and_b32 %[extra], %[k3], 3\n\t"
+               "s_cmp_lt_u32 %[extra], 2\n\t"
+               "s_cselect_b32 %[extra], 3, 2\n\t"
+               "s_sub_u32 %[n], %[t2], %[it]\n\t"
                "s_lshl_b32 %[n], %[n], %[sh]\n\t"
                "s_add_u32 %[n], %[n], %[extra]\n\t"
                "s_mov_b32 %[t2], %[t1]\n\t"
@@ -723,8 +727,8 @@ __device__ __forceinline__ void wait_after_crossing(uint32_t &t1, uint32_t &t2, 
                "8:\n\t"
                "s_waitcnt vmcnt(8)\n"
                "9:"
-               : [n] "=&s"(n), [t1] "+s"(t1), [t2] "+s"(t2)
-               : [it] "s"(iters), [extra] "s"(extra), [sh] "n"(STORES_PER_ITERATION == 2 ? 1 : 0)
+               : [n] "=&s"(n), [extra] "=&s"(extra), [t1] "+s"(t1), [t2] "+s"(t2)
+               : [it] "s"(iters), [k3] "s"(k3), [sh] "n"(STORES_PER_ITERATION == 2 ? 1 : 0)
                : "scc", "memory");
 }
 
