@@ -47,6 +47,9 @@ constexpr uint32_t kConsume = 1u << 15; // rans.h:8 DecodeConsumePoint16
 // (`make stamps` -> lib/libhsrans_hip_stamps.so: -DHSRANS_HAVE_STAMPS=1 -DHSRANS_GROUP_STAMPS=1; the Python layer loads it when
 // HSRANS_DEBUG_STAMPS=1).  Compiled in but switched off, their bookkeeping (five 64-bit time values kept across the decode loop)
 // cost the shipped kernels 3-4 %: 39.9 -> 38.1 us for the replayed 100 MB decode, 61.9 -> 59.4 us at 15 bits, 8 % in run_grouped.
+#ifndef HSRANS_FORCE_STRICT // A/B builds: the constant wait at chunk crossings in every hand-scheduled single-chain loop
+#define HSRANS_FORCE_STRICT 0
+#endif
 #ifndef HSRANS_HAVE_STAMPS
 #define HSRANS_HAVE_STAMPS 0
 #endif
@@ -758,7 +761,8 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
   // Measured (same box, 100 MB raw 11 bit / 2^30-byte mt_ stream in 256 KiB blocks): one pair replayed 39.1 -> 37.8 us exact,
   // 37.5 strict; four pairs rotated 44.6 -> 45.3 exact (noise), 45.9 strict (the cold stores' acknowledgements are slow: waiting
   // for them costs); the grouped launch 484-497 -> 494-497 us exact, 475-477 strict.  Hence exact for the one-chain-per-wave
-  // launches and strict for the grouped ones.
+  // launches and strict for the grouped ones and the uniform-interval plans (checkpoint every 32 groups, replayed: 0.479 -> 0.499;
+  // one chain per wave replayed 0.519 -> 0.526 as well, but rotated — what the bench reports — it loses those 3 %).
   uint8_t *outp = (uint8_t *)uni64((uint64_t)(uintptr_t)(c.out + uni64(o_ref)));
   uint32_t iters = steps >> 2;
   steps &= 3;
@@ -803,7 +807,7 @@ template <int MODE, bool FAST = false, bool STRICT = false> // STRICT: the const
 __device__ __forceinline__ void run_groups(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps)
 {
   if (FAST && MODE == kModePack64 && c.S == 64 && r.mirror_lanes == 0xFFFFFFFFu)
-    run_groups_fast<STRICT>(x, sw, r, c, o, steps); // the hand-scheduled loop; leaves < 4 groups
+    run_groups_fast<STRICT || HSRANS_FORCE_STRICT>(x, sw, r, c, o, steps); // the hand-scheduled loop; leaves < 4 groups
   if (c.S == 64)
     run_groups_impl<MODE, true>(x, sw, r, c, o, steps);
   else
@@ -1261,7 +1265,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
     ring_ready(x);
     if (HSRANS_STAMPS(kp))
       t_ready = __builtin_amdgcn_s_memrealtime();
-    run_groups<MODE, true>(x, sw, r, c, g.o, g.steps);
+    run_groups<MODE, true, true>(x, sw, r, c, g.o, g.steps); // (strict wait: 0.479 -> 0.499 replayed with a checkpoint every 32 groups)
     run_tail<MODE>(x, r, c, g.o, g.tail);
   }
   const uint64_t t_static = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -1286,7 +1290,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
     const uint32_t ch = lo + (uint32_t)t;
     g = run_begin<MODE>(c, pa, sw, ch, ch + 1, x, r);
     ring_ready(x);
-    run_groups<MODE, true>(x, sw, r, c, g.o, g.steps);
+    run_groups<MODE, true, true>(x, sw, r, c, g.o, g.steps); // (strict wait: 0.479 -> 0.499 replayed with a checkpoint every 32 groups)
     run_tail<MODE>(x, r, c, g.o, g.tail);
   }
 
