@@ -47,6 +47,9 @@ constexpr uint32_t kConsume = 1u << 15; // rans.h:8 DecodeConsumePoint16
 // (`make stamps` -> lib/libhsrans_hip_stamps.so: -DHSRANS_HAVE_STAMPS=1 -DHSRANS_GROUP_STAMPS=1; the Python layer loads it when
 // HSRANS_DEBUG_STAMPS=1).  Compiled in but switched off, their bookkeeping (five 64-bit time values kept across the decode loop)
 // cost the shipped kernels 3-4 %: 39.9 -> 38.1 us for the replayed 100 MB decode, 61.9 -> 59.4 us at 15 bits, 8 % in run_grouped.
+#ifndef HSRANS_PERSIST_STRICT // A/B builds: 0 = the exact wait in the uniform-interval launches
+#define HSRANS_PERSIST_STRICT 1
+#endif
 #ifndef HSRANS_FORCE_STRICT // A/B builds: the constant wait at chunk crossings in every hand-scheduled single-chain loop
 #define HSRANS_FORCE_STRICT 0
 #endif
@@ -704,7 +707,6 @@ __device__ __forceinline__ uint32_t fast_groups4(uint32_t &x, uint32_t &s_addr, 
 // issued (another ring's requests), which only makes "at most n outstanding" stricter than needed.  One asm statement with
 // t1 / t2 tied to their registers: left to the compiler, the count became an induction variable of its own (a v_add and a
 // v_readfirstlane per iteration) and the rotation of the marks put register moves on the path WITHOUT a crossing.
-template <int STORES_PER_ITERATION = 1>
 __device__ __forceinline__ void wait_after_crossing(uint32_t &t1, uint32_t &t2, uint32_t iters, uint32_t k3)
 {
   static_assert(HSRANS_RING_AHEAD == 3 || HSRANS_RING_AHEAD == 2, "");
@@ -714,7 +716,6 @@ __device__ __forceinline__ void wait_after_crossing(uint32_t &t1, uint32_t &t2, 
                "s_cmp_lt_u32 %[extra], 2\n\t"
                "s_cselect_b32 %[extra], 3, 2\n\t"
                "s_sub_u32 %[n], %[t2], %[it]\n\t"
-               "s_lshl_b32 %[n], %[n], %[sh]\n\t"
                "s_add_u32 %[n], %[n], %[extra]\n\t"
                "s_mov_b32 %[t2], %[t1]\n\t"
                "s_mov_b32 %[t1], %[it]\n\t"
@@ -731,7 +732,7 @@ __device__ __forceinline__ void wait_after_crossing(uint32_t &t1, uint32_t &t2, 
                "s_waitcnt vmcnt(8)\n"
                "9:"
                : [n] "=&s"(n), [extra] "=&s"(extra), [t1] "+s"(t1), [t2] "+s"(t2)
-               : [it] "s"(iters), [k3] "s"(k3), [sh] "n"(STORES_PER_ITERATION == 2 ? 1 : 0)
+               : [it] "s"(iters), [k3] "s"(k3)
                : "scc", "memory");
 }
 
@@ -758,11 +759,11 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
   //   STRICT: "at most 4 outstanding" — there is at least one store between any two crossings (a crossing is looked for once per
   //           iteration, after the iteration's store), so 4 always implies it; stricter than exact by a store or two issued two
   //           chunks ago.
-  // Measured (same box, 100 MB raw 11 bit / 2^30-byte mt_ stream in 256 KiB blocks): one pair replayed 39.1 -> 37.8 us exact,
-  // 37.5 strict; four pairs rotated 44.6 -> 45.3 exact (noise), 45.9 strict (the cold stores' acknowledgements are slow: waiting
-  // for them costs); the grouped launch 484-497 -> 494-497 us exact, 475-477 strict.  Hence exact for the one-chain-per-wave
-  // launches and strict for the grouped ones and the uniform-interval plans (checkpoint every 32 groups, replayed: 0.479 -> 0.499;
-  // one chain per wave replayed 0.519 -> 0.526 as well, but rotated — what the bench reports — it loses those 3 %).
+  // Measured (100 MB raw 11 bit / 2^30-byte mt_ stream in 256 KiB blocks, against the loop as it was): one pair replayed
+  // 39.1 -> 37.8 us exact, 37.5 strict; the grouped launch 484-497 -> 494-497 us exact, 475-477 strict; a checkpoint every 32 groups
+  // replayed 0.479 -> 0.499 strict, rotated 45.5 -> 44.8 us.  Four pairs rotated, one chain per wave — what the bench reports —
+  // strict against exact, alternating runs: 45.9 / 44.4 us on one box (three runs each), 42.1 / 43.5 on another (six each): inside
+  // the run-to-run spread (39-45 us).  Strict everywhere but in that launch, which keeps the exact wait.
   uint8_t *outp = (uint8_t *)uni64((uint64_t)(uintptr_t)(c.out + uni64(o_ref)));
   uint32_t iters = steps >> 2;
   steps &= 3;
@@ -992,6 +993,7 @@ __device__ __forceinline__ void run_pair_groups(uint32_t &x, const StreamWin &sw
     auto crossed = [&](FastCursor &f, Ring &r, uint32_t &t1, uint32_t &t2) {
       fast_cursor_cross(f, r);
       ring_request(sw, r, c, r.k + HSRANS_RING_AHEAD);
+      // (exact here: the constant wait — at most 4 outstanding — gives 0.407 -> 0.417 replayed and takes 4 % rotated: 53.5 -> 55.5 us)
       if (HSRANS_RING_AHEAD == 3)
         wait_after_crossing(t1, t2, iters, r.k + HSRANS_RING_AHEAD); // (the other ring's requests are not counted: stricter, never weaker)
       else
@@ -1265,7 +1267,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
     ring_ready(x);
     if (HSRANS_STAMPS(kp))
       t_ready = __builtin_amdgcn_s_memrealtime();
-    run_groups<MODE, true, true>(x, sw, r, c, g.o, g.steps); // (strict wait: 0.479 -> 0.499 replayed with a checkpoint every 32 groups)
+    run_groups<MODE, true, HSRANS_PERSIST_STRICT>(x, sw, r, c, g.o, g.steps); // (strict wait: 0.479 -> 0.499 replayed with a checkpoint every 32 groups)
     run_tail<MODE>(x, r, c, g.o, g.tail);
   }
   const uint64_t t_static = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -1290,7 +1292,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
     const uint32_t ch = lo + (uint32_t)t;
     g = run_begin<MODE>(c, pa, sw, ch, ch + 1, x, r);
     ring_ready(x);
-    run_groups<MODE, true, true>(x, sw, r, c, g.o, g.steps); // (strict wait: 0.479 -> 0.499 replayed with a checkpoint every 32 groups)
+    run_groups<MODE, true, HSRANS_PERSIST_STRICT>(x, sw, r, c, g.o, g.steps); // (strict wait: 0.479 -> 0.499 replayed with a checkpoint every 32 groups)
     run_tail<MODE>(x, r, c, g.o, g.tail);
   }
 
@@ -2541,18 +2543,19 @@ __device__ __forceinline__ void run_dual_fast(uint32_t &xa, uint32_t &xb, const 
   const OutLanes ol = out_lanes(c.lane, 64);
   const uint32_t s_table = uni(lds_address(c.table));
   FastCursor fa = fast_cursor_open(ra.r), fb = fast_cursor_open(rb.r);
-  // (the loop's bookkeeping as in run_groups_fast: the iteration counter is the only count — two stores per iteration here —
-  // and the waits are made up at the crossings)
+  // (the loop's bookkeeping as in run_groups_fast: nothing is counted but the iterations, one output pointer per chain)
   uint32_t iters = both >> 2;
-  uint32_t ta1 = iters, ta2 = iters, tb1 = iters, tb2 = iters;
   uint8_t *pa = (uint8_t *)uni64((uint64_t)(uintptr_t)(c.out + oa)), *pb = (uint8_t *)uni64((uint64_t)(uintptr_t)(c.out + ob)); // one pointer per chain, not base + offset
   oa += (uint64_t)iters * 256;
   ob += (uint64_t)iters * 256;
-  auto crossed = [&](FastCursor &f, RingD &d, uint32_t &t1, uint32_t &t2) {
+  auto crossed = [&](FastCursor &f, RingD &d) {
     fast_cursor_cross(f, d.r);
     ring_request(sw, d.r, c, d.r.k + HSRANS_RING_AHEAD);
+    // (the constant wait: at most 6 outstanding = this ring's requests for k + 2 and k + 3 and the two stores of each of the two
+    // iterations that any three of its crossings span.  Against the exact count (wait_after_crossing<2>): 13 / 14 / 15 bits replayed
+    // 0.455 / 0.413 / 0.411 -> 0.475 / 0.421 / 0.420, 15 bits rotated 54.2 -> 53.0 us)
     if (HSRANS_RING_AHEAD == 3)
-      wait_after_crossing<2>(t1, t2, iters, d.r.k + HSRANS_RING_AHEAD); // (the other ring's requests are not counted: stricter, never weaker)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); // (this ring's request for k + 2 and the two stores of an iteration)
   };
@@ -2570,9 +2573,9 @@ __device__ __forceinline__ void run_dual_fast(uint32_t &xa, uint32_t &xb, const 
     pa += 256;
     pb += 256;
     if (fa.addr >= fa.next_cross)
-      crossed(fa, ra, ta1, ta2);
+      crossed(fa, ra);
     if (fb.addr >= fb.next_cross)
-      crossed(fb, rb, tb1, tb2);
+      crossed(fb, rb);
   }
   vm = 0;
   ra.seq1 = ra.seq2 = ra.seq3 = rb.seq1 = rb.seq2 = rb.seq3 = 0; // (not kept in the loop; the caller drains the queue behind it anyway)
