@@ -2476,7 +2476,7 @@ __device__ __forceinline__ void dual_groups4(uint32_t &xa, uint32_t &xb, uint32_
 // Per group and chain: 10 vector instructions (+ packing), 3 LDS.  Measured (15 bits, 100 MB): 12.3 vector instructions and
 // 13.3 LDS cycles per group, 7.3 of them bank conflicts — 5 from the byte gather alone: 64 random dwords over the LDS's 32 banks
 // (with every lane reading ONE entry the conflicts fall to 5.0, with the byte read made conflict-free as well to 0.03 and the
-// LDS cycles to 6.1: tools/debug/session21.sh).
+// LDS cycles to 6.1; one-off builds with the gathers' addresses replaced, not kept).
 #define HSRANS_DUAL_GROUP_RANK(A0, A1, B0, B1)                                                                                                       \
   "v_and_b32 %[ga], %[xa], %[vmask]\n\t"                                                                                                             \
   "v_and_b32 %[gb], %[xb], %[vmask]\n\t"                                                                                                             \

@@ -679,19 +679,20 @@ def test_random_sweep_gpu_encoder(gpu_ctx, oracle, zipf, nonstat):
         assert gpu_ctx.status(dplan) == 0 and torch.equal(back, d_in), tag
 
 
+@pytest.mark.parametrize("states", (32, 64))
 @pytest.mark.parametrize("bits", (14, 15))
-def test_wide_histogram_rank_table_on_awkward_histograms(gpu_ctx, oracle, bits):
+def test_wide_histogram_rank_table_on_awkward_histograms(gpu_ctx, oracle, bits, states):
     """14 / 15-bit persistent launches decode through the rank table (a byte per slot = the symbol's rank by frequency, then 256
     entries ordered by rank): all 256 symbols present with equal counts (ties in the ranking), two symbols (254 zero counts),
     non-stationary and text-shaped data; uniform-interval plans (the generic loop) and one chain per wave (the two-chain kernel's
-    hand-scheduled loop, with chains of different lengths behind it)."""
+    hand-scheduled loop, with chains of different lengths behind it); 32 states: the pair loops."""
     for name, d in (("uniform", synth.uniform_bytes(1_000_003, seed=4)), ("two", synth.two_symbol(500_000, seed=2)),
                     ("nonstat", synth.nonstationary(2_000_000)), ("zipf", synth.enwik8_shaped(300_000, seed=1))):
-        plans = [H.encode(H.RAW, 64, bits, d, index_interval=interval) for interval in (4, 32)]
-        plans.append(H.encode(H.RAW, 64, bits, d, index_groups=H.index_boundaries(64, bits, d.size, gpu_ctx)))
+        plans = [H.encode(H.RAW, states, bits, d, index_interval=interval) for interval in (4, 32)]
+        plans.append(H.encode(H.RAW, states, bits, d, index_groups=H.index_boundaries(states, bits, d.size, gpu_ctx)))
         for k, (s, plan) in enumerate(plans):
-            r0, want = oracle.decode(RAW, 64, bits, s, d.size)
-            r, got = gpu_ctx.decode_host(H.RAW, 64, bits, s, d.size, plan=plan)
+            r0, want = oracle.decode(RAW, states, bits, s, d.size)
+            r, got = gpu_ctx.decode_host(H.RAW, states, bits, s, d.size, plan=plan)
             assert r == r0 == d.size and np.array_equal(got, want), (name, k)
 
 
