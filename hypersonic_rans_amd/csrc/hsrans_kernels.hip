@@ -3171,7 +3171,7 @@ static uint32_t g_direct_weights4[8] = {1097, 1053, 977, 873, 1098, 1053, 977, 8
 static uint32_t g_direct_weights3[8] = {1052, 1025, 986, 936, 1052, 1025, 986, 936};
 // 32-state plans (two chains per wave, one per half: run_direct_pair, hand-scheduled pair loop; HSRANS_DIRECT_WEIGHTS_PAIR): with 7
 // scalar instructions per group the CU's scalar unit is contended and the oldest waves get nearly all of it
-static uint32_t g_direct_weights_pair[8] = {1847, 1695, 1471, 1174, 780, 512, 317, 204};
+static uint32_t g_direct_weights_pair[8] = {1737, 1597, 1391, 1144, 856, 609, 405, 260}; // (re-fitted after the pair loop's bookkeeping change: spread of the classes' finish 10.5 -> 0.7 us)
 // HSRANS_PRIVATE_PAIR: 0 = never, 1 = when there are more chains than wave slots (default), 2 = always pair the
 // chains of 32-state plans in private-table launches.  Measured: 2^30 B in 16,384 blocks 1.40 -> 1.33 ms, but 100 MB in 1,526
 // blocks 0.25 -> 0.30 ms (everything is latency-bound there and half as many waves are in flight)
@@ -3190,8 +3190,8 @@ static bool g_rank_table = true;      // HSRANS_NO_RANK_TABLE: the wide histogra
 static uint32_t g_dual_waves = 16; // HSRANS_DUAL_WAVES: waves per workgroup of k_decode_dual (12: two workgroups per CU fit beside a 16 KiB table)
 static uint32_t g_dual = 1; // HSRANS_DUAL: 0 = never run two chains per wave (k_decode_dual), 1 = where it pays (default), 2 = for every width (experiment)
 // the one-chain-per-wave weights of the dual kernel's launches (one 16-wave workgroup per CU, two chains per wave)
-static uint32_t g_dual_weights[8] = {1249, 1118, 925, 708, 1249, 1118, 925, 708};        // 13 bits (8-byte table)
-static uint32_t g_dual_weights_wide[8] = {1170, 1083, 953, 795, 1170, 1083, 953, 795}; // 14 / 15 bits (rank table; fitted with 4 pairs rotated: spread of the classes' finish 5.4 -> 0.2 us)
+static uint32_t g_dual_weights[8] = {1232, 1112, 934, 722, 1232, 1112, 934, 722};        // 13 bits (8-byte table)
+static uint32_t g_dual_weights_wide[8] = {1160, 1077, 955, 810, 1160, 1077, 955, 810}; // 14 / 15 bits (rank table; fitted with 4 pairs rotated: spread of the classes' finish 5.4 -> 0.2 us)
 
 typedef void (*KernelFn)(KParams);
 static KernelFn kernel_for(int mode, bool shared)
