@@ -422,14 +422,16 @@ def sharded_workload(args, world, rank, dv: _Dev, dist):
     n, S, bits = args.size, args.states, args.bits
     data = _tiled(n, seed=20241008)
     t0 = time.perf_counter()
-    stream, plan = H.encode(H.MT, S, bits, data, block_size=args.block, index_interval=args.interval)
+    container = H.BLOCK if args.container == "block" else H.MT
+    cname = "block_" if container == H.BLOCK else "mt_"
+    stream, plan = H.encode(container, S, bits, data, block_size=args.block, index_interval=args.interval)
     t_enc = time.perf_counter() - t0
     d_ref = torch.from_numpy(data).to(dv.dev)
     alg = stream.size + n
 
     def make(parts=1, weights=None, root=None):
         if dv.rehearse:
-            return sharded.HostRehearsalDecoder(plan, H.MT, S, bits, parts=parts, weights=weights, root=root)
+            return sharded.HostRehearsalDecoder(plan, container, S, bits, parts=parts, weights=weights, root=root)
         return sharded.ShardedDecoder(dv.ctx, plan, parts=parts, weights=weights, root=root)
 
     def check(dec, out, gathered: bool):
@@ -538,17 +540,17 @@ def sharded_workload(args, world, rank, dv: _Dev, dist):
     dist.all_reduce(seen)
     if rank != 0:
         return None
-    cpu = _mt_cpu_baseline(stream, data, S, bits) if (world == 1 and not args.no_cpu and not dv.rehearse) else None
+    cpu = _mt_cpu_baseline(stream, data, S, bits) if (world == 1 and not args.no_cpu and not dv.rehearse and container == H.MT) else None
     one_ms = legs["one"]["ms_per_step"] if world > 1 else main["ms_per_step"]
     result = {
         "metric": "decode MiB/s (bit-exact), one stream sharded over the GPUs, decoded ranges gathered to rank 0" if world > 1 else
-                  "decode MiB/s (bit-exact), one mt_ stream, one GPU",
+                  f"decode MiB/s (bit-exact), one {cname} stream, one GPU",
         "value": main["MiB_s"], "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main["ms_per_step"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 state / u16 word / u8 symbol (integer)", "data": "synthetic",
-        "config": {"workload": f"mt_rANS32x{S} 16w {bits}-bit, ONE {n}-byte stream in {args.block}-byte blocks + index every {args.interval} groups, chains sharded "
+        "config": {"workload": f"{cname}rANS32x{S} 16w {bits}-bit, ONE {n}-byte stream in {args.block}-byte blocks + index every {args.interval} groups, chains sharded "
                                f"over {world} rank(s) by hsrans_plan_slice, decoded ranges gathered to rank 0 point-to-point over "
                                f"{'RCCL' if not dv.rehearse else 'gloo'}, exchange pipelined behind the decode in {args.parts} sub-runs, root share {root_share:.3f}",
-                   "container": "mt_", "states": S, "bits": bits, "decoded_bytes": n, "compressed_bytes": int(stream.size), "ratio": stream.size / n,
+                   "container": cname, "states": S, "bits": bits, "decoded_bytes": n, "compressed_bytes": int(stream.size), "ratio": stream.size / n,
                    "plan_bytes": int(plan.size), "plan_over_compressed": plan.size / stream.size, "chains": H.plan_chain_count(plan), "block": args.block,
                    "index_interval_groups": args.interval, "gather": "root" if world > 1 else "none", "parts": args.parts, "root_share": root_share,
                    "backend": dist.get_backend(), "n_ranks_seen": int(seen.item()), "host_encode_s": t_enc, "bit_exact": True},
@@ -676,7 +678,8 @@ def main() -> None:
     ap.add_argument("--states", type=int, default=64)
     ap.add_argument("--index", default="wave", help="'wave' = one chain per resident wavefront (hsrans_index_boundaries); or G = a checkpoint every G groups")
     ap.add_argument("--pairs", type=int, default=4, help="distinct (stream, output) pairs rotated through the timed loop")
-    ap.add_argument("--block", type=int, default=1 << 18, help="sharded: mt_ block size in bytes")
+    ap.add_argument("--block", type=int, default=1 << 18, help="sharded: block size in bytes")
+    ap.add_argument("--container", choices=("mt", "block"), default="mt", help="sharded: the stream's container (BASELINE config 4 names block_; same kernel, same plan shape)")
     ap.add_argument("--interval", type=int, default=256, help="sharded: checkpoint interval inside the blocks, in groups")
     ap.add_argument("--parts", type=int, default=4, help="sharded: sub-runs per rank; sub-run k's exchange overlaps sub-run k+1's decode")
     ap.add_argument("--root-share", type=float, default=0.0, help="sharded: the root's share of the decoded bytes (0 = balance it against the measured inbound rate)")
