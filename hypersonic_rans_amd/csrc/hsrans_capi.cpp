@@ -1550,7 +1550,11 @@ try
     rc = plan_bytes == 0 ? HSRANS_E_FORMAT : HSRANS_OK;
   } while (false);
   if (rc != HSRANS_OK)
+  {
+    (void)hipStreamSynchronize(s); // nothing queued above may still be writing the staging buffers (or the caller's d_out) after the return
+    (void)hipGetLastError();
     return rc;
+  }
   return hsrans_dplan_create(ctx, plan, plan_bytes, indexed);
 }
 catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)

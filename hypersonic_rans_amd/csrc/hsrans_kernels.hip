@@ -92,6 +92,11 @@ __host__ __device__ constexpr uint32_t table_bytes_for(int mode, uint32_t bits)
                                : 4u << bits;
 }
 
+// Modes whose 64-state loop is hand-scheduled: their rings carry a whole-chunk mirror (kFastRingBytes per wave) ...
+__host__ __device__ constexpr bool fast_ring_mode(int mode) { return mode == kModePack64 || mode == kModeRank; }
+// ... and the one whose table sits at the START of the workgroup's LDS (address 0: the slot is the address of its rank byte)
+__host__ __device__ constexpr bool table_first_mode(int mode) { return mode == kModeRank; }
+
 __device__ __forceinline__ uint32_t lds_address(const void *p)
 {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)p;
@@ -464,7 +469,7 @@ __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, u
       tab[slot] = make_uint2((uint32_t)cnt[s] | (s << 24), slot - (uint32_t)cum[s]);
     }
   }
-  else if (MODE != kModeTwoLevel)
+  else if (MODE != kModeTwoLevel && MODE != kModeRank)
   {
     uint32_t *tab = (uint32_t *)c.table;
     for (uint32_t slot = tid; slot < total; slot += nthreads)
@@ -480,23 +485,46 @@ __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, u
   {
     uint32_t *sym4 = (uint32_t *)c.table;                  // uint8 sym[total], written 4 slots per store
     uint32_t *symtab = (uint32_t *)(c.table + total);      // freq | cumul << 16
-    for (uint32_t q = tid; q < total / 4; q += nthreads)
+    // every thread a contiguous run of dwords: ONE search for its first slot, then the symbol only moves forward (a search per
+    // slot — 8 dependent LDS reads each — made the build of a 15-bit table the longest part of a grouped launch's round)
+    const uint32_t dwords = total / 4;
+    const uint32_t per = (dwords + nthreads - 1) / nthreads;
+    const uint32_t q0 = tid * per, q1 = q0 + per < dwords ? q0 + per : dwords;
+    if (q0 < q1)
     {
-      uint32_t packed = 0;
+      uint32_t s = 0;
 #pragma unroll
-      for (uint32_t b = 0; b < 4; b++)
+      for (uint32_t step = 128; step >= 1; step >>= 1)
+        s += ((uint32_t)cum[s + step] <= 4 * q0) ? step : 0;
+      uint32_t next = s < 255 ? (uint32_t)cum[s + 1] : 0x10000u; // first slot of the next symbol (zero-count symbols share theirs and are stepped over)
+      for (uint32_t q = q0; q < q1; q++)
       {
-        const uint32_t slot = 4 * q + b;
-        uint32_t s = 0;
+        uint32_t packed = 0;
 #pragma unroll
-        for (uint32_t step = 128; step >= 1; step >>= 1)
-          s += ((uint32_t)cum[s + step] <= slot) ? step : 0;
-        packed |= s << (8 * b);
+        for (uint32_t b = 0; b < 4; b++)
+        {
+          const uint32_t slot = 4 * q + b;
+          while (next <= slot)
+          {
+            s++;
+            next = s < 255 ? (uint32_t)cum[s + 1] : 0x10000u;
+          }
+          packed |= s << (8 * b);
+        }
+        sym4[q] = packed;
       }
-      sym4[q] = packed;
     }
-    for (uint32_t s = tid; s < 256; s += nthreads)
-      symtab[s] = (uint32_t)cnt[s] | ((uint32_t)cum[s] << 16);
+    // kModeRank built on the device (the grouped launches: a table per block): the byte is the symbol itself — ranking 256
+    // counts per block would cost more than the 0.7 conflict cycles per group it saves — and the entries are the 8-byte ones
+    if (MODE == kModeRank)
+    {
+      uint2 *ent = (uint2 *)(c.table + total);
+      for (uint32_t s = tid; s < 256; s += nthreads)
+        ent[s] = make_uint2((uint32_t)cnt[s] | (s << 24), 0u - (uint32_t)cum[s]);
+    }
+    else
+      for (uint32_t s = tid; s < 256; s += nthreads)
+        symtab[s] = (uint32_t)cnt[s] | ((uint32_t)cum[s] << 16);
   }
   sync();
   return true;
@@ -695,6 +723,44 @@ __device__ __forceinline__ uint32_t fast_groups4(uint32_t &x, uint32_t &s_addr, 
   return acc;
 }
 
+// The same group for the rank table (kModeRank; one chain per wave): three dependent LDS reads — the rank byte at LDS address
+// `slot` (the table starts at address 0), the symbol's 8-byte entry behind the bytes (%[sent] = 2^bits), the stream word.
+// 10 vector, 3 LDS, 3 scalar instructions.
+#define HSRANS_FAST_GROUP_RANK(P0, P1)                                                                                                               \
+  "v_and_b32 %[g], %[x], %[vmask]\n\t"                                                                                                               \
+  "ds_read_u8 v" #P0 ", %[g]\n\t"                                                                                                                    \
+  "v_lshrrev_b32 %[x], %[vbits], %[x]\n\t"                                                                                                           \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
+  "v_lshl_add_u32 %[t], v" #P0 ", 3, %[sent]\n\t"                                                                                                    \
+  "ds_read_b64 v[" #P0 ":" #P1 "], %[t]\n\t"                                                                                                         \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
+  "v_mad_u32_u24 %[x], v" #P0 ", %[x], v" #P1 "\n\t"                                                                                                 \
+  "v_add_u32 %[x], %[x], %[g]\n\t"                                                                                                                   \
+  "v_cmpx_gt_u32 vcc, %[lim], %[x]\n\t"                                                                                                              \
+  "s_nop 1\n\t"                                                                                                                                      \
+  "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"                                                                                                           \
+  "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"                                                                                                        \
+  "v_lshl_add_u32 %[t], %[t], 1, %[sa]\n\t"                                                                                                          \
+  "ds_read_u16 %[t], %[t]\n\t"                                                                                                                       \
+  "s_bcnt1_i32_b64 %[st], vcc\n\t"                                                                                                                   \
+  "s_lshl1_add_u32 %[sa], %[st], %[sa]\n\t"                                                                                                          \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
+  "v_lshl_or_b32 %[x], %[x], 16, %[t]\n\t"                                                                                                           \
+  "s_mov_b64 exec, -1\n\t"
+
+__device__ __forceinline__ uint32_t fast_groups4_rank(uint32_t &x, uint32_t &s_addr, const WaveCtx &c, uint32_t s_entries)
+{
+  uint32_t acc, t, g, st;
+  asm volatile(HSRANS_FAST_GROUP_RANK(52, 53) HSRANS_FAST_GROUP_RANK(54, 55) HSRANS_FAST_GROUP_RANK(56, 57) HSRANS_FAST_GROUP_RANK(58, 59)
+               "v_perm_b32 %[acc], v54, v52, %[selp]\n\t"
+               "v_perm_b32 %[t], v58, v56, %[selp]\n\t"
+               "v_perm_b32 %[acc], %[t], %[acc], %[selq]"
+               : [x] "+v"(x), [sa] "+s"(s_addr), [acc] "=&v"(acc), [t] "=&v"(t), [g] "=&v"(g), [st] "=&s"(st)
+               : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [sent] "s"(s_entries), [lim] "s"(kConsume), [selp] "s"(0x0c0c0703u), [selq] "s"(0x05040100u)
+               : "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "vcc", "scc", "memory");
+  return acc;
+}
+
 // (Measured and dropped: the four groups' symbols as four byte stores — global_store_byte / _d16_hi, lane j writing byte idx2idx(j)
 // of its group — instead of pack + quad transpose + one dword store: 1.25 vector instructions per group fewer, the replayed
 // decode unchanged (38.2-38.9 us against 38.8-39.4), the rotated one 4-6 us slower: the loop is not bound by vector issue alone
@@ -736,7 +802,7 @@ __device__ __forceinline__ void wait_after_crossing(uint32_t &t1, uint32_t &t2, 
                : "scc", "memory");
 }
 
-template <bool STRICT>
+template <bool STRICT, int MODE = kModePack64>
 __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o_ref, uint32_t &steps)
 {
   const OutLanes ol = out_lanes(c.lane, 64);
@@ -773,7 +839,7 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
   uint32_t t1 = iters, t2 = iters;
   for (; iters != 0; iters--)
   {
-    const uint32_t acc = quad_transpose(fast_groups4(x, s_addr, c, s_table), ol.sel_a, ol.sel_b);
+    const uint32_t acc = quad_transpose(MODE == kModeRank ? fast_groups4_rank(x, s_addr, c, 1u << c.bits) : fast_groups4(x, s_addr, c, s_table), ol.sel_a, ol.sel_b);
     HSRANS_STORE_U32_SADDR((uint8_t *)uni64((uint64_t)(uintptr_t)outp), ol.store_off, acc);
     outp += 256;
     if (s_addr >= next_cross) // entered the next chunk (at most one per 4 groups: they take <= 512 bytes)
@@ -809,6 +875,8 @@ __device__ __forceinline__ void run_groups(uint32_t &x, const StreamWin &sw, Rin
 {
   if (FAST && MODE == kModePack64 && c.S == 64 && r.mirror_lanes == 0xFFFFFFFFu)
     run_groups_fast<STRICT || HSRANS_FORCE_STRICT>(x, sw, r, c, o, steps); // the hand-scheduled loop; leaves < 4 groups
+  if (FAST && MODE == kModeRank && c.S == 64 && r.mirror_lanes == 0xFFFFFFFFu && uni(lds_address(c.table)) == 0)
+    run_groups_fast<true, kModeRank>(x, sw, r, c, o, steps); // (its rank byte's address is the slot itself: the table at LDS address 0)
   if (c.S == 64)
     run_groups_impl<MODE, true>(x, sw, r, c, o, steps);
   else
@@ -1095,7 +1163,7 @@ __device__ void run_planned_chain(const WaveCtx &c, const PlanView &pv, uint32_t
   uint64_t have_hist = ~(uint64_t)0;
   StreamWin sw;
   Ring r;
-  ring_bind(r, c.rings, 9, MODE == kModePack64);
+  ring_bind(r, c.rings, 9, fast_ring_mode(MODE));
   for (uint32_t pi = first; pi < last; pi++)
   {
     const Piece *pc = pv.pieces + pi;
@@ -1222,7 +1290,7 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
   uint32_t x = 0;
   StreamWin sw;
   Ring r;
-  ring_bind(r, c.rings, 9, MODE == kModePack64);
+  ring_bind(r, c.rings, 9, fast_ring_mode(MODE));
   RunGeom g{};
   // static run of this wave: run_len[class] chains (host guarantees static_total <= n_chains)
   const uint32_t wave_in_wg = w % waves, blk = w / waves;
@@ -1396,7 +1464,7 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
     {
       StreamWin sw;
       Ring r;
-      ring_bind(r, c.rings, 9, MODE == kModePack64 && c.S == 64);
+      ring_bind(r, c.rings, 9, fast_ring_mode(MODE) && c.S == 64);
       uint32_t x = c.lane < c.S ? pa.states[(uint64_t)ch * c.S + c.lane] : 0; // address known up front: in flight beside the piece record
       const DirectPiece d = direct_piece(c, pa, ch);
       win_open(sw, c, d.words, d.limit);
@@ -1788,7 +1856,7 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
       const uint64_t limit = last < begin + count ? uni64(pv.pieces[piece0 + (last - begin)].words_off) : uni64(G->words_end);
       if (issue)
         x = c.lane < c.S ? pv.states[(uint64_t)first * c.S + c.lane] : 0;
-      ring_bind(r, c.rings, 9, MODE == kModePack64);
+      ring_bind(r, c.rings, 9, fast_ring_mode(MODE));
       win_open(sw, c, uni64(p0->words_off), limit);
       ring_begin(sw, r, c, uni64(p0->words_off), issue);
       o = uni64(p0->out_off);
@@ -1946,7 +2014,7 @@ __device__ void run_block_walk(const WaveCtx &c, const PlanView &pv, const KPara
   uint32_t n_blocks = 0;
   StreamWin sw;
   Ring r;
-  ring_bind(r, c.rings, 9, MODE == kModePack64);
+  ring_bind(r, c.rings, 9, fast_ring_mode(MODE));
   do
   {
     if (pos + 8 > c.stream_len)
@@ -2093,12 +2161,13 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
 
   if (SHARED)
   {
-    const uint32_t ring_stride = MODE == kModePack64 ? kFastRingBytes : kWaveRingBytes; // (launch_shape sizes the LDS the same way)
-    c.rings = smem + wave * ring_stride;
-    c.table = smem + waves * ring_stride;
+    const uint32_t ring_stride = fast_ring_mode(MODE) ? kFastRingBytes : kWaveRingBytes; // (launch_shape sizes the LDS the same way)
+    uint8_t *ring0 = table_first_mode(MODE) ? smem + table_bytes : smem;
+    c.rings = ring0 + wave * ring_stride;
+    c.table = table_first_mode(MODE) ? smem : smem + waves * ring_stride;
     c.table_b = c.table;
-    c.scratch_cnt = (uint16_t *)smem;         // wave 0's ring (no request in flight while a table is built)
-    c.scratch_cum = (uint16_t *)(smem + 512);
+    c.scratch_cnt = (uint16_t *)ring0;         // wave 0's ring (no request in flight while a table is built)
+    c.scratch_cum = (uint16_t *)(ring0 + 512);
     const uint64_t hist_off = pv.hdr->aux_off; // shared plans: the one histogram every chain uses
     c.gtable = kp.pa.table;
     if (kp.pa.pieces != nullptr)
@@ -2163,13 +2232,14 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.lane = threadIdx.x & 63;
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
-  const uint32_t ring_stride = MODE == kModePack64 ? kFastRingBytes : kWaveRingBytes; // (launch_shape sizes the LDS the same way)
-  c.rings = smem + wave * ring_stride;
-  c.table = smem + waves * ring_stride;
+  const uint32_t ring_stride = fast_ring_mode(MODE) ? kFastRingBytes : kWaveRingBytes; // (launch_shape sizes the LDS the same way)
+  uint8_t *ring0 = table_first_mode(MODE) ? smem + table_bytes_for(MODE, c.bits) : smem;
+  c.rings = ring0 + wave * ring_stride;
+  c.table = table_first_mode(MODE) ? smem : smem + waves * ring_stride;
   c.table_b = c.table;
   c.gtable = kp.pa.table;
-  c.scratch_cnt = (uint16_t *)smem; // wave 0's ring (no request in flight while a table is built)
-  c.scratch_cum = (uint16_t *)(smem + 512);
+  c.scratch_cnt = (uint16_t *)ring0; // wave 0's ring (no request in flight while a table is built)
+  c.scratch_cum = (uint16_t *)(ring0 + 512);
   const uint32_t chain = blockIdx.x * waves + wave;
   if (c.S == 32)
     run_direct_pair<MODE>(c, kp, waves, chain);
@@ -2232,9 +2302,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.lane = threadIdx.x & 63;
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
-  const uint32_t ring_stride = MODE == kModePack64 ? kFastRingBytes : kWaveRingBytes; // (launch_shape sizes the LDS the same way)
-  c.rings = smem + wave * ring_stride;
-  c.table = smem + waves * ring_stride;
+  const uint32_t ring_stride = fast_ring_mode(MODE) ? kFastRingBytes : kWaveRingBytes; // (launch_shape sizes the LDS the same way)
+  // [rings][table][next-group words][build scratch], or with the table first: [table][next-group words][build scratch][rings]
+  c.rings = (table_first_mode(MODE) ? smem + table_bytes_for(MODE, c.bits) + 64 + 1024 : smem) + wave * ring_stride;
+  c.table = table_first_mode(MODE) ? smem : smem + waves * ring_stride;
   c.table_b = c.table;
   c.gtable = nullptr;
   // the table build's scratch has an area of its own: a round's first stream chunks are requested before its table is built
@@ -3352,7 +3423,8 @@ hipError_t prepare_kernels(DeviceGeom *geom)
   for (KernelFn fn : {(KernelFn)k_decode_single, (KernelFn)k_decode_persist, (KernelFn)k_calibrate, (KernelFn)k_decode_dual<kModePack64>, (KernelFn)k_decode_dual<kModeRank>, (KernelFn)k_decode_direct<kModePack>, (KernelFn)k_decode_direct<kModePackM1>,
                       (KernelFn)k_decode_direct<kModeTwoLevel>, (KernelFn)k_decode_direct<kModePack64>, (KernelFn)k_decode_direct<kModeRank>, (KernelFn)k_decode_direct<kModeSpill>,
                       (KernelFn)k_decode_grouped<kModePack, false>, (KernelFn)k_decode_grouped<kModePackM1, false>, (KernelFn)k_decode_grouped<kModeTwoLevel, false>,
-                      (KernelFn)k_decode_grouped<kModePack64, false>, (KernelFn)k_decode_grouped<kModeTwoLevel, true>, (KernelFn)k_decode_grouped<kModePack64, true>})
+                      (KernelFn)k_decode_grouped<kModePack64, false>, (KernelFn)k_decode_grouped<kModeTwoLevel, true>, (KernelFn)k_decode_grouped<kModePack64, true>,
+                      (KernelFn)k_decode_grouped<kModeRank, false>, (KernelFn)k_decode_grouped<kModeRank, true>})
   {
     const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
     if (e != hipSuccess)
@@ -3383,7 +3455,10 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
   // 64-bit entries only where one table serves a whole workgroup (LDS: 16 KiB table + 16 x 2.25 KiB rings, two per CU)
   const bool rank_table = L.shared && persistent && table_mode == kModeRank;
   const bool spill = L.shared && persistent && table_mode == kModeSpill;
-  L.mode = spill ? kModeSpill : rank_table ? kModeRank : L.shared && h.bits <= pack64_max_bits() ? kModePack64 : h.bits >= 13 ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : kModePack;
+  // (grouped launches from 13 bits on: the rank table, built per block on the device — beside the 64 / 128 KiB one-lookup tables
+  // only one workgroup fits a CU: 100 MB in 256 KiB blocks + G=32: 0.269 / 0.206 / 0.190 at 13 / 14 / 15 bits)
+  const bool grouped_rank = grouped && g_rank_table && h.bits >= 13;
+  L.mode = spill ? kModeSpill : rank_table || grouped_rank ? kModeRank : L.shared && h.bits <= pack64_max_bits() ? kModePack64 : h.bits >= 13 ? kModeTwoLevel : h.bits == 12 ? kModePackM1 : kModePack;
   const bool two_level = L.mode == kModeTwoLevel;
   const uint32_t table_bytes = table_bytes_for(L.mode, h.bits);
   const uint32_t wave_bytes = kWaveRingBytes + ((table_bytes + 15) & ~15u); // private rings + table
@@ -3404,7 +3479,7 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
   else if (L.shared)
   {
     // (k_decode_direct's hand-scheduled loop wants a whole-chunk mirror behind every ring)
-    const uint32_t ring = L.mode == kModePack64 ? kFastRingBytes : kWaveRingBytes;
+    const uint32_t ring = fast_ring_mode(L.mode) ? kFastRingBytes : kWaveRingBytes;
     waves = g_waves_per_wg;
     // Grouped launches (one workgroup per block, round after round): FOUR workgroups of 8 waves per CU instead of two of 16
     // wherever four fit the LDS.  A round is table build + records + first chunks (~12 us in which the workgroup decodes
@@ -3608,6 +3683,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
     case kModePack: fn = k_decode_grouped<kModePack, false>; break;
     case kModePackM1: fn = k_decode_grouped<kModePackM1, false>; break;
     case kModeTwoLevel: fn = kp.groups_lean ? k_decode_grouped<kModeTwoLevel, true> : k_decode_grouped<kModeTwoLevel, false>; break;
+    case kModeRank: fn = kp.groups_lean ? k_decode_grouped<kModeRank, true> : k_decode_grouped<kModeRank, false>; break;
     default: fn = kp.groups_lean ? k_decode_grouped<kModePack64, true> : k_decode_grouped<kModePack64, false>; break;
     }
   else if (persistent && kp.pa.interval == 0 && L.shared)
