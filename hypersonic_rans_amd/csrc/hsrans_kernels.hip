@@ -457,6 +457,7 @@ __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, u
 
   // slot -> symbol: the largest s with cum[s] <= slot (zero-count symbols share cum with their successor and lose
   // the tie; trailing zero-count symbols sit at cum == total and are never hit) == hist.cpp:343-351
+  // (the 8-byte table written by runs like the byte tables below — one search per thread — measured the same: 0.3715 against 0.370)
   if (MODE == kModePack64)
   {
     uint2 *tab = (uint2 *)c.table;

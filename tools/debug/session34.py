@@ -9,7 +9,7 @@ n = 100_000_000
 data = synth.enwik8_shaped(n)
 d_ref = torch.from_numpy(data).cuda()
 for container in (H.MT, H.BLOCK):
-    for bits in (12, 13, 14, 15):
+    for bits in [int(b) for b in os.environ.get("BITS", "12,13,14,15").split(",")]:
         s, plan = H.encode(container, 64, bits, data, index_interval=32, block_size=1 << 18)
         d_in = torch.from_numpy(np.concatenate([s, np.zeros((-s.size) % 16, np.uint8)])).cuda()
         out = torch.zeros(n, dtype=torch.uint8, device="cuda")
