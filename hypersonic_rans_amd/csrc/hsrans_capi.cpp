@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -1482,6 +1483,10 @@ try
   if (hipSetDevice(ctx->device) != hipSuccess)
     return HSRANS_E_HIP;
   hipStream_t s = (hipStream_t)hip_stream;
+  const bool trace = getenv("HSRANS_INDEXING_TRACE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t0 = now();
   const uint32_t S = h.states;
   const uint64_t n_ck = h.decoded_len / S / index_interval + 2;
   // page-locked staging (kept by the context): [checkpoint states | cursors | base plan] down, then the new plan blob up —
@@ -1523,6 +1528,7 @@ try
         hipMemcpyAsync(ck_words, d_ck_words, wd_bytes, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipMemcpyAsync(&status, d->d_status, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
       break;
+    const auto t1 = now();
     if (status != 0) // the pass found a bad histogram / header: reported and cleared like hsrans_dplan_status does
     {
       rc = hipMemsetAsync(d->d_status, 0, 4, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess ? HSRANS_E_DEVICE : HSRANS_E_HIP;
@@ -1537,6 +1543,7 @@ try
     }
     PlanBuilder pb;
     pb.begin((int)h.container, (int)S, h.bits, h.decoded_len, h.stream_len);
+    pb.reserve((size_t)h.n_chains + n_ck);
     pb.hdr.interval = index_interval;
     if (hb.flags & kPlanHasHist)
     {
@@ -1546,8 +1553,11 @@ try
     }
     add_interval_chains(pb, hb, (const uint32_t *)(base + plan_chain_first_off()), (const Piece *)(base + plan_pieces_off(hb.n_chains)),
                         (const uint32_t *)(base + plan_states_off(hb.n_chains, hb.n_pieces)), index_interval, ck_states, ck_words);
+    const auto t2 = now();
     plan_bytes = pb.serialize(plan, new_cap);
     rc = plan_bytes == 0 ? HSRANS_E_FORMAT : HSRANS_OK;
+    if (trace)
+      fprintf(stderr, "hsrans_decode_device_indexing: pass + copies %.3f ms, validate + chains %.3f ms, serialize %.3f ms (%zu bytes)\n", ms(t0, t1), ms(t1, t2), ms(t2, now()), plan_bytes);
   } while (false);
   if (rc != HSRANS_OK)
   {
@@ -1555,7 +1565,11 @@ try
     (void)hipGetLastError();
     return rc;
   }
-  return hsrans_dplan_create(ctx, plan, plan_bytes, indexed);
+  const auto t3 = now();
+  const int rc2 = hsrans_dplan_create(ctx, plan, plan_bytes, indexed);
+  if (trace)
+    fprintf(stderr, "hsrans_decode_device_indexing: hsrans_dplan_create %.3f ms\n", ms(t3, now()));
+  return rc2;
 }
 catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
 {

@@ -672,8 +672,17 @@ void PlanBuilder::add_chain(const Piece &p, const uint32_t *st)
   q.state_idx = (uint32_t)chain_first.size();
   chain_first.push_back((uint32_t)pieces.size());
   pieces.push_back(q);
-  for (uint32_t j = 0; j < hdr.states; j++)
-    states.push_back(st ? st[j] : 0);
+  if (st)
+    states.insert(states.end(), st, st + hdr.states);
+  else
+    states.resize(states.size() + hdr.states, 0u);
+}
+
+void PlanBuilder::reserve(size_t chains)
+{
+  chain_first.reserve(chains + 1);
+  pieces.reserve(chains);
+  states.reserve(chains * (size_t)hdr.states);
 }
 
 void PlanBuilder::add_piece(const Piece &p)

@@ -43,6 +43,7 @@ struct PlanBuilder
   // starts a new chain whose first piece is `p` with start states `st` (S values; may be null for fills)
   void add_chain(const Piece &p, const uint32_t *st);
   void add_piece(const Piece &p); // continuation piece of the current chain
+  void reserve(size_t chains);    // (after begin(): room for that many single-piece chains)
   size_t serialized_size() const;
   size_t serialize(uint8_t *out, size_t cap); // fills shared_hist / aux_off, returns bytes or 0
 };
