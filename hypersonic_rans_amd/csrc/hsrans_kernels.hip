@@ -999,7 +999,28 @@ __device__ __forceinline__ void pair_bind(Ring &ra, Ring &rb, const WaveCtx &c)
 // One group of both chains (lanes 0..31 chain A, 32..63 chain B; 8-byte table entries), hand-scheduled like HSRANS_FAST_GROUP:
 // v_cmpx puts the renormalisation mask of both halves in VCC and EXEC; chain A's ranks come from v_mbcnt_lo, chain B's from
 // v_mbcnt_hi alone (issued under EXEC = mask & upper half, like B's word address), so each half counts from its own scalar
-// cursor.  10 vector, 2 LDS, 7 scalar instructions (the compiler's version: 14 + 2 + 19).
+// cursor.  10 vector, 2 LDS, 7 scalar instructions (the compiler's version: 14 + 2 + 19); since round 3 both halves' word addresses
+// are formed on all lanes and picked by a v_cndmask instead: 11 vector, 5 scalar (a checkpoint every 32 groups 0.388 -> 0.401,
+// one chain per wave the same, rotated 51.0 -> 50.4 us: the CU's one scalar unit is this loop's contended resource).
+#ifndef HSRANS_PAIR_SELECT // 1: both halves' word addresses formed on all lanes and picked with a v_cndmask (5 vector, 0 scalar); 0: chain B's under EXEC = upper half (4 vector, 2 scalar)
+#define HSRANS_PAIR_SELECT 1
+#endif
+#if HSRANS_PAIR_SELECT
+#define HSRANS_PAIR_ADDR                                                                                                                             \
+  "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"                                                                                                           \
+  "v_mbcnt_hi_u32_b32 %[w], vcc_hi, 0\n\t"                                                                                                           \
+  "v_lshl_add_u32 %[t], %[t], 1, %[sa]\n\t"                                                                                                          \
+  "v_lshl_add_u32 %[w], %[w], 1, %[sb]\n\t"                                                                                                          \
+  "v_cndmask_b32 %[w], %[t], %[w], %[up]\n\t"
+#else
+#define HSRANS_PAIR_ADDR                                                                                                                             \
+  "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"                                                                                                           \
+  "v_lshl_add_u32 %[w], %[t], 1, %[sa]\n\t"                                                                                                          \
+  "s_mov_b32 exec_lo, 0\n\t"                                                                                                                         \
+  "v_mbcnt_hi_u32_b32 %[t], vcc_hi, 0\n\t"                                                                                                           \
+  "v_lshl_add_u32 %[w], %[t], 1, %[sb]\n\t"                                                                                                          \
+  "s_mov_b32 exec_lo, vcc_lo\n\t"
+#endif
 #define HSRANS_PAIR_GROUP(P0, P1)                                                                                                                    \
   "v_and_b32 %[t], %[x], %[vmask]\n\t"                                                                                                               \
   "v_lshl_add_u32 %[t], %[t], 3, %[stab]\n\t"                                                                                                        \
@@ -1009,12 +1030,7 @@ __device__ __forceinline__ void pair_bind(Ring &ra, Ring &rb, const WaveCtx &c)
   "v_mad_u32_u24 %[x], v" #P0 ", %[x], v" #P1 "\n\t"                                                                                                 \
   "v_cmpx_gt_u32 vcc, %[lim], %[x]\n\t"                                                                                                              \
   "s_nop 1\n\t"                                                                                                                                      \
-  "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"                                                                                                           \
-  "v_lshl_add_u32 %[w], %[t], 1, %[sa]\n\t"                                                                                                          \
-  "s_mov_b32 exec_lo, 0\n\t"                                                                                                                         \
-  "v_mbcnt_hi_u32_b32 %[t], vcc_hi, 0\n\t"                                                                                                           \
-  "v_lshl_add_u32 %[w], %[t], 1, %[sb]\n\t"                                                                                                          \
-  "s_mov_b32 exec_lo, vcc_lo\n\t"                                                                                                                    \
+  HSRANS_PAIR_ADDR                                                                                                                                   \
   "ds_read_u16 %[w], %[w]\n\t"                                                                                                                       \
   "s_bcnt1_i32_b32 %[st], vcc_lo\n\t"                                                                                                                \
   "s_lshl1_add_u32 %[sa], %[st], %[sa]\n\t"                                                                                                          \
@@ -1032,7 +1048,8 @@ __device__ __forceinline__ uint32_t pair_groups4(uint32_t &x, uint32_t &s_a, uin
                "v_perm_b32 %[t], v58, v56, %[selp]\n\t"
                "v_perm_b32 %[acc], %[t], %[acc], %[selq]"
                : [x] "+v"(x), [sa] "+s"(s_a), [sb] "+s"(s_b), [acc] "=&v"(acc), [t] "=&v"(t), [w] "=&v"(w), [st] "=&s"(st)
-               : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [stab] "s"(s_table), [lim] "s"(kConsume), [selp] "s"(0x0c0c0703u), [selq] "s"(0x05040100u)
+               : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [stab] "s"(s_table), [lim] "s"(kConsume), [selp] "s"(0x0c0c0703u), [selq] "s"(0x05040100u),
+                 [up] "s"(0xFFFFFFFF00000000ull)
                : "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "vcc", "scc", "memory");
   return acc;
 }
@@ -2681,6 +2698,12 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
   if (MODE == kModeRank)
   {
     // the rank bytes at LDS address 0 (this kernel has no static LDS): the hand-scheduled group uses the slot as the address
+    if (uni(lds_address(smem)) != 0) // (would decode garbage silently: report instead; the host discards the output)
+    {
+      if (threadIdx.x == 0)
+        atomicOr(kp.status, kStatusOutOfRange);
+      return;
+    }
     c.table = smem;
     c.rings = smem + table_bytes_for(MODE, c.bits) + wave * 2 * kDualRing;
   }
