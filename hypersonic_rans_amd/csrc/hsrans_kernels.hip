@@ -3266,7 +3266,7 @@ static uint32_t g_direct_weights4[8] = {1097, 1053, 977, 873, 1098, 1053, 977, 8
 static uint32_t g_direct_weights3[8] = {1052, 1025, 986, 936, 1052, 1025, 986, 936};
 // 32-state plans (two chains per wave, one per half: run_direct_pair, hand-scheduled pair loop; HSRANS_DIRECT_WEIGHTS_PAIR): with 7
 // scalar instructions per group the CU's scalar unit is contended and the oldest waves get nearly all of it
-static uint32_t g_direct_weights_pair[8] = {1737, 1597, 1391, 1144, 856, 609, 405, 260}; // (re-fitted after the pair loop's bookkeeping change: spread of the classes' finish 10.5 -> 0.7 us)
+static uint32_t g_direct_weights_pair[8] = {1662, 1550, 1365, 1142, 887, 656, 450, 289}; // (re-fitted twice in round 3 as the pair loop lost scalar instructions: 1847 ... 204 before)
 // HSRANS_PRIVATE_PAIR: 0 = never, 1 = when there are more chains than wave slots (default), 2 = always pair the
 // chains of 32-state plans in private-table launches.  Measured: 2^30 B in 16,384 blocks 1.40 -> 1.33 ms, but 100 MB in 1,526
 // blocks 0.25 -> 0.30 ms (everything is latency-bound there and half as many waves are in flight)
