@@ -838,6 +838,11 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
   // iteration counts (they run down) at the last two crossings; at entry: as if both had just happened, i.e. the first two waits
   // count no stores — stricter than needed by what was stored before this loop, never weaker
   uint32_t t1 = iters, t2 = iters;
+  // Both waits lean on the steady state: two crossings behind the current one, each with a store in front of it.  A chain's first
+  // two crossings have no such past — ring_begin asked for chunks 0..3 in one go, nothing in between — so a loop entered before
+  // them makes sure of chunks 2 and 3 here, once per chain (they were requested with chunk 1, which has landed)
+  if (r.k < 2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (; iters != 0; iters--)
   {
     const uint32_t acc = quad_transpose(MODE == kModeRank ? fast_groups4_rank(x, s_addr, c, 1u << c.bits) : fast_groups4(x, s_addr, c, s_table), ol.sel_a, ol.sel_b);
@@ -1076,6 +1081,8 @@ __device__ __forceinline__ void run_pair_groups(uint32_t &x, const StreamWin &sw
     uint32_t iters = (steps - done) >> 2;
     done += iters * 4;
     uint32_t ta1 = iters, ta2 = iters, tb1 = iters, tb2 = iters;
+    if (ra.k < 2 || rb.k < 2) // (a chain's first two crossings: see run_groups_fast)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     auto crossed = [&](FastCursor &f, Ring &r, uint32_t &t1, uint32_t &t2) {
       fast_cursor_cross(f, r);
       ring_request(sw, r, c, r.k + HSRANS_RING_AHEAD);
