@@ -198,11 +198,12 @@ def index_boundaries(states: int, bits: int, decoded_size: int, ctx: "Context | 
 
 
 def encode(container: int, states: int, bits: int, data, hist: Hist | None = None, block_size: int = 0, index_interval: int = 0,
-           independent_blocks: bool = False, index_groups=None):
-    """Returns ``stream`` (np.uint8) or ``(stream, plan)`` when ``index_interval`` != 0 or ``index_groups`` (explicit checkpoints) is given."""
+           independent_blocks: bool = False, index_groups=None, out_capacity: int | None = None):
+    """Returns ``stream`` (np.uint8) or ``(stream, plan)`` when ``index_interval`` != 0 or ``index_groups`` (explicit checkpoints) is given.
+    ``out_capacity``: room for the stream when a caller-made histogram makes the data EXPAND (default: the reference's capacity)."""
     L = load_library()
     data = _u8(data)
-    cap = L.hsrans_capacity(container, states, data.size)
+    cap = L.hsrans_capacity(container, states, data.size) if out_capacity is None else int(out_capacity)
     out = np.zeros(cap, np.uint8)
     hp = ctypes.byref(hist) if hist is not None else None
     if index_groups is not None:

@@ -104,6 +104,30 @@ def test_reference_encoded_streams(gpu_ctx, oracle, ref, zipf, nonstat, containe
             assert r == r0 and np.array_equal(got, want), (container, states, bits, n)
 
 
+@pytest.mark.parametrize("states", (32, 64))
+@pytest.mark.parametrize("bits", (11, 13, 15))
+def test_streams_that_renormalise_on_nearly_every_step(gpu_ctx, oracle, states, bits):
+    """The most stream a group can consume: a histogram in which one symbol holds nearly all the probability and data made of the
+    255 others only (frequency 1 of 2^bits each: `bits` bits per symbol, so nearly every lane reads a word in nearly every group).
+    The hand-scheduled loops re-base their cursors and look for chunk crossings once per 4 groups (<= 512 stream bytes) and time their
+    waits by crossings: this is the input that crosses a chunk in almost every iteration, from the first one on."""
+    rng = np.random.default_rng(5 + bits)
+    n = 3_000_003
+    d = rng.integers(0, 255, n, dtype=np.uint8)
+    counts = np.ones(256, np.int64)
+    counts[255] = (1 << bits) - 255
+    hist = H.api.hist_from_counts(counts)
+    room = 2 * n + 4096  # (the data expands: `bits` bits per byte)
+    plans = [H.encode(H.RAW, states, bits, d, hist=hist, index_interval=g, out_capacity=room) for g in (4, 32)]
+    plans.append(H.encode(H.RAW, states, bits, d, hist=hist, index_groups=H.index_boundaries(states, bits, n, gpu_ctx), out_capacity=room))
+    for k, (s, plan) in enumerate(plans):
+        assert s.size > n * bits // 8  # (it really is that incompressible)
+        r0, want = oracle.decode(RAW, states, bits, s, n)
+        assert r0 == n and np.array_equal(want, d)
+        r, got = gpu_ctx.decode_host(H.RAW, states, bits, s, n, plan=plan)
+        assert r == n and np.array_equal(got, d), (k,)
+
+
 def test_failure_modes(gpu_ctx, zipf):
     d = zipf[:10000]
     s = H.encode(H.RAW, 64, 11, d)
