@@ -52,8 +52,8 @@ def test_shared_table_decode_occupancy():
             assert r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] == 8, (name, r)
     assert seen == 5 + 6 + 2
     # the grouped launches' kernel (block_/mt_ plans with checkpoints): the 8-byte-table instantiations, lean and general
-    grouped = {name: r for name, r in kernels.items() if re.search(r"k_decode_groupedILi3ELb[01]E", name)}
-    assert len(grouped) == 2
+    grouped = {name: r for name, r in kernels.items() if re.search(r"k_decode_groupedILi[34]ELb[01]E", name)}  # 8-byte table and rank table
+    assert len(grouped) == 4
     for name, r in grouped.items():
         assert r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] == 8, (name, r)
     persist = [r for name, r in kernels.items() if "k_decode_persist" in name]
