@@ -1794,6 +1794,9 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
 #define HSRANS_GS(...)
 #endif
   HSRANS_GS(uint64_t t_first = 0, acc_wait = 0, acc_build = 0, acc_meta = 0, acc_dec = 0, rounds = 0; if (HSRANS_STAMPS(kp)) t_first = __builtin_amdgcn_s_memrealtime();)
+  // (Measured and not kept, round 3: wave 0 pulling the NEXT group's record, piece records and start states through the caches at the
+  // end of its round — LDS-DMA into the build scratch, so that the three dependent round trips behind the barrier hit L2: 64 KiB
+  // blocks 537 / 542 / 534 us against 537 / 540 / 542 with it, 100 MB 0.368 against 0.369.  The other workgroups of the CU hide them.)
   // (Round 2 had measured a ticket counter — drawn by everyone after the round's barrier — and checkpoints placed by wave class
   // inside the blocks, and found neither worth it; what changed the picture in round 3 is below: the draw hidden in wave 0's
   // barrier wait, four 8-wave workgroups per CU (launch_shape) and the younger waves' raised priority.)
