@@ -54,6 +54,18 @@ def test_bench_spawns_its_own_ranks(n):
         assert pr["out_bytes_held"] == pr["range"][1] - pr["range"][0]
 
 
+def test_bench_shards_a_block_stream_too():
+    """BASELINE config 4 names the block_ container: the same sharded workload on a block_ stream (its chains come from the inline
+    headers), three ranks over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--rehearse", "--container", "block", "--size", "2000003", "--block", "65536",
+                        "--interval", "32", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["container"] == "block_" and d["config"]["n_ranks_seen"] == 3 and d["config"]["bit_exact"]
+    assert sum(d["gather"]["all"]["shares"]) == 2000003
+
+
 def test_bench_passes_a_rank_failure_on():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     # --rehearse with the headline workload is refused by every rank: the launcher must exit non-zero and print no result line
