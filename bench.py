@@ -574,7 +574,7 @@ def sharded_workload(args, world, rank, dv: _Dev, dist):
 
 def host_workload(args, world, rank, dv: _Dev, dist):
     """BASELINE config 5's shape: every rank decodes its OWN mt_ stream from page-locked host memory into page-locked host memory
-    (upload overlapped with decode kernels that store straight into the host buffer: hsrans_hpipe) — independent
+    (upload, decode and download of consecutive slices overlapped on three streams: hsrans_hpipe) — independent
     streams, no data-path collective, weak scaling.  PCIe-inclusive by construction, so this is never the headline `value`: it is
     its own workload with its own metric.  The stream is written by the GPU encoder (the scalar host encoder would take minutes)."""
     from hypersonic_rans_amd import pipeline
@@ -618,8 +618,8 @@ def host_workload(args, world, rank, dv: _Dev, dist):
         "value": world * n / 2**20 / (elapsed / args.steps), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 state / u16 word / u8 symbol (integer)", "data": "synthetic",
         "config": {"workload": f"mt_rANS32x{S} 16w {bits}-bit, one {n}-byte stream per GPU in {args.block}-byte blocks + index every {args.interval} groups, "
-                               "compressed stream and decoded output in page-locked host memory, hsrans_hpipe (upload slices overlapped with decode kernels "
-                               "that store straight into the host buffer)",
+                               "compressed stream and decoded output in page-locked host memory, hsrans_hpipe (upload, decode and download of consecutive "
+                               "slices overlapped)",
                    "container": "mt_", "states": S, "bits": bits, "decoded_bytes": n, "compressed_bytes": int(m), "ratio": m / n, "plan_bytes": int(plan.size),
                    "block": args.block, "index_interval_groups": args.interval, "bit_exact": True},
         "decoded_GB_s": world * n / (elapsed / args.steps) / 1e9,

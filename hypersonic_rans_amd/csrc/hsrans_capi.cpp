@@ -31,6 +31,7 @@ struct hsrans_ctx
   DeviceGeom geom{};     // CU count / LDS of THIS context's device (nothing about a device is process-global)
   bool enc_prepared = false;
   std::mutex lock; // guards the staging buffers of the host-pointer entries
+  std::mutex stream_lock; // creation of pipe_streams (hsrans_hpipe_create may run under `lock` or without it)
   hipStream_t stream = nullptr;
   hsrans_dplan *host_dplan = nullptr; // device plan of the host-pointer entries, refilled per call (buffers are kept)
   hsrans_hpipe *cached_pipe = nullptr; // hsrans_decode_host_pipelined: the pipeline of the plan used last
@@ -48,6 +49,10 @@ struct hsrans_ctx
   size_t d_enc_meta_cap = 0;
   uint8_t *d_enc_ck = nullptr; // checkpoint states / cursors of the blocks being encoded
   size_t d_enc_ck_cap = 0;
+  // the three streams of the host pipelines (upload / decode / download): created once and shared by every hsrans_hpipe of the
+  // context.  Streams made per pipe were a trap: the second pipe of a process got streams on ONE hardware queue, its uploads and
+  // kernels ran one after the other, and every codec after the first in the harness read 24-26 instead of 33 GiB/s.
+  hipStream_t pipe_streams[3] = {nullptr, nullptr, nullptr};
   uint8_t *h_pin = nullptr; // page-locked staging of hsrans_decode_device_indexing (checkpoints down, plan blob up); under `lock`
   size_t h_pin_cap = 0;
 };
@@ -334,6 +339,9 @@ void hsrans_ctx_destroy(hsrans_ctx *ctx)
     (void)hipFree(ctx->d_status);
   if (ctx->h_pin)
     (void)hipHostFree(ctx->h_pin);
+  for (hipStream_t st : ctx->pipe_streams)
+    if (st)
+      (void)hipStreamDestroy(st);
   delete ctx;
 }
 
@@ -1614,12 +1622,7 @@ void hsrans_hpipe_destroy(hsrans_hpipe *p)
     (void)hipFree(p->d_stream);
   if (p->d_out)
     (void)hipFree(p->d_out);
-  if (p->up)
-    (void)hipStreamDestroy(p->up);
-  if (p->dec)
-    (void)hipStreamDestroy(p->dec);
-  if (p->down)
-    (void)hipStreamDestroy(p->down);
+  // (up / dec / down belong to the context)
   if (p->h_status)
     (void)hipHostFree(p->h_status);
   delete p;
@@ -1648,9 +1651,18 @@ try
   int rc = HSRANS_E_HIP;
   do
   {
-    if (hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p->dec, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking) != hipSuccess)
-      break;
+    {
+      std::lock_guard<std::mutex> guard(ctx->stream_lock);
+      bool made = true;
+      for (hipStream_t &st : ctx->pipe_streams)
+        if (st == nullptr && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+          made = false;
+      if (!made)
+        break;
+    }
+    p->up = ctx->pipe_streams[0];
+    p->dec = ctx->pipe_streams[1];
+    p->down = ctx->pipe_streams[2];
     // (d_out, the staging buffer of the output, is allocated by the first decode that needs it: a page-locked `out` does not)
     if (hipMalloc((void **)&p->d_stream, (h.stream_len + 15) / 16 * 16 + 16) != hipSuccess ||
         hipHostMalloc((void **)&p->h_status, n_slices * 4, hipHostMallocDefault) != hipSuccess)
@@ -1721,12 +1733,14 @@ size_t hsrans_hpipe_decode(hsrans_hpipe *p, const uint8_t *in, size_t in_length,
   std::lock_guard<std::mutex> guard(p->lock); // a pipe's device buffers, streams and events serve one decode at a time
   if (hipSetDevice(p->ctx->device) != hipSuccess)
     return 0;
-  // Output leg.  Page-locked `out` (the documented way to call this): the decode kernels store STRAIGHT into it — every
-  // wavefront's 256-byte streaming stores cross PCIe themselves, so there is no device-side output buffer pass, no download
-  // copies and nothing for the copy engines to interleave badly (measured at 2^30 bytes: kernel with its output in host memory
-  // 19.6 ms against 18.8 ms for the plain download of the same bytes; staged through d_out with >= 8 slices the two copy
-  // directions serialised: 31 ms).  Pageable or unaligned `out`: staged through d_out and copied down slice by slice.
-  uint8_t *out_view = getenv("HSRANS_HPIPE_STAGED") == nullptr && ((uintptr_t)out & 3) == 0 ? device_view_of_host(out, (size_t)p->hdr.decoded_len) : nullptr;
+  // Output leg: staged through d_out and copied down slice by slice on the third stream, so that the copy engines carry both PCIe
+  // directions at once while the kernels run at HBM speed.  HSRANS_HPIPE_DIRECT=1 (page-locked, 4-byte-aligned `out` only): the
+  // decode kernels store STRAIGHT into it instead — no device-side output buffer, no download copies; every wavefront's streaming
+  // stores cross PCIe themselves.  Measured with the context's shared streams (see hsrans_ctx::pipe_streams — per-pipe streams had
+  // made every comparison before that a comparison of hardware-queue assignments): 2^30 bytes 47.4 GB/s either way; 100 MB
+  // 36.2-38.8 k MiB/s staged against 29.3-33.8 k direct (the 32-state kernels' 128-byte rows make poor PCIe writes), 27.4-30.9 k
+  // for upload, decode, download one after the other.
+  uint8_t *out_view = getenv("HSRANS_HPIPE_DIRECT") != nullptr && ((uintptr_t)out & 3) == 0 ? device_view_of_host(out, (size_t)p->hdr.decoded_len) : nullptr;
   const bool direct = out_view != nullptr;
   if (!direct && p->d_out == nullptr && hipMalloc((void **)&p->d_out, p->hdr.decoded_len + 16) != hipSuccess)
     return 0;

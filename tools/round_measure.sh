@@ -19,7 +19,7 @@ PY
 hypersonic_rans_amd/bin/hsrans_harness /tmp/zipf100.bin --bits 11 --runs 2 --decode-runs 8 --test > $OUT/harness_100mb_11bit.txt 2>&1
 hypersonic_rans_amd/bin/hsrans_harness /tmp/zipf100.bin --bits 14 --only "(raw)" --runs 1 --decode-runs 8 --test > $OUT/harness_100mb_14bit_raw.txt 2>&1
 python tools/host_pipeline_rate.py > $OUT/host_pipeline_1gib.jsonl 2> $OUT/pipeline.err
-HSRANS_HPIPE_STAGED=1 python tools/host_pipeline_rate.py >> $OUT/host_pipeline_1gib.jsonl 2>> $OUT/pipeline.err
+HSRANS_HPIPE_DIRECT=1 python tools/host_pipeline_rate.py >> $OUT/host_pipeline_1gib.jsonl 2>> $OUT/pipeline.err
 python tools/host_decoder_vs_reference.py --size 100000000 --budget 2.0 --cases 32:11,32:12,32:13,32:14,32:15,64:11,64:12,64:13,64:14,64:15 > $OUT/host_decoder_vs_reference.jsonl 2> $OUT/host_decoder.err
 python tools/stamps_grouped.py 2>/dev/null | grep -v amdgpu > $OUT/stamps_grouped_1gib.txt
 python tools/encode_rate.py > $OUT/encode_rate_100mb.jsonl 2> $OUT/encode.err
