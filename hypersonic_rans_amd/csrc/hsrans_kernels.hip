@@ -997,8 +997,8 @@ __device__ __forceinline__ void fast_cursor_close(const FastCursor &f, Ring &r) 
 template <int MODE>
 __device__ __forceinline__ void pair_bind(Ring &ra, Ring &rb, const WaveCtx &c)
 {
-  ring_bind(ra, c.rings, 8, MODE == kModePack64);
-  ring_bind(rb, c.rings + (MODE == kModePack64 ? 1280 : 1152), 8, MODE == kModePack64);
+  ring_bind(ra, c.rings, 8, fast_ring_mode(MODE));
+  ring_bind(rb, c.rings + (fast_ring_mode(MODE) ? 1280 : 1152), 8, fast_ring_mode(MODE));
 }
 
 // One group of both chains (lanes 0..31 chain A, 32..63 chain B; 8-byte table entries), hand-scheduled like HSRANS_FAST_GROUP:
@@ -1059,6 +1059,44 @@ __device__ __forceinline__ uint32_t pair_groups4(uint32_t &x, uint32_t &s_a, uin
   return acc;
 }
 
+// The pair group for the rank table (14 / 15 bits; the table at LDS address 0, both halves use the one table): rank byte, entry,
+// stream word — 12 vector, 3 LDS, 5 scalar instructions
+#define HSRANS_PAIR_GROUP_RANK(P0, P1)                                                                                                               \
+  "v_and_b32 %[g], %[x], %[vmask]\n\t"                                                                                                               \
+  "ds_read_u8 v" #P0 ", %[g]\n\t"                                                                                                                    \
+  "v_lshrrev_b32 %[x], %[vbits], %[x]\n\t"                                                                                                           \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
+  "v_lshl_add_u32 %[t], v" #P0 ", 3, %[sent]\n\t"                                                                                                    \
+  "ds_read_b64 v[" #P0 ":" #P1 "], %[t]\n\t"                                                                                                         \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
+  "v_mad_u32_u24 %[x], v" #P0 ", %[x], v" #P1 "\n\t"                                                                                                 \
+  "v_add_u32 %[x], %[x], %[g]\n\t"                                                                                                                   \
+  "v_cmpx_gt_u32 vcc, %[lim], %[x]\n\t"                                                                                                              \
+  "s_nop 1\n\t"                                                                                                                                      \
+  HSRANS_PAIR_ADDR                                                                                                                                   \
+  "ds_read_u16 %[w], %[w]\n\t"                                                                                                                       \
+  "s_bcnt1_i32_b32 %[st], vcc_lo\n\t"                                                                                                                \
+  "s_lshl1_add_u32 %[sa], %[st], %[sa]\n\t"                                                                                                          \
+  "s_bcnt1_i32_b32 %[st], vcc_hi\n\t"                                                                                                                \
+  "s_lshl1_add_u32 %[sb], %[st], %[sb]\n\t"                                                                                                          \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
+  "v_lshl_or_b32 %[x], %[x], 16, %[w]\n\t"                                                                                                           \
+  "s_mov_b64 exec, -1\n\t"
+
+__device__ __forceinline__ uint32_t pair_groups4_rank(uint32_t &x, uint32_t &s_a, uint32_t &s_b, const WaveCtx &c, uint32_t s_entries)
+{
+  uint32_t acc, t, w, g, st;
+  asm volatile(HSRANS_PAIR_GROUP_RANK(52, 53) HSRANS_PAIR_GROUP_RANK(54, 55) HSRANS_PAIR_GROUP_RANK(56, 57) HSRANS_PAIR_GROUP_RANK(58, 59)
+               "v_perm_b32 %[acc], v54, v52, %[selp]\n\t"
+               "v_perm_b32 %[t], v58, v56, %[selp]\n\t"
+               "v_perm_b32 %[acc], %[t], %[acc], %[selq]"
+               : [x] "+v"(x), [sa] "+s"(s_a), [sb] "+s"(s_b), [acc] "=&v"(acc), [t] "=&v"(t), [w] "=&v"(w), [g] "=&v"(g), [st] "=&s"(st)
+               : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [sent] "s"(s_entries), [lim] "s"(kConsume), [selp] "s"(0x0c0c0703u), [selq] "s"(0x05040100u),
+                 [up] "s"(0xFFFFFFFF00000000ull)
+               : "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "vcc", "scc", "memory");
+  return acc;
+}
+
 // `steps` whole 32-symbol groups of chain A (lanes 0..31, output at oa) and of chain B (lanes 32..63, output at ob)
 template <int MODE, bool FAST = false> // FAST: see run_groups
 __device__ __forceinline__ void run_pair_groups(uint32_t &x, const StreamWin &sw, Ring &ra, Ring &rb, const WaveCtx &c, uint64_t &oa_ref, uint64_t &ob_ref,
@@ -1072,7 +1110,7 @@ __device__ __forceinline__ void run_pair_groups(uint32_t &x, const StreamWin &sw
   const uint32_t sel_b = (c.lane & 2) ? 0x03020706u : 0x05040100u;
   uint8_t *vout = c.out + (c.lane < 32 ? oa : ob) + row * 32 + dcol * 4; // per-lane: this half's output row
   uint32_t done = 0;
-  if (FAST && MODE == kModePack64 && ra.mirror_lanes == 0xFFFFu)
+  if (FAST && ra.mirror_lanes == 0xFFFFu && (MODE == kModePack64 || (MODE == kModeRank && c.table_b == c.table && uni(lds_address(c.table)) == 0)))
   {
     // the hand-scheduled loop; its waits are counted from here on (everything issued before is older than anything it waits for)
     const uint32_t s_table = uni(lds_address(c.table));
@@ -1094,7 +1132,7 @@ __device__ __forceinline__ void run_pair_groups(uint32_t &x, const StreamWin &sw
     };
     for (; iters != 0; iters--)
     {
-      const uint32_t acc = quad_transpose(pair_groups4(x, fa.addr, fb.addr, c, s_table), sel_a, sel_b);
+      const uint32_t acc = quad_transpose(MODE == kModeRank ? pair_groups4_rank(x, fa.addr, fb.addr, c, 1u << c.bits) : pair_groups4(x, fa.addr, fb.addr, c, s_table), sel_a, sel_b);
       asm volatile("global_store_dword %0, %1, off nt" : : "v"(vout), "v"(acc) : "memory");
       vout += 128;
       if (fa.addr >= fa.next_cross)
