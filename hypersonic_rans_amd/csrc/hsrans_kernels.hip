@@ -2382,9 +2382,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
 
 // The same for uniform-interval raw plans with the 8-byte table (run_persistent / run_persistent_pair): in a kernel of their own
 // the 32-state pair loop can be the hand-scheduled one as well (inside k_decode<3, true> its pinned registers mean scratch).
+template <int MODE> // kModePack64, kModeRank (14 / 15 bits)
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_decode_persist(KParams kp)
 {
-  constexpr int MODE = kModePack64;
   extern __shared__ u32x4 smem_v[];
   uint8_t *smem = (uint8_t *)smem_v;
   const uint32_t waves = blockDim.x >> 6;
@@ -2401,12 +2401,13 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.lane = threadIdx.x & 63;
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
-  c.rings = smem + wave * kFastRingBytes;
-  c.table = smem + waves * kFastRingBytes;
+  uint8_t *ring0 = table_first_mode(MODE) ? smem + table_bytes_for(MODE, c.bits) : smem;
+  c.rings = ring0 + wave * kFastRingBytes;
+  c.table = table_first_mode(MODE) ? smem : smem + waves * kFastRingBytes;
   c.table_b = c.table;
   c.gtable = kp.pa.table;
-  c.scratch_cnt = (uint16_t *)smem;
-  c.scratch_cum = (uint16_t *)(smem + 512);
+  c.scratch_cnt = (uint16_t *)ring0;
+  c.scratch_cum = (uint16_t *)(ring0 + 512);
   const uint32_t chain = blockIdx.x * waves + wave;
   if (c.S == 32)
     run_persistent_pair<MODE, true>(c, kp, waves, chain);
@@ -3492,7 +3493,7 @@ hipError_t prepare_kernels(DeviceGeom *geom)
       if (e != hipSuccess)
         return e;
     }
-  for (KernelFn fn : {(KernelFn)k_decode_single, (KernelFn)k_decode_persist, (KernelFn)k_calibrate, (KernelFn)k_decode_dual<kModePack64>, (KernelFn)k_decode_dual<kModeRank>, (KernelFn)k_decode_direct<kModePack>, (KernelFn)k_decode_direct<kModePackM1>,
+  for (KernelFn fn : {(KernelFn)k_decode_single, (KernelFn)k_decode_persist<kModePack64>, (KernelFn)k_decode_persist<kModeRank>, (KernelFn)k_calibrate, (KernelFn)k_decode_dual<kModePack64>, (KernelFn)k_decode_dual<kModeRank>, (KernelFn)k_decode_direct<kModePack>, (KernelFn)k_decode_direct<kModePackM1>,
                       (KernelFn)k_decode_direct<kModeTwoLevel>, (KernelFn)k_decode_direct<kModePack64>, (KernelFn)k_decode_direct<kModeRank>, (KernelFn)k_decode_direct<kModeSpill>,
                       (KernelFn)k_decode_grouped<kModePack, false>, (KernelFn)k_decode_grouped<kModePackM1, false>, (KernelFn)k_decode_grouped<kModeTwoLevel, false>,
                       (KernelFn)k_decode_grouped<kModePack64, false>, (KernelFn)k_decode_grouped<kModeTwoLevel, true>, (KernelFn)k_decode_grouped<kModePack64, true>,
@@ -3746,8 +3747,8 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
   KernelFn fn = kernel_for(L.mode, L.shared);
   if (L.dual)
     fn = L.mode == kModeRank ? (KernelFn)k_decode_dual<kModeRank> : (KernelFn)k_decode_dual<kModePack64>;
-  else if (persistent && kp.pa.interval != 0 && L.shared && L.mode == kModePack64 && !index_pass && g_persist_kernel)
-    fn = k_decode_persist;
+  else if (persistent && kp.pa.interval != 0 && L.shared && (L.mode == kModePack64 || L.mode == kModeRank) && kp.pa.table != nullptr && !index_pass && g_persist_kernel)
+    fn = L.mode == kModeRank ? (KernelFn)k_decode_persist<kModeRank> : (KernelFn)k_decode_persist<kModePack64>;
 
   else if (grouped && L.shared)
     switch (L.mode)

@@ -57,7 +57,7 @@ def test_shared_table_decode_occupancy():
     for name, r in grouped.items():
         assert r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] == 8, (name, r)
     persist = [r for name, r in kernels.items() if "k_decode_persist" in name]
-    assert len(persist) == 1 and persist[0]["VGPRs"] <= 64 and persist[0]["Occupancy [waves/SIMD]"] == 8, persist
+    assert len(persist) == 2 and all(r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] == 8 for r in persist), persist  # 8-byte table and rank table
 
 
 # ---------------------------------------------------------------------------------------------------------------
