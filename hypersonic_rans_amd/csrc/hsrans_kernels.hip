@@ -774,6 +774,7 @@ __device__ __forceinline__ uint32_t fast_groups4_rank(uint32_t &x, uint32_t &s_a
 // issued (another ring's requests), which only makes "at most n outstanding" stricter than needed.  One asm statement with
 // t1 / t2 tied to their registers: left to the compiler, the count became an induction variable of its own (a v_add and a
 // v_readfirstlane per iteration) and the rotation of the marks put register moves on the path WITHOUT a crossing.
+// n >= 3 always (a store precedes every crossing); 3 only at a chain's first crossings, whose requests ring_begin made in one go.
 __device__ __forceinline__ void wait_after_crossing(uint32_t &t1, uint32_t &t2, uint32_t iters, uint32_t k3)
 {
   static_assert(HSRANS_RING_AHEAD == 3 || HSRANS_RING_AHEAD == 2, "");
@@ -790,6 +791,11 @@ __device__ __forceinline__ void wait_after_crossing(uint32_t &t1, uint32_t &t2, 
                "s_cbranch_scc1 8f\n\t"
                "s_cmp_ge_u32 %[n], 6\n\t"
                "s_cbranch_scc1 6f\n\t"
+               "s_cmp_ge_u32 %[n], 4\n\t"
+               "s_cbranch_scc1 4f\n\t"
+               "s_waitcnt vmcnt(3)\n\t"
+               "s_branch 9f\n"
+               "4:\n\t"
                "s_waitcnt vmcnt(4)\n\t"
                "s_branch 9f\n"
                "6:\n\t"
@@ -838,11 +844,8 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
   // iteration counts (they run down) at the last two crossings; at entry: as if both had just happened, i.e. the first two waits
   // count no stores — stricter than needed by what was stored before this loop, never weaker
   uint32_t t1 = iters, t2 = iters;
-  // Both waits lean on the steady state: two crossings behind the current one, each with a store in front of it.  A chain's first
-  // two crossings have no such past — ring_begin asked for chunks 0..3 in one go, nothing in between — so a loop entered before
-  // them makes sure of chunks 2 and 3 here, once per chain (they were requested with chunk 1, which has landed)
-  if (r.k < 2)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (The constant wait leans on the steady state: two crossings behind the current one, each with a store in front of it.  A
+  // chain's first crossings have no such past — ring_begin asked for chunks 0..3 in one go — and wait for one operation more.)
   for (; iters != 0; iters--)
   {
     const uint32_t acc = quad_transpose(MODE == kModeRank ? fast_groups4_rank(x, s_addr, c, 1u << c.bits) : fast_groups4(x, s_addr, c, s_table), ol.sel_a, ol.sel_b);
@@ -863,7 +866,9 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
         wait_after_crossing(t1, t2, iters, r.k + HSRANS_RING_AHEAD);
       else
       {
-        if (HSRANS_RING_AHEAD == 3)
+        if (HSRANS_RING_AHEAD == 3 && r.k <= 2)
+          asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); // (the chain's first crossings: behind the request in question only the next one, one store, this one)
+        else if (HSRANS_RING_AHEAD == 3)
           asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else
           asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); // (request k + 2 and one store)
@@ -1119,8 +1124,6 @@ __device__ __forceinline__ void run_pair_groups(uint32_t &x, const StreamWin &sw
     uint32_t iters = (steps - done) >> 2;
     done += iters * 4;
     uint32_t ta1 = iters, ta2 = iters, tb1 = iters, tb2 = iters;
-    if (ra.k < 2 || rb.k < 2) // (a chain's first two crossings: see run_groups_fast)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     auto crossed = [&](FastCursor &f, Ring &r, uint32_t &t1, uint32_t &t2) {
       fast_cursor_cross(f, r);
       ring_request(sw, r, c, r.k + HSRANS_RING_AHEAD);
