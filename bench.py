@@ -488,8 +488,8 @@ def sharded_workload(args, world, rank, dv: _Dev, dist):
                 "out_bytes_held": dec.out_len, "stream_ms" if not split_legs else "decode_ms": dec_ms}
         if split_legs:
             mine["gather_ms"] = gat_ms
-        if not dv.rehearse and getattr(dec, "dplan", None) is not None:
-            mine["launch"] = dec.dplan.launch_info()  # kernel geometry of the rank's last launch (grid, LDS, class weights, dynamic block order)
+        if not dv.rehearse and dec.launch_info() is not None:
+            mine["launch"] = dec.launch_info()  # kernel geometry of what step() launched: the rank's first sub-run (grid, LDS, class weights, dynamic block order)
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         ms = elapsed * 1e3 / steps

@@ -307,7 +307,11 @@ int hsrans_ctx_create(int device, hsrans_ctx **out_ctx)
   // call hsrans_ctx_calibrate themselves, e.g. the drop-in entries, which create their one context on first use)
   if (const char *e = getenv("HSRANS_CALIBRATE"))
     if (atoi(e) != 0)
-      (void)hsrans_ctx_calibrate(ctx, 11, 0, nullptr);
+    {
+      const int crc = hsrans_ctx_calibrate(ctx, 11, 0, nullptr); // (a failed fit leaves the compiled-in lengths in place: the context is still usable)
+      if (crc != HSRANS_OK)
+        fprintf(stderr, "hsrans: HSRANS_CALIBRATE=1: hsrans_ctx_calibrate failed (code %d); the compiled-in class lengths stay in use\n", crc);
+    }
   *out_ctx = ctx;
   return HSRANS_OK;
 }
@@ -389,7 +393,7 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
   const bool mergeable_raw = (h.flags & kPlanMergeable) && h.container == HSRANS_RAW;
   const bool may_group = !(h.flags & (kPlanWalk | kPlanMergeable)) && h.n_chains > 1;
   const size_t counter_bytes = (size_t)kCounterSets * kDynQueues * kDynQueueStride * 8;
-  const bool need_counters = (mergeable_raw && h.interval != 0) || may_group; // (one-chain-per-wave plans draw nothing)
+  const bool need_counters = mergeable_raw || may_group; // (one-chain-per-wave plans draw tickets for their pool of short chains, if they have one)
   auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t table_bound = mergeable_raw && (h.flags & kPlanHasHist) ? up256(std::max<size_t>((size_t)8 << h.bits, rank_table_entries(h.bits >= 13 ? h.bits : 13) * 8)) : 0;
   const size_t group_bound = may_group ? up256(((size_t)h.n_chains + 16) * sizeof(Group)) : 0;
@@ -998,8 +1002,10 @@ static int launch_ranges(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_window,
   if (hipSetDevice(ctx->device) != hipSuccess)
     return HSRANS_E_HIP;
   const uint64_t end = std::min<uint64_t>((uint64_t)window_offset + window_length, d->hdr.stream_len);
-  return dplan_launch(d, (const uint8_t *)d_window - window_offset, (size_t)end, (uint8_t *)d_out - out_offset, (size_t)d->hdr.decoded_len, (hipStream_t)hip_stream,
-                      window_offset);
+  // (the kernels' own bound on the output is the end of the caller's window, not of the whole output: a path that rounded a store
+  // up past a chain's end must not reach past a rank's smaller buffer either)
+  const uint64_t out_end = std::min<uint64_t>((uint64_t)out_offset + out_length, d->hdr.decoded_len);
+  return dplan_launch(d, (const uint8_t *)d_window - window_offset, (size_t)end, (uint8_t *)d_out - out_offset, (size_t)out_end, (hipStream_t)hip_stream, window_offset);
 }
 
 int hsrans_decode_device_window(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_window, size_t window_offset, size_t window_length, void *d_out,
@@ -1834,9 +1840,11 @@ size_t hsrans_decode_host_pipelined(hsrans_ctx *ctx, int container, int states, 
       h.decoded_len > out_capacity)
     return 0;
   // The pipeline (slice plans on the device, streams, buffers) is kept for the plan seen last, recognised by address, size and
-  // a checksum over the header, 64 bytes of every 4 KiB and the last 64 bytes (a whole-plan checksum cost more than the decode
-  // it guards: 2.5 ms for the 12.9 MB index of a 100 MB stream).  A different plan of the same size at the same address differs
-  // in its start states (random 32-bit words) at every sample; whatever plan a pipe holds was validated when the pipe was made.
+  // a checksum over EVERYTHING the kernels take an address or a length from — header, chain table and piece records, all of them
+  // (a plan rewritten in place that differs in one words_off / out_off must not meet the old slice plans: ADVICE r3) — and, of
+  // the start states behind them (most of the blob: random 32-bit words), 64 bytes of every 4 KiB and the last 64 bytes (a
+  // whole-plan checksum cost more than the decode it guards: 2.5 ms for the 12.9 MB index of a 100 MB stream; the records of
+  // that index are 2.5 MB).  Whatever plan a pipe holds was validated when the pipe was made.
   uint64_t sum = 0x9E3779B97F4A7C15ull ^ n_slices;
   auto mix = [&](size_t from, size_t to) {
     for (size_t i = from; i + 8 <= to; i += 8)
@@ -1846,7 +1854,9 @@ size_t hsrans_decode_host_pipelined(hsrans_ctx *ctx, int container, int states, 
       sum = (sum ^ v) * 0x100000001B3ull + (sum >> 29);
     }
   };
-  for (size_t at = 0; at < plan_size; at += 4096)
+  const size_t records_end = std::min(plan_size, (size_t)plan_states_off(h.n_chains, h.n_pieces));
+  mix(0, records_end);
+  for (size_t at = records_end & ~(size_t)7; at < plan_size; at += 4096)
     mix(at, std::min(at + 64, plan_size));
   mix(plan_size >= 64 ? plan_size - 64 : 0, plan_size);
   std::lock_guard<std::mutex> guard(ctx->lock);
@@ -1912,14 +1922,41 @@ try
   const size_t stream_len = encode(HSRANS_RAW, 64, bits, data.data(), n, stream.data(), stream.size(), nullptr, nullptr);
   if (stream_len == 0)
     return HSRANS_E_FORMAT;
-  uint8_t *d_stream = nullptr, *d_out = nullptr;
-  uint64_t *d_finish = nullptr;
+  // Scope guards first: whatever leaves this function — a return, or an exception on its way to the handler below (bad_alloc from
+  // one of the vectors) — frees the device buffers, destroys the plan of the iteration in flight and puts the context's launch
+  // geometry back (the iterations overwrite it with trial lengths).  The context's lock is held throughout: other entries read
+  // ctx->geom (hsrans_index_boundaries, every launch_shape).
+  std::lock_guard<std::mutex> calibration_guard(ctx->lock);
+  struct DeviceBuffers
+  {
+    uint8_t *stream = nullptr, *out = nullptr;
+    uint64_t *finish = nullptr;
+    hsrans_dplan *dplan = nullptr;
+    ~DeviceBuffers()
+    {
+      if (dplan)
+        hsrans_dplan_destroy(dplan);
+      if (stream)
+        (void)hipFree(stream);
+      if (out)
+        (void)hipFree(out);
+      if (finish)
+        (void)hipFree(finish);
+    }
+  } dev;
+  struct GeomRestore
+  {
+    hsrans_ctx *ctx;
+    DeviceGeom saved;
+    ~GeomRestore() { ctx->geom = saved; }
+  } geom_restore{ctx, ctx->geom};
+  uint8_t *&d_stream = dev.stream, *&d_out = dev.out;
+  uint64_t *&d_finish = dev.finish;
   std::vector<uint64_t> groups(1 << 16), finish;
   std::vector<uint8_t> plan(plan_capacity_chains(HSRANS_RAW, 64, n, 1 << 14, 0));
   uint32_t best_w[8] = {}, cur_w[8];
   double best_last = 1e30, first_last = 0, first_spread = 0, best_spread = 0;
   int rc = HSRANS_E_HIP;
-  const DeviceGeom saved = ctx->geom;
   do
   {
     if (hipMalloc((void **)&d_stream, (stream_len + 15) / 16 * 16 + 16) != hipSuccess || hipMalloc((void **)&d_out, n) != hipSuccess ||
@@ -1953,7 +1990,7 @@ try
         break;
       }
       const size_t plan_len = cpu::index_build(cpu::best_level(), 1, HSRANS_RAW, 64, bits, stream.data(), stream_len, groups.data(), chains - 1, plan.data(), plan.size());
-      hsrans_dplan *dp = nullptr;
+      hsrans_dplan *&dp = dev.dplan; // (owned by the guard until the iteration hands it back)
       if (plan_len == 0 || hsrans_dplan_create(ctx, plan.data(), plan_len, &dp) != HSRANS_OK)
       {
         failed = true;
@@ -1962,7 +1999,6 @@ try
       const uint32_t W = (uint32_t)chains; // one chain per wave
       if (W > (1u << 14)) // (the finish-time buffer below is sized for 16,384 waves: twice an MI355X)
       {
-        hsrans_dplan_destroy(dp);
         failed = true;
         break;
       }
@@ -1998,6 +2034,7 @@ try
       dp->d_finish = nullptr;
       uint32_t status_ok = hsrans_dplan_status(ctx, dp, nullptr) == HSRANS_OK;
       hsrans_dplan_destroy(dp);
+      dp = nullptr;
       if (failed || !status_ok)
       {
         failed = true;
@@ -2031,18 +2068,11 @@ try
       break;
     rc = HSRANS_OK;
   } while (false);
-  if (d_stream)
-    (void)hipFree(d_stream);
-  if (d_out)
-    (void)hipFree(d_out);
-  if (d_finish)
-    (void)hipFree(d_finish);
-  ctx->geom = saved;
   if (rc == HSRANS_OK)
   {
-    ctx->geom.have_direct_weights = 1;
+    geom_restore.saved.have_direct_weights = 1; // (what the guard puts back: the geometry as it was, with the fitted lengths)
     for (int k = 0; k < 8; k++)
-      ctx->geom.direct_weights[k] = best_w[k];
+      geom_restore.saved.direct_weights[k] = best_w[k];
     if (report)
     {
       for (int k = 0; k < 8; k++)

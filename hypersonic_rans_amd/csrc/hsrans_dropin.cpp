@@ -130,6 +130,10 @@ size_t mt_rANS32x64_16w_capacity(const size_t n) { return hsrans_capacity(HSRANS
   }                                                                                                                                                \
   size_t rANS32x##S##_16w_decode_hip_##N(const uint8_t *i, const size_t l, uint8_t *o, const size_t c) { return decode_any(HSRANS_RAW, S, N, i, l, o, c); } \
   size_t rANS32x##S##_16w_decode_auto_##N(const uint8_t *i, const size_t l, uint8_t *o, const size_t c) { return decode_auto(HSRANS_RAW, S, N, i, l, o, c); } \
+  /* the reference's own decoder names (rANS32x64_16w.h:48, block_rANS32x64_16w.h:19, mt_rANS32x64_16w.h:20): the runtime-dispatch route */            \
+  size_t rANS32x##S##_16w_decode_scalar_##N(const uint8_t *i, const size_t l, uint8_t *o, const size_t c) { return decode_auto(HSRANS_RAW, S, N, i, l, o, c); } \
+  size_t block_rANS32x##S##_16w_decode_##N(const uint8_t *i, const size_t l, uint8_t *o, const size_t c) { return decode_auto(HSRANS_BLOCK, S, N, i, l, o, c); } \
+  size_t mt_rANS32x##S##_16w_decode_##N(const uint8_t *i, const size_t l, uint8_t *o, const size_t c) { return decode_auto(HSRANS_MT, S, N, i, l, o, c); } \
   size_t block_rANS32x##S##_16w_decode_auto_##N(const uint8_t *i, const size_t l, uint8_t *o, const size_t c) { return decode_auto(HSRANS_BLOCK, S, N, i, l, o, c); } \
   size_t mt_rANS32x##S##_16w_decode_auto_##N(const uint8_t *i, const size_t l, uint8_t *o, const size_t c) { return decode_auto(HSRANS_MT, S, N, i, l, o, c); } \
   size_t block_rANS32x##S##_16w_encode_##N(const uint8_t *i, const size_t l, uint8_t *o, const size_t c)                                           \
@@ -145,7 +149,7 @@ size_t mt_rANS32x64_16w_capacity(const size_t n) { return hsrans_capacity(HSRANS
     return hsrans_encode(HSRANS_MT, S, N, i, l, o, c, nullptr);                                                                                    \
   }                                                                                                                                                \
   size_t mt_rANS32x##S##_16w_decode_hip_##N(const uint8_t *i, const size_t l, uint8_t *o, const size_t c) { return decode_any(HSRANS_MT, S, N, i, l, o, c); } \
-  size_t mt_rANS32x##S##_16w_decode_mt_##N(const uint8_t *i, const size_t l, uint8_t *o, const size_t c, thread_pool *) { return decode_any(HSRANS_MT, S, N, i, l, o, c); } \
+  size_t mt_rANS32x##S##_16w_decode_mt_##N(const uint8_t *i, const size_t l, uint8_t *o, const size_t c, thread_pool *) { return decode_auto(HSRANS_MT, S, N, i, l, o, c); } \
   HSRANS_DEF_INDEXED(rANS32x##S##_16w, HSRANS_RAW, S, N)                                                                                           \
   HSRANS_DEF_INDEXED(block_rANS32x##S##_16w, HSRANS_BLOCK, S, N)                                                                                   \
   HSRANS_DEF_INDEXED(mt_rANS32x##S##_16w, HSRANS_MT, S, N)
@@ -159,3 +163,38 @@ HSRANS_DEF_BITS(14)
 HSRANS_DEF_BITS(15)
 
 } // namespace hsrans_hip
+
+// ---- include/hsrans_names.h: the same entries with C linkage, hsrans_<reference name> ------------------------------------------
+#include "../../include/hsrans_names.h"
+extern "C" {
+size_t hsrans_rANS32x32_16w_capacity(size_t n) { return hsrans_capacity(HSRANS_RAW, 32, n); }
+size_t hsrans_rANS32x64_16w_capacity(size_t n) { return hsrans_capacity(HSRANS_RAW, 64, n); }
+size_t hsrans_block_rANS32x32_16w_capacity(size_t n) { return hsrans_capacity(HSRANS_BLOCK, 32, n); }
+size_t hsrans_block_rANS32x64_16w_capacity(size_t n) { return hsrans_capacity(HSRANS_BLOCK, 64, n); }
+size_t hsrans_mt_rANS32x32_16w_capacity(size_t n) { return hsrans_capacity(HSRANS_MT, 32, n); }
+size_t hsrans_mt_rANS32x64_16w_capacity(size_t n) { return hsrans_capacity(HSRANS_MT, 64, n); }
+#define HSRANS_C_DEF(S, N)                                                                                                                        \
+  size_t hsrans_rANS32x##S##_16w_encode_scalar_##N(const uint8_t *i, size_t l, uint8_t *o, size_t c, const hsrans_hist *h)                         \
+  {                                                                                                                                                \
+    return hsrans_hip::rANS32x##S##_16w_encode_scalar_##N(i, l, o, c, h);                                                                           \
+  }                                                                                                                                                \
+  size_t hsrans_rANS32x##S##_16w_decode_scalar_##N(const uint8_t *i, size_t l, uint8_t *o, size_t c) { return hsrans_hip::rANS32x##S##_16w_decode_scalar_##N(i, l, o, c); } \
+  size_t hsrans_rANS32x##S##_16w_decode_hip_##N(const uint8_t *i, size_t l, uint8_t *o, size_t c) { return hsrans_hip::rANS32x##S##_16w_decode_hip_##N(i, l, o, c); } \
+  size_t hsrans_block_rANS32x##S##_16w_encode_##N(const uint8_t *i, size_t l, uint8_t *o, size_t c) { return hsrans_hip::block_rANS32x##S##_16w_encode_##N(i, l, o, c); } \
+  size_t hsrans_block_rANS32x##S##_16w_decode_##N(const uint8_t *i, size_t l, uint8_t *o, size_t c) { return hsrans_hip::block_rANS32x##S##_16w_decode_##N(i, l, o, c); } \
+  size_t hsrans_block_rANS32x##S##_16w_decode_hip_##N(const uint8_t *i, size_t l, uint8_t *o, size_t c) { return hsrans_hip::block_rANS32x##S##_16w_decode_hip_##N(i, l, o, c); } \
+  size_t hsrans_mt_rANS32x##S##_16w_encode_##N(const uint8_t *i, size_t l, uint8_t *o, size_t c) { return hsrans_hip::mt_rANS32x##S##_16w_encode_##N(i, l, o, c); } \
+  size_t hsrans_mt_rANS32x##S##_16w_decode_##N(const uint8_t *i, size_t l, uint8_t *o, size_t c) { return hsrans_hip::mt_rANS32x##S##_16w_decode_##N(i, l, o, c); } \
+  size_t hsrans_mt_rANS32x##S##_16w_decode_hip_##N(const uint8_t *i, size_t l, uint8_t *o, size_t c) { return hsrans_hip::mt_rANS32x##S##_16w_decode_hip_##N(i, l, o, c); } \
+  size_t hsrans_mt_rANS32x##S##_16w_decode_mt_##N(const uint8_t *i, size_t l, uint8_t *o, size_t c, void *pool)                                   \
+  {                                                                                                                                                \
+    return hsrans_hip::mt_rANS32x##S##_16w_decode_mt_##N(i, l, o, c, (thread_pool *)pool);                                                          \
+  }
+#define HSRANS_C_DEF_BITS(N) HSRANS_C_DEF(32, N) HSRANS_C_DEF(64, N)
+HSRANS_C_DEF_BITS(10)
+HSRANS_C_DEF_BITS(11)
+HSRANS_C_DEF_BITS(12)
+HSRANS_C_DEF_BITS(13)
+HSRANS_C_DEF_BITS(14)
+HSRANS_C_DEF_BITS(15)
+} // extern "C"

@@ -194,6 +194,9 @@ struct Ring
   // operations of a wave complete in issue order, so "chunk k+1 has landed" == at most (vm - seq1) operations outstanding.
   // Operations the compiler issues on its own are not counted: that only makes a wait stricter than needed, never weaker.
   uint32_t vm, seq1, seq2, seq3;
+#if HSRANS_HAVE_STAMPS
+  uint32_t diag_wait = 0, diag_store = 0; // diagnostic build: shader clocks spent in the crossing waits / issuing the output stores (run_groups_fast)
+#endif
 };
 
 // clog = 9: 2 KiB ring + 128 B mirror (a group reads <= 64 words); clog = 8: 1 KiB ring + 64 B mirror (<= 32 words)
@@ -622,6 +625,9 @@ __device__ __forceinline__ OutLanes out_lanes(uint32_t lane, uint32_t S)
   const uint32_t row = lane & 3, quad = lane >> 2;
   const uint32_t dcol = (quad & 8) | ((quad & 1) << 2) | ((quad & 6) >> 1); // dword column of this quad = lane_to_byte(lane) >> 2
   ol.store_off = row * S + dcol * 4;
+#if defined(HSRANS_DIAG_LINEAR_STORES) // diagnostic build (wrong output order!): what would the launch cost if lane L stored dword L of the 256-byte row?
+  ol.store_off = lane * 4;
+#endif
   ol.sel_a = (lane & 1) ? 0x03070105u : 0x06020400u;
   ol.sel_b = (lane & 2) ? 0x03020706u : 0x05040100u;
   return ol;
@@ -844,15 +850,47 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
   // iteration counts (they run down) at the last two crossings; at entry: as if both had just happened, i.e. the first two waits
   // count no stores — stricter than needed by what was stored before this loop, never weaker
   uint32_t t1 = iters, t2 = iters;
+#if defined(HSRANS_DIAG_WIDE_STORES)
+  uint32_t dw0 = 0, dw1 = 0, dw2 = 0;
+#endif
   // (The constant wait leans on the steady state: two crossings behind the current one, each with a store in front of it.  A
   // chain's first crossings have no such past — ring_begin asked for chunks 0..3 in one go — and wait for one operation more.)
   for (; iters != 0; iters--)
   {
     const uint32_t acc = quad_transpose(MODE == kModeRank ? fast_groups4_rank(x, s_addr, c, 1u << c.bits) : fast_groups4(x, s_addr, c, s_table), ol.sel_a, ol.sel_b);
+#if HSRANS_HAVE_STAMPS && defined(HSRANS_DIAG_STORE_TIME)
+    const uint64_t ds0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+#if defined(HSRANS_DIAG_WIDE_STORES) // diagnostic build (wrong byte order!): the same bytes as ONE 1 KiB store per 16 groups (16 B per lane) instead of four 256-byte ones
+    {
+      const uint32_t ph = iters & 3;
+      if (ph == 3)
+        dw0 = acc;
+      else if (ph == 2)
+        dw1 = acc;
+      else if (ph == 1)
+        dw2 = acc;
+      else
+      {
+        u32x4 v4 = {dw0, dw1, dw2, acc};
+        asm volatile("global_store_dwordx4 %0, %1, %2 offset:-768 nt" : : "v"(c.lane * 16), "v"(v4), "s"((uint8_t *)uni64((uint64_t)(uintptr_t)outp)) : "memory");
+      }
+    }
+#elif !defined(HSRANS_DIAG_NO_STORES)
     HSRANS_STORE_U32_SADDR((uint8_t *)uni64((uint64_t)(uintptr_t)outp), ol.store_off, acc);
+#else
+    asm volatile("" ::"v"(acc)); // (diagnostic build: what does the launch cost without its output stores?  The waits below then count one operation too many: stricter)
+#endif
+#if HSRANS_HAVE_STAMPS && defined(HSRANS_DIAG_STORE_TIME)
+    r.diag_store += (uint32_t)(__builtin_amdgcn_s_memtime() - ds0);
+#endif
     outp += 256;
     if (s_addr >= next_cross) // entered the next chunk (at most one per 4 groups: they take <= 512 bytes)
     {
+#if HSRANS_HAVE_STAMPS
+      const uint64_t dw0 = __builtin_amdgcn_s_memtime();
+#endif
       r.k++;
       next_cross += kChunkBytes;
       if (s_addr >= r.lds + kRingBytes) // ... which was slot 0, read through the mirror so far: back to the ring proper
@@ -862,6 +900,13 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
         moved += kRingBytes;
       }
       ring_request(sw, r, c, r.k + HSRANS_RING_AHEAD);
+#if defined(HSRANS_DIAG_WIDE_STORES)
+      // younger than the request for chunk k + 1: the requests for k + 2 and k + 3 and at least one of the (rarer) stores
+      if (r.k <= 2)
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#else
       if (!STRICT && HSRANS_RING_AHEAD == 3)
         wait_after_crossing(t1, t2, iters, r.k + HSRANS_RING_AHEAD);
       else
@@ -873,6 +918,10 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
         else
           asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); // (request k + 2 and one store)
       }
+#endif
+#if HSRANS_HAVE_STAMPS
+      r.diag_wait += (uint32_t)(__builtin_amdgcn_s_memtime() - dw0);
+#endif
     }
   }
   r.cur = words0 + ((s_addr + moved - s_addr0) >> 1);
@@ -1476,6 +1525,9 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
   const uint64_t t_entry = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;
   const uint64_t c_entry = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memtime() : 0; // shader clock (diagnostics: what does the chip run at under this load?)
   uint64_t t_table = 0, t_ready = 0, t_static = 0;
+#if HSRANS_HAVE_STAMPS
+  uint32_t diag_wait = 0, diag_store = 0;
+#endif
   const bool host_table = (MODE == kModePack64 || MODE == kModeRank || MODE == kModeSpill) && pa.table != nullptr;
   if (kp.finish != nullptr && w == 0 && c.lane == 0) // calibration launches: the launch's time zero
     kp.finish[W] = __builtin_amdgcn_s_memrealtime();
@@ -1547,6 +1599,9 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
       uint32_t steps = d.steps;
       run_groups<MODE, true>(x, sw, r, c, o, steps);
       run_tail<MODE>(x, r, c, o, d.tail);
+#if HSRANS_HAVE_STAMPS
+      diag_wait += r.diag_wait, diag_store += r.diag_store;
+#endif
     }
     if (HSRANS_STAMPS(kp) && t_static == 0)
       t_static = __builtin_amdgcn_s_memrealtime();
@@ -1585,6 +1640,9 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
     uint32_t hw_id, xcc_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_id), "=s"(xcc_id));
     st[6] = (uint64_t)hw_id | ((uint64_t)xcc_id << 32);
+#if HSRANS_HAVE_STAMPS
+    st[7] = (uint64_t)diag_wait | ((uint64_t)diag_store << 32); // shader clocks waiting at chunk crossings | issuing stores (-DHSRANS_DIAG_STORE_TIME)
+#endif
   }
 }
 
@@ -3635,8 +3693,9 @@ size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, u
   // (at most W / 2 of them: on big streams they get longer instead of more numerous, the index stays <= 1.5 chains per wave)
   uint64_t dyn_unit = g_direct_dyn_groups / 4 ? g_direct_dyn_groups / 4 : 1;
   const uint64_t dyn_units_total = all_units * g_direct_dyn_permille / 1000;
-  if (dyn_units_total / dyn_unit > W / 2)
-    dyn_unit = (dyn_units_total + W / 2 - 1) / (W / 2);
+  const uint64_t dyn_max = getenv("HSRANS_DIRECT_DYN_MAX") ? (uint64_t)atoll(getenv("HSRANS_DIRECT_DYN_MAX")) : W / 2;
+  if (dyn_units_total / dyn_unit > dyn_max)
+    dyn_unit = (dyn_units_total + dyn_max - 1) / dyn_max;
   uint64_t n_dyn = chains == W * runs_per_wave ? dyn_units_total / dyn_unit : 0;
   if (n_dyn * dyn_unit + chains * 8 > all_units)
     n_dyn = 0;

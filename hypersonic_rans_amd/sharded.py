@@ -179,14 +179,14 @@ class ShardedDecoder:
         self.total, self.stream_len = self.layout.total, self.layout.stream_len
         self.first, self.count = self.runs[self.rank]
         self.window = self.layout.windows[self.rank]
-        self.dplan = None
-        self.part_dplans = []
-        if self.count:
-            self.dplan = ctx.make_device_plan(api.plan_slice(plan, self.first, self.count))
-            if self.layout.parts > 1:
-                self.part_dplans = [ctx.make_device_plan(api.plan_slice(plan, f, c)) if c else None for f, c in self.layout.sub_runs[self.rank]]
-            else:
-                self.part_dplans = [self.dplan]
+        # device plans: one per sub-run (what step() launches); the plan of the rank's WHOLE run is only made when decode() /
+        # decode_window() ask for it (with parts > 1 nothing launches it: building and uploading it would cost HBM and set-up time)
+        self._plan = plan
+        self._dplan = None
+        if self.count and self.layout.parts > 1:
+            self.part_dplans = [ctx.make_device_plan(api.plan_slice(plan, f, c)) if c else None for f, c in self.layout.sub_runs[self.rank]]
+        elif self.count:
+            self.part_dplans = [self.dplan]
         else:
             self.part_dplans = [None] * self.layout.parts
         # the output bytes this rank has to hold: everything, or (root gathers, this rank is not the root) its own range
@@ -194,6 +194,18 @@ class ShardedDecoder:
         if root is not None and self.rank != root:
             b, e = self.ranges[self.rank]
             self.out_base, self.out_len = b, e - b
+
+    @property
+    def dplan(self):
+        """Device plan of this rank's whole chain run (None for a rank without chains), made on first use."""
+        if self._dplan is None and self.count:
+            self._dplan = self.ctx.make_device_plan(api.plan_slice(self._plan, self.first, self.count))
+        return self._dplan
+
+    def launch_info(self) -> dict | None:
+        """Kernel geometry of what step() launches on this rank: the first sub-run's device plan (None: a rank without chains)."""
+        dp = next((p for p in self.part_dplans if p is not None), None)
+        return dp.launch_info() if dp is not None else None
 
     def alloc_out(self, device) -> torch.Tensor:
         return torch.zeros(max(self.out_len, 4), dtype=torch.uint8, device=device)
@@ -245,7 +257,7 @@ class ShardedDecoder:
     def status_tensor(self, device) -> torch.Tensor:
         """This rank's device status words OR-ed into one int32 tensor on `device` (no host round trip beyond the per-plan reads)."""
         st = 0
-        for dp in {id(p): p for p in [self.dplan, *self.part_dplans] if p is not None}.values():
+        for dp in {id(p): p for p in [self._dplan, *self.part_dplans] if p is not None}.values():
             st |= 1 if self.ctx.status(dp) else 0
         return torch.tensor([st], dtype=torch.int32, device=device)
 
@@ -258,7 +270,7 @@ class ShardedDecoder:
         return int(t.item())
 
     def check(self) -> None:
-        for dp in [self.dplan, *self.part_dplans]:
+        for dp in [self._dplan, *self.part_dplans]:
             if dp is not None and self.ctx.status(dp) != 0:
                 raise api.HsransError("device reported a malformed histogram / block header")
 

@@ -11,13 +11,19 @@
 //   reference symbol (src/…)                                      replacement here
 //   rANS32x64_16w_capacity            rANS32x64_16w.cpp:10        hsrans_hip::rANS32x64_16w_capacity
 //   rANS32x64_16w_encode_scalar_N     rANS32x64_16w.cpp:4189-     hsrans_hip::rANS32x64_16w_encode_scalar_N
-//   rANS32x64_16w_decode_scalar_N, rANS32x64_*_16w_decode_avx2_var{A,B,C}_N, …avx512…  ->  hsrans_hip::rANS32x64_16w_decode_hip_N
-//   block_rANS32x64_16w_{capacity,encode_N,decode_N}  block_rANS32x64_16w.h:6-20  ->  hsrans_hip::block_rANS32x64_16w_{capacity,encode_N,decode_hip_N}
-//   mt_rANS32x64_16w_{capacity,encode_N,decode_N,decode_mt_N}  mt_rANS32x64_16w.h:7-28  ->  hsrans_hip::mt_rANS32x64_16w_{capacity,encode_N,decode_hip_N}
+//   rANS32x64_16w_decode_scalar_N     rANS32x64_16w.h:48          hsrans_hip::rANS32x64_16w_decode_scalar_N  (the SAME name: runtime dispatch, = _auto_)
+//   rANS32x64_*_16w_decode_avx2_var{A,B,C}_N, …avx512…  rANS32x64_16w.h:54-177  ->  hsrans_hip::rANS32x64_16w_decode_{auto,hip}_N
+//   block_rANS32x64_16w_{capacity,encode_N,decode_N}  block_rANS32x64_16w.h:6-20  ->  hsrans_hip::block_rANS32x64_16w_{capacity,encode_N,decode_N} (+ decode_hip_N)
+//   mt_rANS32x64_16w_{capacity,encode_N,decode_N,decode_mt_N}  mt_rANS32x64_16w.h:7-28  ->  hsrans_hip::mt_rANS32x64_16w_{capacity,encode_N,decode_N,decode_mt_N} (+ decode_hip_N)
+//   => a caller written against rANS32x64_16w.h:48, block_rANS32x64_16w.h:19, mt_rANS32x64_16w.h:20 compiles and links with nothing but
+//      `using namespace hsrans_hip;` (tests/test_dropin_link.py builds such a caller around the reference's codec_info_t).  The names the
+//      reference itself uses route like `*_decode_auto_N`: what is ONE dependent chain goes to the host SIMD decoder, mt_ to the GPU.
+//      include/hsrans_names.h exports every one of them with C linkage as hsrans_<reference name> for FFI callers.
 //   (and the rANS32x32 twins: rANS32x32_16w.h, block_rANS32x32_16w.h, mt_rANS32x32_16w.h);  N = 10 … 15
 //   make_hist                         hist.cpp:217                hsrans_hip::make_hist
 //   mt_rANS32x64_16w_decode_mt_N(…, thread_pool *)  mt_rANS32x64_16w.h:23-28  ->  hsrans_hip::mt_rANS32x{32,64}_16w_decode_mt_N (same five
-//       arguments, so main.cpp's decode_with_thread_pool_wrapper :163-170 wraps it unchanged; the pool pointer is ignored)
+//       arguments, so main.cpp's decode_with_thread_pool_wrapper :163-170 wraps it unchanged; the pool pointer is ignored: the GPU grid takes
+//       the pool's place, and without a gfx950 device the blocks go to this library's host decoder on all cores, like `_auto_`)
 //
 //   block_rANS32x64_decode_wrapper's runtime dispatch (block_rANS32x64_16w_decode.cpp:130-152)  ->  `*_decode_auto_N`: the same
 //       decodeFunc signature, routed at run time: a stream that is ONE dependent chain (raw / block_ without an index) goes to this
@@ -63,6 +69,12 @@ hsrans_ctx *default_context();
 #define HSRANS_DECL_BITS(N)                                                                                                                        \
   size_t rANS32x32_16w_encode_scalar_##N(const uint8_t *pInData, const size_t length, uint8_t *pOutData, const size_t outCapacity, const hist_t *pHist); \
   size_t rANS32x64_16w_encode_scalar_##N(const uint8_t *pInData, const size_t length, uint8_t *pOutData, const size_t outCapacity, const hist_t *pHist); \
+  size_t rANS32x32_16w_decode_scalar_##N(const uint8_t *pInData, const size_t inLength, uint8_t *pOutData, const size_t outCapacity);               \
+  size_t rANS32x64_16w_decode_scalar_##N(const uint8_t *pInData, const size_t inLength, uint8_t *pOutData, const size_t outCapacity);               \
+  size_t block_rANS32x32_16w_decode_##N(const uint8_t *pInData, const size_t inLength, uint8_t *pOutData, const size_t outCapacity);                \
+  size_t block_rANS32x64_16w_decode_##N(const uint8_t *pInData, const size_t inLength, uint8_t *pOutData, const size_t outCapacity);                \
+  size_t mt_rANS32x32_16w_decode_##N(const uint8_t *pInData, const size_t inLength, uint8_t *pOutData, const size_t outCapacity);                   \
+  size_t mt_rANS32x64_16w_decode_##N(const uint8_t *pInData, const size_t inLength, uint8_t *pOutData, const size_t outCapacity);                   \
   size_t rANS32x32_16w_decode_auto_##N(const uint8_t *pInData, const size_t inLength, uint8_t *pOutData, const size_t outCapacity);                 \
   size_t rANS32x64_16w_decode_auto_##N(const uint8_t *pInData, const size_t inLength, uint8_t *pOutData, const size_t outCapacity);                 \
   size_t block_rANS32x32_16w_decode_auto_##N(const uint8_t *pInData, const size_t inLength, uint8_t *pOutData, const size_t outCapacity);           \

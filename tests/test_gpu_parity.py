@@ -247,12 +247,17 @@ def test_output_window_and_window_lower_edge(gpu_ctx, nonstat):
         lo, hi = layout.windows[rank]
         window = torch.full((hi - lo + 16,), 0xEE, dtype=torch.uint8, device="cuda")
         window[:hi - lo] = torch.from_numpy(stream[lo:hi]).cuda()
-        out = torch.full((e - b,), 0xCC, dtype=torch.uint8, device="cuda")
+        # a canary behind (and in front of) the rank's range: nothing a kernel rounds up may leave the window (the kernels'
+        # own output bound is now the window's end, not the end of the whole output)
+        guard = 4096
+        buf = torch.full((guard + e - b + guard,), 0xCC, dtype=torch.uint8, device="cuda")
+        out = buf[guard:guard + e - b]
         for f, c in layout.sub_runs[rank]:
             dplan = gpu_ctx.make_device_plan(H.plan_slice(plan, f, c))
             gpu_ctx.decode_device_ranges(dplan, window, lo, hi - lo, out, b, e - b)
             assert gpu_ctx.status(dplan) == 0
         assert torch.equal(out.cpu(), torch.from_numpy(d[b:e])), rank
+        assert bool((buf[:guard] == 0xCC).all()) and bool((buf[guard + e - b:] == 0xCC).all()), f"rank {rank} wrote outside its output window"
     # refusals: rank 1's plan with a window that begins 16 bytes too late / an output range that begins too late or is too short
     f, c = layout.runs[1]
     b, e = layout.ranges[1]
