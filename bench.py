@@ -124,22 +124,40 @@ def _mt_cpu_baseline(stream, data, states, bits):
     return out
 
 
+def kernel_source_sha256() -> str:
+    """SHA-256 over the device code's sources (csrc/*.hip and the headers they include): the identity of the kernels a counter
+    run was made with.  bench.py puts it into its line (config.kernel_source_sha256), tools/pmc_summary.py keeps that line next
+    to the counters, and _pmc_profile refuses counters of other kernels."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "hypersonic_rans_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _pmc_profile(n: int, states: int, bits: int, index: str, pairs: int = 0):
     """The committed rocprofv3 PMC run of this very workload (profiles/*_pmc.json, written by tools/pmc_summary.py: FETCH_SIZE /
     WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  PMC counters cannot be collected
-    from inside this process, so traffic is null unless such a run matches the workload; the source file is named."""
-    best = None
+    from inside this process, so traffic is null unless such a run matches the workload AND was made with the kernels as they
+    are now (config.kernel_source_sha256 of the line it recorded; VERDICT r3: a stale file must not be reported as this
+    build's traffic).  Returns (path, json) of the match, or (path, None) for the newest run of this workload that is stale."""
+    best, stale = None, None
+    now = kernel_source_sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             j = json.load(open(f))
             cfg = j["bench_line_under_trace"]["config"]
             if (cfg["decoded_bytes"], cfg["states"], cfg["bits"], str(cfg.get("index", cfg.get("index_interval_groups")))) == (n, states, bits, index):
+                if cfg.get("kernel_source_sha256") != now:
+                    stale = (os.path.relpath(f, ROOT), None)
+                    continue
                 if best is None or cfg.get("pairs") == pairs:  # same rotation (cache state) preferred; counters carry FETCH_SIZE and WRITE_SIZE
                     if "hbm_traffic_bytes_per_launch" in j or best is None:
                         best = (os.path.relpath(f, ROOT), j)
         except (KeyError, ValueError, OSError):
             continue
-    return best
+    return best or stale
 
 
 def _permuted(data: np.ndarray, k: int) -> np.ndarray:
@@ -198,26 +216,41 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
     # ---- timed region: exactly K steps, barrier + synchronize on both sides ------------------------------------------
     # One HIP event pair brackets the K launches ON THE LAUNCH STREAM (hsrans_decode_device launches on torch's current
     # stream, which is where torch.cuda.Event records): span / K = the kernel's average launch duration for the roofline.
-    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for i in range(args.warmup):  # W untimed warm-up steps, immediately in front of the timed region
-        step(i)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev_a.record()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    ev_b.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms_span = ev_a.elapsed_time(ev_b) / args.steps
+    # The region — W warm-up steps, barrier + synchronize, EXACTLY K timed steps, synchronize + barrier — runs R = --repeats
+    # times in this process (one 0.9 ms window cannot resolve the 2-5 % a kernel change is worth; the reference's
+    # harness reports min / mean / sigma over its runs too, src/main.cpp:72-118).  `value` is the MEDIAN region; the spread goes
+    # into mib_s.  With several ranks every region's time is the maximum over the ranks.
+    def timed_region(first_step):
+        ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(args.warmup):  # W untimed warm-up steps, immediately in front of the timed region
+            step(first_step + i)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev_a.record()
+        for i in range(args.steps):
+            step(first_step + args.warmup + i)
+        ev_b.record()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, ev_a.elapsed_time(ev_b) / args.steps
+
+    regions = [timed_region(r * (args.warmup + args.steps)) for r in range(max(1, args.repeats))]
+    region_s = np.array([r[0] for r in regions])
+    region_span_ms = np.array([r[1] for r in regions])
+    elapsed = float(np.median(region_s))
+    kernel_ms_span = float(np.median(region_span_ms))
 
     if args.timed_only:
         # tools/profile.sh: nothing but the rotation is launched, so that the rocprofv3 per-kernel average IS the timed region's
-        warm_ms, warm_each, kernel_ms = float("nan"), [], [kernel_ms_span]
+        warm_ms, warm_each, kernel_ms = float("nan"), [], [float(region_span_ms.min())]
     else:
         # warm: ONE pair replayed back to back (stream + output + index stay in the Infinity Cache); outside the timed region.
         # Every pair in turn: the replayed time depends on where the pair's buffers landed physically (measured 40.8 / 45.1 /
@@ -250,10 +283,22 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
         shas.append(hashlib.sha256(got.tobytes()).hexdigest())
         assert shas[-1] == hashlib.sha256(p["data"].tobytes()).hexdigest()
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # the P streams as INDEPENDENT work in flight together (SURVEY.md §7 hard part 1 asks for "N independent streams" beside "1 stream
+    # + index"): the same K steps, launched alternately on two HIP streams, so that one launch's prologue and tail overlap its
+    # neighbour's decode.  Not the headline: a step there is one launch with the GPU to itself.
+    overlapped_ms = None
+    if not args.timed_only and world == 1:
+        side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        samples = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(2 * args.steps):
+                p = pairs[i % P]
+                ctx.decode_device(p["dplan"], p["d_in"], p["d_out"], stream=side[i % 2], stream_length=p["stream"].size)
+            torch.cuda.synchronize()
+            samples.append((time.perf_counter() - t0) / (2 * args.steps) * 1e3)
+        overlapped_ms = float(np.median(samples))
     if rank != 0:
         return None
 
@@ -261,12 +306,15 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
     stream, plan = pairs[0]["stream"], pairs[0]["plan"]
     ms_per_step = elapsed * 1e3 / args.steps
     k_avg = float(kernel_ms_span)
+    to_mib_s = lambda seconds: float(world * n / 2**20 / seconds * args.steps)
     alg_bytes = int(np.mean([p["stream"].size for p in pairs])) + n  # compressed bytes read once + decoded bytes written once
     achieved = alg_bytes / (k_avg * 1e-3) / 1e9
     groups_per_launch = n // S
     prof = _pmc_profile(n, S, bits, args.index, P)
-    traffic, traffic_source, issue = None, None, None
-    if prof is not None:
+    traffic, traffic_source, issue, traffic_stale = None, None, None, None
+    if prof is not None and prof[1] is None:
+        traffic_stale = prof[0]  # counters of this workload exist, but of kernels that have changed since: not reported
+    elif prof is not None:
         traffic_source, j = prof
         traffic = float(j["hbm_traffic_bytes_per_launch"]["total"])
         valu = j["counters"].get("SQ_INSTS_VALU", {}).get("mean")
@@ -300,15 +348,28 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
             # once per (stream, plan), outside the timed region: hsrans_dplan_create = plan validation + host-built table + upload of the index
             "plan_setup_ms": t_setup / P * 1e3,
             "calibration": calibration,
+            "kernel_source_sha256": kernel_source_sha256(),
         },
         # the reference harness prints min/mean throughput per decoder (src/main.cpp:72-118): same two numbers here
-        "mib_s": {"mean_over_timed_region": world * n / 2**20 / elapsed * args.steps, "best_single_launch": n / 2**20 / (float(np.min(kernel_ms)) * 1e-3),
-                  "warm_one_pair_replayed": n / 2**20 / (warm_ms * 1e-3), "launches_in_timed_region": args.steps},
+        "mib_s": {"median": to_mib_s(np.median(region_s)), "min": to_mib_s(region_s.max()), "max": to_mib_s(region_s.min()), "p10": to_mib_s(np.percentile(region_s, 90)),
+                  "p90": to_mib_s(np.percentile(region_s, 10)), "mean": to_mib_s(region_s.mean()), "repeats": int(region_s.size),
+                  "per_repeat": [to_mib_s(x) for x in region_s], "ms_per_step_per_repeat": [float(x / args.steps * 1e3) for x in region_s],
+                  "note": "each repeat = W warm-up steps + barrier/synchronize + K timed steps + synchronize/barrier; `value` is the median repeat",
+                  "best_single_launch": n / 2**20 / (float(np.min(kernel_ms)) * 1e-3),
+                  "warm_one_pair_replayed": n / 2**20 / (warm_ms * 1e-3), "launches_in_timed_region": args.steps,
+                  # "1 stream, no index" = single_wavefront_no_plan below, "1 stream + index" = value, and "N independent streams":
+                  "independent_streams_overlapped": None if overlapped_ms is None else
+                  {"value": n / 2**20 / (overlapped_ms * 1e-3), "ms_per_stream": overlapped_ms, "frac_of_hbm_peak": alg_bytes / (overlapped_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "note": f"the same {P} streams as independent work: launches alternate between two HIP streams, so a launch's prologue and tail overlap its "
+                           "neighbour's decode (wall clock over 2K launches, median of 5); a step of the headline has the GPU to itself"}},
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             # the same fraction from the wall clock of the timed region (B_alg / ms_per_step): what the driver's number implies
             "frac_wall": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": (traffic_source + " (rocprofv3 --pmc run of this workload, not this process)") if traffic_source else None,
+            "traffic": traffic, "traffic_source": (traffic_source + " (rocprofv3 --pmc run of this workload with these kernels, not this process)") if traffic_source else None,
+            "traffic_stale": (traffic_stale + ": counters of this workload, but the kernel sources have changed since (sha-256 mismatch): not reported") if traffic_stale else None,
+            "kernel_ms_avg_spread": {"min": float(region_span_ms.min()), "max": float(region_span_ms.max()), "p10": float(np.percentile(region_span_ms, 10)),
+                                     "p90": float(np.percentile(region_span_ms, 90)), "repeats": int(region_span_ms.size)},
             "algorithmic_bytes_per_launch": alg_bytes, "index_bytes_read_per_launch": int(plan.size),
             "kernel_ms_avg": k_avg, "kernel_ms_single_launch_min": float(np.min(kernel_ms)),
             "cache_state": f"cold: {P} (stream, output) pairs rotated, working set {P * alg_bytes / 2**20:.0f} MiB > 256 MiB Infinity Cache",
@@ -530,7 +591,7 @@ def sharded_workload(args, world, rank, dv: _Dev, dist):
         import copy
 
         a2 = copy.copy(args)
-        a2.size, a2.no_single, a2.no_cpu, a2.timed_only = 100_000_000 if args.size >= (1 << 28) else args.size, True, True, True
+        a2.size, a2.no_single, a2.no_cpu, a2.timed_only, a2.repeats = 100_000_000 if args.size >= (1 << 28) else args.size, True, True, True, 3
         r = headline(a2, world, rank, dv.dev, dv.dev.index, dv.ctx, dist)
         if r is not None:
             replicas = {"value": r["value"], "unit": "MiB/s", "ms_per_step": r["ms_per_step"], "scaling": "weak", "roofline_frac_per_gpu": r["roofline"]["frac"],
@@ -670,6 +731,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=15, help="headline: the (W warm-up + K timed steps) region is run this many times; `value` is the median region")
     ap.add_argument("--workload", choices=("headline", "sharded", "host"), default=None,
                     help="default: headline (100 MB raw stream per GPU) on one GPU, sharded (ONE 2^30-byte mt_ stream over all GPUs) on several; "
                          "host: one 2^30-byte mt_ stream per GPU from / to page-locked host memory (BASELINE config 5's shape, PCIe-inclusive)")

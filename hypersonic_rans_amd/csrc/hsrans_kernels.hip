@@ -107,19 +107,21 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v)
   return (uint64_t)uni((uint32_t)v) | ((uint64_t)uni((uint32_t)(v >> 32)) << 32);
 }
 
-// The decoded bytes are written once and never read again by this kernel: streaming (non-temporal) stores, so that the
-// lines leave L2 as they fill instead of waiting for the write-back at the end of the kernel (measured on two boxes:
-// 48.5 -> 46.1 us and 49.5 -> 48.2 us for the 100 MB headline decode; -DHSRANS_NT_STORES=0 builds the plain-store variant)
-#if defined(HSRANS_STORE_POLICY) // experiments: cache-policy bits of the scalar-base output store, e.g. -DHSRANS_STORE_POLICY='" sc1"'
-#define HSRANS_STORE_U32(ptr, v) __builtin_nontemporal_store((v), (ptr))
-#define HSRANS_STORE_U32_SADDR(base, voff, v) asm volatile("global_store_dword %0, %1, %2" HSRANS_STORE_POLICY : : "v"(voff), "v"(v), "s"(base) : "memory")
-#elif !defined(HSRANS_NT_STORES) || HSRANS_NT_STORES
-#define HSRANS_STORE_U32(ptr, v) __builtin_nontemporal_store((v), (ptr))
-#define HSRANS_STORE_U32_SADDR(base, voff, v) asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(voff), "v"(v), "s"(base) : "memory")
-#else
-#define HSRANS_STORE_U32(ptr, v) (*(ptr) = (v))
-#define HSRANS_STORE_U32_SADDR(base, voff, v) asm volatile("global_store_dword %0, %1, %2" : : "v"(voff), "v"(v), "s"(base) : "memory")
+// The decoded bytes are written once and never read again by this kernel, so the stores carry cache-policy bits.  Which ones is
+// a measurement, made in ONE process on the same buffers with the variants' launches alternating (tools/ab_probe.py; between
+// processes the same binary moves by +-3 us), 100 MB raw 11 bit, one chain per wave, sustained, rotated over 4 pairs / one pair
+// replayed (profiles/r04_store_policy_ab.jsonl):
+//     nt (rounds 1-3)   44.0 / 34.1 us        plain   41.7 / 35.9        sc1 nt   44.0 / 33.1
+//     sc1               41.1 / 33.0           sc0 sc1 41.0 / 32.8        no stores at all (diagnostic)   31.5 / 31.2
+// sc1 / sc0 sc1 write through and DROP the line from the XCD's L2 (MI355X_MICROARCH.md, "stores of each flavour"); nt keeps it
+// there.  The stores are what a rotated launch loses its time to: per-wave clocks around the store instruction (diagnostic build,
+// -DHSRANS_DIAG_STORE_TIME) show the slowest tenth of the waves blocked 10 us at store issue, the median wave 2.7 us.
+// -DHSRANS_STORE_POLICY='" nt"' (or '""') builds the other variants.
+#ifndef HSRANS_STORE_POLICY
+#define HSRANS_STORE_POLICY " sc0 sc1"
 #endif
+#define HSRANS_STORE_U32(ptr, v) asm volatile("global_store_dword %0, %1, off" HSRANS_STORE_POLICY : : "v"(ptr), "v"(v) : "memory")
+#define HSRANS_STORE_U32_SADDR(base, voff, v) asm volatile("global_store_dword %0, %1, %2" HSRANS_STORE_POLICY : : "v"(voff), "v"(v), "s"(base) : "memory")
 
 // are the 512 bytes of a histogram at stream offset `off` there to be read?
 #define HSRANS_HIST_IN_RANGE(c, off) ((off) >= (c).stream_lo && (off) <= (c).stream_len && (c).stream_len - (off) >= 512)
@@ -851,7 +853,7 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
   // count no stores — stricter than needed by what was stored before this loop, never weaker
   uint32_t t1 = iters, t2 = iters;
 #if defined(HSRANS_DIAG_WIDE_STORES)
-  uint32_t dw0 = 0, dw1 = 0, dw2 = 0;
+  uint32_t dw0 = 0, dw1 = 0, dw2 = 0, dwn = 0;
 #endif
   // (The constant wait leans on the steady state: two crossings behind the current one, each with a store in front of it.  A
   // chain's first crossings have no such past — ring_begin asked for chunks 0..3 in one go — and wait for one operation more.)
@@ -864,12 +866,12 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
 #endif
 #if defined(HSRANS_DIAG_WIDE_STORES) // diagnostic build (wrong byte order!): the same bytes as ONE 1 KiB store per 16 groups (16 B per lane) instead of four 256-byte ones
     {
-      const uint32_t ph = iters & 3;
-      if (ph == 3)
+      const uint32_t ph = ++dwn & 3; // (counted from this loop's start: the first store comes after four iterations, inside the chain's own output)
+      if (ph == 1)
         dw0 = acc;
       else if (ph == 2)
         dw1 = acc;
-      else if (ph == 1)
+      else if (ph == 3)
         dw2 = acc;
       else
       {
@@ -1185,7 +1187,7 @@ __device__ __forceinline__ void run_pair_groups(uint32_t &x, const StreamWin &sw
     for (; iters != 0; iters--)
     {
       const uint32_t acc = quad_transpose(MODE == kModeRank ? pair_groups4_rank(x, fa.addr, fb.addr, c, 1u << c.bits) : pair_groups4(x, fa.addr, fb.addr, c, s_table), sel_a, sel_b);
-      asm volatile("global_store_dword %0, %1, off nt" : : "v"(vout), "v"(acc) : "memory");
+      HSRANS_STORE_U32(vout, acc);
       vout += 128;
       if (fa.addr >= fa.next_cross)
         crossed(fa, ra, ta1, ta2);

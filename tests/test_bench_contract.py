@@ -28,6 +28,14 @@ def test_bench_line_has_the_contract_keys():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["value"] > 0 and d["ms_per_step"] > 0
+    # the timed region is repeated in the process: `value` is the median region, the spread is reported
+    m = d["mib_s"]
+    assert m["repeats"] >= 15 and len(m["per_repeat"]) == m["repeats"] and m["min"] <= m["p10"] <= m["median"] <= m["p90"] <= m["max"]
+    assert abs(m["median"] - d["value"]) < 1e-6 * d["value"]
+    assert m["independent_streams_overlapped"]["value"] > 0 and d["single_wavefront_no_plan"]["value"] > 0  # all three figures
+    # counters are only ever reported for the kernels as they are now
+    assert len(d["config"]["kernel_source_sha256"]) == 64
+    assert rf["traffic"] is None or rf["traffic_stale"] is None
 
 
 @pytest.mark.parametrize("n", (2, 4, 8))

@@ -27,25 +27,43 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--variant", action="append", required=True, help="tag[:library path (relative to hypersonic_rans_amd/, or absolute)[:ENV=VAL,ENV=VAL...]]")
 ap.add_argument("--size", type=int, default=100_000_000)
 ap.add_argument("--bits", type=int, default=11)
+ap.add_argument("--states", type=int, default=64)
+ap.add_argument("--container", choices=("raw", "mt", "block"), default="raw")
+ap.add_argument("--index", default="wave", help="raw: 'wave' (one chain per resident wavefront) or a checkpoint interval in groups; mt/block: the interval")
+ap.add_argument("--block", type=int, default=1 << 18, help="mt/block: block size in bytes")
 ap.add_argument("--pairs", type=int, default=4)
 ap.add_argument("--window", type=int, default=200)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--no-check", default="", help="comma-separated tags of diagnostic variants whose output is not the decoded data")
 ap.add_argument("--calibrate", action="store_true")
 a = ap.parse_args()
-n, S, bits, P = a.size, 64, a.bits, a.pairs
-cache = f"/tmp/zipf_{n}_20241008.bin"
+n, S, bits, P = a.size, a.states, a.bits, a.pairs
+container = {"raw": H.RAW, "mt": H.MT, "block": H.BLOCK}[a.container]
+tile = min(n, 100_000_000)
+cache = f"/tmp/zipf_{tile}_20241008.bin"
 if os.path.exists(cache):
     base = np.fromfile(cache, np.uint8)
 else:
-    base = synth.enwik8_shaped(n, seed=20241008)
+    base = synth.enwik8_shaped(tile, seed=20241008)
     base.tofile(cache)
-datas = [base if k == 0 else synth._permutation(1000 + k)[base] for k in range(P)]
+if n > tile:  # bigger workloads: tiles of the base block under byte permutations (as bench.py's _tiled)
+    big = np.empty(n, np.uint8)
+    for t, o in enumerate(range(0, n, tile)):
+        c = min(tile, n - o)
+        big[o:o + c] = (base if t % 7 == 0 else synth._permutation(1000 + t % 7)[base])[:c]
+    base = big
+datas = [base if k == 0 else synth._permutation(2000 + k)[base] for k in range(P)]
 no_check = set(a.no_check.split(",")) if a.no_check else set()
 tmpdir = tempfile.mkdtemp(prefix="hsrans_ab_")
 
 variants = []
 d_in, d_out, lens = [], [], []
+
+
+def env_changes_index(env):
+    return any(k.startswith(("HSRANS_DIRECT", "HSRANS_DUAL", "HSRANS_SLOT")) for k in env)
+
+
 for spec in a.variant:
     parts = spec.split(":", 2)
     tag = parts[0]
@@ -61,10 +79,20 @@ for spec in a.variant:
     api._LIB = None
     ctx = H.Context(0)  # loads `private` and reads the tuning environment
     cal = ctx.calibrate(bits=bits) if a.calibrate else None
-    groups = H.index_boundaries(S, bits, n, ctx)
+    groups = H.index_boundaries(S, bits, n, ctx) if (a.container == "raw" and a.index == "wave") else None
     dplans = []
     for k in range(P):
-        s, p = H.encode(H.RAW, S, bits, datas[k], index_groups=groups)
+        if len(d_in) > k and hasattr(a, "_streams") and not env_changes_index(env):
+            s, p = a._streams[k]  # the host encoders take seconds per GiB: encode once per pair when the index cannot differ
+        elif groups is not None:
+            s, p = H.encode(container, S, bits, datas[k], index_groups=groups)
+        elif a.container == "raw":
+            s, p = H.encode(container, S, bits, datas[k], index_interval=int(a.index))
+        else:
+            s, p = H.encode(container, S, bits, datas[k], block_size=a.block, index_interval=int(a.index) if a.index != "wave" else 256)
+        if not hasattr(a, "_streams"):
+            a._streams = {}
+        a._streams.setdefault(k, (s, p))
         if len(d_in) <= k:
             lens.append(s.size)
             d_in.append(torch.from_numpy(np.concatenate([s, np.zeros((-s.size) % 16, np.uint8)])).cuda())
