@@ -74,7 +74,6 @@ struct hsrans_dplan
   uint64_t *d_finish = nullptr; // hsrans_ctx_calibrate: per-wave finish times of the plan's launches (owned by the calibration)
   unsigned long long *d_counters = nullptr; // uniform persistent launches: kCounterSets sets of monotonic queue heads
   std::atomic<uint32_t> epoch{0};           // launches so far: launch k uses counter set k % kCounterSets
-  std::atomic<uint64_t> claim_epoch{0};     // one-chain-per-wave launches so far (PersistentArgs::epoch)
   uint8_t *d_table = nullptr;               // host-built decode table (plans that carry their histogram)
   size_t d_table_cap = 0;
   uint8_t *d_groups = nullptr;              // grouped launches (block_/mt_ plans with checkpoints)
@@ -398,8 +397,7 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
   auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t table_bound = mergeable_raw && (h.flags & kPlanHasHist) ? up256(std::max<size_t>((size_t)8 << h.bits, rank_table_entries(h.bits >= 13 ? h.bits : 13) * 8)) : 0;
   const size_t group_bound = may_group ? up256(((size_t)h.n_chains + 16) * sizeof(Group)) : 0;
-  const size_t claim_bytes = mergeable_raw && h.interval == 0 ? ((size_t)h.n_chains + 64) * 4 : 0; // run_direct's claim words, one per chain (zero = no launch's epoch)
-  const size_t arena_need = 256 + (need_counters ? up256(counter_bytes) : 0) + up256(claim_bytes) + up256(plan_size) + table_bound + group_bound;
+  const size_t arena_need = 256 + (need_counters ? up256(counter_bytes) : 0) + up256(plan_size) + table_bound + group_bound;
   if (!grow(&d->d_arena, &d->d_arena_cap, arena_need))
     return HSRANS_E_HIP;
   d->arena_used = 0;
@@ -410,7 +408,6 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
   };
   d->d_status = (uint32_t *)carve(64);
   d->d_counters = need_counters ? (unsigned long long *)carve(counter_bytes) : nullptr;
-  d->pa.claims = claim_bytes ? (uint32_t *)carve(claim_bytes) : nullptr;
   // status word and ticket counters start from zero on every (re)fill: "ticket mod draws-per-launch" only works while every
   // launch on a set of heads draws the same number of tickets, i.e. for ONE plan
   if (hipMemsetAsync(d->d_arena, 0, d->arena_used, s) != hipSuccess)
@@ -721,8 +718,6 @@ static int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_len
   kp.single_states = (const uint32_t *)(d->d_plan + plan_states_off(d->hdr.n_chains, d->hdr.n_pieces));
   if (kp.pa.counters != nullptr) // uniform persistent launch: its own set of queue heads
     kp.pa.counters += (size_t)(d->epoch.fetch_add(1, std::memory_order_relaxed) % kCounterSets) * kDynQueues * kDynQueueStride;
-  if (kp.pa.claims != nullptr) // one-chain-per-wave launch: a claim word equal to this number = claimed in this launch (never zero, never the previous launch's)
-    kp.pa.epoch = (uint32_t)(d->claim_epoch.fetch_add(1, std::memory_order_relaxed) % 0xFFFFFFFEu) + 1;
   if (d->n_groups)
   {
     kp.groups = (const Group *)d->d_groups;
@@ -1988,7 +1983,7 @@ try
       for (int k = 0; k < 8; k++)
         ctx->geom.direct_weights[k] = cur_w[k];
       const uint64_t T = (n - 63) / 64; // whole groups (hsrans_index_boundaries)
-      const size_t chains = direct_boundaries(ctx->geom, 64, bits, T, groups.data(), groups.size(), 0); // (bare chains: the fit is of the classes' own rates)
+      const size_t chains = direct_boundaries(ctx->geom, 64, bits, T, groups.data(), groups.size());
       if (chains < 2)
       {
         failed = true;

@@ -54,7 +54,7 @@ static const uint32_t kBlockIndexInterval = 64; // block_/mt_: checkpoints every
 static size_t index_capacity_any(int container, int states, size_t n)
 {
   if (container == HSRANS_RAW)
-    return hsrans_plan_capacity_chains(container, states, n, 4 * 8192 + 64, 0); // (one chain per resident wavefront + up to 3 tail chains each)
+    return hsrans_plan_capacity_chains(container, states, n, 2 * 8192 + 64, 0);
   return hsrans_plan_capacity(container, states, n, kBlockIndexInterval, 0);
 }
 
@@ -72,7 +72,7 @@ static size_t encode_indexed_any(int container, int states, uint32_t bits, const
   if (container == HSRANS_RAW)
   {
     // one chain per resident wavefront of the default device (or of an MI355X when no device is present at encode time)
-    groups.resize(4 * 8192 + 64);
+    groups.resize(2 * 8192 + 64);
     const size_t n = hsrans_index_boundaries(default_context(), states, bits, length, groups.data(), groups.size());
     if (n == 0)
       opts.index_interval = 4; // a stream too short for more than one chain: any interval gives the one-chain plan

@@ -31,11 +31,9 @@ struct PersistentArgs
   uint32_t dual;            // two chains per wave: k_decode_dual
   const uint16_t *hist_copy; // the 256 counts that table was built from (device copy inside the plan)
   unsigned long long *counters; // [kDynQueues * kDynQueueStride] monotonic queue heads of THIS launch's counter set (never reset, see run_persistent)
-  // one-chain-per-wave launches (interval == 0, 64 states): the plan's chains are dealt to the waves as runs of run_chains consecutive
-  // chains; a run's chains behind the first ("tail chains") can be taken over by waves that are done early (run_direct).
-  // claims[chain] == epoch: the chain has been claimed in THIS launch (never reset: every launch brings a new epoch)
-  uint32_t *claims;
-  uint32_t epoch, run_chains, steal_mode;
+  // one-chain-per-wave launches (interval == 0, 64 states): the plan's chains are dealt to the launch's waves as runs of run_chains
+  // consecutive chains, each decoded as one chain (run_direct; 1 for the index hsrans_index_boundaries makes for this device)
+  uint32_t run_chains;
 };
 constexpr uint32_t kDynQueues = 64;
 constexpr uint32_t kDynQueueStride = 32; // in uint64: one head per 256 B, so that heads never share a line / atomic unit
@@ -160,8 +158,7 @@ struct TableChoice
 };
 TableChoice choose_table(uint32_t bits, uint32_t states, bool direct);
 // chain boundaries (in groups) of the direct launch: one chain per resident wave, sized by class weight; see hsrans_kernels.hip
-// tail_pieces: tail chains per wave for run_direct's stealing (< 0: as configured, HSRANS_DIRECT_TAIL_PIECES; 0: none — the calibration fits bare chains)
-size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, uint64_t total_groups, uint64_t *out, size_t cap, int tail_pieces = -1);
+size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, uint64_t total_groups, uint64_t *out, size_t cap);
 bool table_spill(); // HSRANS_TABLE_SPILL: leave host-built tables in global memory (comparison only)
 // host-side builder of the bits >= 13 coarse/fine decode table (layout: kModeCoarse in hsrans_kernels.hip); returns entries written
 size_t build_rank_table(const uint16_t counts[256], uint32_t bits, uint2 *out, size_t capacity_entries);

@@ -157,7 +157,6 @@ struct WaveCtx
   uint32_t bits, S, lane;
   uint32_t v_mask, v_bits; // 2^bits - 1 and bits, each held in a VGPR: a VALU op with an SGPR operand issues at half rate
   uint8_t *rings;        // LDS, kWaveRingBytes: this wave's stream ring + mirror
-  uint8_t *aside;        // LDS, kAsideBytes (one-chain-per-wave launches only): claim words fetched ahead of time (run_direct)
   uint8_t *table;        // LDS
   uint8_t *table_b;      // LDS: the table lanes 32..63 use in the paired 32-state modes (== table unless the halves decode different blocks)
   const uint2 *gtable;   // kModeSpill: the table in global memory
@@ -285,7 +284,10 @@ static_assert(HSRANS_RING_AHEAD == 2 || HSRANS_RING_AHEAD == 3, "the ring has 4 
 // start streaming a chain whose first word is at absolute stream byte `pos` (>= sw.base, < sw.base + 4 GiB)
 // (`issue` false: the requests of exactly this call were issued earlier — run_grouped asks for a round's first chunks before
 // the round's table build — and only the ring's bookkeeping is set up)
-__device__ __forceinline__ void ring_begin(const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t pos, bool issue = true)
+// (`later` true: only chunks 0 and 1 are asked for now, the caller asks for the others with ring_begin_rest — the one-chain-per-
+// wave launch, in which every wave of the device is in its prologue at once and a CU takes in about 11 bytes per clock: the
+// bytes a wave needs before its first group come first)
+__device__ __forceinline__ void ring_begin(const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t pos, bool issue = true, bool later = false)
 {
   pos = uni64(pos);
   const uint32_t rel = (uint32_t)(pos - sw.base);
@@ -302,16 +304,22 @@ __device__ __forceinline__ void ring_begin(const StreamWin &sw, Ring &r, const W
   }
   r.vm += 3; // chunk 0, its mirror, chunk 1
   r.seq1 = r.vm;
-  if (issue)
+  if (issue && !later)
     ring_request(sw, r, c, 2);
   r.seq2 = ++r.vm;
   if (HSRANS_RING_AHEAD == 3)
   {
-    if (issue)
+    if (issue && !later)
       ring_request(sw, r, c, 3);
     r.vm++;
   }
   r.seq3 = r.vm;
+}
+__device__ __forceinline__ void ring_begin_rest(const StreamWin &sw, Ring &r, const WaveCtx &c)
+{
+  ring_request(sw, r, c, 2);
+  if (HSRANS_RING_AHEAD == 3)
+    ring_request(sw, r, c, 3);
 }
 
 // chunks 0 and 1 (and the mirror) have landed: ring_begin issues {chunk 0, mirror, chunk 1, chunk 2 [, chunk 3]} and anything
@@ -839,20 +847,8 @@ __device__ __forceinline__ void wait_after_crossing(uint32_t &t1, uint32_t &t2, 
                : "scc", "memory");
 }
 
-// What a caller wants done at given points of a chain that the hand-scheduled loop decodes (run_direct's claim protocol): the loop
-// runs first() iterations (of 4 groups), then asks next(iterations done) — which does what is due there and returns the length of
-// the next segment, 0 = stop here.  Everything the loop keeps in registers stays there across a segment boundary: leaving and
-// re-entering the loop through its caller cost 0.7 us per boundary (a wave that leaves the loop's rhythm executes its ~150
-// bookkeeping instructions at one per 12 cycles while seven other waves keep the SIMD busy).
-struct NoEvents
-{
-  __device__ __forceinline__ uint32_t first(uint32_t total) { return total; }
-  __device__ __forceinline__ uint32_t next(uint32_t, uint32_t) { return 0; }
-  __device__ __forceinline__ bool stopped() const { return false; }
-};
-
-template <bool STRICT, int MODE = kModePack64, bool WT = false, class EV = NoEvents>
-__device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o_ref, uint32_t &steps, EV &ev)
+template <bool STRICT, int MODE = kModePack64, bool WT = false>
+__device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o_ref, uint32_t &steps)
 {
   const OutLanes ol = out_lanes(c.lane, 64);
   const uint32_t s_table = uni(lds_address(c.table));
@@ -880,18 +876,16 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
   // strict against exact, alternating runs: 45.9 / 44.4 us on one box (three runs each), 42.1 / 43.5 on another (six each): inside
   // the run-to-run spread (39-45 us).  Strict everywhere but in that launch, which keeps the exact wait.
   uint8_t *outp = (uint8_t *)uni64((uint64_t)(uintptr_t)(c.out + uni64(o_ref)));
-  const uint32_t total = steps >> 2;
-  uint32_t done = 0;
-  uint32_t iters = ev.first(total);
+  uint32_t iters = steps >> 2;
+  steps &= 3;
+  o_ref += (uint64_t)iters * 256;
   // iteration counts (they run down) at the last two crossings; at entry: where the previous call on this chain left off (r.st1 /
   // r.st2 stores ago), or, on a fresh chain, as if both had just happened.  Whatever else the wave issued in between is younger
   // than the requests these counts are about: stricter, never weaker.
   uint32_t t1 = iters + r.st1, t2 = iters + r.st2;
   // (The constant wait leans on the steady state: two crossings behind the current one, each with a store in front of it.  A
   // chain's first crossings have no such past — ring_begin asked for chunks 0..3 in one go — and wait for one operation more.)
-  while (true)
   {
-    done += iters;
     for (; iters != 0; iters--)
     {
       const uint32_t acc = quad_transpose(MODE == kModeRank ? fast_groups4_rank(x, s_addr, c, 1u << c.bits) : fast_groups4(x, s_addr, c, s_table), ol.sel_a, ol.sel_b);
@@ -938,13 +932,7 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
 #endif
       }
     }
-    iters = done < total ? ev.next(done, total) : 0;
-    if (iters == 0)
-      break;
-    t1 += iters, t2 += iters; // (they were "stores since" at iters == 0: the counter restarts at the segment's length)
   }
-  steps -= done * 4;
-  o_ref += (uint64_t)done * 256;
   r.cur = words0 + ((s_addr + moved - s_addr0) >> 1);
   r.st1 = t1, r.st2 = t2; // (iters == 0 here: the counts are "stores since")
   r.vm = r.seq1 = r.seq2 = r.seq3 = 0; // (not kept here; zero only makes the waits of the few groups behind this loop stricter)
@@ -952,25 +940,17 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
 
 // FAST: the call sites that carry the bulk of a launch's groups (every inlined copy of the hand-scheduled loop pins v52-v59 and
 // costs the big multi-path kernel registers: with it at every call site k_decode<3, true> went to 97 VGPRs and spilled)
-template <int MODE, bool FAST = false, bool STRICT = false, bool WT = false, class EV = NoEvents> // STRICT: the constant wait of run_groups_fast (the grouped launches); WT: write-through stores
-__device__ __forceinline__ void run_groups(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps, EV &ev)
+template <int MODE, bool FAST = false, bool STRICT = false, bool WT = false> // STRICT: the constant wait of run_groups_fast (the grouped launches); WT: write-through stores
+__device__ __forceinline__ void run_groups(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps)
 {
   if (FAST && MODE == kModePack64 && c.S == 64 && r.mirror_lanes == 0xFFFFFFFFu)
-    run_groups_fast<STRICT || HSRANS_FORCE_STRICT, kModePack64, WT>(x, sw, r, c, o, steps, ev); // the hand-scheduled loop; leaves < 4 groups
+    run_groups_fast<STRICT || HSRANS_FORCE_STRICT, kModePack64, WT>(x, sw, r, c, o, steps); // the hand-scheduled loop; leaves < 4 groups
   if (FAST && MODE == kModeRank && c.S == 64 && r.mirror_lanes == 0xFFFFFFFFu && uni(lds_address(c.table)) == 0)
-    run_groups_fast<true, kModeRank, WT>(x, sw, r, c, o, steps, ev); // (its rank byte's address is the slot itself: the table at LDS address 0)
-  if (ev.stopped()) // (the caller's events ended the chain early: what is left is not this wave's)
-    return;
+    run_groups_fast<true, kModeRank, WT>(x, sw, r, c, o, steps); // (its rank byte's address is the slot itself: the table at LDS address 0)
   if (c.S == 64)
     run_groups_impl<MODE, true>(x, sw, r, c, o, steps);
   else
     run_groups_impl<MODE, false>(x, sw, r, c, o, steps);
-}
-template <int MODE, bool FAST = false, bool STRICT = false, bool WT = false>
-__device__ __forceinline__ void run_groups(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps)
-{
-  NoEvents none;
-  run_groups<MODE, FAST, STRICT, WT, NoEvents>(x, sw, r, c, o, steps, none);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1523,42 +1503,21 @@ __device__ void run_persistent(const WaveCtx &c, const KParams &kp, uint32_t wav
 // Direct launch (kPlanMergeable plans with chains of any length, PlanHeader::interval == 0: hsrans_index_boundaries /
 // hsrans_plan_thin): the plan's chains are dealt to the launch's W waves as W RUNS of R = ceil(n_chains / W) consecutive chains.
 // Chains of such a plan are back to back in stream and output, so a wave decodes its run as ONE chain from the first one's start
-// states; everything it needs is in its Piece records, fetched with scalar loads.  R == 1 is round 1-3's one chain per wave.
+// states; everything it needs is in two Piece records, fetched with scalar loads; no queues, no atomics, nothing per launch on the
+// device, so launches of one plan may overlap freely.  R == 1 — hsrans_index_boundaries makes exactly one chain per resident
+// wavefront, sized by the wave's scheduling class — is the headline's shape; an index made for a smaller launch gives R > 1.
 //
-// R in 2..4 (hsrans_index_boundaries cuts the last HSRANS_DIRECT_TAIL_PERMILLE of every wave's share into R - 1 short "tail"
-// chains): TAIL STEALING.  A rotated launch ends 5-7 us after its median wave, because the waves of whole workgroups spend that
-// long blocked at store issue (see the store policy above) — which workgroups, changes from buffer to buffer, so no static
-// split can know.  Every tail chain has a claim word (PersistentArgs::claims, the launch's epoch = claimed):
-//   * the run's OWNER walks into its tail chains without reloading anything (they continue its chain).  Before the last
-//     kClaimLead groups in front of a tail chain it asks for that chain's claim word — one lane's LDS-DMA into the wave's LDS
-//     aside, counted like a ring request, so nothing waits — and looks at it when it gets there: claimed means a thief has this
-//     chain AND every later one of the run (thieves take a run's chains from the back), the owner's run ends here; else it
-//     stores its own claim (fire and forget) and goes on.  Cost to an undisturbed wave: one 4-byte request + one store per tail.
-//   * a wave that is DONE (its run, or a stolen chain) becomes a thief.  It already holds a sample of the claim words of
-//     2 x 64 consecutive chains at a pseudo-random place (two LDS-DMA requests issued kClaimLead groups before it finished: no
-//     latency at the end, and a wave that finds nothing to steal is gone at once — nothing here may delay the launch's last
-//     wave).  Candidates = unclaimed tail chains whose successor in the run is claimed or does not exist; it claims one with
-//     an atomic exchange, loads that chain's record and states (in flight beside the exchange) and decodes it like any chain.
-// Who is unclaimed when the first waves finish?  The tails of exactly those runs whose owners are far behind.  Claims are
-// best effort: owner and thief can both decode a chain (the owner's look is kClaimLead groups old) — the same bytes twice,
-// nothing else; a chain is never left to nobody, because an owner only stops at a word that a thief of THIS launch wrote.
-// Launches of one plan may still overlap (another epoch just looks unclaimed).
+// (Round 4 built late-phase rebalancing on top of this and took it out again — branch r4-tail-stealing-experiment,
+// profiles/r04_tail_stealing_ab.jsonl.  The last fifth of every wave's share was cut into 1-3 "tail" chains with a claim word
+// each; the owner walked into them seamlessly, asking for the claim word 16 groups ahead by LDS-DMA; waves that were done sampled
+// 128 claim words (requested before their own last groups) and took unclaimed tail chains with an atomic exchange.  Every variant
+// was slower than none, 41-50 us against 40-42 rotated: a steal costs the exchange, the chain's own prologue (two dependent round
+// trips) and its decode by a lone wave, 4-7 us in all, while the launch's tail is 3-7 us — and "unclaimed" does not tell a late
+// owner from one that is on time, because the young wave classes run slowly first and fast at the end.  What the experiment left
+// behind: the loop's crossing bookkeeping survives across calls (Ring::st1 / st2), and its finding about where a rotated launch
+// loses its time — the stores, not the stream — is why the stores of this launch write through now.)
 typedef const __attribute__((address_space(4))) uint64_t *kptr64; // constant address space: s_load through the scalar cache
 typedef const __attribute__((address_space(4))) uint32_t *kptr32;
-__device__ __forceinline__ void lds_write_u32(uint32_t lds_addr, uint32_t v)
-{
-  asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(lds_addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ uint32_t lds_read_u32(uint32_t lds_addr)
-{
-  uint32_t v;
-  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr) : "memory");
-  return v;
-}
-
-constexpr uint32_t kClaimLead = 16;   // groups (multiple of 4) between asking for a claim word / a sample and looking at it: ~2.5 us
-constexpr uint32_t kAsideBytes = 576; // per wave: two 256-byte samples of claim words + the run's tail chains' claim words (4 x 4 bytes, + padding)
-constexpr uint32_t kClaimNotHere = 0xFFFFFFFFu; // never an epoch (hsrans_capi.cpp numbers the launches 1 .. 0xFFFFFFFE)
 
 struct DirectPiece
 {
@@ -1580,88 +1539,6 @@ __device__ __forceinline__ DirectPiece direct_piece(const WaveCtx &c, const Pers
   return d;
 }
 
-// claim words [first, first + 64) (clipped by the descriptor) -> LDS at `dst`, asynchronously: one vector-memory operation
-__device__ __forceinline__ void claims_request(const WaveCtx &c, const u32x4 &rs, uint32_t first, uint32_t dst, uint64_t lanes)
-{
-  const uint32_t voff = (first + c.lane) * 4;
-  asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %3\n\tbuffer_load_dword %0, %2, 0 offen sc1 lds\n\ts_mov_b64 exec, -1"
-               :
-               : "v"(voff), "s"(dst), "s"(rs), "s"(lanes)
-               : "memory");
-}
-
-// run_direct's claim protocol as events of the hand-scheduled loop (iterations of 4 groups, counted from the run's start):
-//   tail chain t (t = 0 .. tails - 1) begins at iteration bound(t): kClaimLead / 4 iterations before it the owner asks for its
-//   claim word, at it the owner looks: claimed -> stop (the run ends here), else claim it and go on;
-//   kClaimLead / 4 iterations before the round's end: the sample of claim words for the thief this wave is about to become.
-struct TailEvents
-{
-  const WaveCtx &c;
-  const u32x4 &rs; // claim words' buffer descriptor
-  uint32_t aside, epoch;
-  uint32_t *claims;
-  uint32_t first_tail; // chain index of the run's first tail chain
-  uint32_t tails;      // tail chains in this run (0: a stolen chain, or no stealing)
-  uint32_t b0, b1, b2; // iteration at which tail chains 0, 1, 2 begin
-  uint32_t mode, n;    // PersistentArgs::steal_mode; chains in the plan
-  uint32_t t = 0;      // tail chains passed
-  bool requested = false, stolen = false, sampled = false;
-  uint32_t seed = 0, sample_first = 0;
-
-  __device__ __forceinline__ bool stopped() const { return stolen; }
-  __device__ __forceinline__ uint32_t first(uint32_t total) { return plan(0, total); }
-  __device__ __forceinline__ uint32_t next(uint32_t done, uint32_t total) { return plan(done, total); }
-  // does what is due at iteration `done`, returns the iterations until the next event (0: stop)
-  __device__ __forceinline__ uint32_t plan(uint32_t done, uint32_t total)
-  {
-    constexpr uint32_t lead = kClaimLead / 4;
-    while (t < tails)
-    {
-      uint32_t bound = t == 0 ? b0 : t == 1 ? b1 : b2;
-      bound = bound < total ? bound : total;
-      if (!requested)
-      {
-        const uint32_t at = bound > lead ? bound - lead : 0;
-        if (done < at)
-          return at - done;
-        if (mode != 3 && mode != 5)
-          claims_request(c, rs, first_tail + t, aside + 512 + 4 * t, 1);
-        requested = true;
-      }
-      if (done < bound)
-        return bound - done;
-      // The owner does NOT wait for its claim word: vector-memory operations complete in order, so "the word has landed" would also
-      // mean "every store before it has been acknowledged" — 3 us per tail chain with write-through stores (measured).  The word
-      // was set to kClaimNotHere before the request; still that = not here yet = taken as unclaimed (at worst owner and thief
-      // decode the chain twice).  Every tail chain of the run has a word of its own: a late arrival cannot be taken for another's.
-      if (uni(lds_read_u32(aside + 512 + 4 * t)) == epoch)
-      {
-        stolen = true; // a thief has this chain and all behind it
-        return 0;
-      }
-      if (c.lane == 0 && mode != 4 && mode != 5)
-        __hip_atomic_store(claims + first_tail + t, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      t++;
-      requested = false;
-    }
-    if (!sampled && mode == 2)
-    {
-      const uint32_t at = total > lead ? total - lead : 0;
-      if (done < at)
-        return at - done;
-      // claim words of 2 x 64 consecutive chains at a pseudo-random place, marked "not here" first
-      seed = seed * 1664525u + 1013904223u;
-      sample_first = n > 128 ? (seed >> 8) % (n - 127) : 0;
-      lds_write_u32(aside + c.lane * 4, kClaimNotHere);
-      lds_write_u32(aside + 256 + c.lane * 4, kClaimNotHere);
-      claims_request(c, rs, sample_first, aside, ~0ull);
-      claims_request(c, rs, sample_first + 64, aside + 256, ~0ull);
-      sampled = true;
-    }
-    return total - done;
-  }
-};
-
 template <int MODE>
 __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, uint32_t w)
 {
@@ -1671,15 +1548,13 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
   const uint64_t c_entry = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memtime() : 0; // shader clock (diagnostics: what does the chip run at under this load?)
   uint64_t t_table = 0, t_ready = 0, t_static = 0;
 #if HSRANS_HAVE_STAMPS
-  uint32_t diag_wait = 0, diag_store = 0, diag_stolen = 0, diag_calls = 0, diag_groups = 0;
-  uint64_t diag_gap = 0, diag_decode = 0, diag_last = 0; // shader clocks between / inside the decode body's calls
+  uint32_t diag_wait = 0, diag_store = 0;
 #endif
   const bool host_table = (MODE == kModePack64 || MODE == kModeRank || MODE == kModeSpill) && pa.table != nullptr;
   if (kp.finish != nullptr && w == 0 && c.lane == 0) // calibration launches: the launch's time zero
     kp.finish[W] = __builtin_amdgcn_s_memrealtime();
   if (!host_table) // the in-kernel build borrows ring space: it has to come before the first stream request
     build_table<MODE, true>(c, pa.hist_off, threadIdx.x, blockDim.x);
-  bool table_pending = host_table;
   // the host-built table: one coalesced 16 B load + LDS store per thread (while the wave's first stream chunks and its
   // states are in flight); the first wave also checks that the stream really carries the histogram the table was built
   // from (else: status, as a failed sum check)
@@ -1710,137 +1585,49 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
     if (HSRANS_STAMPS(kp))
       t_table = __builtin_amdgcn_s_memrealtime();
   };
-
   const uint32_t n = pa.n_chains;
-  const uint32_t R = pa.run_chains ? pa.run_chains : 1;            // launch_decode: W * R >= n
-  const bool stealing = R >= 2 && R <= 4 && pa.claims != nullptr && pa.steal_mode != 0; // (longer runs — an index made for a much smaller launch — are decoded whole by their owners)
-  const uint32_t epoch = pa.epoch;
-  const uint32_t aside = uni(lds_address(c.aside));
-  u32x4 rs_claims; // buffer descriptor of the claim words: requests beyond the last chain are dropped
+  const uint32_t R = pa.run_chains ? pa.run_chains : 1; // launch_decode: W * R >= n
+  const uint32_t ch = w * R;                            // this wave's run: chains [ch, end)
+  const uint32_t end = ch + R < n ? ch + R : n;
+  if (ch < n)
   {
-    const uint64_t a = (uint64_t)(uintptr_t)pa.claims;
-    rs_claims.x = uni((uint32_t)a);
-    rs_claims.y = uni((uint32_t)(a >> 32) & 0xFFFF);
-    rs_claims.z = n * 4;
-    rs_claims.w = 0x00020000;
+    StreamWin sw;
+    Ring r;
+    ring_bind(r, c.rings, 9, fast_ring_mode(MODE) && c.S == 64);
+    uint32_t x = c.lane < c.S ? pa.states[(uint64_t)ch * c.S + c.lane] : 0; // address known up front: in flight beside the piece records
+    const DirectPiece d = direct_piece(c, pa, ch);
+    // the run's last record (the first one again when R == 1): where the run's words and its output end, the stream's final partial group
+    const kptr64 plast = (kptr64)(uintptr_t)(pa.pieces + (end - 1));
+    const uint64_t run_limit = end < n ? plast[6] : c.stream_len;
+    const uint32_t last_steps = ((kptr32)plast)[8], last_tail = ((kptr32)plast)[9] & 0xFFFFu;
+    const uint64_t run_end_out = plast[1] + (uint64_t)last_steps * c.S;
+    win_open(sw, c, d.words, run_limit);
+#if defined(HSRANS_PROLOGUE_SPLIT) && HSRANS_PROLOGUE_SPLIT
+    // chunks 0 and 1 first (what the first ~25 groups read), the table, and only then the chunks the ring keeps ahead
+    ring_begin(sw, r, c, d.words, true, true);
+    if (host_table)
+      fetch_table();
+    ring_begin_rest(sw, r, c);
+    asm volatile("s_waitcnt vmcnt(2)" : "+v"(x)::"memory"); // (the two requests just made are the only younger ones: chunks 0, 1 and the states have landed)
+#else
+    ring_begin(sw, r, c, d.words);
+    if (host_table)
+      fetch_table();
+    ring_ready(x);
+#endif
+    if (HSRANS_STAMPS(kp))
+      t_ready = __builtin_amdgcn_s_memrealtime();
+    uint64_t o = d.out;
+    run_groups<MODE, true, false, true>(x, sw, r, c, o, (uint32_t)((run_end_out - o) / c.S));
+    run_tail<MODE>(x, r, c, o, end == n ? last_tail : 0);
+#if HSRANS_HAVE_STAMPS
+    diag_wait += r.diag_wait, diag_store += r.diag_store;
+#endif
   }
-  uint32_t sample_first = 0; // first chain of the sample in the aside
-  uint32_t seed = (w * 2654435761u) ^ (epoch * 40503u);
-  uint32_t ch = w * R;                           // this round's chains: [ch, end)
-  uint32_t end = ch + R < n ? ch + R : n;
-  bool have = ch < n;
-  while (true) // one loop, one call site of the decode body (a second copy of it pushes the kernel over the inliner's budget)
-  {
-    bool sampled = false;
-    if (have)
-    {
-      StreamWin sw;
-      Ring r;
-      ring_bind(r, c.rings, 9, fast_ring_mode(MODE) && c.S == 64);
-      uint32_t x = c.lane < c.S ? pa.states[(uint64_t)ch * c.S + c.lane] : 0; // address known up front: in flight beside the piece record
-      const DirectPiece d = direct_piece(c, pa, ch);
-      // the run's other records: where the run's words end, where its tail chains begin (R <= 4: a handful of scalar loads, all
-      // in flight together with the first record's), what its last chain's final partial group holds
-      const kptr64 plast = (kptr64)(uintptr_t)(pa.pieces + (end - 1));
-      const uint64_t run_limit = end < n ? plast[6] : c.stream_len;
-      const uint32_t last_steps = ((kptr32)plast)[8], last_tail = ((kptr32)plast)[9] & 0xFFFFu;
-      const uint64_t run_end_out = plast[1] + (uint64_t)last_steps * c.S;
-      uint64_t cut0 = run_end_out, cut1 = run_end_out, cut2 = run_end_out; // output offsets at which chains ch + 1, + 2, + 3 begin
-      if (stealing && ch + 1 < end)
-        cut0 = ((kptr64)(uintptr_t)(pa.pieces + ch + 1))[1];
-      if (stealing && ch + 2 < end)
-        cut1 = ((kptr64)(uintptr_t)(pa.pieces + ch + 2))[1];
-      if (stealing && ch + 3 < end)
-        cut2 = ((kptr64)(uintptr_t)(pa.pieces + ch + 3))[1];
-      win_open(sw, c, d.words, run_limit);
-      ring_begin(sw, r, c, d.words);
-      if (table_pending)
-      {
-        fetch_table();
-        table_pending = false;
-      }
-      ring_ready(x);
-      if (HSRANS_STAMPS(kp) && t_ready == 0)
-        t_ready = __builtin_amdgcn_s_memrealtime();
-      uint64_t o = d.out;
-      const uint32_t run_steps = (uint32_t)((run_end_out - o) / c.S);
-      const uint32_t tails = stealing ? end - ch - 1 : 0;
-      if (tails != 0)
-        lds_write_u32(aside + 512 + (c.lane & 3) * 4, kClaimNotHere); // the run's claim words: "not fetched yet"
-      TailEvents ev{c, rs_claims, aside, epoch, pa.claims, ch + 1, tails, (uint32_t)((cut0 - o) >> 8), (uint32_t)((cut1 - o) >> 8), (uint32_t)((cut2 - o) >> 8),
-                    stealing ? pa.steal_mode : 0, n};
-      ev.seed = seed;
-#if HSRANS_HAVE_STAMPS
-      const uint64_t seg_t0 = __builtin_amdgcn_s_memtime();
-#endif
-      run_groups<MODE, true, false, true, TailEvents>(x, sw, r, c, o, run_steps, ev); // ONE call site of the decode body
-#if HSRANS_HAVE_STAMPS
-      diag_decode += __builtin_amdgcn_s_memtime() - seg_t0;
-      diag_calls++;
-#endif
-      seed = ev.seed;
-      sample_first = ev.sample_first;
-      sampled = ev.sampled;
-      const bool stolen = ev.stolen;
-      if (!stolen && end == n)
-        run_tail<MODE>(x, r, c, o, last_tail);
-#if HSRANS_HAVE_STAMPS
-      diag_wait += r.diag_wait, diag_store += r.diag_store;
-#endif
-    }
-    if (HSRANS_STAMPS(kp) && t_static == 0)
-      t_static = __builtin_amdgcn_s_memrealtime();
-    if (!stealing || !sampled || pa.steal_mode < 2)
-      break;
-    // ---- thief ----
-    // A claim is made with an atomic exchange (the old value decides).  What may be claimed: (1) the chain in FRONT of the one
-    // this wave has just decoded as a thief, if that is still a tail chain — it knows that everything behind it in the run is
-    // claimed, because it claimed it; (2) a run's LAST chain that the sample shows unclaimed (nothing behind it to orphan).
-    // Nothing else: the sample is hearsay (asked for kClaimLead groups ago, possibly not even here yet — the thief does not
-    // wait for it either: the launch's last wave comes through here too, and must be gone at once), and an owner stops at the
-    // first claimed chain it meets, so whoever claims a chain must know that all chains behind it in the run have takers.
-    const bool was_thief = have && end == ch + 1 && R > 1 && ch % R != 0;
-    uint32_t back = was_thief && ch % R >= 2 ? ch - 1 : 0xFFFFFFFFu; // (position >= 2: the chain in front is a tail chain too)
-    have = false;
-    unsigned long long cand = 0;
-    uint32_t cand_base = 0;
-    for (uint32_t tries = 0; tries < 4 && !have; tries++)
-    {
-      uint32_t target = back;
-      back = 0xFFFFFFFFu;
-      if (target == 0xFFFFFFFFu)
-      {
-        if (cand == 0 && tries < 3)
-        {
-          const uint32_t half = tries ? 1 : 0; // (first look: the sample's first 64 chains; then its second 64)
-          const uint32_t chain = sample_first + half * 64 + c.lane;
-          const uint32_t word = lds_read_u32(aside + half * 256 + c.lane * 4);
-          cand = __builtin_amdgcn_ballot_w64(chain < n && chain % R != 0 && (chain % R == R - 1 || chain == n - 1) && word != epoch && word != kClaimNotHere);
-          cand_base = sample_first + half * 64;
-        }
-        if (cand == 0)
-          continue;
-        target = cand_base + (uint32_t)__builtin_ctzll(cand);
-        cand &= cand - 1;
-      }
-      uint32_t old = 0;
-      if (c.lane == 0)
-        old = __hip_atomic_exchange(pa.claims + target, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (uni(old) != epoch)
-      {
-        ch = target;
-        end = target + 1;
-        have = true;
-#if HSRANS_HAVE_STAMPS
-        diag_stolen++;
-#endif
-      }
-    }
-    if (!have)
-      break;
-  }
-  if (table_pending) // a wave without a chain still takes part in the workgroup's table copy
+  else if (host_table) // a wave without a chain still takes part in the workgroup's table copy
     fetch_table();
+  if (HSRANS_STAMPS(kp))
+    t_static = __builtin_amdgcn_s_memrealtime();
   if (kp.finish != nullptr && c.lane == 0) // calibration launches (hsrans_ctx_calibrate): when this wave was done
     kp.finish[w] = __builtin_amdgcn_s_memrealtime();
   if (HSRANS_STAMPS(kp) && c.lane == 0)
@@ -1857,8 +1644,7 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_id), "=s"(xcc_id));
     st[6] = (uint64_t)hw_id | ((uint64_t)xcc_id << 32);
 #if HSRANS_HAVE_STAMPS
-    st[7] = (uint64_t)diag_wait | ((uint64_t)(diag_store + (diag_stolen << 28)) << 32); // shader clocks waiting at chunk crossings | issuing stores (-DHSRANS_DIAG_STORE_TIME) | chains stolen << 28
-    st[1] = (diag_gap & 0xFFFFFFull) | ((diag_decode & 0xFFFFFFull) << 24) | ((uint64_t)(diag_calls & 0xFF) << 48) | ((uint64_t)(diag_groups & 0xFF) << 56); // (instead of t_table)
+    st[7] = (uint64_t)diag_wait | ((uint64_t)diag_store << 32); // shader clocks waiting at chunk crossings | issuing stores (-DHSRANS_DIAG_STORE_TIME)
 #endif
   }
 }
@@ -2563,7 +2349,6 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.gtable = kp.pa.table;
   c.scratch_cnt = (uint16_t *)ring0; // wave 0's ring (no request in flight while a table is built)
   c.scratch_cum = (uint16_t *)(ring0 + 512);
-  c.aside = smem + waves * ring_stride + table_bytes_for(MODE, c.bits) + wave * kAsideBytes; // behind rings and table, whichever comes first
   const uint32_t chain = blockIdx.x * waves + wave;
   if (c.S == 32)
     run_direct_pair<MODE>(c, kp, waves, chain);
@@ -2599,7 +2384,6 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_c
   c.gtable = kp.pa.table;
   c.scratch_cnt = (uint16_t *)smem;
   c.scratch_cum = (uint16_t *)(smem + 512);
-  c.aside = smem + waves * kFastRingBytes + table_bytes_for(MODE, c.bits) + wave * kAsideBytes;
   run_direct<MODE>(c, kp, waves, blockIdx.x * waves + wave);
 }
 
@@ -3583,14 +3367,6 @@ static bool g_weights_two_level = false; // HSRANS_WEIGHTS_TWO_LEVEL: apply the 
 static bool g_table_spill = false;       // HSRANS_TABLE_SPILL: host-built tables stay in global memory (kModeSpill; comparison only)
 // one-chain-per-wave plans (hsrans_index_boundaries): share of the stream (per mille) left to short chains that the ticket
 // queues hand to waves that are done early, and the length of those chains in groups
-// Tail stealing of the one-chain-per-wave launches (run_direct): the last g_tail_permille of every wave's share of the stream is cut
-// into g_tail_pieces short chains that the wave walks into on its own and a wave that is done early may take off its hands.
-// HSRANS_DIRECT_TAIL_PIECES (0 = off .. 3), HSRANS_DIRECT_TAIL_PERMILLE (of the wave's share, all tail chains together).
-// (Rounds 2-3 had tried a pool of short chains at the END of the stream behind ticket queues: every wave paid a prologue of three
-// dependent round trips per chain; 46.2 -> 49.8 us.  Here an undisturbed wave pays one 4-byte request and one store per tail chain.)
-static uint32_t g_steal_mode = 2; // HSRANS_DIRECT_STEAL (diagnostics): 0 = runs are decoded whole by their owners, 1 = owners keep the claim protocol but nobody steals, 2 = stealing
-static uint32_t g_tail_pieces = 0;
-static uint32_t g_tail_permille = 200;
 
 static void read_tuning_once();
 static uint32_t g_persist_kernel = 1; // HSRANS_PERSIST_KERNEL: 0 = uniform-interval plans on k_decode<3, true> (A/B)
@@ -3735,12 +3511,6 @@ static void read_tuning_impl()
   read_weights("HSRANS_DUAL_WEIGHTS", g_dual_weights);               // 13 bits (8-byte table)
   read_weights("HSRANS_DUAL_WEIGHTS_WIDE", g_dual_weights_wide); // 14 / 15 bits (rank table)
   g_rank_table = getenv("HSRANS_NO_RANK_TABLE") == nullptr;
-  if (const char *e = getenv("HSRANS_DIRECT_STEAL"))
-    g_steal_mode = (uint32_t)atoi(e);
-  if (const char *e = getenv("HSRANS_DIRECT_TAIL_PIECES"))
-    g_tail_pieces = (uint32_t)atoi(e) > 3 ? 3 : (uint32_t)atoi(e);
-  if (const char *e = getenv("HSRANS_DIRECT_TAIL_PERMILLE"))
-    g_tail_permille = (uint32_t)atoi(e) > 600 ? 600 : (uint32_t)atoi(e) < 10 ? 10 : (uint32_t)atoi(e);
 }
 
 // per device (the CURRENT device): dynamic-LDS limit of every kernel variant, CU count
@@ -3836,8 +3606,6 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
     while (waves > 1 && (waves / 2 >= h.n_chains || waves * ring + table_bytes > dg.max_lds))
       waves /= 2;
     lds = waves * ring + table_bytes + (grouped ? 64 + 1024 : 0); // (run_grouped's two next-group words and its table-build scratch)
-    if (direct && persistent)
-      lds += waves * kAsideBytes; // (run_direct: claim words fetched ahead of time)
     grid = (h.n_chains + waves - 1) / waves;
     if (grouped)
       grid = n_groups;
@@ -3878,7 +3646,7 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
 // for a mergeable plan of (states, bits): chain w belongs to wave w, its length follows the wave's class weight.
 // Boundaries are multiples of 4 groups (the decode loop stores 4 groups at a time).  Returns the number of chains;
 // out[k] = first group of chain k + 1 (k < chains - 1).
-size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, uint64_t total_groups, uint64_t *out, size_t cap, int tail_pieces)
+size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, uint64_t total_groups, uint64_t *out, size_t cap)
 {
   PlanHeader h{};
   h.states = states;
@@ -3895,11 +3663,7 @@ size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, u
     chains = all_units / 8 ? all_units / 8 : 1;
   if (chains <= 1)
     return 1;
-  // tail chains (run_direct's stealing): only where a wave decodes ONE run and the machine is full; tail_pieces < 0 = the configured number
-  uint32_t K = tail_pieces < 0 ? g_tail_pieces : (uint32_t)tail_pieces;
-  if (runs_per_wave != 1 || chains != W || K > 3)
-    K = 0;
-  if (chains * (K + 1) - 1 > cap)
+  if (chains - 1 > cap)
     return 0;
   // cumulative weight up to chain k, then boundaries at units * cum / all
   const uint32_t first_half = (L.grid + 1) / 2;
@@ -3915,27 +3679,15 @@ size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, u
     all += weight_of(k);
   uint64_t cum = 0, prev = 0;
   size_t n = 0;
-  for (uint64_t k = 0; k < chains; k++)
+  for (uint64_t k = 0; k + 1 < chains; k++)
   {
     cum += weight_of(k);
-    uint64_t b = k + 1 == chains ? all_units : (uint64_t)((unsigned __int128)all_units * cum / all); // where share k ends
+    uint64_t b = (uint64_t)((unsigned __int128)all_units * cum / all);
     if (b <= prev)
-      b = prev + 1; // every share gets at least one unit
-    if (b > all_units)
-      b = all_units;
-    if (K != 0)
-    {
-      // the share's last g_tail_permille in K chains of equal length (at least one unit each, and at least one left in front)
-      const uint64_t len = b - prev;
-      uint64_t piece = len * g_tail_permille / 1000 / K;
-      piece = piece ? piece : 1;
-      if (piece * K >= len)
-        return 0; // (cannot happen with >= 8 units per share and <= 600 per mille; the caller falls back to no index)
-      for (uint32_t t = K; t >= 1; t--)
-        out[n++] = (b - t * piece) * 4;
-    }
-    if (k + 1 < chains)
-      out[n++] = b * 4;
+      b = prev + 1; // every chain gets at least one unit
+    if (b >= all_units)
+      break;
+    out[n++] = b * 4;
     prev = b;
   }
   return n + 1;
@@ -4001,7 +3753,6 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
     // one-chain-per-wave launches: the plan's chains as W runs of consecutive chains (run_direct); 32-state and two-chain launches keep their own dealing
     const uint64_t W = (uint64_t)grid * waves;
     kp.pa.run_chains = h.states == 64 && !L.dual ? (uint32_t)((h.n_chains + W - 1) / W) : 1;
-    kp.pa.steal_mode = g_steal_mode;
   }
   if (kp.single.valid && !index_pass && g_single_fast)
   {

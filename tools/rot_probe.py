@@ -88,11 +88,6 @@ def stamp_summary(dp):
              "store_us_mean_all": round(float(store_us.mean()), 2), "store_us_mean_slowest10pct": round(float(store_us[slow].mean()), 2), "store_us_mean_fastest50pct": round(float(store_us[fast].mean()), 2),
              "lifetime_us_slowest10pct": round(float((rel[slow, 3] - rel[slow, 2]).mean()), 2), "lifetime_us_fastest50pct": round(float((rel[fast, 3] - rel[fast, 2]).mean()), 2),
              "corr_wait_done": round(float(np.corrcoef(wait_us, done)[0, 1]), 3)}
-    gap = (st[:, 1] & 0xFFFFFF) / (ghz * 1e3)
-    dec = ((st[:, 1] >> 24) & 0xFFFFFF) / (ghz * 1e3)
-    calls = (st[:, 1] >> 48) & 0xFF
-    extra.update({"decode_body_us_mean": round(float(dec.mean()), 2), "between_calls_us_mean": round(float(gap.mean()), 2), "calls_mean": round(float(calls.mean()), 2),
-                  "stolen_total": int(((st[:, 7] >> 60) & 0xF).sum())})
     return {**extra, "ready_p50": q(2, 50), "static_done_p50": q(4, 50), "done_p10": q(3, 10), "done_p50": q(3, 50), "done_p90": q(3, 90), "done_p99": q(3, 99), "done_max": q(3, 100),
             "done_mean": round(float(rel[:, 3].mean()), 2), "GHz_p50": round(float(np.median(st[:, 5] / ((st[:, 3] - st[:, 0]) * 10.0))), 3)}
 
