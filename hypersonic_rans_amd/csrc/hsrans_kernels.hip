@@ -230,7 +230,7 @@ __device__ __forceinline__ void ring_bind(Ring &r, const uint8_t *lds_ring, uint
 }
 __device__ __forceinline__ uint32_t ring_bytes(const Ring &r) { return kRingSlots << r.clog; }
 
-__device__ __forceinline__ void ring_request(const StreamWin &sw, const Ring &r, const WaveCtx &c, uint32_t chunk)
+__device__ __forceinline__ void ring_request(const StreamWin &sw, const Ring &r, const WaveCtx &c, uint32_t chunk, bool with_mirror = true)
 {
   const uint32_t voff = r.voff0 + (chunk << r.clog) + c.lane * 16;
   const uint32_t slot = chunk & (kRingSlots - 1);
@@ -241,11 +241,21 @@ __device__ __forceinline__ void ring_request(const StreamWin &sw, const Ring &r,
                :
                : "v"(voff), "s"(dst), "s"(sw.rs), "s"((uint64_t)lanes)
                : "memory");
-  if (slot == 0) // wave-uniform: the ring's first 128 (64) bytes once more, behind its end (lanes 0..7 / 0..3)
+  if (slot == 0 && with_mirror) // wave-uniform: the ring's first 128 (64) bytes once more, behind its end (lanes 0..7 / 0..3)
     asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 exec, %3\n\tbuffer_load_dwordx4 %0, %2, 0 offen" HSRANS_STREAM_LOAD_FLAGS " lds\n\ts_mov_b64 exec, -1"
                  :
                  : "v"(voff), "s"(uni(r.lds + ring_bytes(r))), "s"(sw.rs), "s"((uint64_t)r.mirror_lanes)
                  : "memory");
+}
+
+// chunk 0's mirror alone (ring_begin with `later`: the mirror is first read when the cursor nears the ring's end, three chunks on)
+__device__ __forceinline__ void ring_request_mirror0(const StreamWin &sw, const Ring &r, const WaveCtx &c)
+{
+  const uint32_t voff = r.voff0 + c.lane * 16;
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %3\n\tbuffer_load_dwordx4 %0, %2, 0 offen" HSRANS_STREAM_LOAD_FLAGS " lds\n\ts_mov_b64 exec, -1"
+               :
+               : "v"(voff), "s"(uni(r.lds + ring_bytes(r))), "s"(sw.rs), "s"((uint64_t)r.mirror_lanes)
+               : "memory");
 }
 
 // `pos` = first stream byte the descriptor must reach, `limit` = first stream byte the chain(s) can NOT need (the next
@@ -299,7 +309,7 @@ __device__ __forceinline__ void ring_begin(const StreamWin &sw, Ring &r, const W
   r.vm = 0;
   if (issue)
   {
-    ring_request(sw, r, c, 0);
+    ring_request(sw, r, c, 0, !later);
     ring_request(sw, r, c, 1);
   }
   r.vm += 3; // chunk 0, its mirror, chunk 1
@@ -317,6 +327,7 @@ __device__ __forceinline__ void ring_begin(const StreamWin &sw, Ring &r, const W
 }
 __device__ __forceinline__ void ring_begin_rest(const StreamWin &sw, Ring &r, const WaveCtx &c)
 {
+  ring_request_mirror0(sw, r, c);
   ring_request(sw, r, c, 2);
   if (HSRANS_RING_AHEAD == 3)
     ring_request(sw, r, c, 3);
@@ -1602,13 +1613,16 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
     const uint32_t last_steps = ((kptr32)plast)[8], last_tail = ((kptr32)plast)[9] & 0xFFFFu;
     const uint64_t run_end_out = plast[1] + (uint64_t)last_steps * c.S;
     win_open(sw, c, d.words, run_limit);
-#if defined(HSRANS_PROLOGUE_SPLIT) && HSRANS_PROLOGUE_SPLIT
-    // chunks 0 and 1 first (what the first ~25 groups read), the table, and only then the chunks the ring keeps ahead
+    // Every wave of the device is in its prologue at the same time, and a CU takes in about 11 bytes per clock then
+    // (MI355X_MICROARCH.md, "prologue HBM burst"): what the first ~25 groups read — states, chunks 0 and 1 — is asked for first,
+    // then the table; chunk 0's mirror and the chunks the ring keeps ahead come after that.  Rotated 39.3 -> 38.7 us, replayed
+    // 32.65 -> 32.4 (profiles/r04_prologue_ab.jsonl; -DHSRANS_PROLOGUE_SPLIT=0: all five requests up front, as in rounds 1-3).
+#if !defined(HSRANS_PROLOGUE_SPLIT) || HSRANS_PROLOGUE_SPLIT
     ring_begin(sw, r, c, d.words, true, true);
     if (host_table)
       fetch_table();
     ring_begin_rest(sw, r, c);
-    asm volatile("s_waitcnt vmcnt(2)" : "+v"(x)::"memory"); // (the two requests just made are the only younger ones: chunks 0, 1 and the states have landed)
+    asm volatile("s_waitcnt vmcnt(3)" : "+v"(x)::"memory"); // (the three requests just made are the only younger ones: chunks 0, 1 and the states have landed)
 #else
     ring_begin(sw, r, c, d.words);
     if (host_table)
@@ -2507,13 +2521,22 @@ __device__ __forceinline__ void ring_request_counted(const StreamWin &sw, const 
   vm += (chunk & (kRingSlots - 1)) == 0 ? 2 : 1; // slot 0 also refills the mirror
 }
 
-__device__ __forceinline__ void ring_begin_counted(const StreamWin &sw, RingD &d, const WaveCtx &c, uint64_t pos, uint32_t &vm)
+// (`later`: chunks 0 and 1 only, without chunk 0's mirror — the caller asks for the rest once what its first groups read has landed: ring_begin)
+__device__ __forceinline__ void ring_begin_counted(const StreamWin &sw, RingD &d, const WaveCtx &c, uint64_t pos, uint32_t &vm, bool later = false)
 {
   pos = uni64(pos);
   const uint32_t rel = (uint32_t)(pos - sw.base);
   d.r.voff0 = rel & ~15u;
   d.r.cur = (rel - d.r.voff0) >> 1;
   d.r.k = 0;
+  if (later)
+  {
+    ring_request(sw, d.r, c, 0, false);
+    ring_request(sw, d.r, c, 1);
+    vm += 2;
+    d.seq1 = d.seq2 = d.seq3 = vm;
+    return;
+  }
   ring_request_counted(sw, d.r, c, 0, vm);
   ring_request_counted(sw, d.r, c, 1, vm);
   d.seq1 = vm;
@@ -2855,17 +2878,34 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
     ring_bind(rb.r, c.rings + kDualRing, 9, true);
     uint32_t vm = 0; // vector-memory instructions issued from here on (everything older completes before them anyway)
     win_open(sw, c, da.words, have_b ? db.limit : da.limit); // the two chains are neighbours in the stream: one window
-    ring_begin_counted(sw, ra, c, da.words, vm);
+    // what the first groups read first (states, chunks 0 and 1 of both rings, the table), the chunks the rings keep ahead and the
+    // mirrors behind that: every wave of the device is here at the same time and a CU takes in ~11 bytes per clock (run_direct)
+    ring_begin_counted(sw, ra, c, da.words, vm, true);
     if (have_b)
-      ring_begin_counted(sw, rb, c, db.words, vm);
-    else
-      rb = ra;
+      ring_begin_counted(sw, rb, c, db.words, vm, true);
     if (table_pending)
     {
       fetch_table();
       table_pending = false;
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa), "+v"(xb)::"memory"); // start of a chain pair: states, table and the first chunks of both rings
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa), "+v"(xb)::"memory"); // start of a chain pair: states, table and the first two chunks of both rings
+    ring_request_mirror0(sw, ra.r, c);
+    ring_request(sw, ra.r, c, 2);
+    if (have_b)
+    {
+      ring_request_mirror0(sw, rb.r, c);
+      ring_request(sw, rb.r, c, 2);
+    }
+    if (HSRANS_RING_AHEAD == 3)
+    {
+      ring_request(sw, ra.r, c, 3);
+      if (have_b)
+        ring_request(sw, rb.r, c, 3);
+    }
+    if (!have_b)
+      rb = ra;
+    // (the loop's constant wait — at most 6 outstanding at a crossing — holds from its first crossing on: behind a ring's request for
+    // chunk 2 there are the other requests just made and two stores per iteration since)
     vm = 0;
     ra.seq1 = ra.seq2 = ra.seq3 = rb.seq1 = rb.seq2 = rb.seq3 = 0;
     if (HSRANS_STAMPS(kp) && t_ready == 0)
