@@ -1,0 +1,247 @@
+// kernels_grouped.h — block_/mt_ plans with checkpoints: one workgroup per block, round after round (BASELINE config 4) — run_grouped, k_decode_grouped.
+// Part of the one device translation unit hsrans_kernels.hip (which includes the parts in dependency order and holds the host-side launcher).
+#ifndef HSRANS_KERNELS_GROUPED_H
+#define HSRANS_KERNELS_GROUPED_H
+
+namespace hsrans
+{
+
+// Grouped launch: workgroup b walks groups b, b + gridDim.x, ...; per group one table build, then every wave decodes an
+// equal contiguous share of the group's chains.
+// LEAN: the host promises a 64-state plan whose groups are all mergeable runs or fills (every block_/mt_ stream with checkpoints
+// this library's encoders or index builders make): the 32-state pair path and the general chain runner are left out of the
+// kernel, which is what keeps it at 8 waves per SIMD
+template <int MODE, bool LEAN = false, bool FAST = false> // FAST: the hand-scheduled 32-state pair loop too (measured in a kernel of its own: 71 VGPRs, 7 waves per SIMD — not used)
+__device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams &kp, uint32_t waves, uint32_t wave)
+{
+  // -DHSRANS_GROUP_STAMPS=1 builds (tools/stamps_grouped.py; needs HSRANS_DEBUG_STAMPS=1 at run time): where a wave's time goes,
+  // summed over its rounds: [0] first entry, [1] waiting at the round's barrier, [2] table build, [3] plan records + first chunks
+  // (until the decode loop starts), [4] decode, [5] rounds, [6] last exit.  Compile-time because even switched off the extra
+  // bookkeeping cost this kernel 8 % (0.405 -> 0.44 of 8 TB/s on the 1 GiB mt_ workload without it).
+#if defined(HSRANS_GROUP_STAMPS) && HSRANS_GROUP_STAMPS
+#define HSRANS_GS(...) __VA_ARGS__
+#else
+#define HSRANS_GS(...)
+#endif
+  HSRANS_GS(uint64_t t_first = 0, acc_wait = 0, acc_build = 0, acc_meta = 0, acc_dec = 0, rounds = 0; if (HSRANS_STAMPS(kp)) t_first = __builtin_amdgcn_s_memrealtime();)
+  // (Measured and not kept, round 3: wave 0 pulling the NEXT group's record, piece records and start states through the caches at the
+  // end of its round — LDS-DMA into the build scratch, so that the three dependent round trips behind the barrier hit L2: 64 KiB
+  // blocks 537 / 542 / 534 us against 537 / 540 / 542 with it, 100 MB 0.368 against 0.369.  The other workgroups of the CU hide them.)
+  // (Round 2 had measured a ticket counter — drawn by everyone after the round's barrier — and checkpoints placed by wave class
+  // inside the blocks, and found neither worth it; what changed the picture in round 3 is below: the draw hidden in wave 0's
+  // barrier wait, four 8-wave workgroups per CU (launch_shape) and the younger waves' raised priority.)
+  // Which group next.  Static: b, b + gridDim.x, ...  Dynamic (kp.group_tickets): round 0 is static, every later group comes from
+  // a ticket counter.  The draw is made by WAVE 0 alone, at the end of its share of the round, and waited for on the spot: wave 0
+  // is the oldest wave of the workgroup, the SIMDs serve it first, it finishes first and would spend the round trip (and several
+  // microseconds more) at the round's barrier anyway — so the draw costs the workgroup nothing, the decision is made as late as
+  // it can be, and no register carries a ticket across the decode loop.  (Drawn after the barrier by everyone it cost ~2 us per
+  // round and made the launch slower than the static order it was meant to beat.)  The group goes through one of two LDS words,
+  // alternating by round: round r's word is written before barrier r and read behind it; the next write to it comes behind
+  // barrier r + 1.  Every workgroup draws once at the end of every round it runs, the launch as a whole exactly n_groups times:
+  // ticket mod n_groups is the launch-local order whatever the counter has seen before (it is never reset).
+  const bool dynamic = kp.group_tickets != nullptr && kp.n_groups > gridDim.x;
+  volatile uint32_t *lds_next = (volatile uint32_t *)(c.table + table_bytes_for(MODE, c.bits)); // 2 words: launch_shape reserves 64 bytes behind the table
+  uint32_t gi = blockIdx.x;
+  for (uint32_t round = 0;; round++)
+  {
+    if (!(dynamic && round >= 1) && gi >= kp.n_groups) // (dynamic rounds: decided below, from the published group)
+      break;
+    // `advance` runs at the end of the round (every path of the loop body ends in it)
+    auto advance = [&]() {
+      if (!dynamic)
+        gi += gridDim.x;
+      else if (wave == 0 && c.lane == 0)
+      {
+        const uint32_t j = (uint32_t)(atomicAdd(kp.group_tickets, 1ull) % kp.n_groups);
+        lds_next[(round + 1) & 1] = j < kp.n_groups - gridDim.x ? gridDim.x + j : 0xFFFFFFFFu;
+      }
+    };
+    HSRANS_GS(const uint64_t t0 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no stream request of the previous group may still land in the scratch slot
+    __syncthreads();                                    // every wave is done with the previous group's table and rings
+    if (dynamic && round >= 1)
+    {
+      gi = uni(lds_next[round & 1]);
+      if (gi >= kp.n_groups) // (the same in every wave)
+        break;
+    }
+    const Group *G = kp.groups + gi;
+    const uint32_t begin = uni(G->begin), count = uni(G->count), flags = uni(G->flags);
+    // mergeable groups: chain `begin + i` is piece `piece0 + i` and its start states are states[begin + i] (the host checks this
+    // when it marks a group mergeable), so a wave's records come straight from the group record: one level of loads, not three
+    const uint32_t piece0 = uni(G->piece0);
+    HSRANS_GS(const uint64_t t1 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;)
+    // kp.group_overlap (64-state mergeable groups): the wave's piece records, start states and first stream chunks are requested
+    // BEFORE the table build and land while it runs (the build's scratch then has an LDS area of its own: launch_shape) — the
+    // ~4.5 us of dependent round trips a round used to spend after the build overlap its ~3 us instead
+    const bool overlap = LEAN && kp.group_overlap != 0 && (flags & kGroupMergeable); // (the general instantiation has no registers to spare for it)
+#if defined(HSRANS_GROUP_STAMPS) && HSRANS_GROUP_STAMPS
+    const uint64_t t2 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;
+    acc_wait += t1 - t0;
+    acc_build += t2 - t1;
+    rounds++;
+    auto stamp_out = [&]() {
+      if (HSRANS_STAMPS(kp) && c.lane == 0)
+      {
+        uint64_t *st = kp.stamps + (uint64_t)(blockIdx.x * waves + wave) * 8;
+        st[0] = t_first;
+        st[1] = acc_wait;
+        st[2] = acc_build;
+        st[3] = acc_meta;
+        st[4] = acc_dec;
+        st[5] = rounds;
+        st[6] = __builtin_amdgcn_s_memrealtime();
+      }
+    };
+#endif
+    const uint32_t half = blockIdx.x >= (gridDim.x + 1) / 2 ? 1 : 0;
+    // age-class weights only where a wave gets enough chains for them to mean something (else an even split)
+    const bool weighted = count >= 8 * waves;
+    const uint32_t cum_all = weighted ? kp.group_cum[half][waves] : waves;
+    const uint32_t first = begin + (uint32_t)((uint64_t)(weighted ? kp.group_cum[half][wave] : wave) * count / cum_all);
+    const uint32_t last = begin + (uint32_t)((uint64_t)(weighted ? kp.group_cum[half][wave + 1] : wave + 1) * count / cum_all);
+    // the wave's run of a mergeable 64-state group: chains [first, last) as one chain.  With `early` it is opened twice: before
+    // the table build for the sake of its requests (start states, first stream chunks: in flight during the build), and again
+    // after it without them — the records come from the caches then — so that only the state register lives across the build
+    // (the window, the ring and the run's geometry are 20 scalar registers the builder has no room for: they spilled).
+    StreamWin sw;
+    Ring r;
+    uint32_t x = 0, run_tail_syms = 0;
+    uint64_t o = 0, run_steps = 0;
+    auto open_run = [&](bool issue) {
+      const Piece *p0 = pv.pieces + (piece0 + (first - begin));
+      const Piece *p1 = pv.pieces + (piece0 + (last - 1 - begin));
+      const uint64_t limit = last < begin + count ? uni64(pv.pieces[piece0 + (last - begin)].words_off) : uni64(G->words_end);
+      if (issue)
+        x = c.lane < c.S ? pv.states[(uint64_t)first * c.S + c.lane] : 0;
+      ring_bind(r, c.rings, 9, fast_ring_mode(MODE));
+      win_open(sw, c, uni64(p0->words_off), limit);
+      ring_begin(sw, r, c, uni64(p0->words_off), issue);
+      o = uni64(p0->out_off);
+      run_steps = (uni64(p1->out_off) - o) / c.S + uni(p1->steps);
+      run_tail_syms = uni(p1->tail);
+    };
+    const bool early = overlap && first < last;
+    if (early)
+      open_run(true);
+    if (!(flags & kGroupFill)) // (one call site: every inlined copy of the builder costs the kernel registers)
+      build_table<MODE, true>(c, uni64(G->hist_off), threadIdx.x, blockDim.x);
+    if (first >= last)
+    {
+      advance();
+      continue;
+    }
+    if (!LEAN && (flags & kGroupMergeable) && c.S == 32)
+    {
+      // 32-state chains: the wave's share is cut in two runs that are decoded side by side, A on lanes 0..31 and B on
+      // lanes 32..63 (group_step_pair), like run_persistent_pair; whatever the pair loop leaves is finished one run at a time
+      const uint32_t mid = first + (last - first + 1) / 2;
+      const bool have_b = mid < last;
+      const Piece *a0 = pv.pieces + (piece0 + (first - begin));
+      const Piece *a1 = pv.pieces + (piece0 + (mid - 1 - begin));
+      const Piece *b0 = pv.pieces + (piece0 + ((have_b ? mid : first) - begin));
+      const Piece *b1 = pv.pieces + (piece0 + (last - 1 - begin));
+      const uint64_t limit = last < begin + count ? uni64(pv.pieces[piece0 + (last - begin)].words_off) : uni64(G->words_end);
+      StreamWin sw;
+      Ring ra, rb;
+      pair_bind<MODE>(ra, rb, c);
+      win_open(sw, c, uni64(a0->words_off), limit);
+      ring_begin(sw, ra, c, uni64(a0->words_off));
+      if (have_b)
+        ring_begin(sw, rb, c, uni64(b0->words_off));
+      const uint32_t src = (c.lane < 32 || !have_b) ? first : mid;
+      uint32_t x = pv.states[(uint64_t)src * 32 + (c.lane & 31)];
+      uint64_t oa = uni64(a0->out_off), ob = have_b ? uni64(b0->out_off) : 0;
+      uint32_t sa = (uint32_t)((uni64(a1->out_off) - oa) / 32) + uni(a1->steps);
+      uint32_t sb = have_b ? (uint32_t)((uni64(b1->out_off) - ob) / 32) + uni(b1->steps) : 0;
+      ring_ready(x);
+      if (have_b)
+      {
+        const uint32_t both = (sa < sb ? sa : sb) & ~3u;
+        run_pair_groups<MODE, FAST>(x, sw, ra, rb, c, oa, ob, both);
+        sa -= both;
+        sb -= both;
+        uint32_t xb = __shfl(x, (c.lane & 31) + 32, 64); // B's states move down to lanes 0..31 and B is finished alone
+        run_groups<MODE>(xb, sw, rb, c, ob, sb);
+        run_tail<MODE>(xb, rb, c, ob, uni(b1->tail));
+      }
+      run_groups<MODE>(x, sw, ra, c, oa, sa);
+      run_tail<MODE>(x, ra, c, oa, uni(a1->tail));
+    }
+    else if (flags & kGroupMergeable)
+    {
+      open_run(!early);
+      ring_ready(x);
+      HSRANS_GS(const uint64_t t3 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;)
+      // kp.group_prio (per mille; 350 by default): the younger half of the workgroup's waves decodes that share of its run at
+      // raised instruction priority (s_setprio) — the SIMD otherwise serves its oldest wave first, the older half of the waves is
+      // done 8 us before the younger one and waits at the round's barrier.  Unlike the one-chain-per-wave launch, whose index
+      // gives the classes chains of different lengths, a block's checkpoints are where the encoder put them.
+      // (not where the wave's share was already sized by its age class: 100 MB in 256 KiB blocks + G=32: 0.359 -> 0.340 with both)
+      const uint32_t prio_steps = kp.group_prio != 0 && !weighted && wave >= waves / 2 ? (uint32_t)(run_steps * kp.group_prio / 1000) & ~3u : 0;
+      if (prio_steps != 0)
+      {
+        __builtin_amdgcn_s_setprio(1);
+        run_groups<MODE, true, true>(x, sw, r, c, o, prio_steps);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      run_groups<MODE, true, true>(x, sw, r, c, o, (uint32_t)run_steps - prio_steps);
+      run_tail<MODE>(x, r, c, o, run_tail_syms);
+      HSRANS_GS(if (HSRANS_STAMPS(kp)) {
+        acc_meta += t3 - t2;
+        acc_dec += __builtin_amdgcn_s_memrealtime() - t3;
+      })
+    }
+    else if (LEAN) // fill chains (single-symbol blocks): one fill piece each
+      for (uint32_t ch = first; ch < last; ch++)
+      {
+        const Piece *pc = pv.pieces + uni(pv.chain_first[ch]);
+        wave_fill(c, uni64(pc->out_off), uni64(pc->fill_len), (uint32_t)uni64(pc->hist_off) & 0xFF);
+      }
+    else
+      for (uint32_t ch = first; ch < last; ch++)
+        run_planned_chain<MODE, true>(c, pv, ch, kp);
+    HSRANS_GS(stamp_out();)
+    advance();
+  }
+}
+
+// The kernel of the grouped launches (block_/mt_ plans with checkpoints: one workgroup per block, run_grouped) — BASELINE config 4's
+// kernel.  A kernel of its own for the same reason as k_decode_direct: inside k_decode<MODE, true> it shared one register
+// allocation with five other launch shapes (two more VGPRs there are the difference between 8 and 7 waves per SIMD).
+// LDS: [waves x ring][table][2 next-group words, 64 B][table-build scratch, 1 KiB].
+template <int MODE, bool LEAN>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_decode_grouped(KParams kp)
+{
+  extern __shared__ u32x4 smem_v[];
+  uint8_t *smem = (uint8_t *)smem_v;
+  const PlanView pv = plan_view(kp.plan);
+  const uint32_t waves = blockDim.x >> 6;
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  WaveCtx c;
+  c.stream = kp.stream;
+  c.stream_len = kp.stream_len;
+  c.stream_lo = kp.stream_lo;
+  c.out = kp.out;
+  c.out_cap = kp.out_cap;
+  c.status = kp.status;
+  c.bits = pv.hdr->bits;
+  c.S = pv.hdr->states;
+  c.lane = threadIdx.x & 63;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
+  const uint32_t ring_stride = fast_ring_mode(MODE) ? kFastRingBytes : kWaveRingBytes; // (launch_shape sizes the LDS the same way)
+  // [rings][table][next-group words][build scratch], or with the table first: [table][next-group words][build scratch][rings]
+  c.rings = (table_first_mode(MODE) ? smem + table_bytes_for(MODE, c.bits) + 64 + 1024 : smem) + wave * ring_stride;
+  c.table = table_first_mode(MODE) ? smem : smem + waves * ring_stride;
+  c.table_b = c.table;
+  c.gtable = nullptr;
+  // the table build's scratch has an area of its own: a round's first stream chunks are requested before its table is built
+  c.scratch_cnt = (uint16_t *)(c.table + table_bytes_for(MODE, c.bits) + 64);
+  c.scratch_cum = c.scratch_cnt + 256;
+  run_grouped<MODE, LEAN>(c, pv, kp, waves, wave);
+}
+
+} // namespace hsrans
+
+#endif // HSRANS_KERNELS_GROUPED_H

@@ -1,0 +1,159 @@
+// kernels_walk.h — K2: the mt_ header chain followed on the device — k_mt_chase, k_mt_fill.
+// Part of the one device translation unit hsrans_kernels.hip (which includes the parts in dependency order and holds the host-side launcher).
+#ifndef HSRANS_KERNELS_WALK_H
+#define HSRANS_KERNELS_WALK_H
+
+namespace hsrans
+{
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2: mt_ header-chain walk on the device (one wavefront; lane 0 steers, all lanes copy states / sum counts).
+// Mirrors hsrans::plan_build's mt_ branch step by step, which mirrors mt_rANS32x64_16w_decode.cpp:41-96.
+// plan == nullptr: count only.  Otherwise plan is a blob sized for `n_chains` single-piece chains: the kernel fills
+// chain_first, pieces and states (the host writes the 64-byte header).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t load_u64_2b(const uint8_t *p) // stream offsets are only 2-byte aligned
+{
+  uint64_t v = 0;
+  for (int b = 3; b >= 0; b--)
+    v = (v << 16) | *(const uint16_t *)(p + 2 * b);
+  return v;
+}
+
+// Pass 1, the pointer chase (one wavefront, all lanes in lockstep on uniform values): per block ONE 16-byte read
+// {size, skip}, nothing else — the next header's position depends on it, so this read is the whole critical path.  Every
+// block's {header position, output offset} goes to `blocks`; everything that is not needed to find the next header (start
+// states, histogram sum check, the piece records) is left to pass 2, which is parallel over the blocks.
+__global__ void __launch_bounds__(64) k_mt_chase(const uint8_t *in, uint64_t in_len, uint64_t out_cap, uint32_t S, uint64_t *blocks, uint32_t max_blocks,
+                                                 WalkResult *result)
+{
+  uint32_t count = 0, error = 0;
+  uint64_t out_len = 0;
+  do
+  {
+    // the checks every reference decoder opens with (mt_…decode.cpp:15-32)
+    if (in_len < 16 + 4 * (uint64_t)S + 512) { error = 1; break; }
+    out_len = uni64(load_u64_2b(in));
+    const uint64_t stored = uni64(load_u64_2b(in + 8));
+    if (out_len > out_cap || in_len < stored || out_len == 0 || out_len + 1 < S) { error = 1; break; }
+    const uint64_t whole = out_len - S + 1;
+    uint64_t pos = 16, i = 0;
+    bool last_is_rans = false;
+    do
+    {
+      if (pos + 8 > in_len) { error = 2; break; }
+      const uint64_t at = pos;
+      // {size, skip} in one go; the skip word only exists (and is only used) for coded blocks, so it is read only when in range
+      const bool have16 = pos + 16 <= in_len;
+      uint64_t size_val = load_u64_2b(in + pos);
+      uint64_t skip = have16 ? load_u64_2b(in + pos + 8) : 0;
+      size_val = uni64(size_val);
+      skip = uni64(skip);
+      pos += 8;
+      const uint64_t i0 = i;
+      if (size_val >> 63)
+      {
+        const uint64_t len = size_val & (((uint64_t)1 << 54) - 1);
+        if (len == 0 || i > out_len || len > out_len - i) { error = 3; break; }
+        i += len;
+        last_is_rans = false;
+      }
+      else
+      {
+        if (pos + 8 + 4 * (uint64_t)S + 512 > in_len) { error = 2; break; }
+        pos += 8;
+        if (skip > in_len) { error = 2; break; }
+        const uint64_t after = pos + 2 * (skip + 1);
+        uint64_t end = i + size_val;
+        if (end > whole || end < i)
+          end = whole;
+        else if (end & (S - 1)) { error = 5; break; }
+        const uint64_t steps = end > i ? (end - i + S - 1) / S : 0;
+        if (steps > 0xFFFFFFFFull || size_val == 0) { error = 5; break; }
+        i += steps * S;
+        last_is_rans = true;
+        pos = i > whole ? ~(uint64_t)0 : after; // both outcomes of mt_…decode.cpp:86-92 leave the loop
+      }
+      if (i >= whole && i < out_len && (!last_is_rans || out_len - i >= S)) { error = 6; break; } // see hsrans::plan_build
+      if (count >= max_blocks) { error = 7; break; } // the block list is full: the host retries with a larger one
+      if (threadIdx.x == 0)
+      {
+        blocks[2 * (uint64_t)count] = at;
+        blocks[2 * (uint64_t)count + 1] = i0;
+      }
+      count++;
+      if (pos == ~(uint64_t)0)
+        break;
+    } while (i < whole);
+  } while (false);
+  if (threadIdx.x == 0)
+  {
+    result->n_chains = count;
+    result->error = error;
+    result->decoded_len = out_len;
+  }
+}
+
+// Pass 2, one wavefront per block: the block's chain record, start states and histogram sum check (what
+// mt_…decode.cpp:62-72 reads from a block header), written into the plan blob sized for n_chains chains.
+__global__ void __launch_bounds__(64) k_mt_fill(const uint8_t *in, uint64_t in_len, uint32_t S, uint32_t bits, const uint64_t *blocks, uint8_t *plan,
+                                                uint32_t n_chains, uint64_t out_len, WalkResult *result)
+{
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  uint32_t *cf = (uint32_t *)(plan + plan_chain_first_off());
+  Piece *pieces = (Piece *)(plan + plan_pieces_off(n_chains));
+  uint32_t *states = (uint32_t *)(plan + plan_states_off(n_chains, n_chains));
+  const uint64_t whole = out_len - S + 1;
+  uint64_t pos = blocks[2 * (uint64_t)b];
+  const uint64_t i = blocks[2 * (uint64_t)b + 1];
+  const uint64_t size_val = uni64(load_u64_2b(in + pos));
+  pos += 8;
+  Piece p{};
+  uint64_t i_end = i;
+  if (size_val >> 63)
+  {
+    p.flags = kPieceFill | kPieceChainStart;
+    p.out_off = i;
+    p.fill_len = size_val & (((uint64_t)1 << 54) - 1);
+    p.hist_off = (size_val >> 54) & 0xFF;
+    i_end = i + p.fill_len;
+  }
+  else
+  {
+    pos += 8; // skip
+    if (lane < S)
+      states[(uint64_t)b * S + lane] = (uint32_t)*(const uint16_t *)(in + pos + 4 * lane) | ((uint32_t)*(const uint16_t *)(in + pos + 4 * lane + 2) << 16);
+    pos += 4 * (uint64_t)S;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < 4; k++)
+      sum += *(const uint16_t *)(in + pos + 2 * (4 * lane + k));
+    for (int d = 32; d >= 1; d >>= 1)
+      sum += __shfl_xor(sum, d, 64);
+    if (uni(sum) != (1u << bits) && lane == 0) // inplace_complete_hist, hist.cpp:308-324
+      atomicMax(&result->error, 4u);
+    p.flags = kPieceChainStart;
+    p.hist_off = pos;
+    p.words_off = pos + 512;
+    p.out_off = i;
+    uint64_t end = i + size_val;
+    if (end > whole || end < i)
+      end = whole;
+    const uint64_t steps = end > i ? (end - i + S - 1) / S : 0;
+    p.steps = (uint32_t)steps;
+    i_end = i + steps * S;
+  }
+  p.state_idx = b;
+  if (i_end >= whole && i_end < out_len)
+    p.tail = (uint16_t)(out_len - i_end); // final partial group: a tail on the last chain (mt_…decode.cpp:99-130)
+  if (lane == 0)
+  {
+    pieces[b] = p;
+    cf[b] = b;
+    if (b + 1 == n_chains)
+      cf[n_chains] = n_chains;
+  }
+}
+
+} // namespace hsrans
+
+#endif // HSRANS_KERNELS_WALK_H
