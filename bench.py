@@ -125,12 +125,13 @@ def _mt_cpu_baseline(stream, data, states, bits):
 
 
 def kernel_source_sha256() -> str:
-    """SHA-256 over the device code's sources (csrc/*.hip and the headers they include): the identity of the kernels a counter
+    """SHA-256 over the decode kernels' sources (csrc/hsrans_kernels.hip and the headers of this repository it includes): the identity of the kernels a counter
     run was made with.  bench.py puts it into its line (config.kernel_source_sha256), tools/pmc_summary.py keeps that line next
     to the counters, and _pmc_profile refuses counters of other kernels."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "hypersonic_rans_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+    files = [os.path.join(csrc, n) for n in ("hsrans_kernels.hip", "hsrans_kernels.h", "hsrans_plan.h")] + glob.glob(os.path.join(csrc, "kernels_*.h"))
+    for f in sorted(files):  # (the decode kernels' translation unit and everything it includes of this repository; not the encoder, not the host code)
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
     return h.hexdigest()

@@ -205,16 +205,23 @@ __device__ void run_direct_pair(const WaveCtx &c, const KParams &kp, uint32_t wa
       const DirectPiece da = direct_piece(c, pa, a);
       const DirectPiece db = have_b ? direct_piece(c, pa, a + 1) : da;
       win_open(sw, c, da.words, have_b ? db.limit : da.limit);
-      ring_begin(sw, ra, c, da.words);
+      // (as run_direct: what the first groups read — states, chunks 0 and 1 of both rings, the table — first; mirrors and the chunks kept ahead after it)
+      ring_begin(sw, ra, c, da.words, true, true);
       if (have_b)
-        ring_begin(sw, rb, c, db.words);
+        ring_begin(sw, rb, c, db.words, true, true);
       uint32_t x = pa.states[(uint64_t)((c.lane < 32 || !have_b) ? a : a + 1) * 32 + (c.lane & 31)];
       if (table_pending)
       {
         copy_table();
         table_pending = false;
       }
-      ring_ready(x);
+      ring_begin_rest(sw, ra, c);
+      if (have_b)
+        ring_begin_rest(sw, rb, c);
+      if (have_b)
+        asm volatile("s_waitcnt vmcnt(6)" : "+v"(x)::"memory"); // (the six requests just made are the only younger ones)
+      else
+        asm volatile("s_waitcnt vmcnt(3)" : "+v"(x)::"memory");
       if (HSRANS_STAMPS(kp) && t_ready == 0)
         t_ready = __builtin_amdgcn_s_memrealtime();
       uint64_t oa = da.out, ob = db.out;

@@ -8,11 +8,15 @@
  * This header is the C form of exactly that boundary (container / state count / histogram bits become arguments
  * instead of name suffixes) plus what a GPU replacement has to add: a context, a device-pointer
  * entry for device-resident pipelines, and an optional decode plan ("index") that lets many wavefronts work on ONE
- * stream.  include/hsrans_dropin.hpp declares the same functionality under the reference's own C++ names.
+ * stream.  include/hsrans_dropin.hpp declares the same functionality under the reference's own C++ names, include/hsrans_names.h
+ * under the same names with C linkage (hsrans_<reference name>).
  *
  * Conventions kept from the reference: plain pointers + sizes, caller owns all buffers, return = bytes produced,
  * 0 on any failure, no exceptions cross this boundary, all entry points are re-entrant (per context).
- * No CPU decode path exists in this library: decoding without a usable GPU fails (returns 0 / an error code).
+ * The GPU entries (hsrans_decode_host, hsrans_decode_device*, hsrans_hpipe_*, ...) never fall back to the host: without a usable
+ * gfx950 device they fail (return 0 / an error code).  The library's own host SIMD decoder sits behind entries that say so in
+ * their name — hsrans_decode_cpu, hsrans_index_build_host — and behind the runtime-dispatch names of hsrans_dropin.hpp /
+ * hsrans_names.h (`*_decode_auto_N` and the reference's own decoder names), the counterpart of the reference's CPUID dispatch.
  */
 #ifndef HSRANS_HIP_H
 #define HSRANS_HIP_H
