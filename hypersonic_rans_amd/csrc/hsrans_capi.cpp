@@ -1503,6 +1503,111 @@ try
   const auto t0 = now();
   const uint32_t S = h.states;
   const uint64_t n_ck = h.decoded_len / S / index_interval + 2;
+  // mt_ streams (one single-piece chain per block, histograms in the stream): the indexed plan is assembled ON THE DEVICE behind the
+  // recording pass — one allocation, three launches, one synchronisation; nothing but two words comes back to the host
+  // (HSRANS_INDEX_ASSEMBLE_ON_HOST=1: round 3's path — checkpoints down, blob built by one core, blob up — still what raw plans take)
+  if (h.container == HSRANS_MT && (h.flags & (kPlanWalk | kPlanHasHist | kPlanMergeable)) == 0 && getenv("HSRANS_INDEX_ASSEMBLE_ON_HOST") == nullptr)
+  {
+    std::lock_guard<std::mutex> guard(ctx->lock); // (the checkpoint buffer belongs to the context)
+    const uint64_t max_chains64 = std::min<uint64_t>((uint64_t)h.n_chains + n_ck, 0xFFFFFFF0u);
+    const uint32_t max_chains = (uint32_t)max_chains64;
+    const size_t st_bytes = (size_t)n_ck * S * 4, wd_bytes = (size_t)n_ck * 8;
+    if (!grow(&ctx->d_enc_ck, &ctx->d_enc_ck_cap, st_bytes + wd_bytes))
+      return HSRANS_E_HIP;
+    const uint32_t nb = h.n_chains;
+    // few large blocks: every block's chains in parts, so that there are about two workgroup tasks per resident workgroup (as dplan_fill)
+    const size_t want = (size_t)2 * ctx->geom.num_cus;
+    uint32_t group_split = 1;
+    if (nb < want)
+      group_split = (uint32_t)std::max<size_t>(1, std::min<size_t>({(want + nb - 1) / nb, (size_t)(n_ck / nb + 1) / 128, (size_t)64}));
+    auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t plan_max = (size_t)plan_size(max_chains, max_chains, S, 0);
+    const size_t counter_bytes = (size_t)kCounterSets * kDynQueues * kDynQueueStride * 8;
+    const size_t group_bytes = (size_t)nb * group_split * sizeof(Group);
+    hsrans_dplan *nd = new (std::nothrow) hsrans_dplan;
+    if (nd == nullptr)
+      return HSRANS_E_HIP;
+    nd->ctx = ctx;
+    const size_t arena = 256 + up256(counter_bytes) + up256(plan_max) + up256(group_bytes) + up256((size_t)nb * 4) + 256;
+    if (!grow(&nd->d_arena, &nd->d_arena_cap, arena))
+    {
+      hsrans_dplan_destroy(nd);
+      return HSRANS_E_HIP;
+    }
+    uint8_t *at = nd->d_arena;
+    auto carve = [&](size_t bytes) { uint8_t *ptr = at; at += up256(bytes); return ptr; };
+    nd->d_status = (uint32_t *)carve(64);
+    nd->d_counters = (unsigned long long *)carve(counter_bytes);
+    nd->d_plan = carve(plan_max);
+    nd->d_plan_cap = plan_max;
+    nd->d_groups = carve(group_bytes);
+    nd->d_groups_cap = group_bytes;
+    uint32_t *d_chain_off = (uint32_t *)carve((size_t)nb * 4);
+    uint64_t *d_result = (uint64_t *)carve(64);
+    nd->arena_used = (size_t)(at - nd->d_arena);
+    KParams kp{};
+    kp.stream = (const uint8_t *)d_stream;
+    kp.stream_len = stream_length;
+    kp.out = (uint8_t *)d_out;
+    kp.out_cap = out_capacity;
+    kp.plan = d->d_plan;
+    kp.status = d->d_status;
+    kp.ckpt_states = (uint32_t *)ctx->d_enc_ck;
+    kp.ckpt_words = (uint64_t *)(ctx->d_enc_ck + st_bytes);
+    kp.ckpt_interval = index_interval;
+    PlanHeader hl = h;
+    hl.shared_hist = 0; // private tables, as in hsrans_index_build's pass
+    IndexArgs ia{};
+    ia.base = d->d_plan;
+    ia.n_base = nb;
+    ia.S = S;
+    ia.interval = index_interval;
+    ia.ck_states = kp.ckpt_states;
+    ia.ck_words = kp.ckpt_words;
+    ia.chain_off = d_chain_off;
+    ia.result = d_result;
+    ia.plan = nd->d_plan;
+    ia.max_chains = max_chains;
+    ia.groups = (Group *)nd->d_groups;
+    ia.group_split = group_split;
+    ia.stream_len = h.stream_len;
+    uint32_t status = 0xFFFFFFFF;
+    uint64_t counted[3] = {}; // chains in all, blocks with a histogram, the (one) histogram's offset
+    const uint64_t &total = counted[0];
+    const bool ok = hipMemsetAsync(nd->d_arena, 0, nd->arena_used, s) == hipSuccess && launch_decode(kp, hl, ctx->geom, s, nullptr) == hipSuccess &&
+                    launch_index_assemble(ia, s) == hipSuccess && hipMemcpyAsync(counted, d_result, sizeof(counted), hipMemcpyDeviceToHost, s) == hipSuccess &&
+                    hipMemcpyAsync(&status, d->d_status, 4, hipMemcpyDeviceToHost, s) == hipSuccess;
+    const bool synced = hipStreamSynchronize(s) == hipSuccess; // (nothing queued above may still be running when this returns, whatever failed)
+    int rc = ok && synced ? HSRANS_OK : HSRANS_E_HIP;
+    if (rc == HSRANS_OK && status != 0) // the pass found a bad histogram / header: reported and cleared like hsrans_dplan_status does
+      rc = hipMemsetAsync(d->d_status, 0, 4, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess ? HSRANS_E_DEVICE : HSRANS_E_HIP;
+    if (rc == HSRANS_OK && (total < nb || total > max_chains))
+      rc = HSRANS_E_FORMAT;
+    if (rc != HSRANS_OK)
+    {
+      (void)hipGetLastError();
+      hsrans_dplan_destroy(nd);
+      return rc;
+    }
+    nd->hdr = h;
+    nd->hdr.n_chains = nd->hdr.n_pieces = (uint32_t)total;
+    nd->hdr.interval = index_interval;
+    nd->hdr.shared_hist = counted[1] == 1 ? 1 : 0;
+    nd->hdr.aux_off = nd->hdr.shared_hist ? counted[2] : 0;
+    nd->plan_bytes = (size_t)plan_size((uint32_t)total, (uint32_t)total, S, 0);
+    nd->out_hi = h.decoded_len;
+    const bool grouped = total > nb; // (no checkpoint fell inside any block: one chain per block, the ungrouped launch)
+    nd->n_groups = grouped ? nb * group_split : 0;
+    nd->groups_lean = grouped && S == 64;
+    if (!grouped)
+      nd->d_groups = nullptr, nd->d_counters = nullptr;
+    if (getenv("HSRANS_DEBUG_STAMPS") && hipMalloc((void **)&nd->d_stamps, kStampWaves * 8 * 8) == hipSuccess)
+      (void)hipMemset(nd->d_stamps, 0, kStampWaves * 8 * 8);
+    if (trace)
+      fprintf(stderr, "hsrans_decode_device_indexing: on the device: %.3f ms in all (%llu chains, %zu plan bytes)\n", ms(t0, now()), (unsigned long long)total, nd->plan_bytes);
+    *indexed = nd;
+    return HSRANS_OK;
+  }
   // page-locked staging (kept by the context): [checkpoint states | cursors | base plan] down, then the new plan blob up —
   // from pageable memory these copies (12.5 MB of states each way for 100 MB at 32 groups) took 15 ms, the decode 0.25
   std::lock_guard<std::mutex> guard(ctx->lock);

@@ -149,6 +149,24 @@ hipError_t launch_mt_chase(const uint8_t *d_stream, uint64_t stream_len, uint64_
 hipError_t launch_mt_fill(const uint8_t *d_stream, uint64_t stream_len, uint32_t S, uint32_t bits, const uint64_t *d_blocks, uint8_t *d_plan, uint32_t n_chains,
                           uint64_t out_len, WalkResult *d_result, hipStream_t stream);
 
+// the indexed plan assembled on the device from a base plan + recorded checkpoints (hsrans_decode_device_indexing; kernels_walk.h)
+struct IndexArgs
+{
+  const uint8_t *base;       // base plan blob (device): one single-piece chain per mt_ block
+  uint32_t n_base;           // its chains
+  uint32_t S, interval;
+  const uint32_t *ck_states; // [slot * S]: coder states at absolute group slot * interval
+  const uint64_t *ck_words;  // [slot]: absolute stream byte of the read cursor there
+  uint32_t *chain_off;       // [n_base] first chain of block b in the new plan (k_index_count)
+  uint64_t *result;          // [0] chains of the new plan
+  uint8_t *plan;             // the new plan blob (zeroed, sized for max_chains)
+  uint32_t max_chains;
+  Group *groups;             // [n_base * group_split] or null
+  uint32_t group_split;
+  uint64_t stream_len;
+};
+hipError_t launch_index_assemble(const IndexArgs &a, hipStream_t stream);
+
 DeviceGeom default_geom(); // MI355X: 256 CUs, 160 KiB LDS (used where no device is at hand: host-side index sizing)
 LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persistent, uint32_t table_mode, uint32_t n_groups, bool index_pass, bool direct, bool dual);
 struct TableChoice

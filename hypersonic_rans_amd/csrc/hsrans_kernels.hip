@@ -60,6 +60,14 @@ hipError_t launch_mt_chase(const uint8_t *d_stream, uint64_t stream_len, uint64_
   return hipGetLastError();
 }
 
+hipError_t launch_index_assemble(const IndexArgs &a, hipStream_t stream)
+{
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(k_index_count, dim3(1), dim3(1024), 0, stream, a);
+  hipLaunchKernelGGL(k_index_fill, dim3(a.n_base), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_mt_fill(const uint8_t *d_stream, uint64_t stream_len, uint32_t S, uint32_t bits, const uint64_t *d_blocks, uint8_t *d_plan, uint32_t n_chains,
                           uint64_t out_len, WalkResult *d_result, hipStream_t stream)
 {

@@ -154,6 +154,164 @@ __global__ void __launch_bounds__(64) k_mt_fill(const uint8_t *in, uint64_t in_l
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The indexed plan of a stream whose first decode has just recorded its checkpoints (hsrans_decode_device_indexing), assembled
+// ON THE DEVICE: the base plan (one single-piece chain per mt_ block), the states and read cursors the recording pass left every
+// `interval` groups (slot = absolute group / interval) -> the plan with one chain per block start and per checkpoint inside the
+// blocks, byte for byte what the host writes for the same input (hsrans_capi.cpp add_interval_chains + PlanBuilder::serialize),
+// plus the Group records of the grouped launch.  (Round 3 brought 7.5-15 MB of checkpoints down to the host, assembled the blob
+// on one core and sent it up again: 0.8 ms of the first decode's 1.3-2.5 ms.)
+//   k_index_count   one workgroup: chains per block, their exclusive scan -> chain_off[], total -> result[0]
+//   k_index_fill    one wavefront per block: header, chain table, pieces, start states, groups
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t index_chains_of(const Piece &bp, uint32_t interval)
+{
+  if (bp.flags & kPieceFill)
+    return 1;
+  return bp.steps == 0 ? 1 : (bp.steps + interval - 1) / interval; // (add_interval_chains: g = 0, interval, ... < steps; at least g = 0)
+}
+
+__global__ void __launch_bounds__(1024) k_index_count(IndexArgs a)
+{
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  const uint32_t *cf0 = (const uint32_t *)(a.base + plan_chain_first_off());
+  const Piece *pc0 = (const Piece *)(a.base + plan_pieces_off(a.n_base));
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0)
+    carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < a.n_base; base += 1024)
+  {
+    const uint32_t ch = base + threadIdx.x;
+    uint32_t v = 0;
+    if (ch < a.n_base)
+    {
+      const Piece bp = pc0[cf0[ch]];
+      v = index_chains_of(bp, a.interval);
+      if (!(bp.flags & kPieceFill)) // blocks with a histogram: when there is exactly one, the plan's chains share its table
+      {                             // (PlanBuilder::serialize: shared_hist = every non-fill piece has the same hist_off; mt_ blocks never share one)
+        atomicAdd((unsigned long long *)&a.result[1], 1ull);
+        atomicMax((unsigned long long *)&a.result[2], (unsigned long long)bp.hist_off);
+      }
+    }
+    uint32_t incl = v;
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      const uint32_t o = __shfl_up(incl, d, 64);
+      if ((int)lane >= d)
+        incl += o;
+    }
+    if (lane == 63)
+      wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t before = carry_s;
+    for (uint32_t w = 0; w < wave; w++)
+      before += wave_tot[w];
+    if (ch < a.n_base)
+      a.chain_off[ch] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023)
+      carry_s = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    a.result[0] = carry_s;
+}
+
+__global__ void __launch_bounds__(64) k_index_fill(IndexArgs a)
+{
+  const uint32_t ch = blockIdx.x, lane = threadIdx.x, S = a.S;
+  const uint32_t nc = (uint32_t)a.result[0];
+  if (nc > a.max_chains) // (the host sized the blob for max_chains: it reads result[0] and fails the call)
+    return;
+  const uint32_t *cf0 = (const uint32_t *)(a.base + plan_chain_first_off());
+  const Piece *pc0 = (const Piece *)(a.base + plan_pieces_off(a.n_base));
+  const uint32_t *st0 = (const uint32_t *)(a.base + plan_states_off(a.n_base, a.n_base));
+  uint32_t *chain_first = (uint32_t *)(a.plan + plan_chain_first_off());
+  Piece *pieces = (Piece *)(a.plan + plan_pieces_off(nc));
+  uint32_t *states = (uint32_t *)(a.plan + plan_states_off(nc, nc));
+  const Piece bp = pc0[cf0[ch]];
+  const bool fill = (bp.flags & kPieceFill) != 0;
+  const uint32_t c0 = a.chain_off[ch], count = index_chains_of(bp, a.interval);
+  if (ch == 0 && lane == 0)
+  {
+    PlanHeader h = *(const PlanHeader *)a.base; // container, states, bits, lengths: the base plan's
+    h.n_chains = h.n_pieces = nc;
+    h.interval = a.interval;
+    h.shared_hist = a.result[1] == 1 ? 1 : 0; // (plans K2 wrote leave these two clear even for a single block)
+    h.aux_off = h.shared_hist ? a.result[2] : 0;
+    *(PlanHeader *)a.plan = h;
+    chain_first[nc] = nc;
+  }
+  const uint64_t T = bp.steps, g_abs0 = bp.out_off / S;
+  for (uint32_t k = lane; k < count; k += 64)
+  {
+    Piece p{};
+    if (fill)
+      p = bp;
+    else
+    {
+      const uint64_t g = (uint64_t)k * a.interval;
+      const uint64_t slot = (g_abs0 + g) / a.interval;
+      p.hist_off = bp.hist_off;
+      p.out_off = bp.out_off + g * S;
+      p.words_off = k == 0 ? bp.words_off : a.ck_words[slot];
+      const uint64_t steps = T - g < a.interval ? T - g : a.interval;
+      p.steps = (uint32_t)steps;
+      p.tail = (uint16_t)(g + steps == T ? bp.tail : 0);
+    }
+    p.flags |= kPieceChainStart;
+    p.state_idx = c0 + k;
+    pieces[c0 + k] = p;
+    chain_first[c0 + k] = c0 + k;
+  }
+  for (uint32_t k = 0; k < count; k++)
+    if (lane < S)
+    {
+      uint32_t v = 0;
+      if (!fill)
+        v = k == 0 ? st0[(uint64_t)bp.state_idx * S + lane] : a.ck_states[((g_abs0 + (uint64_t)k * a.interval) / a.interval) * S + lane];
+      states[(uint64_t)(c0 + k) * S + lane] = v;
+    }
+  if (a.groups != nullptr && lane < a.group_split)
+  {
+    // the block's words end at the next rANS block's histogram (as hsrans_capi.cpp dplan_fill has it), or at the stream's end
+    uint64_t words_end = a.stream_len;
+    for (uint32_t nx = ch + 1; nx < a.n_base; nx++)
+    {
+      const Piece &q = pc0[cf0[nx]];
+      if (!(q.flags & kPieceFill))
+      {
+        words_end = q.hist_off;
+        break;
+      }
+    }
+    const uint32_t by_size = (count + 143) / 144 < a.group_split ? (count + 143) / 144 : a.group_split;
+    const uint32_t parts = fill || by_size < 1 ? 1 : by_size;
+    Group g{};
+    g.flags = fill ? kGroupFill : kGroupMergeable;
+    g.hist_off = fill ? 0 : bp.hist_off;
+    if (lane < parts)
+    {
+      const uint32_t lo = (uint32_t)((uint64_t)count * lane / parts), hi = (uint32_t)((uint64_t)count * (lane + 1) / parts);
+      g.begin = c0 + lo;
+      g.piece0 = c0 + lo;
+      g.count = hi - lo;
+      g.words_end = hi < count ? a.ck_words[(g_abs0 + (uint64_t)hi * a.interval) / a.interval] : words_end;
+    }
+    else
+    {
+      g.begin = c0;
+      g.piece0 = c0;
+      g.count = 0;
+      g.flags = kGroupFill;
+      g.words_end = words_end;
+    }
+    a.groups[(uint64_t)ch * a.group_split + lane] = g;
+  }
+}
+
 } // namespace hsrans
 
 #endif // HSRANS_KERNELS_WALK_H

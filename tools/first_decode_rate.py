@@ -23,14 +23,14 @@ alg = stream.size + n
 
 
 def timed(fn, reps=5):
-    best = 1e9
+    best, keep = 1e9, []
     for _ in range(reps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        r = fn()
+        keep.append(fn())  # (kept: dropping the previous result here would put its hipFree inside the next timed call)
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
-    return best, r
+    return best, keep[-1]
 
 
 def gpu_ms(fn, reps=10):
@@ -68,4 +68,5 @@ for interval in (32, 64):
                       "k2_walk_ms": round(t_k2 * 1e3, 3), "plain_unindexed_decode_ms": round(t_plain * 1e3, 3), "plain_frac": frac(t_plain),
                       "first_decode_indexing_ms": round(t_first * 1e3, 3), "later_decode_ms": round(t_later * 1e3, 3), "later_decode_ms_events": round(ev_later, 4), "later_frac_events": frac(ev_later * 1e-3),
                       "indexed_chains": indexed.launch_info()["chains"],
-                      "note": "wall clock around each call incl. its synchronisation; first_decode includes the plan download/assembly/upload"}), flush=True)
+                      "assembly": "host" if os.environ.get("HSRANS_INDEX_ASSEMBLE_ON_HOST") else "device",
+                      "note": "wall clock around each call incl. its synchronisation (best of 3 / 5 / 10 calls); first_decode includes the recording pass and the plan assembly"}), flush=True)
