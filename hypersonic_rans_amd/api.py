@@ -126,6 +126,8 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_dplan_create_from_device_stream.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _sz, _vp, ctypes.POINTER(_vp)]
     L.hsrans_dplan_read_plan.restype = _sz
     L.hsrans_dplan_read_plan.argtypes = [_vp, _vp, _sz]
+    L.hsrans_encode_device_raw.restype = _sz
+    L.hsrans_encode_device_raw.argtypes = [_vp, _i, _u32, _vp, _sz, _vp, _sz, _vp, _u32, _vp, _sz, _vp, _sz, ctypes.POINTER(_sz), _vp, ctypes.POINTER(_vp)]
     L.hsrans_encode_device.restype = _sz
     L.hsrans_encode_device.argtypes = [_vp, _i, _i, _u32, _vp, _sz, _vp, _sz, _u32, _u32, _vp, ctypes.POINTER(_vp)]
     L.hsrans_index_build.restype = _sz
@@ -526,6 +528,31 @@ class Context:
         if n == 0:
             raise HsransError("hsrans_encode_device failed")
         return (n, DevicePlan(self, h)) if want_plan else n
+
+    def encode_device_raw(self, states: int, bits: int, d_in: torch.Tensor, d_out: torch.Tensor, hist=None, index_interval: int = 0, index_groups=None,
+                          want_plan: bool = False, want_device_plan: bool = False, stream: torch.cuda.Stream | None = None):
+        """GPU encoder for the raw format (one wavefront: hsrans_encode_device_raw).  Returns the stream length, followed by the plan
+        blob (``want_plan``) and/or a DevicePlan (``want_device_plan``) when an index (``index_interval`` or ``index_groups``) is asked for."""
+        s = stream if stream is not None else torch.cuda.current_stream(d_in.device)
+        groups = np.ascontiguousarray(index_groups, dtype=np.uint64) if index_groups is not None else None
+        n_groups = 0 if groups is None else groups.size
+        plan, psize, h = None, _sz(0), _vp()
+        if want_plan:
+            pcap = (self.L.hsrans_plan_capacity_chains(RAW, states, d_in.numel(), n_groups, 0) if n_groups
+                    else self.L.hsrans_plan_capacity(RAW, states, d_in.numel(), index_interval, 0))
+            plan = np.zeros(pcap, np.uint8)
+        n = self.L.hsrans_encode_device_raw(self.handle, states, bits, d_in.data_ptr(), d_in.numel(), d_out.data_ptr(), d_out.numel(),
+                                            ctypes.addressof(hist) if hist is not None else None, index_interval, _p(groups) if n_groups else None, n_groups,
+                                            _p(plan) if want_plan else None, plan.size if want_plan else 0, ctypes.byref(psize),
+                                            ctypes.c_void_p(s.cuda_stream), ctypes.byref(h) if want_device_plan else None)
+        if n == 0:
+            raise HsransError("hsrans_encode_device_raw failed")
+        out = [n]
+        if want_plan:
+            out.append(plan[: psize.value].copy())
+        if want_device_plan:
+            out.append(DevicePlan(self, h))
+        return out[0] if len(out) == 1 else tuple(out)
 
     def index_build_at(self, container: int, states: int, bits: int, stream, groups) -> np.ndarray:
         stream = _u8(stream)

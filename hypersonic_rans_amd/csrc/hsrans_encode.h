@@ -34,6 +34,11 @@ struct EncParams
   void *groups;          // Group[n_blocks * group_split] for the grouped decode launch (K_plan) or null
   uint32_t group_split;  // parts a block's chains are cut into (few large blocks: more workgroup tasks than blocks)
   uint32_t n_chains;     // total, known after K_scan (K_plan)
+  // raw streams (launch_encode_raw): n_blocks = 1, block = n, one slot
+  const uint32_t *raw_counts;   // [256] byte counts of the input (k_raw_histogram's output), normalised by the coding wavefront
+  const uint16_t *given_counts; // [256] or null: the caller's normalised histogram (hist_t::symbolCount), used instead
+  const uint32_t *ck_groups;    // or null: ascending group indices (multiples of 4) to checkpoint at, instead of `interval`
+  uint32_t n_ck_groups;
   uint64_t *stamps; // diagnostics (HSRANS_DEBUG_STAMPS=1): per block {start, histogram done, table done, words done} s_memrealtime; else null
 };
 
@@ -43,6 +48,8 @@ constexpr uint32_t kEncResultWords = 8;
 // asynchronous on `stream`: K_enc, K_scan, K_gather.  `prepared` is the calling context's flag: the dynamic-LDS attribute
 // is per device, so it is raised once per context, not once per process
 hipError_t launch_encode(const EncParams &ep, hipStream_t stream, bool *prepared);
+// asynchronous on `stream`: [memset + K_hist ->] K_raw -> K_copy.  result[0] stream length, [1] fits out_cap, [2] listed checkpoints not met (0)
+hipError_t launch_encode_raw(const EncParams &ep, uint32_t *d_counts, hipStream_t stream, bool *prepared);
 // asynchronous on `stream`: K_plan (needs ep.plan, ep.n_chains; after launch_encode's results are known)
 hipError_t launch_encode_plan(const EncParams &ep, hipStream_t stream);
 

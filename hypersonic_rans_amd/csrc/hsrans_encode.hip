@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "hsrans_encode.h"
 #include "hsrans_kernels.h"
 
@@ -323,23 +325,28 @@ __device__ __forceinline__ void encode_group_fast(uint32_t &x, const uint4 &e, u
   x = __umul24(q, e.w) + x + e.y; // x + bias + q * (2^bits - freq)
 }
 
-template <uint32_t S>
-__global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep)
+// One wavefront's job.  RAW = false: block b of an mt_ stream with independent blocks (own histogram, own header).
+// RAW = true: a whole raw stream (rANS32x64_16w.cpp:34-166 is ONE dependent chain per coder state, so one wavefront is all the
+// format has work for): the counts come from the caller or from k_raw_histogram, checkpoints may sit at listed groups, and the
+// image in the slot is the finished stream [n][total][counts][states][words].
+template <uint32_t S, bool RAW>
+__device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t b, WaveLds &L, const uint32_t lane)
 {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-  const uint32_t lane = lane_id();
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t b = blockIdx.x * kWavesPerWG + wave;
-  if (b >= ep.n_blocks)
-    return;
-  WaveLds &L = *(WaveLds *)(lds_raw + (size_t)wave * sizeof(WaveLds));
-  const uint64_t begin = (uint64_t)b * ep.block;
-  const uint64_t end = b + 1 == ep.n_blocks ? ep.n : begin + ep.block;
+  const uint64_t begin = RAW ? 0 : (uint64_t)b * ep.block;
+  const uint64_t end = RAW || b + 1 == ep.n_blocks ? ep.n : begin + ep.block;
   const uint32_t size = (uint32_t)(end - begin);
   const uint8_t *in = ep.in;
   uint8_t *slot_end = ep.scratch + (uint64_t)(b + 1) * ep.slot_bytes;
 
   const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  uint32_t raw[4] = {0, 0, 0, 0};
+  if constexpr (RAW)
+  {
+    for (uint32_t k = 0; k < 4; k++) // byte counts of the whole input (k_raw_histogram) or, with given_counts, nothing to count
+      raw[k] = ep.given_counts ? ep.given_counts[lane * 4 + k] : ep.raw_counts[lane * 4 + k];
+  }
+  else
+  {
   // ---- byte histogram: kSubHists copies, copy = lane & 7 ----
   uint32_t *sub = (uint32_t *)L.table;
   for (uint32_t k = lane; k < kSubHists * kSubStride; k += 64)
@@ -370,7 +377,6 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
     }
   }
   wave_sync();
-  uint32_t raw[4] = {0, 0, 0, 0};
   for (uint32_t c = 0; c < kSubHists; c++)
     for (uint32_t k = 0; k < 4; k++)
       raw[k] += sub[c * kSubStride + lane * 4 + k];
@@ -393,6 +399,7 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
     }
     return;
   }
+  } // !RAW
 
   const uint64_t t1 = __builtin_amdgcn_s_memrealtime();
   // ---- normalisation (hist.cpp:16-215; hsrans_host.cpp normalize_counts) ----
@@ -400,19 +407,22 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
   const float factor = (float)target / (float)(uint64_t)size;
   uint32_t sc[4];
   uint32_t part = 0;
+  const bool normalised = RAW && ep.given_counts != nullptr; // the caller's hist_t: already sums to 2^bits (checked on the host)
   for (uint32_t k = 0; k < 4; k++)
   {
     const float v = __fmul_rn((float)raw[k], factor); // one rounding per operation, like the reference's build
     uint32_t c = (uint32_t)(uint16_t)__fadd_rn(v, 0.5f);
     if (c == 0 && raw[k] != 0)
       c = 1;
+    if (normalised)
+      c = raw[k];
     sc[k] = c;
     part += c;
     L.order[lane * 4 + k] = (c << 8) | (lane * 4 + k);
   }
   const uint32_t sum = wave_sum(part);
   wave_sync();
-  if (sum != target)
+  if (sum != target && !normalised)
   {
     adjust_counts(L, lane, sc, sum, target);
     part = sc[0] + sc[1] + sc[2] + sc[3];
@@ -473,15 +483,28 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
   // sidecar checkpoints (hsrans_host.cpp encode(): after group gr of the block is coded, gr % interval == 0, gr != 0, the
   // group whole): the decoder's states and read cursor when it is about to start group gr
   const uint32_t whole_groups = size / S;
-  auto checkpoint = [&](uint32_t gr) {
-    const uint64_t ck = (uint64_t)b * ep.max_ck + (gr / ep.interval - 1);
+  auto checkpoint_at = [&](uint64_t ck) {
     if (lane < S)
       ep.ck_states[ck * S + lane] = x;
     if (lane == 0)
       ep.ck_pos[ck] = (uint32_t)ep.slot_bytes - p;
   };
-  if (lane == 0)
+  auto checkpoint = [&](uint32_t gr) { checkpoint_at((uint64_t)b * ep.max_ck + (gr / ep.interval - 1)); };
+  if (!RAW && lane == 0)
     ep.chain_count[b] = 1 + (ep.interval != 0 && whole_groups >= 1 ? (whole_groups - 1) / ep.interval : 0);
+  // RAW with listed checkpoints (ascending group indices, multiples of 4; hsrans_host.cpp encode(): `wanted`): the list is walked
+  // from its end; entries at or behind the last whole group are never checkpoints
+  uint32_t ck_left = RAW && ep.ck_groups ? ep.n_ck_groups : 0;
+  while (ck_left != 0 && ep.ck_groups[ck_left - 1] >= whole_groups)
+    ck_left--;
+  uint32_t ck_want = ck_left ? ep.ck_groups[ck_left - 1] : 0; // (0 is never asked for)
+  auto listed = [&](uint32_t gr) {
+    if (!RAW || gr != ck_want || gr == 0)
+      return;
+    checkpoint_at(ck_left - 1);
+    ck_left--;
+    ck_want = ck_left ? ep.ck_groups[ck_left - 1] : 0;
+  };
 
   uint32_t g = (size + S - 1) / S; // groups of the block still to code; group i covers bytes [i*S, i*S+S)
   if (size % S != 0)               // only the file's last group can be partial
@@ -497,6 +520,8 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
 
   if (ep.interval != 0 && g != 0 && g % ep.interval == 0 && g < whole_groups)
     checkpoint(g);
+  if (g < whole_groups)
+    listed(g);
 
   constexpr uint32_t kSetBytes = 4 * S;
   constexpr uint32_t kSetsPerChunk = kChunk / kSetBytes;
@@ -528,6 +553,7 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
   auto chunk_done = [&](int32_t t) { // set t (groups 4t .. 4t+3) is coded
     if (ep.interval != 0 && t != 0 && (uint32_t)(4 * t) % ep.interval == 0)
       checkpoint((uint32_t)(4 * t));
+    listed((uint32_t)(4 * t));
     if ((uint32_t)t % kSetsPerChunk == 0)
       chunk_finished((uint32_t)t / kSetsPerChunk);
   };
@@ -563,8 +589,30 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
     ep.stamps[b * 4 + 2] = t2;
     ep.stamps[b * 4 + 3] = t3;
   }
-  // ---- block header in front of the words: [size u64][skip u64][states S x u32][counts 256 x u16] ----
   const uint32_t words_bytes = (uint32_t)ep.slot_bytes - p;
+  if constexpr (RAW)
+  {
+    // ---- the stream's header in front of the words: [n u64][total u64][counts 256 x u16][states S x u32] (rANS32x64_16w.cpp:150-166) ----
+    constexpr uint32_t kRawHeader = 16 + 512 + 4 * S;
+    uint8_t *h = slot + p - kRawHeader;
+    const uint64_t total = (uint64_t)kRawHeader + words_bytes;
+    if (lane == 0)
+    {
+      ((U64a2 *)h)->v = ep.n;
+      ((U64a2 *)(h + 8))->v = total;
+      ep.image_bytes[0] = total;
+      ep.image_off[0] = 0;
+      ep.result[0] = total;
+      ep.result[1] = total <= ep.out_cap ? 1 : 0;
+      ep.result[2] = ck_left; // (listed checkpoints that were not met: 0 unless the list was not what the host validated)
+    }
+    for (uint32_t k = 0; k < 4; k++)
+      *(uint16_t *)(h + 16 + 2 * (lane * 4 + k)) = (uint16_t)sc[k];
+    if (lane < S)
+      ((U32a2 *)(h + 16 + 512 + 4 * lane))->v = x;
+    return;
+  }
+  // ---- block header in front of the words: [size u64][skip u64][states S x u32][counts 256 x u16] ----
   constexpr uint32_t kHeader = 16 + 4 * S + 512;
   uint8_t *h = slot + p - kHeader;
   // skip: uint16 units from the state array to the next block header, minus one; the last block's is one less
@@ -580,6 +628,51 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
     ((U32a2 *)(h + 16 + 4 * lane))->v = x;
   for (uint32_t k = 0; k < 4; k++)
     *(uint16_t *)(h + 16 + 4 * S + 2 * (lane * 4 + k)) = (uint16_t)sc[k];
+}
+
+template <uint32_t S>
+__global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  const uint32_t lane = lane_id();
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t b = blockIdx.x * kWavesPerWG + wave;
+  if (b >= ep.n_blocks)
+    return;
+  encode_body<S, false>(ep, b, *(WaveLds *)(lds_raw + (size_t)wave * sizeof(WaveLds)), lane);
+}
+
+// ---- raw streams: K_hist (wide) -> K_raw (one wavefront) -> K_copy (wide) -----------------------------------------------
+// byte counts of the whole input into counts[256] (zeroed by the launcher): per-workgroup LDS histograms (the sub-histogram layout
+// of the block encoder), one global atomic per symbol and workgroup
+__global__ void __launch_bounds__(256) k_raw_histogram(const uint8_t *in, uint64_t n, uint32_t *counts)
+{
+  __shared__ uint32_t sub[kSubHists * kSubStride];
+  for (uint32_t k = threadIdx.x; k < kSubHists * kSubStride; k += 256)
+    sub[k] = 0;
+  __syncthreads();
+  uint32_t *mine = sub + (threadIdx.x & (kSubHists - 1)) * kSubStride;
+  for (uint64_t off = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; off < n; off += (uint64_t)gridDim.x * 4096)
+  {
+    const uint4 d = load16_guarded(in, off, n);
+    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+    const uint32_t have = n - off < 16 ? (uint32_t)(n - off) : 16;
+    for (uint32_t k = 0; k < have; k++)
+      atomicAdd(&mine[(w[k >> 2] >> (8 * (k & 3))) & 0xFF], 1u);
+  }
+  __syncthreads();
+  uint32_t v = 0;
+  for (uint32_t c = 0; c < kSubHists; c++)
+    v += sub[c * kSubStride + threadIdx.x];
+  if (v)
+    atomicAdd(&counts[threadIdx.x], v);
+}
+
+template <uint32_t S>
+__global__ void __launch_bounds__(64) k_encode_raw(EncParams ep)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  encode_body<S, true>(ep, 0, *(WaveLds *)lds_raw, lane_id());
 }
 
 // ---- K_scan: one workgroup ----------------------------------------------------------------------------------------
@@ -778,6 +871,24 @@ __global__ void __launch_bounds__(256) k_gather_images(EncParams ep)
     *(uint16_t *)(dst + i) = *(const uint16_t *)(src + i);
 }
 
+// the one image of a raw encode (the whole stream), copied by the whole grid
+__global__ void __launch_bounds__(256) k_copy_image(EncParams ep)
+{
+  if (ep.result[1] == 0)
+    return;
+  const uint64_t bytes = ep.image_bytes[0];
+  const uint8_t *src = ep.scratch + ep.slot_bytes - bytes; // 2-byte aligned; ep.out is 16-byte aligned
+  const uint64_t body = bytes / 16;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < body; i += (uint64_t)gridDim.x * 256)
+  {
+    const U128a2 v = *(const U128a2 *)(src + i * 16);
+    *(uint4 *)(ep.out + i * 16) = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+  }
+  if (blockIdx.x == 0)
+    for (uint64_t i = body * 16 + threadIdx.x * 2; i < bytes; i += 512)
+      *(uint16_t *)(ep.out + i) = *(const uint16_t *)(src + i);
+}
+
 } // namespace
 
 uint32_t encode_block_count(uint64_t n, uint64_t block, uint32_t S)
@@ -818,6 +929,38 @@ hipError_t launch_encode(const EncParams &ep, hipStream_t stream, bool *prepared
     hipLaunchKernelGGL(k_encode_blocks<32>, dim3(grid), dim3(64 * kWavesPerWG), lds, stream, ep);
   hipLaunchKernelGGL(k_scan_images, dim3(1), dim3(1024), 0, stream, ep);
   hipLaunchKernelGGL(k_gather_images, dim3(ep.n_blocks), dim3(256), 0, stream, ep);
+  return hipGetLastError();
+}
+
+hipError_t launch_encode_raw(const EncParams &ep, uint32_t *d_counts, hipStream_t stream, bool *prepared_flag)
+{
+  bool local = false;
+  bool &prepared = prepared_flag ? *prepared_flag : local;
+  const size_t lds = sizeof(WaveLds);
+  if (!prepared)
+  {
+    hipError_t e = hipFuncSetAttribute((const void *)k_encode_raw<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)k_encode_raw<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess)
+      return e;
+    prepared = true;
+  }
+  (void)hipGetLastError();
+  if (ep.given_counts == nullptr)
+  {
+    hipError_t e = hipMemsetAsync(d_counts, 0, 256 * 4, stream);
+    if (e != hipSuccess)
+      return e;
+    const uint64_t per_wg = 1 << 16; // 16 passes of a workgroup's 4 KiB
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((ep.n + per_wg - 1) / per_wg, 4096);
+    hipLaunchKernelGGL(k_raw_histogram, dim3(grid ? grid : 1), dim3(256), 0, stream, ep.in, ep.n, d_counts);
+  }
+  if (ep.S == 64)
+    hipLaunchKernelGGL(k_encode_raw<64>, dim3(1), dim3(64), lds, stream, ep);
+  else
+    hipLaunchKernelGGL(k_encode_raw<32>, dim3(1), dim3(64), lds, stream, ep);
+  hipLaunchKernelGGL(k_copy_image, dim3(1024), dim3(256), 0, stream, ep);
   return hipGetLastError();
 }
 

@@ -583,28 +583,18 @@ size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_
   std::reverse(cps.begin(), cps.end()); // now ascending by group
   if (container == HSRANS_RAW)
   {
-    pb.set_hist(c.hist.symbolCount);
-    const uint64_t G_total = last_group_start / S + 1; // groups incl. a partial one
-    uint64_t g = 0;
-    size_t k = 0;
-    const uint32_t *st = c.x;
-    uint64_t wfe = payload;
-    while (true)
+    std::vector<uint64_t> ck_group(cps.size()), ck_wfe(cps.size());
+    std::vector<uint32_t> ck_states(cps.size() * (size_t)S);
+    for (size_t k = 0; k < cps.size(); k++)
     {
-      const uint64_t g_next = k < cps.size() ? cps[k].group : G_total;
-      Piece p = rans_piece(g, g_next, wfe, 16);
-      p.tail = (uint16_t)(g_next == G_total ? tail : 0);
-      p.flags = kPieceChainStart;
-      pb.add_chain(p, st);
-      if (k == cps.size())
-        break;
-      g = g_next;
-      st = cps[k].states;
-      wfe = cps[k].words_from_end;
-      k++;
+      ck_group[k] = cps[k].group;
+      ck_wfe[k] = cps[k].words_from_end;
+      memcpy(&ck_states[k * S], cps[k].states, 4 * (size_t)S);
     }
+    opts->plan_size = raw_plan_from_checkpoints(states, bits, n, total, c.hist.symbolCount, c.x, cps.size(), ck_group.data(), ck_wfe.data(), ck_states.data(), interval,
+                                                opts->plan_out, opts->plan_capacity);
+    return opts->plan_size ? total : 0;
   }
-  else
   {
     size_t k = 0;
     for (size_t b = metas.size(); b-- > 0;) // metas are back to front: walk in output order
@@ -645,6 +635,51 @@ size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_
   }
   opts->plan_size = pb.serialize(opts->plan_out, opts->plan_capacity);
   return opts->plan_size ? total : 0;
+}
+
+// The sidecar plan of a raw stream from what its encoder recorded (the host encoder above, or the gfx950 one: hsrans_capi.cpp
+// hsrans_encode_device_raw): chain 0 from the header's states, then one chain per checkpoint, ascending by group.
+size_t raw_plan_from_checkpoints(int states, uint32_t bits, uint64_t n, uint64_t total, const uint16_t counts[256], const uint32_t *start_states, size_t n_ck,
+                                 const uint64_t *ck_group, const uint64_t *ck_words_from_end, const uint32_t *ck_states, uint32_t interval, uint8_t *plan_out,
+                                 size_t plan_capacity)
+{
+  const uint32_t S = (uint32_t)states;
+  const uint64_t T = n + 1 >= S ? (n - S + 1 + S - 1) / S : 0; // whole groups (rANS32x64_16w.cpp:220-250)
+  const uint32_t tail = (uint32_t)(n - T * S);
+  const uint64_t G_total = (n - 1) / S + 1; // groups incl. a partial one
+  const uint64_t header_bytes = 16 + 512 + 4 * (uint64_t)S;
+  if (n == 0 || total < header_bytes)
+    return 0;
+  PlanBuilder pb;
+  pb.begin(HSRANS_RAW, states, bits, n, total);
+  pb.hdr.interval = interval;
+  pb.set_hist(counts);
+  uint64_t g = 0;
+  size_t k = 0;
+  const uint32_t *st = start_states;
+  uint64_t wfe = total - header_bytes;
+  while (true)
+  {
+    const uint64_t g_next = k < n_ck ? ck_group[k] : G_total;
+    if (g_next <= g && k < n_ck)
+      return 0;
+    Piece p{};
+    p.words_off = total - wfe;
+    p.out_off = g * S;
+    p.hist_off = 16;
+    const uint64_t whole_end = std::min<uint64_t>(g_next, T); // only groups below T are whole (the last chain adds the tail)
+    p.steps = (uint32_t)(whole_end > g ? whole_end - g : 0);
+    p.tail = (uint16_t)(g_next == G_total ? tail : 0);
+    p.flags = kPieceChainStart;
+    pb.add_chain(p, st);
+    if (k == n_ck)
+      break;
+    g = g_next;
+    st = ck_states + k * S;
+    wfe = ck_words_from_end[k];
+    k++;
+  }
+  return pb.serialize(plan_out, plan_capacity);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

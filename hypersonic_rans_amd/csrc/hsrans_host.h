@@ -28,6 +28,11 @@ void normalize_counts(hsrans_hist *hist, const uint32_t raw[256], size_t data_by
 size_t encode(int container, int states, uint32_t bits, const uint8_t *in, size_t n, uint8_t *out, size_t cap, const hsrans_hist *hist,
               hsrans_encode_opts *opts);
 
+// plan of a raw stream from its encoder's checkpoints (ascending by group; states n_ck x `states`): what encode() emits
+size_t raw_plan_from_checkpoints(int states, uint32_t bits, uint64_t n, uint64_t total, const uint16_t counts[256], const uint32_t *start_states, size_t n_ck,
+                                 const uint64_t *ck_group, const uint64_t *ck_words_from_end, const uint32_t *ck_states, uint32_t interval, uint8_t *plan_out,
+                                 size_t plan_capacity);
+
 // in-memory plan under construction
 struct PlanBuilder
 {

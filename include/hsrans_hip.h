@@ -218,6 +218,19 @@ int hsrans_decode_device_indexing(hsrans_ctx *ctx, hsrans_dplan *dplan, const vo
 size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t bits, const void *d_in, size_t length, void *d_out, size_t out_capacity,
                             uint32_t block_size, uint32_t index_interval, void *hip_stream, hsrans_dplan **out_dplan);
 
+/* The raw format on the GPU (replaces src/rANS32x64_16w.cpp:34-166 `rANS32x64_16w_encode_scalar_N` / src/rANS32x32_16w.cpp for
+ * data that lives in HBM): the format carries every coder state from the last symbol to the first, so it
+ * is ONE wavefront's work — about 10x one host core, not a throughput kernel; mt_ (hsrans_encode_device) is the format to encode
+ * at HBM rates.  `hist` NULL: the histogram of the input is counted and normalised on the device (what make_hist gives); else the
+ * caller's normalised counts are used (they must sum to 1 << bits), as the reference's encode signature passes them.
+ * The sidecar index: a checkpoint every `index_interval` groups, or at `index_groups` (hsrans_index_boundaries) when
+ * n_index_groups != 0; the plan goes to plan_out (host; *plan_size receives its size; hsrans_plan_capacity[_chains]) and/or is
+ * returned as a device plan.  Stream and plan are byte-identical to hsrans_encode_ex's.  length <= 2^31 - 2^16.
+ * hsrans_encode_device(HSRANS_RAW, ...) is this call with hist = NULL and a uniform interval.  Returns the stream length, 0 on failure. */
+size_t hsrans_encode_device_raw(hsrans_ctx *ctx, int states, uint32_t bits, const void *d_in, size_t length, void *d_out, size_t out_capacity, const hsrans_hist *hist,
+                                uint32_t index_interval, const uint64_t *index_groups, size_t n_index_groups, uint8_t *plan_out, size_t plan_capacity,
+                                size_t *plan_size, void *hip_stream, hsrans_dplan **out_dplan);
+
 /* Build a plan with checkpoints every `index_interval` groups for an EXISTING stream (e.g. one written by the
  * reference's encoder) by one decode pass on the GPU that records the states at the checkpoints: HSRANS_RAW (one
  * sequential wavefront), HSRANS_MT (one wavefront per block) and HSRANS_BLOCK (one sequential wavefront that also reports

@@ -659,13 +659,98 @@ def test_gpu_encoder_rejects_bad_arguments(gpu_ctx, zipf):
     import torch
     d_in = torch.from_numpy(zipf[:4096].copy()).cuda()
     d_out = torch.empty(H.capacity(H.MT, 64, 4096), dtype=torch.uint8, device="cuda")
-    for kw in (dict(container=H.RAW), dict(block_size=100), dict(block_size=0), dict(bits=9), dict(states=16)):
+    for kw in (dict(container=H.BLOCK), dict(block_size=100), dict(block_size=0), dict(bits=9), dict(states=16)):
         a = dict(container=H.MT, states=64, bits=11, block_size=1024)
         a.update(kw)
         with pytest.raises(H.HsransError):
             gpu_ctx.encode_device(a["container"], a["states"], a["bits"], d_in, d_out, block_size=a["block_size"])
     with pytest.raises(H.HsransError):
         gpu_ctx.encode_device(H.MT, 64, 11, d_in, d_out[:1000], block_size=1024)  # capacity contract
+
+
+# ---- the raw format's encoder on the device (raw half: src/rANS32x64_16w.cpp:34-166) ------------------------
+def _gpu_encode_raw(ctx, states, bits, data, **kw):
+    import torch
+    d_in = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+    d_out = torch.full((kw.pop("capacity", None) or H.capacity(H.RAW, states, data.size),), 0xA5, dtype=torch.uint8, device="cuda")
+    r = ctx.encode_device_raw(states, bits, d_in, d_out, **kw)
+    n = r if isinstance(r, int) else r[0]
+    return (d_out[:n].cpu().numpy(), d_out, d_in) + (() if isinstance(r, int) else tuple(r[1:]))
+
+
+@pytest.mark.parametrize("states", (32, 64))
+@pytest.mark.parametrize("bits", (10, 11, 12, 13, 14, 15))
+def test_gpu_raw_encoder_matches_host_encoder_and_reference(gpu_ctx, oracle, ref, zipf, nonstat, states, bits):
+    """the stream one wavefront writes == hsrans_encode (host) == the real reference's rANS32x{32,64}_16w_encode_scalar_N, with the
+    histogram made on the device (make_hist's result) and with the caller's; the oracle decodes it"""
+    runs = np.concatenate([np.full(70_000, 7, np.uint8), zipf[:100_000], np.full(200_000, 200, np.uint8), zipf[:33]])
+    one = np.full(50_000, 65, np.uint8)
+    for src, n in ((zipf, 1), (zipf, 31), (zipf, 63), (zipf, 64), (zipf, 65), (zipf, 255), (zipf, 256), (zipf, 4096 + 17), (zipf, 8192), (zipf, 12288 + 64 + 3), (zipf, 100_000),
+                   (zipf, 300_001), (nonstat, 1_000_003), (runs, runs.size), (one, one.size)):
+        d = src[:n]
+        want = H.encode(H.RAW, states, bits, d)
+        got = _gpu_encode_raw(gpu_ctx, states, bits, d)[0]
+        assert got.size == want.size and np.array_equal(got, want), (states, bits, n, got.size, want.size)
+        assert np.array_equal(got, ref.encode(RAW, states, bits, d)), (states, bits, n)
+        hist = H.make_hist(zipf[:500_000] if src is zipf else d, bits)  # zipf: a histogram that is NOT the data's own
+        if src is zipf and n < 256:
+            hist = H.make_hist(d, bits)
+        want_h = H.encode(H.RAW, states, bits, d, hist=hist, out_capacity=2 * n + 4096)
+        got_h = _gpu_encode_raw(gpu_ctx, states, bits, d, hist=hist, capacity=2 * n + 4096)[0]
+        assert got_h.size == want_h.size and np.array_equal(got_h, want_h), (states, bits, n, "given histogram")
+        if n >= states - 1:  # shorter inputs are undefined behaviour in the reference decoders (SURVEY.md §8 quirks)
+            r, back = oracle.decode(RAW, states, bits, got, n)
+            assert r == n and np.array_equal(back, d), (states, bits, n)
+
+
+@pytest.mark.parametrize("states", (32, 64))
+def test_gpu_raw_encoder_emits_the_host_encoders_index(gpu_ctx, zipf, nonstat, states):
+    """uniform intervals and listed checkpoints (incl. the one-chain-per-wavefront boundaries): stream and plan == hsrans_encode_ex's;
+    the device plan it returns decodes the stream it wrote, nothing having left HBM"""
+    import torch
+    for src, n, bits, kw in ((zipf, 300_001, 11, dict(index_interval=4)), (zipf, 300_001, 14, dict(index_interval=32)), (zipf, 64 * 8, 11, dict(index_interval=4)),
+                             (zipf, 64 * 8 + 5, 11, dict(index_interval=8)), (zipf, 100, 11, dict(index_interval=4)), (nonstat, 3_000_000, 11, dict(index_interval=256)),
+                             (nonstat, 3_000_000, 11, dict(index_groups="wave")), (nonstat, 3_000_000, 15, dict(index_groups="wave")),
+                             (zipf, 300_001, 12, dict(index_groups=[4, 8, 400, 404, 4000, 1 << 20])), (zipf, 64 * 100, 11, dict(index_groups=[96, 100, 104]))):
+        d = src[:n]
+        kw = dict(kw)
+        if isinstance(kw.get("index_groups"), str):
+            kw["index_groups"] = H.index_boundaries(states, bits, n, gpu_ctx)
+            assert len(kw["index_groups"]) > 100
+        want_stream, want_plan = H.encode(H.RAW, states, bits, d, **kw)
+        got, d_out, d_in, plan, dplan = _gpu_encode_raw(gpu_ctx, states, bits, d, want_plan=True, want_device_plan=True, **kw)
+        assert np.array_equal(got, want_stream), (states, n, bits)
+        assert plan.size == want_plan.size and np.array_equal(plan, want_plan), (states, n, bits, kw.keys())
+        back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        gpu_ctx.decode_device(dplan, d_out, back, stream_length=got.size)
+        assert gpu_ctx.status(dplan) == 0 and torch.equal(back, d_in), (states, n, bits)
+    # hsrans_encode_device(HSRANS_RAW) is the same call
+    d = zipf[:200_000]
+    d_in = torch.from_numpy(d.copy()).cuda()
+    d_out = torch.empty(H.capacity(H.RAW, states, d.size), dtype=torch.uint8, device="cuda")
+    m, dplan = gpu_ctx.encode_device(H.RAW, states, 11, d_in, d_out, index_interval=32, want_plan=True)
+    want_stream, want_plan = H.encode(H.RAW, states, 11, d, index_interval=32)
+    assert m == want_stream.size and np.array_equal(d_out[:m].cpu().numpy(), want_stream) and np.array_equal(gpu_ctx.read_device_plan(dplan), want_plan)
+
+
+def test_gpu_raw_encoder_rejects_bad_arguments(gpu_ctx, zipf):
+    import torch
+    d = zipf[:4096].copy()
+    d_in = torch.from_numpy(d).cuda()
+    d_out = torch.empty(H.capacity(H.RAW, 64, 4096) + 16, dtype=torch.uint8, device="cuda")
+    bad_hist = H.make_hist(d, 11)
+    bad_hist.symbolCount[int(d[0])] += 1  # no longer sums to 2^11
+    for kw in (dict(bits=9), dict(states=16), dict(hist=bad_hist), dict(index_interval=6, want_plan=True), dict(index_groups=[6], want_plan=True),
+               dict(index_groups=[8, 8], want_plan=True), dict(index_groups=[0], want_plan=True)):
+        a = dict(states=64, bits=11)
+        a.update(kw)
+        with pytest.raises(H.HsransError):
+            gpu_ctx.encode_device_raw(a.pop("states"), a.pop("bits"), d_in, d_out, **a)
+    with pytest.raises(H.HsransError):
+        gpu_ctx.encode_device_raw(64, 11, d_in, d_out[:1000])  # capacity contract
+    with pytest.raises(H.HsransError):
+        gpu_ctx.encode_device_raw(64, 11, d_in, d_out[2:])  # alignment
+    assert gpu_ctx.encode_device_raw(64, 11, d_in, d_out) == H.encode(H.RAW, 64, 11, d).size  # (the context still works)
 
 
 # ---- seeded random sweep over the whole configuration space ---------------------------------------------------------------

@@ -64,3 +64,39 @@ if args.cpu_sample:
     same = n == s_host.size and bool((d_out[:n].cpu().numpy() == s_host).all())
     print(json.dumps({"codec": "mt_ rANS32x64 16w 11 host encoder (1 core)", "block": 1 << 16, "size": int(sample.size), "ms": round(dt * 1e3, 1),
                       "MiB_s": round(sample.size / dt / 2**20, 1), "gpu_stream_identical": same}))
+
+# ---- the raw format: one dependent chain per coder state = one wavefront (hsrans_encode_device_raw) ----
+for states, bits in ((64, 11), (32, 11), (64, 15)):
+    d_out = torch.empty(H.capacity(H.RAW, states, d.size), dtype=torch.uint8, device="cuda")
+    n = ctx.encode_device_raw(states, bits, d_in, d_out)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ctx.encode_device_raw(states, bits, d_in, d_out)
+        ts.append(time.perf_counter() - t0)
+    groups = H.index_boundaries(states, bits, d.size, ctx)
+    t0 = time.perf_counter()
+    n2, dplan = ctx.encode_device_raw(states, bits, d_in, d_out, index_groups=groups, want_device_plan=True)
+    t_plan = time.perf_counter() - t0
+    back = torch.empty(d.size, dtype=torch.uint8, device="cuda")
+    ctx.decode_device(dplan, d_out, back, stream_length=n2)
+    torch.cuda.synchronize()
+    ok = n2 == n and ctx.status(dplan) == 0 and bool(torch.equal(back, d_in))
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(args.reps):
+        ctx.decode_device(dplan, d_out, back, stream_length=n2)
+    b.record()
+    torch.cuda.synchronize()
+    dec_ms = a.elapsed_time(b) / args.reps
+    line = {"codec": f"raw rANS32x{states} 16w {bits}", "size": args.size, "stream": n, "ratio": round(n / args.size, 4), "ms_best": round(min(ts) * 1e3, 2),
+            "MB_s_best": round(args.size / min(ts) / 1e6, 1), "with_wave_index_and_device_plan_ms": round(t_plan * 1e3, 2), "index_chains": dplan.launch_info()["chains"],
+            "decode_with_that_plan_ms": round(dec_ms, 4), "round_trip_bit_exact": ok, "note": "one wavefront: the format is one dependent chain per coder state"}
+    if args.cpu_sample and states == 64 and bits == 11:
+        sample = d[: args.cpu_sample]
+        t0 = time.perf_counter()
+        s_host = H.encode(H.RAW, 64, 11, sample)
+        dt = time.perf_counter() - t0
+        line["host_encoder_1_core_MB_s"] = round(sample.size / dt / 1e6, 1)
+        line["host_encoder_sample"] = int(sample.size)
+    print(json.dumps(line), flush=True)
