@@ -100,6 +100,8 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_ctx_create.argtypes = [_i, ctypes.POINTER(_vp)]
     L.hsrans_ctx_destroy.restype = None
     L.hsrans_ctx_destroy.argtypes = [_vp]
+    L.hsrans_ctx_host_index_chains.restype = _u32
+    L.hsrans_ctx_host_index_chains.argtypes = [_vp]
     L.hsrans_ctx_device_name.restype = ctypes.c_char_p
     L.hsrans_ctx_device_name.argtypes = [_vp]
     L.hsrans_decode_host.restype = _sz
@@ -436,6 +438,10 @@ class Context:
         r = self.L.hsrans_decode_host(self.handle, container, states, bits, _p(stream), stream.size if in_length is None else in_length, _p(out),
                                       out_capacity, pp, pn)
         return r, out[:out_capacity]
+
+    def host_index_chains(self) -> int:
+        """chains of the index decode_host keeps from its last plan-less call on an mt_/raw stream (0 = none)"""
+        return int(self.L.hsrans_ctx_host_index_chains(self.handle))
 
     def decode(self, container: int, states: int, bits: int, stream, plan=None) -> np.ndarray:
         stream = _u8(stream)

@@ -166,6 +166,8 @@ struct IndexArgs
   uint64_t stream_len;
 };
 hipError_t launch_index_assemble(const IndexArgs &a, hipStream_t stream);
+// 64-bit fingerprint of d_stream[0, stream_len) into *d_sum (16-byte aligned stream; asynchronous: memset + one launch)
+hipError_t launch_stream_checksum(const uint8_t *d_stream, uint64_t stream_len, uint64_t *d_sum, hipStream_t stream);
 
 DeviceGeom default_geom(); // MI355X: 256 CUs, 160 KiB LDS (used where no device is at hand: host-side index sizing)
 LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persistent, uint32_t table_mode, uint32_t n_groups, bool index_pass, bool direct, bool dual);

@@ -68,6 +68,16 @@ hipError_t launch_index_assemble(const IndexArgs &a, hipStream_t stream)
   return hipGetLastError();
 }
 
+hipError_t launch_stream_checksum(const uint8_t *d_stream, uint64_t stream_len, uint64_t *d_sum, hipStream_t stream)
+{
+  hipError_t e = hipMemsetAsync(d_sum, 0, 8, stream);
+  if (e != hipSuccess)
+    return e;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(k_stream_checksum, dim3(kChecksumGrid), dim3(kChecksumBlock), 0, stream, d_stream, stream_len, (unsigned long long *)d_sum);
+  return hipGetLastError();
+}
+
 hipError_t launch_mt_fill(const uint8_t *d_stream, uint64_t stream_len, uint32_t S, uint32_t bits, const uint64_t *d_blocks, uint8_t *d_plan, uint32_t n_chains,
                           uint64_t out_len, WalkResult *d_result, hipStream_t stream)
 {

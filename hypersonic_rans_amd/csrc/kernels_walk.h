@@ -312,6 +312,34 @@ __global__ void __launch_bounds__(64) k_index_fill(IndexArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 64-bit fingerprint of a stream in device memory (hsrans_decode_host's index cache: the index a first decode left behind may only
+// serve a later call when EVERY byte of the stream is the same).  Fixed launch shape (the value depends on which thread reads which
+// word): thread t folds the 16-byte words t, t + T, t + 2T, ... in order; the per-thread values are mixed with t and summed.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kChecksumGrid = 1024, kChecksumBlock = 256;
+__global__ void __launch_bounds__(kChecksumBlock) k_stream_checksum(const uint8_t *in, uint64_t n, unsigned long long *sum)
+{
+  const uint64_t T = (uint64_t)kChecksumGrid * kChecksumBlock, t = (uint64_t)blockIdx.x * kChecksumBlock + threadIdx.x;
+  uint64_t h = 0x9E3779B97F4A7C15ull * (t + 1);
+  const uint64_t words = n / 16;
+  for (uint64_t i = t; i < words; i += T)
+  {
+    const uint4 w = ((const uint4 *)in)[i];
+    h = (h ^ ((uint64_t)w.x | ((uint64_t)w.y << 32))) * 0xFF51AFD7ED558CCDull;
+    h = (h ^ (h >> 29) ^ ((uint64_t)w.z | ((uint64_t)w.w << 32))) * 0xC4CEB9FE1A85EC53ull;
+  }
+  if (t == 0)
+    for (uint64_t i = words * 16; i < n; i++)
+      h = (h ^ in[i]) * 0xFF51AFD7ED558CCDull;
+  h ^= h >> 32;
+  // wave sum first: 4,096 atomics instead of 262,144
+  for (int d = 32; d >= 1; d >>= 1)
+    h += __shfl_xor(h, d, 64);
+  if ((threadIdx.x & 63) == 0)
+    atomicAdd(sum, (unsigned long long)h);
+}
+
 } // namespace hsrans
 
 #endif // HSRANS_KERNELS_WALK_H

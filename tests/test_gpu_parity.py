@@ -668,6 +668,52 @@ def test_gpu_encoder_rejects_bad_arguments(gpu_ctx, zipf):
         gpu_ctx.encode_device(H.MT, 64, 11, d_in, d_out[:1000], block_size=1024)  # capacity contract
 
 
+@pytest.mark.parametrize("container", ("mt", "raw"))
+def test_plain_host_decode_keeps_the_index_of_its_first_call(gpu_ctx, ref, nonstat, container):
+    """hsrans_decode_host without a plan (the reference's decodeFunc shape): the first call on an mt_/raw stream records an index, the
+    next call on the same bytes uses it, and other bytes at the same address — even one flipped bit — are noticed (device-side
+    fingerprint of the whole stream) and decoded from scratch."""
+    C, RC = (H.MT, MT) if container == "mt" else (H.RAW, RAW)
+    n = 3_000_000
+    d = nonstat[:n]
+    s = np.ascontiguousarray(ref.encode(RC, 64, 11, d))
+    ctx = H.Context(0)  # (its own context: the cache belongs to it)
+    assert ctx.host_index_chains() == 0
+    r, got = ctx.decode_host(C, 64, 11, s, n)
+    assert r == n and np.array_equal(got, d)
+    chains = ctx.host_index_chains()
+    assert chains > 100
+    for _ in range(3):
+        r, got = ctx.decode_host(C, 64, 11, s, n)
+        assert r == n and np.array_equal(got, d) and ctx.host_index_chains() == chains
+    # one bit of one word flipped IN PLACE: a decoder that trusted the address would emit the old states' bytes
+    s[s.size // 2] ^= 0x10
+    want_r, want = hsrans_cpu_decode(C, 64, 11, s, n)
+    r, got = ctx.decode_host(C, 64, 11, s, n)
+    assert r == want_r and np.array_equal(got[:r], want[:r]) and not np.array_equal(got, d)
+    s[s.size // 2] ^= 0x10
+    r, got = ctx.decode_host(C, 64, 11, s, n)
+    assert r == n and np.array_equal(got, d)
+    # another stream, another codec, short streams: never served from the cache
+    d2 = np.ascontiguousarray(nonstat[:n][::-1])
+    s2 = np.ascontiguousarray(ref.encode(RC, 32, 12, d2))
+    r, got = ctx.decode_host(C, 32, 12, s2, n)
+    assert r == n and np.array_equal(got, d2)
+    small = np.ascontiguousarray(ref.encode(RC, 64, 11, d[:300_000]))
+    r, got = ctx.decode_host(C, 64, 11, small, 300_000)
+    assert r == 300_000 and np.array_equal(got, d[:300_000])
+    r, got = ctx.decode_host(C, 64, 11, s, n)
+    assert r == n and np.array_equal(got, d)
+
+
+def hsrans_cpu_decode(container, states, bits, stream, n):
+    """the library's host decoder (hsrans_decode_cpu, scalar route): a second implementation for streams no encoder wrote"""
+    out = np.full(n, 0xCC, np.uint8)
+    L = H.load_library()
+    r = L.hsrans_decode_cpu(0, 1, container, states, bits, stream.ctypes.data, stream.size, out.ctypes.data, n, None, 0)
+    return r, out
+
+
 # ---- the raw format's encoder on the device (SURVEY.md §8(f) row 2, raw half: src/rANS32x64_16w.cpp:34-166) ------------------------
 def _gpu_encode_raw(ctx, states, bits, data, **kw):
     import torch
