@@ -571,53 +571,18 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
         groups.push_back(g);
       }
     }
-    // Few, large blocks would leave workgroup slots empty (one workgroup per group): cut mergeable groups into parts of
-    // >= 128 chains (8 per wave: below that the per-part prologue costs more than the idle slots) while there are fewer
-    // groups than resident workgroups.  A part is a group of its own: same histogram, a sub-range of the chains, and its
-    // words end where the next part's first chain starts reading.  Measured: 382 groups of 128 chains are best left alone.
-    // Round 3, measured and left off (HSRANS_GROUP_FINE_SPLIT=1): cutting finer instead — parts of >= 32 chains until there are
-    // four per CU, so that launch_shape runs four 8-wave workgroups per CU and hands the parts out by ticket (382 blocks on 256
-    // CUs otherwise leave half the CUs with two blocks and half with one).  100 MB in 256 KiB blocks + G=32: 0.319 of 8 TB/s
-    // against 0.356 as it is: a part of 85 KiB is 11 us of decode behind 11 us of table build and records, three times per block.
-    const size_t want8 = (size_t)4 * ctx->geom.num_cus;
-    bool fine_split = false;
-    if (groups.size() < h.n_chains && groups.size() < want8 && getenv("HSRANS_GROUP_FINE_SPLIT") && atoi(getenv("HSRANS_GROUP_FINE_SPLIT")) == 1)
-    {
-      const uint32_t k_max = (uint32_t)((want8 + groups.size() - 1) / groups.size());
-      size_t total = 0;
-      for (const Group &g : groups)
-        total += (g.flags & kGroupMergeable) ? std::max<uint32_t>(1, std::min(k_max, g.count / 32)) : 1;
-      if (total >= want8)
-      {
-        std::vector<Group> parts;
-        parts.reserve(total);
-        for (const Group &g : groups)
-        {
-          const uint32_t k = (g.flags & kGroupMergeable) ? std::max<uint32_t>(1, std::min(k_max, g.count / 32)) : 1;
-          for (uint32_t part = 0; part < k; part++)
-          {
-            Group q = g;
-            const uint32_t lo = (uint32_t)((uint64_t)g.count * part / k), hi = (uint32_t)((uint64_t)g.count * (part + 1) / k);
-            q.begin = g.begin + lo;
-            q.piece0 = g.piece0 + lo;
-            q.count = hi - lo;
-            if (part + 1 < k)
-              q.words_end = pc[cf[g.begin + hi]].words_off;
-            parts.push_back(q);
-          }
-        }
-        groups.swap(parts);
-        fine_split = true;
-      }
-    }
-    const size_t want = (size_t)2 * ctx->geom.num_cus; // (two 16-wave workgroups per CU: with this few groups launch_shape stays with those)
-    if (!fine_split && groups.size() < h.n_chains && groups.size() < want)
+    // Few, large blocks would leave workgroup slots empty (one workgroup per group): mergeable groups are cut into parts of
+    // >= kGroupPartChains chains while there are fewer groups than kGroupPartsPerCU per CU (hsrans_kernels.h: the rule and what was
+    // measured).  A part is a group of its own: same histogram, a sub-range of the chains, and its words end where the next part's
+    // first chain starts reading.
+    const size_t want = (size_t)kGroupPartsPerCU * ctx->geom.num_cus;
+    if (groups.size() < h.n_chains && groups.size() < want)
     {
       const uint32_t k_max = (uint32_t)((want + groups.size() - 1) / groups.size());
       std::vector<Group> parts;
       for (const Group &g : groups)
       {
-        uint32_t k = (g.flags & kGroupMergeable) ? std::min(k_max, (g.count + 143) / 144) : 1;
+        const uint32_t k = (g.flags & kGroupMergeable) ? group_parts_of(g.count, k_max) : 1;
         if (k < 2)
         {
           parts.push_back(g);
@@ -637,47 +602,9 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
       }
       groups.swap(parts);
     }
-    // Dynamic group order (run_grouped): the groups are handed out in list order, so the END of the list decides how evenly the
-    // launch finishes — a workgroup that draws a whole block last is still busy a round after the others are done (at 2^30
-    // bytes: lifetimes p50 360, max 403 us).  Cutting the last part of the list into half-blocks (parts like the ones above:
-    // same histogram, half the chains, >= one chain per wave) was built and measured: 0.454-0.458 ms with the last eighth in
-    // halves, 0.451-0.456 without, 0.455-0.458 with a quarter — the extra table builds cost what the evener finish gains — so
-    // it is off unless HSRANS_GROUP_TAIL_PERMILLE (and _PARTS) ask for it.
-    {
-      const LaunchShape ls = launch_shape(h, ctx->geom, false, 0, (uint32_t)groups.size(), false, false, false);
-      uint32_t permille = 0, tail_parts = 2;
-      if (const char *e = getenv("HSRANS_GROUP_TAIL_PERMILLE"))
-        permille = (uint32_t)atoi(e) > 1000 ? 1000 : (uint32_t)atoi(e);
-      if (const char *e = getenv("HSRANS_GROUP_TAIL_PARTS"))
-        tail_parts = (uint32_t)atoi(e) >= 1 && atoi(e) <= 16 ? (uint32_t)atoi(e) : 2;
-      if (groups.size() < h.n_chains && groups.size() >= (size_t)2 * ls.grid && permille != 0 && tail_parts > 1)
-      {
-        const size_t first_cut = groups.size() - groups.size() * permille / 1000;
-        std::vector<Group> cut(groups.begin(), groups.begin() + first_cut);
-        for (size_t i = first_cut; i < groups.size(); i++)
-        {
-          const Group &g = groups[i];
-          const uint32_t k = (g.flags & kGroupMergeable) ? std::min(tail_parts, g.count / ls.waves) : 1;
-          if (k < 2)
-          {
-            cut.push_back(g);
-            continue;
-          }
-          for (uint32_t part = 0; part < k; part++)
-          {
-            Group q = g;
-            const uint32_t lo = (uint32_t)((uint64_t)g.count * part / k), hi = (uint32_t)((uint64_t)g.count * (part + 1) / k);
-            q.begin = g.begin + lo;
-            q.piece0 = g.piece0 + lo;
-            q.count = hi - lo;
-            if (part + 1 < k)
-              q.words_end = pc[cf[g.begin + hi]].words_off;
-            cut.push_back(q);
-          }
-        }
-        groups.swap(cut);
-      }
-    }
+    // (Dynamic group order, run_grouped: the END of the list decides how evenly the launch finishes.  Cutting the last eighth /
+    // quarter of the list into half-blocks was built and measured in round 3 at 2^30 bytes — 0.454-0.458 ms against 0.451-0.456
+    // without: the extra table builds cost what the evener finish gains — and is gone.)
     if (groups.size() < h.n_chains)
     {
       d->d_groups = carve(groups.size() * sizeof(Group)); // (the dynamic group order's ticket counters: d_counters, zeroed above)
@@ -742,7 +669,6 @@ static int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_len
     kp.group_prio = getenv("HSRANS_GROUP_PRIO") != nullptr ? (uint32_t)atoi(getenv("HSRANS_GROUP_PRIO")) : 350;
     // (requesting a round's records and first chunks before its table build: measured, no gain — the other workgroups of the CU
     // fill the gap either way — so off unless asked for)
-    kp.group_overlap = getenv("HSRANS_GROUP_OVERLAP") != nullptr ? (uint32_t)atoi(getenv("HSRANS_GROUP_OVERLAP")) : 0;
     // dynamic group order: this launch's own ticket counter (the counter sets of the persistent launches, one head of each used)
     if (d->d_counters != nullptr && getenv("HSRANS_GROUP_STATIC") == nullptr)
       kp.group_tickets = d->d_counters + (size_t)(d->epoch.fetch_add(1, std::memory_order_relaxed) % kCounterSets) * kDynQueues * kDynQueueStride;
@@ -1388,10 +1314,10 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   const bool grouped = ep.interval != 0 && ep.n_blocks < h.n_chains;
   // few large blocks: cut every block's chains into parts so that there are about two workgroup tasks per resident workgroup
   // (parts of >= 128 chains, only while there are fewer blocks than resident workgroups: see hsrans_dplan_create)
-  const size_t want = (size_t)2 * ctx->geom.num_cus;
+  const size_t want = (size_t)kGroupPartsPerCU * ctx->geom.num_cus;
   ep.group_split = 1;
   if (grouped && nb < want)
-    ep.group_split = (uint32_t)std::max<size_t>(1, std::min<size_t>({(want + nb - 1) / nb, (size_t)(ep.max_ck + 1) / 128, (size_t)64}));
+    ep.group_split = (uint32_t)std::max<size_t>(1, std::min<size_t>({(want + nb - 1) / nb, (size_t)(ep.max_ck + 1) / kGroupPartChains, (size_t)64}));
   bool ok = hipMalloc((void **)&d->d_plan, bytes) == hipSuccess && hipMalloc((void **)&d->d_status, 64) == hipSuccess &&
             (!grouped || grow(&d->d_groups, &d->d_groups_cap, nb * ep.group_split * sizeof(Group))) && hipMemsetAsync(d->d_plan, 0, bytes, s) == hipSuccess &&
             hipMemsetAsync(d->d_status, 0, 64, s) == hipSuccess && hipMemcpyAsync(d->d_plan, &h, sizeof(h), hipMemcpyHostToDevice, s) == hipSuccess;
@@ -1758,10 +1684,10 @@ try
       return HSRANS_E_HIP;
     const uint32_t nb = h.n_chains;
     // few large blocks: every block's chains in parts, so that there are about two workgroup tasks per resident workgroup (as dplan_fill)
-    const size_t want = (size_t)2 * ctx->geom.num_cus;
+    const size_t want = (size_t)kGroupPartsPerCU * ctx->geom.num_cus;
     uint32_t group_split = 1;
     if (nb < want)
-      group_split = (uint32_t)std::max<size_t>(1, std::min<size_t>({(want + nb - 1) / nb, (size_t)(n_ck / nb + 1) / 128, (size_t)64}));
+      group_split = (uint32_t)std::max<size_t>(1, std::min<size_t>({(want + nb - 1) / nb, (size_t)(n_ck / nb + 1) / kGroupPartChains, (size_t)64}));
     auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t plan_max = (size_t)plan_size(max_chains, max_chains, S, 0);
     const size_t counter_bytes = (size_t)kCounterSets * kDynQueues * kDynQueueStride * 8;

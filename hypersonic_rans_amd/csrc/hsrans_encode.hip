@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(64) k_plan_blocks(EncParams ep)
   {
     // one Group per part: a block is cut into up to group_split parts of >= 128 chains; the parts that are not needed
     // (short last block, single-symbol block) stay empty
-    const uint32_t by_size = (count + 143) / 144 < ep.group_split ? (count + 143) / 144 : ep.group_split; // 128-chain parts, a remainder of > 16 gets its own
+    const uint32_t by_size = group_parts_of(count, ep.group_split); // (hsrans_kernels.h)
     const uint32_t k = single || by_size < 1 ? 1 : by_size;
     Group g{};
     g.flags = single ? kGroupFill : kGroupMergeable;

@@ -98,7 +98,6 @@ struct KParams
   uint64_t *finish;
   uint32_t groups_lean;   // 64-state plan, every group a mergeable run or fills only: the lean instantiation of k_decode_grouped
   uint32_t group_prio;    // grouped launches: per mille of its run the younger half of a workgroup's waves decodes at raised priority (s_setprio)
-  uint32_t group_overlap; // grouped launches: request piece records, states and first chunks before the table build (run_grouped)
   // grouped launches: wave k of a workgroup in grid half h takes chains [count * cum[h][k] / cum[h][waves], count * cum[h][k+1] / cum[h][waves])
   // of its group (the same age-class weights as PersistentArgs::run_len)
   uint16_t group_cum[2][17];
@@ -150,6 +149,19 @@ hipError_t launch_mt_fill(const uint8_t *d_stream, uint64_t stream_len, uint32_t
                           uint64_t out_len, WalkResult *d_result, hipStream_t stream);
 
 // the indexed plan assembled on the device from a base plan + recorded checkpoints (hsrans_decode_device_indexing; kernels_walk.h)
+// Few, large blocks (fewer groups than workgroup slots): a block's chains are cut into parts — groups of their own: same histogram,
+// a sub-range of the chains — of at least kGroupPartChains chains until there are kGroupPartsPerCU parts per CU.  Round 4, in-process
+// A/B on 100 MB (rotated, us; before: parts of >= 128 chains until two per CU): 256 KiB blocks 57.2 -> 51.3, 512 KiB 57.3 -> 53.2,
+// 1 MiB 56.3 -> 52.1, 4 MiB 62.1 -> 51.1, 256 KiB at 13 bits 69.2 -> 58.1, at 15 bits 71.6 -> 62.2; parts of 48 or 32 chains lose again
+// (profiles/r04_group_split_ab.txt).  Host (dplan_fill) and device (k_plan_blocks, k_index_fill) use the same rule.
+constexpr uint32_t kGroupPartChains = 64, kGroupPartsPerCU = 3;
+__host__ __device__ inline uint32_t group_parts_of(uint32_t chains, uint32_t k_max)
+{
+  const uint32_t by_size = chains / kGroupPartChains;
+  const uint32_t k = by_size < k_max ? by_size : k_max;
+  return k < 1 ? 1 : k;
+}
+
 struct IndexArgs
 {
   const uint8_t *base;       // base plan blob (device): one single-piece chain per mt_ block

@@ -226,7 +226,7 @@ static void read_tuning_impl()
     if (atoi(e) >= 9 && atoi(e) <= 14)
       g_pack64_max_bits = (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_WAVES_PER_WG"))
-    if (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 12 || atoi(e) == 16)
+    if (atoi(e) >= 4 && atoi(e) <= 16)
       g_waves_per_wg = (uint32_t)atoi(e);
   auto read_weights = [](const char *name, uint32_t *w) { // 8 comma-separated per-mille values, rescaled to mean 1000
     const char *e = getenv(name);

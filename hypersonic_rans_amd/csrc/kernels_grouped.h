@@ -71,10 +71,9 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
     // when it marks a group mergeable), so a wave's records come straight from the group record: one level of loads, not three
     const uint32_t piece0 = uni(G->piece0);
     HSRANS_GS(const uint64_t t1 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;)
-    // kp.group_overlap (64-state mergeable groups): the wave's piece records, start states and first stream chunks are requested
-    // BEFORE the table build and land while it runs (the build's scratch then has an LDS area of its own: launch_shape) — the
-    // ~4.5 us of dependent round trips a round used to spend after the build overlap its ~3 us instead
-    const bool overlap = LEAN && kp.group_overlap != 0 && (flags & kGroupMergeable); // (the general instantiation has no registers to spare for it)
+    // (Requesting the wave's piece records, start states and first stream chunks BEFORE the table build, so that their ~4.5 us of
+    // dependent round trips overlap its ~3 us, was built in round 3 and re-measured in round 4 where workgroup slots are empty (100 MB
+    // in 256 KiB - 4 MiB blocks, 11 / 13 / 15 bits): +1 us everywhere but one case inside the noise.  Removed.)
 #if defined(HSRANS_GROUP_STAMPS) && HSRANS_GROUP_STAMPS
     const uint64_t t2 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;
     acc_wait += t1 - t0;
@@ -100,30 +99,23 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
     const uint32_t cum_all = weighted ? kp.group_cum[half][waves] : waves;
     const uint32_t first = begin + (uint32_t)((uint64_t)(weighted ? kp.group_cum[half][wave] : wave) * count / cum_all);
     const uint32_t last = begin + (uint32_t)((uint64_t)(weighted ? kp.group_cum[half][wave + 1] : wave + 1) * count / cum_all);
-    // the wave's run of a mergeable 64-state group: chains [first, last) as one chain.  With `early` it is opened twice: before
-    // the table build for the sake of its requests (start states, first stream chunks: in flight during the build), and again
-    // after it without them — the records come from the caches then — so that only the state register lives across the build
-    // (the window, the ring and the run's geometry are 20 scalar registers the builder has no room for: they spilled).
+    // the wave's run of a mergeable 64-state group: chains [first, last) as one chain
     StreamWin sw;
     Ring r;
     uint32_t x = 0, run_tail_syms = 0;
     uint64_t o = 0, run_steps = 0;
-    auto open_run = [&](bool issue) {
+    auto open_run = [&]() {
       const Piece *p0 = pv.pieces + (piece0 + (first - begin));
       const Piece *p1 = pv.pieces + (piece0 + (last - 1 - begin));
       const uint64_t limit = last < begin + count ? uni64(pv.pieces[piece0 + (last - begin)].words_off) : uni64(G->words_end);
-      if (issue)
-        x = c.lane < c.S ? pv.states[(uint64_t)first * c.S + c.lane] : 0;
+      x = c.lane < c.S ? pv.states[(uint64_t)first * c.S + c.lane] : 0;
       ring_bind(r, c.rings, 9, fast_ring_mode(MODE));
       win_open(sw, c, uni64(p0->words_off), limit);
-      ring_begin(sw, r, c, uni64(p0->words_off), issue);
+      ring_begin(sw, r, c, uni64(p0->words_off));
       o = uni64(p0->out_off);
       run_steps = (uni64(p1->out_off) - o) / c.S + uni(p1->steps);
       run_tail_syms = uni(p1->tail);
     };
-    const bool early = overlap && first < last;
-    if (early)
-      open_run(true);
     if (!(flags & kGroupFill)) // (one call site: every inlined copy of the builder costs the kernel registers)
       build_table<MODE, true>(c, uni64(G->hist_off), threadIdx.x, blockDim.x);
     if (first >= last)
@@ -170,7 +162,7 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
     }
     else if (flags & kGroupMergeable)
     {
-      open_run(!early);
+      open_run();
       ring_ready(x);
       HSRANS_GS(const uint64_t t3 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;)
       // kp.group_prio (per mille; 350 by default): the younger half of the workgroup's waves decodes that share of its run at

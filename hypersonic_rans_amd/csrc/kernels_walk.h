@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(64) k_index_fill(IndexArgs a)
         break;
       }
     }
-    const uint32_t by_size = (count + 143) / 144 < a.group_split ? (count + 143) / 144 : a.group_split;
+    const uint32_t by_size = group_parts_of(count, a.group_split);
     const uint32_t parts = fill || by_size < 1 ? 1 : by_size;
     Group g{};
     g.flags = fill ? kGroupFill : kGroupMergeable;

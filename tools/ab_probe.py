@@ -115,6 +115,8 @@ for spec in a.variant:
 
 
 def window(v, pick):
+    saved = {k: os.environ.get(k) for k in v["env"]}  # (some knobs are read at every launch: the variant's environment is in force while it runs)
+    os.environ.update(v["env"])
     ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ea.record()
     for t in range(a.window):
@@ -122,6 +124,11 @@ def window(v, pick):
         v["ctx"].decode_device(v["dplans"][k], d_in[k], d_out[k], stream_length=lens[k])
     eb.record()
     torch.cuda.synchronize()
+    for k, val in saved.items():
+        if val is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = val
     return round(ea.elapsed_time(eb) / a.window * 1e3, 2)
 
 
