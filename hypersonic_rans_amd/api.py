@@ -41,7 +41,7 @@ class Calibration(ctypes.Structure):
 
 class LaunchInfo(ctypes.Structure):
     _fields_ = [(n, _u32) for n in ("grid", "block", "lds_bytes", "waves_per_block", "chains", "shared_table", "walk", "two_level", "table_mode", "chains_per_wave")] + \
-               [("class_weights", _u32 * 8), ("dynamic_groups", _u32)]
+               [("class_weights", _u32 * 8), ("dynamic_groups", _u32), ("spread", _u32)]
 
 
 def lib_path() -> str:

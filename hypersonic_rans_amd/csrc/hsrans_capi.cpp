@@ -85,6 +85,7 @@ struct hsrans_dplan
   size_t d_groups_cap = 0;
   uint32_t n_groups = 0;
   bool groups_lean = false; // 64 states, every group a mergeable run or fills only
+  uint32_t spread_min_block = 0; // plans k_decode_spread can take (single-piece chains, mergeable / fill groups): the fewest chains of a coded block that is not the last; else 0
   PersistentArgs pa{};
   SingleArgs single{};
   LaunchInfo info{};
@@ -379,6 +380,7 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
   d->single = SingleArgs{};
   d->n_groups = 0;
   d->groups_lean = false;
+  d->spread_min_block = 0;
   {
     d->body_lo = 0;
     d->out_lo = 0;
@@ -575,6 +577,27 @@ static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, co
     // >= kGroupPartChains chains while there are fewer groups than kGroupPartsPerCU per CU (hsrans_kernels.h: the rule and what was
     // measured).  A part is a group of its own: same histogram, a sub-range of the chains, and its words end where the next part's
     // first chain starts reading.
+    // k_decode_spread (all chains dealt out over every resident wave, kernels_spread.h) wants single-piece chains — chain c is piece
+    // c with states c — and no share of the chains touching three blocks: the launcher compares its longest share with the fewest
+    // chains of a coded block that is not the last
+    {
+      bool ok = h.states == 64 && h.n_pieces == h.n_chains && groups.size() < h.n_chains;
+      size_t last_coded = groups.size();
+      for (size_t k = groups.size(); k-- > 0 && last_coded == groups.size();)
+        if (!(groups[k].flags & kGroupFill))
+          last_coded = k;
+      uint32_t fewest = 0xFFFFFFFFu;
+      for (size_t k = 0; k < groups.size() && ok; k++)
+      {
+        const Group &g = groups[k];
+        if (g.flags & kGroupFill)
+          continue;
+        ok = (g.flags & kGroupMergeable) && g.piece0 == g.begin;
+        if (k != last_coded)
+          fewest = std::min(fewest, g.count);
+      }
+      d->spread_min_block = ok ? fewest : 0;
+    }
     const size_t want = (size_t)kGroupPartsPerCU * ctx->geom.num_cus;
     if (groups.size() < h.n_chains && groups.size() < want)
     {
@@ -665,6 +688,7 @@ static int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_len
     kp.groups = (const Group *)d->d_groups;
     kp.n_groups = d->n_groups;
     kp.groups_lean = d->groups_lean ? 1 : 0;
+    kp.spread = d->groups_lean ? d->spread_min_block : 0;
     // (measured at 2^30 bytes, two runs each on one box: 0 -> 0.447-0.450 ms, 300 -> 0.440, 500 -> 0.440-0.445, 700 -> 0.447-0.451, 1000 -> 0.452-0.455)
     kp.group_prio = getenv("HSRANS_GROUP_PRIO") != nullptr ? (uint32_t)atoi(getenv("HSRANS_GROUP_PRIO")) : 350;
     // (requesting a round's records and first chunks before its table build: measured, no gain — the other workgroups of the CU
@@ -1061,6 +1085,7 @@ int hsrans_dplan_launch_info(const hsrans_dplan *d, hsrans_launch_info *info)
   for (int k = 0; k < 8; k++)
     info->class_weights[k] = d->info.class_weights[k];
   info->dynamic_groups = d->info.dynamic_groups;
+  info->spread = d->info.spread;
   return HSRANS_OK;
 }
 
@@ -1338,6 +1363,7 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   d->out_hi = h.decoded_len;
   d->n_groups = grouped ? ep.n_blocks * ep.group_split : 0;
   d->groups_lean = grouped && h.states == 64; // k_plan_blocks writes mergeable runs and fill groups only
+  d->spread_min_block = d->groups_lean ? ep.max_ck + 1 : 0; // (every coded block but the last has max_ck + 1 chains)
   if (grouped)
   {
     // ticket counters of the dynamic group order (as dplan_fill); without them the launch falls back to the static order
@@ -1740,7 +1766,7 @@ try
     ia.group_split = group_split;
     ia.stream_len = h.stream_len;
     uint32_t status = 0xFFFFFFFF;
-    uint64_t counted[3] = {}; // chains in all, blocks with a histogram, the (one) histogram's offset
+    uint64_t counted[4] = {}; // chains in all, blocks with a histogram, the (one) histogram's offset, fewest chains of a coded block but the last
     const uint64_t &total = counted[0];
     const bool ok = hipMemsetAsync(nd->d_arena, 0, nd->arena_used, s) == hipSuccess && launch_decode(kp, hl, ctx->geom, s, nullptr) == hipSuccess &&
                     launch_index_assemble(ia, s) == hipSuccess && hipMemcpyAsync(counted, d_result, sizeof(counted), hipMemcpyDeviceToHost, s) == hipSuccess &&
@@ -1767,6 +1793,8 @@ try
     const bool grouped = total > nb; // (no checkpoint fell inside any block: one chain per block, the ungrouped launch)
     nd->n_groups = grouped ? nb * group_split : 0;
     nd->groups_lean = grouped && S == 64;
+    const uint64_t fewest = counted[3] == 0 ? ~0ull : ~counted[3]; // ([3]: ~(the fewest chains of a coded block that is not the last); 0 = there is none)
+    nd->spread_min_block = nd->groups_lean ? (uint32_t)std::min<uint64_t>(fewest, 0xFFFFFFFFu) : 0;
     if (!grouped)
       nd->d_groups = nullptr, nd->d_counters = nullptr;
     if (getenv("HSRANS_DEBUG_STAMPS") && hipMalloc((void **)&nd->d_stamps, kStampWaves * 8 * 8) == hipSuccess)

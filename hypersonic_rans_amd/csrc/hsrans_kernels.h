@@ -96,6 +96,7 @@ struct KParams
   // calibration launches only (hsrans_ctx_calibrate): wave w of a one-chain-per-wave launch leaves its finish time (s_memrealtime,
   // 100 MHz) in finish[w]; finish[gridDim.x * waves] = the first wave's entry time
   uint64_t *finish;
+  uint32_t spread;        // grouped plans of single-piece chains: the fewest chains of a coded block that is not the last (k_decode_spread takes the launch when its longest share is shorter); 0 = never
   uint32_t groups_lean;   // 64-state plan, every group a mergeable run or fills only: the lean instantiation of k_decode_grouped
   uint32_t group_prio;    // grouped launches: per mille of its run the younger half of a workgroup's waves decodes at raised priority (s_setprio)
   // grouped launches: wave k of a workgroup in grid half h takes chains [count * cum[h][k] / cum[h][waves], count * cum[h][k+1] / cum[h][waves])
@@ -113,6 +114,7 @@ struct LaunchInfo
   uint32_t grid, block, lds_bytes, waves_per_block, chains, shared_table, walk, two_level, table_mode, chains_per_wave;
   uint32_t class_weights[8]; // the per-mille run lengths of the 8 wave classes this launch was shaped with (LaunchShape::weights)
   uint32_t dynamic_groups;   // grouped launches: groups handed out by the ticket counter (1) or in static order (0)
+  uint32_t spread;           // grouped plan launched by k_decode_spread (chains dealt out evenly, two tables per workgroup)
 };
 
 // what the launcher needs to know about the device a context lives on
@@ -161,6 +163,21 @@ __host__ __device__ inline uint32_t group_parts_of(uint32_t chains, uint32_t k_m
   const uint32_t k = by_size < k_max ? by_size : k_max;
   return k < 1 ? 1 : k;
 }
+
+// k_decode_spread (kernels_spread.h): G = two 16-wave workgroups per CU; workgroup b's share of the plan's N chains starts at
+// spread_share_begin(b): the first half of the grid weighs w1 per workgroup, the second half w2 (the sums of their waves' age-class
+// weights).  A share's piece records are kept in LDS: at most kSpreadMaxShare chains.
+constexpr uint32_t kSpreadMaxShare = 127;
+inline uint32_t spread_grid(const DeviceGeom &dg) { return 2 * dg.num_cus; }
+__host__ __device__ inline uint32_t spread_share_begin(uint32_t n_chains, uint32_t b, uint32_t grid, uint32_t w1, uint32_t w2)
+{
+  const uint32_t fh = (grid + 1) / 2;
+  const uint64_t total = (uint64_t)fh * w1 + (uint64_t)(grid - fh) * w2;
+  const uint64_t cum = b <= fh ? (uint64_t)b * w1 : (uint64_t)fh * w1 + (uint64_t)(b - fh) * w2;
+  return (uint32_t)((uint64_t)n_chains * cum / total);
+}
+// the longest share of a launch on this device (0 = the plan is too small or too large for the launch)
+uint32_t spread_longest_share(const DeviceGeom &dg, uint64_t n_chains);
 
 struct IndexArgs
 {

@@ -26,6 +26,7 @@
 //   kernels_persist.h   k_decode_persist   uniform-interval raw plans (static runs + ticket queues)
 //   kernels_direct.h    k_decode_direct    one chain (run of chains) per wave: the headline; k_calibrate
 //   kernels_grouped.h   k_decode_grouped   block_/mt_ plans with checkpoints (BASELINE config 4)
+//   kernels_spread.h    k_decode_spread    the same plans with few, large blocks: the chains dealt out evenly, two tables per workgroup
 //   kernels_generic.h   k_decode           mt_ without index, block_ header walk, index-build passes
 //   kernels_dual.h      k_decode_dual      two chains per wave (13-15 bits)
 //   kernels_single.h    k_decode_single    one dependent chain (raw stream without index)
@@ -44,6 +45,7 @@
 #include "kernels_persist.h"
 #include "kernels_direct.h"
 #include "kernels_grouped.h"
+#include "kernels_spread.h"
 #include "kernels_generic.h"
 #include "kernels_dual.h"
 #include "kernels_single.h"
@@ -92,6 +94,7 @@ hipError_t launch_mt_fill(const uint8_t *d_stream, uint64_t stream_len, uint32_t
 // tuning knobs (environment, read once per process; the defaults are the measured best)
 static uint32_t g_pack64_max_bits = 14; // HSRANS_PACK64_MAX_BITS: widest histogram decoded with the 8-byte-per-slot shared table
 static uint32_t g_waves_per_wg = 16;    // HSRANS_WAVES_PER_WG: waves per workgroup of the shared-table launches
+static uint32_t g_spread = 1;           // HSRANS_SPREAD=0: grouped plans with few large blocks keep the one-block-per-workgroup launch
 static uint32_t g_static_percent = 100; // HSRANS_STATIC_PERCENT: share of the chains handed out statically (uniform persistent launches)
 // HSRANS_SLOT_WEIGHTS: per-mille run length of the 8 wave classes, see PersistentArgs::run_len.  Measured on
 // MI355X at 8 waves per SIMD (bits <= 12): with equal runs the four age classes of a workgroup finish at 33/36/39/42 us,
@@ -225,6 +228,8 @@ static void read_tuning_impl()
   if (const char *e = getenv("HSRANS_PACK64_MAX_BITS"))
     if (atoi(e) >= 9 && atoi(e) <= 14)
       g_pack64_max_bits = (uint32_t)atoi(e);
+  if (const char *e = getenv("HSRANS_SPREAD"))
+    g_spread = atoi(e) != 0;
   if (const char *e = getenv("HSRANS_WAVES_PER_WG"))
     if (atoi(e) >= 4 && atoi(e) <= 16)
       g_waves_per_wg = (uint32_t)atoi(e);
@@ -290,7 +295,7 @@ hipError_t prepare_kernels(DeviceGeom *geom)
                       (KernelFn)k_decode_direct<kModeTwoLevel>, (KernelFn)k_decode_direct<kModePack64>, (KernelFn)k_decode_direct<kModeRank>, (KernelFn)k_decode_direct<kModeSpill>,
                       (KernelFn)k_decode_grouped<kModePack, false>, (KernelFn)k_decode_grouped<kModePackM1, false>, (KernelFn)k_decode_grouped<kModeTwoLevel, false>,
                       (KernelFn)k_decode_grouped<kModePack64, false>, (KernelFn)k_decode_grouped<kModeTwoLevel, true>, (KernelFn)k_decode_grouped<kModePack64, true>,
-                      (KernelFn)k_decode_grouped<kModeRank, false>, (KernelFn)k_decode_grouped<kModeRank, true>})
+                      (KernelFn)k_decode_grouped<kModeRank, false>, (KernelFn)k_decode_grouped<kModeRank, true>, (KernelFn)k_decode_spread<kModePack64>})
   {
     const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
     if (e != hipSuccess)
@@ -306,6 +311,42 @@ DeviceGeom default_geom()
   g.max_lds = 160 * 1024;
   g.num_cus = 256; // MI355X
   return g;
+}
+
+// k_decode_spread's wave weights: the age-class weights of the one-chain-per-wave launch (the device's own once calibrated), as
+// the cumulative table run_grouped's shares use: cum[half of the grid][wave]
+constexpr uint32_t kSpreadWaves = 16;
+static void spread_weights(const DeviceGeom &dg, uint16_t (*cum_out)[17])
+{
+  read_tuning_once();
+  const uint32_t *w8 = dg.have_direct_weights ? dg.direct_weights : g_direct_weights;
+  for (uint32_t hf = 0; hf < 2; hf++)
+  {
+    uint32_t cum = 0;
+    for (uint32_t k = 0; k <= 16; k++)
+    {
+      cum_out[hf][k] = (uint16_t)cum;
+      cum += k < kSpreadWaves ? w8[hf * 4 + k / (kSpreadWaves / 4)] / 10 : 0;
+    }
+  }
+}
+
+uint32_t spread_longest_share(const DeviceGeom &dg, uint64_t n_chains)
+{
+  const uint32_t grid = spread_grid(dg);
+  if (n_chains < (uint64_t)grid * kSpreadWaves || n_chains > (uint64_t)grid * kSpreadMaxShare) // (a chain per wave at least)
+    return 0;
+  uint16_t cum[2][17];
+  spread_weights(dg, cum);
+  uint32_t longest = 0;
+  for (uint32_t b : {0u, (grid + 1) / 2 - 1, (grid + 1) / 2, grid - 1}) // (shares differ by rounding only within a half)
+  {
+    const uint32_t len = spread_share_begin((uint32_t)n_chains, b + 1, grid, cum[0][kSpreadWaves], cum[1][kSpreadWaves]) -
+                         spread_share_begin((uint32_t)n_chains, b, grid, cum[0][kSpreadWaves], cum[1][kSpreadWaves]);
+    longest = len > longest ? len : longest;
+  }
+  longest += 1; // (rounding)
+  return longest > kSpreadMaxShare ? 0 : longest;
 }
 
 // Everything about a launch that follows from the plan header and the device alone (no pointers): the table layout, the
@@ -555,12 +596,33 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
     case kModeSpill: fn = k_decode_direct<kModeSpill>; break;
     default: fn = kp.finish != nullptr && h.states == 64 ? (KernelFn)k_calibrate : (KernelFn)k_decode_direct<kModePack64>; break;
     }
+  // grouped plans with few, large blocks (kp.spread: the fewest chains of a block, where the host found the plan eligible): every
+  // resident workgroup takes its share of ALL chains and builds the one or two tables it needs (kernels_spread.h)
+  uint32_t launch_grid = grid, launch_waves = waves, launch_lds = L.lds;
+  bool spread = false;
+  if (grouped && L.shared && kp.spread != 0 && kp.groups_lean && L.mode == kModePack64 && g_spread)
+  {
+    const uint32_t longest = spread_longest_share(dg, h.n_chains);
+    const uint32_t slds = kSpreadWaves * kFastRingBytes + 2 * table_bytes_for(kModePack64, h.bits) + (kSpreadMaxShare + 1) * (uint32_t)sizeof(Piece);
+    if (longest != 0 && longest < kp.spread && 2 * slds <= dg.max_lds) // (a share shorter than every block touches at most two)
+    {
+      spread = true;
+      fn = k_decode_spread<kModePack64>;
+      launch_grid = spread_grid(dg);
+      launch_waves = kSpreadWaves;
+      launch_lds = slds;
+      spread_weights(dg, kp.group_cum);
+      kp.pa.n_chains = h.n_chains; // (single-piece chains: n_pieces == n_chains)
+      kp.pa.S = h.states;
+      kp.pa.bits = h.bits;
+    }
+  }
   if (info)
   {
-    info->grid = grid;
-    info->block = waves * 64;
-    info->lds_bytes = L.lds;
-    info->waves_per_block = waves;
+    info->grid = launch_grid;
+    info->block = launch_waves * 64;
+    info->lds_bytes = launch_lds;
+    info->waves_per_block = launch_waves;
     info->chains = h.n_chains;
     info->shared_table = L.shared;
     info->walk = L.walk;
@@ -569,10 +631,11 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
     info->chains_per_wave = L.dual ? 2 : 1;
     for (uint32_t k = 0; k < 8; k++)
       info->class_weights[k] = L.weights[k];
-    info->dynamic_groups = grouped && kp.group_tickets != nullptr && kp.n_groups > grid ? 1 : 0;
+    info->dynamic_groups = grouped && !spread && kp.group_tickets != nullptr && kp.n_groups > grid ? 1 : 0;
+    info->spread = spread ? 1 : 0;
   }
   (void)hipGetLastError(); // (sticky per thread: an earlier failed call — e.g. an allocation a hostile stream asked for — is not this launch's error)
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), L.lds, stream, kp);
+  hipLaunchKernelGGL(fn, dim3(launch_grid), dim3(launch_waves * 64), launch_lds, stream, kp);
   return hipGetLastError();
 }
 

@@ -193,6 +193,10 @@ __global__ void __launch_bounds__(1024) k_index_count(IndexArgs a)
       {                             // (PlanBuilder::serialize: shared_hist = every non-fill piece has the same hist_off; mt_ blocks never share one)
         atomicAdd((unsigned long long *)&a.result[1], 1ull);
         atomicMax((unsigned long long *)&a.result[2], (unsigned long long)bp.hist_off);
+        // [3]: the fewest chains of a coded block that is not the plan's last chain (k_decode_spread's condition); stored as ~min so
+        // that the zeroed word means "none seen" (= any number will do)
+        if (ch + 1 < a.n_base)
+          atomicMax((unsigned long long *)&a.result[3], ~(unsigned long long)v);
       }
     }
     uint32_t incl = v;

@@ -302,6 +302,7 @@ typedef struct hsrans_launch_info
   uint32_t class_weights[8]; /* per-mille chain / run lengths of the 8 wave scheduling classes the launch was shaped with (fitted
                               * constants, HSRANS_*_WEIGHTS override them): which table a measurement used */
   uint32_t dynamic_groups;   /* block_/mt_ plans with checkpoints: blocks handed to workgroups by a ticket counter (1) or statically (0) */
+  uint32_t spread;           /* such plans with few, large blocks: all chains dealt out evenly over the resident workgroups (1) */
 } hsrans_launch_info;
 int hsrans_dplan_launch_info(const hsrans_dplan *dplan, hsrans_launch_info *info);
 

@@ -129,9 +129,74 @@ def test_dynamic_block_order_with_many_small_blocks(gpu_ctx, oracle):
     assert dplan2.launch_info()["dynamic_groups"] == 1
 
 
+def test_few_large_blocks_are_dealt_out_evenly(gpu_ctx, oracle):
+    """Fewer blocks than workgroup slots (BASELINE config 4's layout at 100 MB-class sizes): k_decode_spread deals ALL chains out
+    evenly, a workgroup building the two tables its share touches (launch info `spread`).  Shares that start / end inside blocks,
+    single-symbol (fill) blocks in the list, a short last block; plans from the host encoder, from the GPU encoder's plan kernel and
+    from the device-side index assembly of a first decode; several launches; bit-exact against the oracle.  HSRANS_SPREAD=0 (the
+    one-block-per-workgroup launch) decodes the same bytes."""
+    import torch
+    n = (24 << 20) + 70_001
+    data = np.concatenate([synth.nonstationary(12 << 20, seed=79), np.full(1 << 19, 7, np.uint8), synth.enwik8_shaped((12 << 20) - (1 << 19) + 70_001, seed=3)])
+    assert data.size == n
+    for bits, block, interval in ((11, 1 << 18, 8), (10, 1 << 19, 16)):
+        stream, plan = H.encode(MT, 64, bits, data, block_size=block, index_interval=interval, independent_blocks=True)
+        r, want = oracle.decode(MT, 64, bits, stream, n)
+        assert r == n and np.array_equal(want, data)
+        d_in = torch.from_numpy(np.concatenate([stream, np.zeros((-stream.size) % 16, np.uint8)])).cuda()
+        d_out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        d_src = torch.from_numpy(data).cuda()
+        dplan = gpu_ctx.make_device_plan(plan)
+        for launch in range(3):
+            d_out.zero_()
+            gpu_ctx.decode_device(dplan, d_in, d_out, stream_length=stream.size)
+            assert gpu_ctx.status(dplan) == 0 and torch.equal(d_out, d_src), (bits, launch)
+        info = dplan.launch_info()  # (of the last launch)
+        assert info["spread"] == 1 and info["waves_per_block"] == 16 and info["dynamic_groups"] == 0, info
+        # the GPU encoder's device-built plan
+        d_enc = torch.empty(H.capacity(MT, 64, n), dtype=torch.uint8, device="cuda")
+        m, dplan2 = gpu_ctx.encode_device(MT, 64, bits, d_src, d_enc, block_size=block, index_interval=interval, want_plan=True)
+        d_out.zero_()
+        gpu_ctx.decode_device(dplan2, d_enc, d_out, stream_length=m)
+        assert gpu_ctx.status(dplan2) == 0 and torch.equal(d_out, d_src)
+        assert m == stream.size and dplan2.launch_info()["spread"] == 1
+        # the index a first decode leaves behind (assembled on the device)
+        base = gpu_ctx.make_device_plan_from_stream(MT, 64, bits, d_in, stream.size, n)
+        d_out.zero_()
+        dplan3 = gpu_ctx.decode_device_indexing(base, d_in, d_out, interval, stream_length=stream.size)
+        assert torch.equal(d_out, d_src)
+        d_out.zero_()
+        gpu_ctx.decode_device(dplan3, d_in, d_out, stream_length=stream.size)
+        assert gpu_ctx.status(dplan3) == 0 and torch.equal(d_out, d_src) and dplan3.launch_info()["spread"] == 1
+    # blocks shorter than a workgroup's share, 32 states, wide histograms: the grouped launch as before
+    for states, bits, block, interval in ((64, 11, 1 << 14, 8), (32, 11, 1 << 18, 8), (64, 13, 1 << 18, 8)):
+        stream, plan = H.encode(MT, states, bits, data, block_size=block, index_interval=interval, independent_blocks=True)
+        dplan = gpu_ctx.make_device_plan(plan)
+        d_in = torch.from_numpy(np.concatenate([stream, np.zeros((-stream.size) % 16, np.uint8)])).cuda()
+        d_out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        gpu_ctx.decode_device(dplan, d_in, d_out, stream_length=stream.size)
+        assert gpu_ctx.status(dplan) == 0 and torch.equal(d_out, d_src) and dplan.launch_info()["spread"] == 0
+    code = (
+        "import numpy as np, torch\n"
+        "import hypersonic_rans_amd as H\n"
+        "from hypersonic_rans_amd import synth\n"
+        "n = 24 << 20\n"
+        "data = synth.nonstationary(n, seed=80)\n"
+        "stream, plan = H.encode(H.MT, 64, 11, data, block_size=1 << 18, index_interval=8, independent_blocks=True)\n"
+        "ctx = H.Context(0)\n"
+        "d_in = torch.from_numpy(np.concatenate([stream, np.zeros((-stream.size) % 16, np.uint8)])).cuda()\n"
+        "d_out = torch.zeros(n, dtype=torch.uint8, device='cuda')\n"
+        "dp = ctx.make_device_plan(plan)\n"
+        "ctx.decode_device(dp, d_in, d_out, stream_length=stream.size)\n"
+        "assert ctx.status(dp) == 0 and np.array_equal(d_out.cpu().numpy(), data)\n"
+        "print('ok', dp.launch_info()['spread'])\n")
+    for env, want in (({"HSRANS_SPREAD": "0"}, "ok 0"), ({}, "ok 1")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **env))
+        assert r.returncode == 0 and want in r.stdout, (env, r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_dynamic_block_order_variants_in_a_subprocess():
-    """The A/B switches of the grouped launch (static order, half-block tail, records requested before the table build, 16-wave
-    workgroups) all decode the same bytes: each is an environment variable read when a plan is made / launched, so each runs in
+    """The A/B switches of the grouped launch (static order, 16-wave workgroups, no raised priority) all decode the same bytes: each is an environment variable read when a plan is made / launched, so each runs in
     its own process."""
     code = (
         "import numpy as np, torch, hashlib\n"
@@ -148,8 +213,7 @@ def test_dynamic_block_order_variants_in_a_subprocess():
         "    ctx.decode_device(dp, d_in, d_out, stream_length=stream.size)\n"
         "assert ctx.status(dp) == 0 and np.array_equal(d_out.cpu().numpy(), data)\n"
         "print('ok', dp.launch_info()['dynamic_groups'], dp.launch_info()['waves_per_block'])\n")
-    for env, want in (({"HSRANS_GROUP_STATIC": "1"}, "ok 0 8"), ({"HSRANS_GROUP_TAIL_PERMILLE": "250"}, "ok 1 8"), ({"HSRANS_GROUP_OVERLAP": "1"}, "ok 1 8"),
-                      ({"HSRANS_WAVES_PER_WG": "16"}, "ok 1 16"), ({"HSRANS_GROUP_TAIL_PERMILLE": "1000", "HSRANS_GROUP_TAIL_PARTS": "4"}, "ok 1 8")):
+    for env, want in (({"HSRANS_GROUP_STATIC": "1"}, "ok 0 8"), ({"HSRANS_WAVES_PER_WG": "16"}, "ok 1 16"), ({"HSRANS_GROUP_PRIO": "0"}, "ok 1 8")):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **env))
         assert r.returncode == 0 and want in r.stdout, (env, r.stdout[-500:], r.stderr[-2000:])
 
