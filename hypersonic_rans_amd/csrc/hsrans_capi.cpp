@@ -1268,7 +1268,8 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
     return 0;
   const bool stamps = getenv("HSRANS_DEBUG_STAMPS") != nullptr;
   const size_t nb = ep.n_blocks;
-  const size_t meta_bytes = (nb * 2 + kEncResultWords) * 8 + nb * 2 * 4 + (stamps ? nb * 4 * 8 : 0) + 64;
+  const bool wide_hist = getenv("HSRANS_ENC_WAVE_HISTOGRAM") == nullptr; // (=1: the coding wavefront counts its own block, as in rounds 1-3)
+  const size_t meta_bytes = (nb * 2 + kEncResultWords) * 8 + nb * 2 * 4 + (stamps ? nb * 4 * 8 : 0) + 64 + (wide_hist ? nb * 1024 + 16 : 0);
   const size_t ck_slots = nb * (ep.max_ck ? ep.max_ck : 1);
   if (!grow(&ctx->d_enc_scratch, &ctx->d_enc_scratch_cap, nb * ep.slot_bytes) || !grow(&ctx->d_enc_meta, &ctx->d_enc_meta_cap, meta_bytes) ||
       !grow(&ctx->d_enc_ck, &ctx->d_enc_ck_cap, ck_slots * ((size_t)ep.S * 4 + 4)))
@@ -1285,6 +1286,8 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   after += stamps ? nb * 4 : 0;
   ep.chain_count = (uint32_t *)after;
   ep.chain_off = ep.chain_count + nb;
+  if (wide_hist)
+    ep.raw_counts = (const uint32_t *)(((uintptr_t)(ep.chain_off + nb) + 15) & ~(uintptr_t)15);
   ep.ck_states = (uint32_t *)ctx->d_enc_ck;
   ep.ck_pos = ep.ck_states + ck_slots * ep.S;
   hipStream_t s = (hipStream_t)hip_stream;

@@ -35,7 +35,8 @@ struct EncParams
   uint32_t group_split;  // parts a block's chains are cut into (few large blocks: more workgroup tasks than blocks)
   uint32_t n_chains;     // total, known after K_scan (K_plan)
   // raw streams (launch_encode_raw): n_blocks = 1, block = n, one slot
-  const uint32_t *raw_counts;   // [256] byte counts of the input (k_raw_histogram's output), normalised by the coding wavefront
+  const uint32_t *raw_counts;   // raw: [256] byte counts of the input (k_raw_histogram's output), normalised by the coding wavefront;
+                                // mt_: [n_blocks][256] byte counts per block, filled by k_block_histograms in launch_encode (null: every wavefront counts its own block)
   const uint16_t *given_counts; // [256] or null: the caller's normalised histogram (hist_t::symbolCount), used instead
   const uint32_t *ck_groups;    // or null: ascending group indices (multiples of 4) to checkpoint at, instead of `interval`
   uint32_t n_ck_groups;

@@ -347,6 +347,13 @@ __device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t 
   }
   else
   {
+  if (ep.raw_counts != nullptr) // counted by k_block_histograms, a workgroup per block, before this kernel
+  {
+    const uint4 v = ((const uint4 *)(ep.raw_counts + (uint64_t)b * 256))[lane];
+    raw[0] = v.x, raw[1] = v.y, raw[2] = v.z, raw[3] = v.w;
+  }
+  else
+  {
   // ---- byte histogram: kSubHists copies, copy = lane & 7 ----
   uint32_t *sub = (uint32_t *)L.table;
   for (uint32_t k = lane; k < kSubHists * kSubStride; k += 64)
@@ -380,6 +387,7 @@ __device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t 
   for (uint32_t c = 0; c < kSubHists; c++)
     for (uint32_t k = 0; k < 4; k++)
       raw[k] += sub[c * kSubStride + lane * 4 + k];
+  }
   uint32_t present = 0;
   for (uint32_t k = 0; k < 4; k++)
     present += raw[k] != 0;
@@ -668,6 +676,41 @@ __global__ void __launch_bounds__(256) k_raw_histogram(const uint8_t *in, uint64
     atomicAdd(&counts[threadIdx.x], v);
 }
 
+// byte counts of every block of an mt_ encode, a workgroup per block: counts[b][256].  The coding wavefront used to count its own
+// block (33 us of its ~270 at 64 KiB, 130 us at 256 KiB: 64 lanes of LDS atomics); 256 threads per block and every CU at it take
+// a few microseconds for the whole input, and the block is in L2 when the coding wavefront reads it again.
+__global__ void __launch_bounds__(256) k_block_histograms(EncParams ep, uint32_t *counts)
+{
+  __shared__ uint32_t sub[kSubHists * kSubStride];
+  const uint32_t b = blockIdx.x;
+  const uint64_t begin = (uint64_t)b * ep.block;
+  const uint64_t end = b + 1 == ep.n_blocks ? ep.n : begin + ep.block;
+  for (uint32_t k = threadIdx.x; k < kSubHists * kSubStride; k += 256)
+    sub[k] = 0;
+  __syncthreads();
+  uint32_t *mine = sub + (threadIdx.x & (kSubHists - 1)) * kSubStride;
+  for (uint64_t off = begin + threadIdx.x * 16; off < end; off += 4096)
+  {
+    const uint4 d = load16_guarded(ep.in, off, end);
+    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+    const uint32_t have = end - off < 16 ? (uint32_t)(end - off) : 16;
+    if (have == 16)
+    {
+#pragma unroll
+      for (uint32_t k = 0; k < 16; k++)
+        atomicAdd(&mine[(w[k >> 2] >> (8 * (k & 3))) & 0xFF], 1u);
+    }
+    else
+      for (uint32_t k = 0; k < have; k++)
+        atomicAdd(&mine[(w[k >> 2] >> (8 * (k & 3))) & 0xFF], 1u);
+  }
+  __syncthreads();
+  uint32_t v = 0;
+  for (uint32_t c = 0; c < kSubHists; c++)
+    v += sub[c * kSubStride + threadIdx.x];
+  counts[(uint64_t)b * 256 + threadIdx.x] = v;
+}
+
 template <uint32_t S>
 __global__ void __launch_bounds__(64) k_encode_raw(EncParams ep)
 {
@@ -923,6 +966,8 @@ hipError_t launch_encode(const EncParams &ep, hipStream_t stream, bool *prepared
   }
   const uint32_t grid = (ep.n_blocks + kWavesPerWG - 1) / kWavesPerWG;
   (void)hipGetLastError(); // (sticky per thread)
+  if (ep.raw_counts != nullptr)
+    hipLaunchKernelGGL(k_block_histograms, dim3(ep.n_blocks), dim3(256), 0, stream, ep, const_cast<uint32_t *>(ep.raw_counts));
   if (ep.S == 64)
     hipLaunchKernelGGL(k_encode_blocks<64>, dim3(grid), dim3(64 * kWavesPerWG), lds, stream, ep);
   else
