@@ -8,6 +8,9 @@ mkdir -p $OUT
 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 python bench.py --workload sharded > $OUT/bench_sharded_line.json 2> $OUT/bench_sharded.err
 python bench.py --workload sharded --no-cpu --block 65536 --interval 64 > $OUT/bench_sharded_64k_line.json 2> $OUT/bench_sharded_64k.err
+python bench.py --workload sharded --no-cpu --size 100000000 --block 262144 --interval 32 > $OUT/bench_sharded_100mb_256k_line.json 2> $OUT/bench_sharded_100mb_256k.err   # few, large blocks: k_decode_spread
+python tools/first_decode_rate.py > $OUT/first_decode_100mb.jsonl 2> $OUT/first_decode.err
+python tools/host_loop_rate.py > $OUT/host_loop_index_cache.jsonl 2> $OUT/host_loop.err
 python tools/sweep_configs.py > $OUT/config_sweep.jsonl 2> $OUT/sweep.err
 HSRANS_TABLE_SPILL=1 python tools/sweep_configs.py --only-raw --tag "HSRANS_TABLE_SPILL=1 (tables left in global memory)" >> $OUT/config_sweep.jsonl 2>> $OUT/sweep.err
 HSRANS_DUAL=0 python tools/sweep_configs.py --only-raw --tag "HSRANS_DUAL=0 (one chain per wave at 13-15 bits)" >> $OUT/config_sweep.jsonl 2>> $OUT/sweep.err
