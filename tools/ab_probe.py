@@ -5,7 +5,8 @@ decode moves by +-3 us on one box, with no change at all: where the driver puts 
 it loads) with its own context and device plans; the stream bytes do not depend on the index, so the streams and the output
 buffers are shared.  Windows of `--window` launches alternate between the variants, `--rounds` times.
 
-    python tools/ab_probe.py --variant base --variant dyn:lib/variants/libhsrans_hip_dyn.so:HSRANS_DIRECT_DYN_PERMILLE=150,HSRANS_DIRECT_DYN_GROUPS=32
+    python tools/ab_probe.py --variant base --variant other:lib/variants/libhsrans_hip_other.so:HSRANS_DIRECT_WEIGHTS=1400,1330,1240,1130,960,810,640,490
+    python tools/ab_probe.py --container mt --block 262144 --index 32 --variant spread --variant grouped::HSRANS_SPREAD=0
 """
 import argparse
 import ctypes

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B helper: sustained time per 100 MB decode (rotated over P pairs, and one pair replayed) for the library / environment this
-process was started with (HSRANS_LIB, HSRANS_DIRECT_DYN_PERMILLE, ... are read when the library loads: one process per variant).
+process was started with (HSRANS_LIB, HSRANS_DIRECT_WEIGHTS, ... are read when the library loads: one process per variant; for A/Bs
+prefer tools/ab_probe.py: between processes one box moves by +-3 us).
 Every pair is validated bit-exact first.  The synthetic data is cached in /tmp between processes (the generator makes 7 MB/s).
 
     [HSRANS_LIB=...] python tools/rot_probe.py [--tag NAME] [--windows 4] [--window 200] [--stamps]
