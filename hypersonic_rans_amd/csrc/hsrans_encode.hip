@@ -316,11 +316,21 @@ __device__ __forceinline__ void encode_group_fast(uint32_t &x, const uint4 &e, u
   const unsigned long long mask = __builtin_amdgcn_ballot_w64(emit);
   const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
   p -= 2 * (uint32_t)__builtin_popcountll(mask);
+#if !defined(HSRANS_ENC_BRANCHY) || !HSRANS_ENC_BRANCHY
+  // One wavefront, in order: every instruction of the group is on the clock.  The renormalisation as straight-line code — the
+  // masked store between two writes of EXEC, the shift as a select — instead of the compiler's s_and_saveexec / s_cbranch_execz /
+  // s_or around both (EXEC is all ones here: the loop runs in wave-uniform control flow of a 64-thread workgroup)
+  const uint32_t off = p + 2 * rank;
+  const uint32_t xs = x >> 16;
+  asm volatile("s_mov_b64 exec, %2\n\tglobal_store_short %0, %1, %3\n\ts_mov_b64 exec, -1" : : "v"(off), "v"(x), "s"(mask), "s"(slot) : "memory");
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(x) : "v"(x), "v"(xs), "s"(mask));
+#else
   if (emit)
   {
     *(uint16_t *)(slot + (p + 2 * rank)) = (uint16_t)x;
     x >>= 16;
   }
+#endif
   const uint32_t q = __umulhi(x, e.z) >> (e.w >> 24);
   x = __umul24(q, e.w) + x + e.y; // x + bias + q * (2^bits - freq)
 }

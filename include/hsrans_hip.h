@@ -228,7 +228,7 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
 
 /* The raw format on the GPU (replaces src/rANS32x64_16w.cpp:34-166 `rANS32x64_16w_encode_scalar_N` / src/rANS32x32_16w.cpp for
  * data that lives in HBM): the format carries every coder state from the last symbol to the first, so it
- * is ONE wavefront's work — about 10x one host core, not a throughput kernel; mt_ (hsrans_encode_device) is the format to encode
+ * is ONE wavefront's work — about 3.5x one host core, not a throughput kernel; mt_ (hsrans_encode_device) is the format to encode
  * at HBM rates.  `hist` NULL: the histogram of the input is counted and normalised on the device (what make_hist gives); else the
  * caller's normalised counts are used (they must sum to 1 << bits), as the reference's encode signature passes them.
  * The sidecar index: a checkpoint every `index_interval` groups, or at `index_groups` (hsrans_index_boundaries) when
