@@ -352,8 +352,23 @@ __device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t 
   uint32_t raw[4] = {0, 0, 0, 0};
   if constexpr (RAW)
   {
-    for (uint32_t k = 0; k < 4; k++) // byte counts of the whole input (k_raw_histogram) or, with given_counts, nothing to count
+    bool missing = false;
+    for (uint32_t k = 0; k < 4; k++) // byte counts of the whole input (k_raw_histogram); with given_counts they only say which symbols occur
+    {
       raw[k] = ep.given_counts ? ep.given_counts[lane * 4 + k] : ep.raw_counts[lane * 4 + k];
+      missing |= raw[k] == 0 && ep.raw_counts[lane * 4 + k] != 0;
+    }
+    if (__builtin_amdgcn_ballot_w64(missing) != 0) // a symbol of the input has no slot in the caller's histogram: not encodable (hsrans_host.cpp put_group returns 0 too)
+    {
+      if (lane == 0)
+      {
+        ep.image_bytes[0] = 0;
+        ep.result[0] = 0;
+        ep.result[1] = 0;
+        ep.result[2] = 0;
+      }
+      return;
+    }
   }
   else
   {
@@ -1002,8 +1017,8 @@ hipError_t launch_encode_raw(const EncParams &ep, uint32_t *d_counts, hipStream_
     prepared = true;
   }
   (void)hipGetLastError();
-  if (ep.given_counts == nullptr)
   {
+    // (also with the caller's histogram: the coding wavefront checks that every symbol that occurs has a slot in it)
     hipError_t e = hipMemsetAsync(d_counts, 0, 256 * 4, stream);
     if (e != hipSuccess)
       return e;

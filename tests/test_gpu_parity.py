@@ -796,6 +796,13 @@ def test_gpu_raw_encoder_rejects_bad_arguments(gpu_ctx, zipf):
         gpu_ctx.encode_device_raw(64, 11, d_in, d_out[:1000])  # capacity contract
     with pytest.raises(H.HsransError):
         gpu_ctx.encode_device_raw(64, 11, d_in, d_out[2:])  # alignment
+    # a histogram without a slot for a symbol that occurs: not encodable (the host encoder returns 0 as well)
+    other = H.make_hist(np.full(4096, d[0], np.uint8), 11)
+    with pytest.raises(H.HsransError):
+        H.encode(H.RAW, 64, 11, d, hist=other, out_capacity=3 * d.size)
+    big = torch.empty(3 * d.size, dtype=torch.uint8, device="cuda")
+    with pytest.raises(H.HsransError):
+        gpu_ctx.encode_device_raw(64, 11, d_in, big, hist=other)
     assert gpu_ctx.encode_device_raw(64, 11, d_in, d_out) == H.encode(H.RAW, 64, 11, d).size  # (the context still works)
 
 
