@@ -879,6 +879,74 @@ def test_random_sweep_gpu_encoder(gpu_ctx, oracle, zipf, nonstat):
         assert gpu_ctx.status(dplan) == 0 and torch.equal(back, d_in), tag
 
 
+def test_random_sweep_gpu_raw_encoder(gpu_ctx, oracle, zipf, nonstat):
+    """seeded random cases through hsrans_encode_device_raw: stream (and plan, when an index is asked for) byte-identical to
+    hsrans_encode_ex for random lengths, widths, state counts, own / given histograms, uniform and listed checkpoints"""
+    import os
+    import torch
+    rng = np.random.default_rng(int(os.environ.get("HSRANS_SWEEP_SEED", "11")))
+    for case in range(int(os.environ.get("HSRANS_SWEEP_CASES", "160")) * 3 // 8):
+        states = int(rng.choice((32, 64)))
+        bits = int(rng.integers(10, 16))
+        d = _random_case(rng, zipf, nonstat)
+        n = d.size
+        kind = int(rng.integers(0, 3))
+        kw = {}
+        if kind == 1:
+            kw["index_interval"] = int(rng.choice((4, 8, 32, 100, 1024)))
+        elif kind == 2:
+            whole = n // states
+            k = int(rng.integers(1, 40))
+            kw["index_groups"] = np.unique((rng.integers(1, max(2, whole // 4 + 2), size=k) * 4).astype(np.uint64))  # some behind the last whole group
+        hist = H.make_hist(d, bits) if rng.integers(0, 2) else None
+        tag = (case, states, bits, n, kind, hist is not None)
+        want = H.encode(H.RAW, states, bits, d, hist=hist, **kw)
+        got = _gpu_encode_raw(gpu_ctx, states, bits, d, hist=hist, want_plan=bool(kw), want_device_plan=bool(kw), **kw)
+        if kw:
+            want_stream, want_plan = want
+            assert np.array_equal(got[0], want_stream) and np.array_equal(got[3], want_plan), tag
+            back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            gpu_ctx.decode_device(got[4], got[1], back, stream_length=got[0].size)
+            assert gpu_ctx.status(got[4]) == 0 and torch.equal(back, got[2]), tag
+        else:
+            assert np.array_equal(got[0], want), tag
+        if n >= states - 1:
+            r, back = oracle.decode(RAW, states, bits, got[0], n)
+            assert r == n and np.array_equal(back, d), tag
+
+
+def test_random_sweep_few_large_blocks(gpu_ctx, oracle, zipf, nonstat):
+    """seeded random mt_ / block_ streams in FEW large blocks with many checkpoints (the shapes k_decode_spread takes, and their
+    neighbours that fall back to the grouped launch): decoded bytes against the oracle, several launches of one plan"""
+    import os
+    import torch
+    rng = np.random.default_rng(int(os.environ.get("HSRANS_SWEEP_SEED", "13")))
+    base = np.concatenate([nonstat, zipf[:2_000_000], np.full(700_000, 3, np.uint8), nonstat[::-1], zipf[2_000_000:4_000_000]])
+    took = 0
+    for case in range(int(os.environ.get("HSRANS_SWEEP_CASES", "160")) // 8):
+        container = int(rng.choice((MT, BLOCK)))
+        bits = int(rng.choice((10, 11, 11, 12, 13)))
+        n = int(rng.integers(5_000_000, base.size))
+        off = int(rng.integers(0, base.size - n + 1))
+        d = np.ascontiguousarray(base[off:off + n])
+        block = int(rng.choice((1 << 17, 1 << 18, 3 << 17, 1 << 19, 1 << 20)))
+        interval = int(rng.choice((4, 8, 8, 16)))
+        tag = (case, container, bits, n, block, interval)
+        s, plan = H.encode(container, 64, bits, d, block_size=block, index_interval=interval)
+        r0, want = oracle.decode(container, 64, bits, s, n)
+        assert r0 == n and np.array_equal(want, d), tag
+        d_in = torch.from_numpy(np.concatenate([s, np.zeros((-s.size) % 16, np.uint8)])).cuda()
+        d_out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        d_want = torch.from_numpy(d).cuda()
+        dplan = gpu_ctx.make_device_plan(plan)
+        for launch in range(2):
+            d_out.zero_()
+            gpu_ctx.decode_device(dplan, d_in, d_out, stream_length=s.size)
+            assert gpu_ctx.status(dplan) == 0 and torch.equal(d_out, d_want), tag + (launch,)
+        took += dplan.launch_info()["spread"]
+    assert took >= 4  # (the sweep does reach the launch it is about)
+
+
 @pytest.mark.parametrize("states", (32, 64))
 @pytest.mark.parametrize("bits", (14, 15))
 def test_wide_histogram_rank_table_on_awkward_histograms(gpu_ctx, oracle, bits, states):
