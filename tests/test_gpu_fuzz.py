@@ -72,3 +72,49 @@ def test_mutated_streams_never_fault_or_write_outside(gpu_ctx, container, states
     # the unmodified stream still decodes after all that
     r = L.hsrans_decode_host(gpu_ctx.handle, container, states, bits, H.api._p(stream), stream.size, H.api._p(out), n, None, 0)
     assert r == n and np.array_equal(out[:n], data)
+
+
+@pytest.mark.parametrize("container,states,bits", ((H.MT, 64, 11), (H.RAW, 64, 11), (H.MT, 32, 12)))
+def test_mutated_streams_through_the_recording_first_decode_and_the_index_cache(gpu_ctx, container, states, bits):
+    """Streams of >= 1 MiB take the plan-less host entry through the pass that RECORDS checkpoints and — mt_ — through the plan
+    assembled on the device from whatever that pass wrote; the next call may find the cached index.  Mutated bytes, twice each,
+    in ONE buffer (the cache is keyed by its address): no fault, no hang, nothing behind the output, the same result both times,
+    and the unmodified stream decodes afterwards.  The device-resident form (K2 walk + hsrans_decode_device_indexing + a decode
+    with the plan it left) gets every fourth mutation as well."""
+    rng = np.random.default_rng(4321 + container * 10 + states)
+    n = 1_500_000
+    data = synth.nonstationary(n, seed=23)
+    stream = H.encode(container, states, bits, data, block_size=0 if container == H.RAW else 32768)
+    ctx = H.Context(0)
+    L = ctx.L
+    buf = np.zeros(stream.size, np.uint8)
+    out = np.zeros(n + 4096, np.uint8)
+    decoded = 0
+    for it in range(40):
+        s = _mutate(rng, stream)
+        ln = s.size
+        buf[:ln] = s
+        results = []
+        for _ in range(2):
+            out[:] = 0xCC
+            r = L.hsrans_decode_host(ctx.handle, container, states, bits, H.api._p(buf), ln, H.api._p(out), n, None, 0)
+            assert r in (0, n) and (out[n:] == 0xCC).all(), "a decode wrote behind its output buffer"
+            results.append((r, out[:n].copy() if r == n else None))
+        assert results[0][0] == results[1][0] and (results[0][0] == 0 or np.array_equal(results[0][1], results[1][1])), "a cached index changed the result"
+        decoded += results[0][0] == n
+        if container == H.MT and it % 4 == 0:
+            d = torch.from_numpy(np.concatenate([s, np.zeros((-s.size) % 16 + 16, np.uint8)])).cuda()
+            try:
+                base = ctx.make_device_plan_from_stream(container, states, bits, d, s.size, n)
+                d_out = torch.full((n + 4096,), 0xCC, dtype=torch.uint8, device="cuda")
+                indexed = ctx.decode_device_indexing(base, d, d_out[:n], 32, stream_length=s.size)
+                ctx.decode_device(indexed, d, d_out[:n], stream_length=s.size)
+                ctx.status(indexed)
+                assert bool((d_out[n:] == 0xCC).all())
+            except H.HsransError:
+                pass
+    torch.cuda.synchronize()
+    assert decoded >= 1
+    buf[:stream.size] = stream
+    r = L.hsrans_decode_host(ctx.handle, container, states, bits, H.api._p(buf), stream.size, H.api._p(out), n, None, 0)
+    assert r == n and np.array_equal(out[:n], data)
