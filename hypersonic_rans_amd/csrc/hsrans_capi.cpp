@@ -802,9 +802,34 @@ try
     d->hdr = h;
     d->plan_bytes = plan_size;
     hsrans_dplan *ix = nullptr;
-    if (launch_stream_checksum(ctx->d_in, in_length, (uint64_t *)ctx->d_enc_meta, s) == hipSuccess &&
-        hipMemcpyAsync(&sum, ctx->d_enc_meta, 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
-        decode_device_indexing_impl(ctx, d, ctx->d_in, in_length, ctx->d_out, (size_t)h.decoded_len, container == HSRANS_MT ? 64 : 32, s, &ix, true) == HSRANS_OK)
+    bool have_index = launch_stream_checksum(ctx->d_in, in_length, (uint64_t *)ctx->d_enc_meta, s) == hipSuccess &&
+                      hipMemcpyAsync(&sum, ctx->d_enc_meta, 8, hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (have_index && container == HSRANS_RAW)
+    {
+      // a raw stream is ONE chain: the pass that records its checkpoints is the host SIMD decoder's (2-4 GB/s on one core, while the
+      // upload is on its way; one wavefront would need four times as long), at the one-chain-per-wavefront boundaries of this device;
+      // the decode itself is the indexed GPU launch
+      std::vector<uint64_t> groups(2 * 8192 + 64);
+      const size_t ng = hsrans_index_boundaries(ctx, states, bits, (size_t)h.decoded_len, groups.data(), groups.size());
+      std::vector<uint8_t> iplan(ng ? plan_capacity_chains(HSRANS_RAW, states, (size_t)h.decoded_len, ng, 0) : 0);
+      const size_t plen = ng ? cpu::index_build(cpu::best_level(), 1, HSRANS_RAW, states, bits, in, in_length, groups.data(), ng, iplan.data(), iplan.size()) : 0;
+      have_index = plen != 0 && hsrans_dplan_create(ctx, iplan.data(), plen, &ix) == HSRANS_OK;
+      if (have_index)
+      {
+        have_index = hipMemsetAsync(ix->d_status, 0, 4, s) == hipSuccess && dplan_launch(ix, ctx->d_in, in_length, ctx->d_out, (size_t)h.decoded_len, s) == HSRANS_OK &&
+                     hipMemcpyAsync(&status, ix->d_status, 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess && status == 0;
+        status = 0xFFFFFFFF; // (the entry's own status word is read below)
+        if (!have_index)
+        {
+          (void)hipStreamSynchronize(s);
+          hsrans_dplan_destroy(ix);
+          ix = nullptr;
+        }
+      }
+    }
+    else if (have_index)
+      have_index = decode_device_indexing_impl(ctx, d, ctx->d_in, in_length, ctx->d_out, (size_t)h.decoded_len, 64, s, &ix, true) == HSRANS_OK;
+    if (have_index)
     {
       indexed_now = true; // (the recording pass has decoded into d_out and was synchronised: `sum` has arrived too)
       ctx->host_index = ix;

@@ -164,7 +164,8 @@ uint32_t hsrans_ctx_host_index_chains(hsrans_ctx *ctx);
  * — but only counts when a 64-bit fingerprint of ALL stream bytes, computed on the device beside the decode, equals the first
  * call's (otherwise the call starts over; other bytes at the same address cost one wasted launch, never a wrong result short of a
  * 2^-64 collision).  A loop over one file (src/main.cpp:860-889) thus runs the indexed kernels from its second iteration:
- * 100 MB mt_: 0.24 -> 0.06 ms of kernel per call; raw: 125 ms -> 0.05 ms.  HSRANS_HOST_INDEX_CACHE_OFF=1 disables it. */
+ * 100 MB mt_: 0.24 -> 0.06 ms of kernel per call; raw: 125 ms -> 0.04 ms (a raw stream's index comes from the host SIMD decoder's
+ * pass, ~30 ms for 100 MB, during the first call).  HSRANS_HOST_INDEX_CACHE_OFF=1 disables it. */
 size_t hsrans_decode_host(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out,
                           size_t out_capacity, const uint8_t *plan, size_t plan_size);
 
