@@ -779,6 +779,28 @@ def test_gpu_raw_encoder_emits_the_host_encoders_index(gpu_ctx, zipf, nonstat, s
     assert m == want_stream.size and np.array_equal(d_out[:m].cpu().numpy(), want_stream) and np.array_equal(gpu_ctx.read_device_plan(dplan), want_plan)
 
 
+def test_gpu_raw_encode_decode_never_leaves_hbm_1gib(gpu_ctx):
+    """BASELINE config 2's shape at 2^30 bytes: raw stream AND its one-chain-per-wavefront index written by the one coding wavefront
+    (byte offsets inside the 2 GiB scratch slot are 32-bit: this is the size that exercises them), decoded by the headline launch;
+    input, stream, index and output stay on the device.  The stream's header fields and the plan's chain count are checked too."""
+    import torch
+    n = 1 << 30
+    g = torch.Generator(device="cuda").manual_seed(11)
+    u = torch.rand(n, device="cuda", generator=g)
+    d_in = (u.pow_(6).mul_(205)).to(torch.uint8)
+    del u
+    d_out = torch.empty(H.capacity(H.RAW, 64, n), dtype=torch.uint8, device="cuda")
+    groups = H.index_boundaries(64, 11, n, gpu_ctx)
+    m, dplan = gpu_ctx.encode_device_raw(64, 11, d_in, d_out, index_groups=groups, want_device_plan=True)
+    assert 0.3 * n < m < 0.9 * n
+    head = d_out[:16].cpu().numpy().view(np.uint64)
+    assert int(head[0]) == n and int(head[1]) == m
+    back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    gpu_ctx.decode_device(dplan, d_out, back, stream_length=m)
+    assert gpu_ctx.status(dplan) == 0 and torch.equal(back, d_in)
+    assert dplan.launch_info()["chains"] == len(groups) + 1
+
+
 def test_gpu_raw_encoder_rejects_bad_arguments(gpu_ctx, zipf):
     import torch
     d = zipf[:4096].copy()
