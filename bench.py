@@ -432,6 +432,18 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
         result["gpu_encoder"] = {"container": "mt_", "block_size": 1 << 16, "compressed_bytes": int(m), "encode_ms": t_gpu_enc * 1e3,
                                  "encode_GB_s": n / t_gpu_enc / 1e9, "decode_with_device_built_plan_MiB_s": n / 2**20 / (a.elapsed_time(b) * 1e-3),
                                  "round_trip_bit_exact": True}
+        # ... and the raw format (this workload's own container) through the one coding wavefront the format has work for: the
+        # stream it writes is the host encoder's byte for byte, so is the one-chain-per-wavefront index it records on the way
+        if S == 64 and n <= (1 << 30):
+            d_raw = torch.empty(H.capacity(H.RAW, S, n), dtype=torch.uint8, device=dev)
+            t0 = time.perf_counter()
+            kw = {"index_groups": groups} if groups is not None else {"index_interval": int(args.index)}
+            m_raw, plan_raw = ctx.encode_device_raw(S, bits, d_ref, d_raw, want_plan=True, **kw)
+            t_raw = time.perf_counter() - t0
+            same = m_raw == pairs[0]["stream"].size and bool(np.array_equal(d_raw[:m_raw].cpu().numpy(), pairs[0]["stream"])) and \
+                bool(np.array_equal(plan_raw, pairs[0]["plan"]))
+            result["gpu_encoder"]["raw_format"] = {"encode_ms": t_raw * 1e3, "encode_GB_s": n / t_raw / 1e9, "stream_and_index_identical_to_host_encoder": same,
+                                                   "note": "one dependent chain per coder state: one wavefront"}
 
     if not args.no_cpu and world == 1:  # reported baseline, N=1 only
         result["cpu_baseline"] = cpu_baseline(stream, pairs[0]["data"], S, bits)
