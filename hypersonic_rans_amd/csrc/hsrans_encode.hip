@@ -161,22 +161,69 @@ __device__ __forceinline__ uint32_t ballot_count(bool pred) { return (uint32_t)_
 // Heap sort of L.order (count << 8 | symbol) as far as the adjustment needs it: the `take` largest entries in the order
 // the reference's sort puts them at the top of its array.  Returns, per lane, a 4-bit mask of its symbols (4 * lane + k)
 // that are among them.
-__device__ __forceinline__ uint32_t heap_take_largest(const WaveLds &L, uint32_t lane, uint32_t take)
+template <bool PARALLEL_BUILD> // (the raw format's kernel keeps the register form: its one wavefront does this once per 100 MB, and the LDS form costs its pass 6 % through the register allocation)
+__device__ __forceinline__ uint32_t heap_take_largest(WaveLds &L, uint32_t lane, uint32_t take)
 {
   Heap h;
+  if constexpr (PARALLEL_BUILD)
+  // The BUILD of the heap (the sort's first phase: sift nodes 127 ... 0 down, in that order) has a level's nodes working on
+  // disjoint subtrees, and a node only needs the levels below it finished: all nodes of a level sift at once, one per lane, in
+  // LDS — 2 + 3 + ... + 8 dependent steps instead of 128 sifts one after the other — and give the heap the serial order gives.
+  // The extractions that follow depend on one another and stay in the registers.
+  {
+    uint32_t *ord = L.order;
+    auto sift = [&](uint32_t root) { // (per lane; comparisons as heap_sift below: by count, the right child only wins when strictly larger)
+      const uint32_t val = ord[root];
+      uint32_t i = root;
+      while (true)
+      {
+        const uint32_t l = 2 * i + 1;
+        if (l >= 256)
+          break;
+        uint32_t big = l, vb = ord[l];
+        if (l + 1 < 256)
+        {
+          const uint32_t ar = ord[l + 1];
+          if ((ar >> 8) > (vb >> 8))
+            big = l + 1, vb = ar;
+        }
+        if ((vb >> 8) <= (val >> 8))
+          break;
+        ord[i] = vb;
+        i = big;
+      }
+      ord[i] = val;
+    };
+    if (lane == 0)
+      sift(127); // the only level-7 node with a child
+    wave_sync();
+    sift(63 + lane); // level 6: nodes 63 .. 126
+    wave_sync();
+    for (uint32_t first = 31; ; first = (first - 1) / 2) // levels 5 .. 0: nodes first .. 2 * first
+    {
+      if (lane <= first)
+        sift(first + lane);
+      wave_sync();
+      if (first == 0)
+        break;
+    }
+  }
   h.A = L.order[lane < 63 ? lane : 62];
   h.B = L.order[63 + lane];
   h.C = L.order[127 + lane];
   h.D = L.order[191 + lane < 255 ? 191 + lane : 254];
   h.E = __builtin_amdgcn_readfirstlane(L.order[255]);
-  heap_sift<7>(h, 127, 256, heap_get<7>(h, 127)); // the only level-7 node with a child
-  heap_build_level<6>(h, 63, 126);
-  heap_build_level<5>(h, 31, 62);
-  heap_build_level<4>(h, 15, 30);
-  heap_build_level<3>(h, 7, 14);
-  heap_build_level<2>(h, 3, 6);
-  heap_build_level<1>(h, 1, 2);
-  heap_build_level<0>(h, 0, 0);
+  if constexpr (!PARALLEL_BUILD)
+  {
+    heap_sift<7>(h, 127, 256, heap_get<7>(h, 127)); // the only level-7 node with a child
+    heap_build_level<6>(h, 63, 126);
+    heap_build_level<5>(h, 31, 62);
+    heap_build_level<4>(h, 15, 30);
+    heap_build_level<3>(h, 7, 14);
+    heap_build_level<2>(h, 3, 6);
+    heap_build_level<1>(h, 1, 2);
+    heap_build_level<0>(h, 0, 0);
+  }
   uint32_t taken = 0;
   auto mark = [&](uint32_t top) {
     const uint32_t sym = top & 0xFF;
@@ -210,7 +257,8 @@ __device__ __forceinline__ uint32_t heap_take_largest(const WaveLds &L, uint32_t
 //            e - F * m largest of the sort get one more.
 // So the heap sort only has to deliver its largest few entries (heap_take_largest), in exactly the order the reference's
 // sort would put them (ties!).  Counts stay in registers: sc[k] is symbol 4 * lane + k.
-__device__ __forceinline__ void adjust_counts(const WaveLds &L, uint32_t lane, uint32_t (&sc)[4], uint32_t sum, uint32_t target)
+template <bool PARALLEL_BUILD>
+__device__ __forceinline__ void adjust_counts(WaveLds &L, uint32_t lane, uint32_t (&sc)[4], uint32_t sum, uint32_t target)
 {
   auto count_ge = [&](uint32_t t) {
     uint32_t n = 0;
@@ -218,6 +266,8 @@ __device__ __forceinline__ void adjust_counts(const WaveLds &L, uint32_t lane, u
       n += ballot_count(sc[k] >= t);
     return n;
   };
+  // (skipping the sort when the cut between taken and spared symbols does not fall inside a run of equal counts — a bisection over
+  // ballots finds that out — was measured: no gain, the sort is no longer what a block waits for)
   const uint32_t m = count_ge(2); // >= 1: 256 counts <= 1 cannot come from counts that scale to 2^bits >= 1024
   if (sum > target)
   {
@@ -228,7 +278,7 @@ __device__ __forceinline__ void adjust_counts(const WaveLds &L, uint32_t lane, u
       j++;
       mj = count_ge(j + 1);
     }
-    const uint32_t spared = heap_take_largest(L, lane, mj - e);
+    const uint32_t spared = heap_take_largest<PARALLEL_BUILD>(L, lane, mj - e);
     for (uint32_t k = 0; k < 4; k++)
     {
       const uint32_t c = sc[k];
@@ -241,7 +291,7 @@ __device__ __forceinline__ void adjust_counts(const WaveLds &L, uint32_t lane, u
   {
     const uint32_t e = target - sum;
     const uint32_t full = (e - 1) / m;
-    const uint32_t lucky = heap_take_largest(L, lane, e - full * m);
+    const uint32_t lucky = heap_take_largest<PARALLEL_BUILD>(L, lane, e - full * m);
     for (uint32_t k = 0; k < 4; k++)
       sc[k] += (sc[k] >= 2 ? full : 0) + ((lucky >> k) & 1);
   }
@@ -457,7 +507,7 @@ __device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t 
   wave_sync();
   if (sum != target && !normalised)
   {
-    adjust_counts(L, lane, sc, sum, target);
+    adjust_counts<!RAW>(L, lane, sc, sum, target);
     part = sc[0] + sc[1] + sc[2] + sc[3];
   }
   // exclusive prefix over the 256 counts: lane-local then across lanes
