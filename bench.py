@@ -313,6 +313,36 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
             torch.cuda.synchronize()
             samples.append((time.perf_counter() - t0) / (2 * args.steps) * 1e3)
         overlapped_ms = float(np.median(samples))
+    # ... and as ONE launch (hsrans_decode_device_batch): the device's wave slots dealt to the P streams — whole workgroups, every
+    # stream's chains cut into runs by the slots' age class — so that prologue, tail and kernel boundary are paid once for all P.
+    # A step here is one launch that decodes all P streams (657 MB of stream + output: cold by construction).
+    one_launch = None
+    if not args.timed_only and world == 1 and P >= 2:
+        batch = ctx.make_batch([p["dplan"] for p in pairs])
+        b_in, b_out, b_len = [p["d_in"] for p in pairs], [p["d_out"] for p in pairs], [p["stream"].size for p in pairs]
+        for p in pairs:
+            p["d_out"].zero_()
+        ctx.decode_device_batch(batch, b_in, b_out, stream_lengths=b_len)
+        torch.cuda.synchronize()
+        assert ctx.batch_status(batch) == [0] * P
+        for p in pairs:
+            assert np.array_equal(p["d_out"].cpu().numpy(), p["data"]), "batch launch: GPU output is not bit-exact"
+        launches = max(4, args.steps // P)
+        for _ in range(3 * launches):  # (the checks above idled the GPU)
+            ctx.decode_device_batch(batch, b_in, b_out, stream_lengths=b_len)
+        samples = []
+        for _ in range(max(5, args.repeats // 2)):
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            for _ in range(launches):
+                ctx.decode_device_batch(batch, b_in, b_out, stream_lengths=b_len)
+            eb.record()
+            torch.cuda.synchronize()
+            samples.append(ea.elapsed_time(eb) / launches)
+        assert ctx.batch_status(batch) == [0] * P
+        ms_batch = float(np.median(samples))
+        one_launch = {"ms_per_launch": ms_batch, "ms_per_stream": ms_batch / P, "streams": P, "samples_ms_per_launch": [float(x) for x in samples],
+                      "launches_per_sample": launches, "batch": batch.info()}
     if rank != 0:
         return None
 
@@ -377,7 +407,11 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
                   "independent_streams_overlapped": None if overlapped_ms is None else
                   {"value": n / 2**20 / (overlapped_ms * 1e-3), "ms_per_stream": overlapped_ms, "frac_of_hbm_peak": alg_bytes / (overlapped_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "note": f"the same {P} streams as independent work: launches alternate between two HIP streams, so a launch's prologue and tail overlap its "
-                           "neighbour's decode (wall clock over 2K launches, median of 5); a step of the headline has the GPU to itself"}},
+                           "neighbour's decode (wall clock over 2K launches, median of 5); a step of the headline has the GPU to itself"},
+                  "independent_streams_one_launch": None if one_launch is None else
+                  dict(one_launch, value=n / 2**20 / (one_launch["ms_per_stream"] * 1e-3), frac_of_hbm_peak=alg_bytes / (one_launch["ms_per_stream"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       note=f"the same {P} streams decoded by ONE launch (hsrans_decode_device_batch: wave slots dealt to the streams, prologue / tail / kernel "
+                            "boundary paid once); HIP events around the launches of a sample, median sample; value = decoded MiB/s per GPU")},
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             # the same fraction from the wall clock of the timed region (B_alg / ms_per_step): what the driver's number implies

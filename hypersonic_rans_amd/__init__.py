@@ -24,9 +24,10 @@ from .api import (  # noqa: F401
     plan_stream_ranges,
     plan_thin,
     index_boundaries,
+    batch_deal,
 )
 
 __all__ = [
     "RAW", "BLOCK", "MT", "Context", "HsransError", "capacity", "encode", "make_hist", "plan_build", "plan_chain_count",
-    "plan_chain_range", "plan_decoded_length", "plan_slice", "plan_stream_ranges", "plan_thin", "index_boundaries", "lib_path", "load_library",
+    "plan_chain_range", "plan_decoded_length", "plan_slice", "plan_stream_ranges", "plan_thin", "index_boundaries", "batch_deal", "lib_path", "load_library",
 ]

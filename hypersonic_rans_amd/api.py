@@ -44,6 +44,11 @@ class LaunchInfo(ctypes.Structure):
                [("class_weights", _u32 * 8), ("dynamic_groups", _u32), ("spread", _u32)]
 
 
+class BatchInfo(ctypes.Structure):
+    _fields_ = [(n, _u32) for n in ("members", "launches", "direct_members", "solo_members", "grid", "block", "lds_bytes")] + \
+               [("class_weights", _u32 * 8), ("imbalance", ctypes.c_double)]
+
+
 def lib_path() -> str:
     # HSRANS_LIB: A/B a differently built libhsrans_hip.so in one process environment (kernel tuning only)
     if os.environ.get("HSRANS_LIB"):
@@ -120,6 +125,20 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_decode_device_indexing.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _vp, ctypes.POINTER(_vp)]
     L.hsrans_ctx_calibrate.restype = _i
     L.hsrans_ctx_calibrate.argtypes = [_vp, _u32, _u32, ctypes.POINTER(Calibration)]
+    L.hsrans_dplan_batch_create.restype = _i
+    L.hsrans_dplan_batch_create.argtypes = [_vp, _vp, _u32, ctypes.POINTER(_vp)]
+    L.hsrans_dplan_batch_destroy.restype = None
+    L.hsrans_dplan_batch_destroy.argtypes = [_vp]
+    L.hsrans_decode_device_batch.restype = _i
+    L.hsrans_decode_device_batch.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.hsrans_dplan_batch_status.restype = _i
+    L.hsrans_dplan_batch_status.argtypes = [_vp, _vp, _vp, _vp]
+    L.hsrans_dplan_batch_info.restype = _i
+    L.hsrans_dplan_batch_info.argtypes = [_vp, ctypes.POINTER(BatchInfo)]
+    L.hsrans_batch_deal.restype = ctypes.c_double
+    L.hsrans_batch_deal.argtypes = [_vp, _vp, _u32, _u32, _u32, _vp, _vp]
+    L.hsrans_dplan_batch_read_finish.restype = _sz
+    L.hsrans_dplan_batch_read_finish.argtypes = [_vp, _vp, _sz]
     L.hsrans_dplan_status.restype = _i
     L.hsrans_dplan_status.argtypes = [_vp, _vp, _vp]
     L.hsrans_dplan_launch_info.restype = _i
@@ -364,9 +383,52 @@ def plan_tables(plan):
     return hdr, cf, pieces
 
 
+def batch_deal(chain_starts, grid: int = 512, waves: int = 16, weights=None):
+    """hsrans_batch_deal: how one launch's wave slots would be dealt to members whose chains start at ``chain_starts[m]`` (groups,
+    ascending, last entry = the member's total).  Returns (imbalance, slots[grid * waves, 4] = member, first chain, end chain, flags)."""
+    L = load_library()
+    arrs = [np.ascontiguousarray(c, dtype=np.uint64) for c in chain_starts]
+    ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    n_chains = np.array([a.size - 1 for a in arrs], np.uint32)
+    slots = np.zeros(grid * waves * 4, np.uint32)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.uint32)
+    imb = L.hsrans_batch_deal(ptrs, _p(n_chains), len(arrs), grid, waves, None if w is None else _p(w), _p(slots))
+    if imb < 0:
+        raise HsransError("hsrans_batch_deal: bad arguments")
+    return float(imb), slots.reshape(-1, 4)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # GPU side
 # ---------------------------------------------------------------------------------------------------------------------
+class Batch:
+    """hsrans_batch: K device plans decoded by one launch (Context.make_batch / Context.decode_device_batch)."""
+
+    def __init__(self, ctx: "Context", handle, dplans):
+        self.ctx, self.handle, self.dplans = ctx, handle, list(dplans)  # (keeps the member plans alive)
+
+    def info(self) -> dict:
+        info = BatchInfo()
+        load_library().hsrans_dplan_batch_info(self.handle, ctypes.byref(info))
+        return {n: (list(getattr(info, n)) if n == "class_weights" else getattr(info, n)) for n, _ in BatchInfo._fields_}
+
+    def read_finish(self) -> np.ndarray:
+        out = np.zeros(1 << 16, np.uint64)
+        n = load_library().hsrans_dplan_batch_read_finish(self.handle, _p(out), out.size)
+        return out[:n].copy()
+
+    def close(self):
+        if self.handle:
+            load_library().hsrans_dplan_batch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DevicePlan:
     def __init__(self, ctx: "Context", handle):
         self.ctx, self.handle = ctx, handle
@@ -518,6 +580,35 @@ class Context:
                                                 out_offset, out_length, ctypes.c_void_p(s.cuda_stream))
         if rc != 0:
             raise HsransError(f"hsrans_decode_device_ranges failed with code {rc}")
+
+    # -- K independent streams, one launch -------------------------------------------------------------------------
+    def make_batch(self, dplans) -> Batch:
+        dplans = list(dplans)
+        arr = (ctypes.c_void_p * len(dplans))(*[d.handle.value if isinstance(d.handle, ctypes.c_void_p) else d.handle for d in dplans])
+        h = _vp()
+        rc = self.L.hsrans_dplan_batch_create(self.handle, arr, len(dplans), ctypes.byref(h))
+        if rc != 0:
+            raise HsransError(f"hsrans_dplan_batch_create failed with code {rc}")
+        return Batch(self, h, dplans)
+
+    def decode_device_batch(self, batch: Batch, d_streams, d_outs, stream: torch.cuda.Stream | None = None, stream_lengths=None):
+        """Asynchronous on ``stream`` (default: torch's current stream): member k decodes d_streams[k] into d_outs[k]."""
+        K = len(batch.dplans)
+        assert len(d_streams) == K and len(d_outs) == K
+        s = stream if stream is not None else torch.cuda.current_stream(d_streams[0].device)
+        sp = (ctypes.c_void_p * K)(*[t.data_ptr() for t in d_streams])
+        op = (ctypes.c_void_p * K)(*[t.data_ptr() for t in d_outs])
+        sl = (ctypes.c_size_t * K)(*[(t.numel() if stream_lengths is None else int(stream_lengths[k])) for k, t in enumerate(d_streams)])
+        oc = (ctypes.c_size_t * K)(*[t.numel() for t in d_outs])
+        rc = self.L.hsrans_decode_device_batch(self.handle, batch.handle, sp, sl, op, oc, ctypes.c_void_p(s.cuda_stream))
+        if rc != 0:
+            raise HsransError(f"hsrans_decode_device_batch failed with code {rc}")
+
+    def batch_status(self, batch: Batch, stream: torch.cuda.Stream | None = None) -> list:
+        s = stream if stream is not None else torch.cuda.current_stream()
+        codes = (ctypes.c_int * len(batch.dplans))()
+        self.L.hsrans_dplan_batch_status(self.handle, batch.handle, ctypes.c_void_p(s.cuda_stream), codes)
+        return list(codes)
 
     def status(self, dplan: DevicePlan, stream: torch.cuda.Stream | None = None) -> int:
         s = stream if stream is not None else torch.cuda.current_stream()

@@ -1,0 +1,494 @@
+// hsrans_batch.cpp — K independent streams decoded by ONE launch (include/hsrans_hip.h: hsrans_dplan_batch_*, hsrans_decode_device_batch).
+//
+// The reference's analogue is its pool of independent work items: a task per mt_ block (mt_rANS32x64_16w_decode.cpp:182-224), a file
+// after another in its benchmark loop (main.cpp:841-898).  Here the pool is the device's resident wave slots.  This file is the host
+// side: which members of a batch can share a launch, how the launch's wave slots are dealt to them (batch_deal), and the launch itself.
+// The device side is kernels_batch.h (one-chain-per-wave form) and run_grouped's Group::member (block_/mt_ plans with checkpoints).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "hsrans_batch.h"
+#include "hsrans_internal.h"
+
+namespace hsrans
+{
+
+// wave `pos` of a workgroup's slot order with class runs of `run` waves: the classes (wave / 4) take turns, `run` waves each.
+// run == 4 is the natural order 0..15; run == 1 is 0, 4, 8, 12, 1, 5, ...  (16-wave workgroups)
+static uint32_t order_wave(uint32_t pos, uint32_t run)
+{
+  const uint32_t per_turn = 4 * run; // waves placed per turn over the four classes
+  const uint32_t turn = pos / per_turn, in_turn = pos % per_turn;
+  const uint32_t cls = in_turn / run, u = in_turn % run;
+  return cls * 4 + turn * run + u;
+}
+
+// Deals wave slots to the members' chains.  See hsrans_batch.h.
+BatchDeal batch_deal(const std::vector<BatchDealMember> &members, uint32_t grid, uint32_t waves, const uint32_t weights[8])
+{
+  BatchDeal out;
+  const uint32_t M = (uint32_t)members.size();
+  const uint32_t W = grid * waves;
+  // (a slot no member's chains reach names member 0 and no chains: its wave only takes part in its workgroup's table copy)
+  const uint32_t idle = members.empty() ? 0 : members[0].n_chains;
+  out.slots.assign(W, BatchSlot{0, idle, idle, 0});
+  out.wg_first.assign(M, 0);
+  out.wg_count.assign(M, 0);
+  out.order_run.assign(M, 4);
+  if (M == 0 || grid < 2 || waves == 0)
+    return out;
+  // 1. workgroups: the grid's first half (a CU's older workgroup) and its second half are dealt separately and alike, so that every
+  //    member gets waves of all 8 age classes in the launch's own proportion.  Min-max: one workgroup pair each, then one more to
+  //    whoever has the most groups per pair, until the pairs are used up.
+  const uint32_t first_half = (grid + 1) / 2, pairs = grid - first_half; // (grid odd: the first half's last workgroup stays idle)
+  std::vector<uint32_t> n(M, 0);
+  uint32_t used = 0;
+  for (uint32_t m = 0; m < M && used < pairs; m++)
+    if (members[m].total_groups != 0 || members[m].n_chains != 0)
+      n[m] = 1, used++;
+  for (; used < pairs; used++)
+  {
+    uint32_t best = M;
+    double best_load = 0;
+    for (uint32_t m = 0; m < M; m++)
+    {
+      // (a member cannot use more waves than it has chains)
+      if (n[m] == 0 || (uint64_t)n[m] * 2 * waves >= members[m].n_chains)
+        continue;
+      const double load = (double)members[m].total_groups / n[m];
+      if (best == M || load > best_load)
+        best = m, best_load = load;
+    }
+    if (best == M)
+      break;
+    n[best]++;
+  }
+  // 2. per member: its slots in order, its chains dealt to them by cumulative weight, boundaries at the nearest chain start.  The
+  //    order of the slots inside a workgroup is tried three ways (class runs of 4, 2, 1 waves): an index made for a launch of its own
+  //    (hsrans_index_boundaries: chains sized by class, four of a class in a row) is matched exactly by one of them when the member
+  //    gets 1/1, 1/2 or 1/4 of the device; a uniform index does not care.  The order with the least (longest run / weight) wins.
+  uint32_t wg0 = 0;
+  double worst = 0, mean_num = 0, mean_den = 0;
+  const bool can_reorder = waves == 16;
+  for (uint32_t m = 0; m < M; m++)
+  {
+    const BatchDealMember &mem = members[m];
+    out.wg_first[m] = wg0;
+    out.wg_count[m] = n[m];
+    if (n[m] == 0)
+      continue;
+    const uint32_t nslots = n[m] * 2 * waves;
+    const uint32_t nc = mem.n_chains;
+    std::vector<uint32_t> best_bounds;
+    double best_cost = -1;
+    uint32_t best_run = 4;
+    std::vector<uint32_t> slot_of(nslots), bounds(nslots + 1);
+    std::vector<uint64_t> cumw(nslots + 1);
+    for (uint32_t run : {4u, 2u, 1u})
+    {
+      if (run != 4 && !can_reorder)
+        break;
+      // slot list: first-half workgroups wg0 .. wg0 + n, then second-half workgroups first_half + wg0 ..
+      for (uint32_t i = 0; i < nslots; i++)
+      {
+        const uint32_t wg_local = i / waves, pos = i % waves;
+        const uint32_t wg = wg_local < n[m] ? wg0 + wg_local : first_half + wg0 + (wg_local - n[m]);
+        const uint32_t wave = can_reorder ? order_wave(pos, run) : pos;
+        slot_of[i] = wg * waves + wave;
+      }
+      cumw[0] = 0;
+      for (uint32_t i = 0; i < nslots; i++)
+      {
+        const uint32_t wg = slot_of[i] / waves, wave = slot_of[i] % waves;
+        const uint32_t per_class = waves >= 4 ? waves / 4 : 1;
+        const uint32_t cls = (wg >= first_half ? 4 : 0) + std::min(3u, wave / per_class);
+        cumw[i + 1] = cumw[i] + weights[cls];
+      }
+      const uint64_t G = mem.chain_start[nc];
+      bounds[0] = 0;
+      double cost = 0;
+      for (uint32_t i = 0; i < nslots; i++)
+      {
+        uint32_t b = nc;
+        if (i + 1 < nslots)
+        {
+          const uint64_t target = (uint64_t)((unsigned __int128)G * cumw[i + 1] / cumw[nslots]);
+          const uint64_t *lo = std::lower_bound(mem.chain_start, mem.chain_start + nc + 1, target);
+          b = (uint32_t)(lo - mem.chain_start);
+          if (b > 0 && b <= nc && target - mem.chain_start[b - 1] < mem.chain_start[std::min(b, nc)] - target)
+            b--;
+          b = std::min(std::max(b, bounds[i]), nc);
+        }
+        bounds[i + 1] = b;
+        const uint64_t len = mem.chain_start[b] - mem.chain_start[bounds[i]];
+        const uint32_t wt = (uint32_t)(cumw[i + 1] - cumw[i]);
+        cost = std::max(cost, (double)len / (wt ? wt : 1));
+      }
+      if (best_cost < 0 || cost < best_cost * 0.999)
+      {
+        best_cost = cost;
+        best_run = run;
+        best_bounds = bounds;
+      }
+    }
+    // write the winner's slots
+    for (uint32_t i = 0; i < nslots; i++)
+    {
+      const uint32_t wg_local = i / waves, pos = i % waves;
+      const uint32_t wg = wg_local < n[m] ? wg0 + wg_local : first_half + wg0 + (wg_local - n[m]);
+      const uint32_t wave = can_reorder ? order_wave(pos, best_run) : pos;
+      BatchSlot &s = out.slots[wg * waves + wave];
+      s.member = m;
+      s.begin = best_bounds[i] < best_bounds[i + 1] ? best_bounds[i] : nc;
+      s.end = best_bounds[i] < best_bounds[i + 1] ? best_bounds[i + 1] : nc;
+      s.flags = wg_local == 0 ? kBatchSlotCheckHist : 0;
+    }
+    out.order_run[m] = best_run;
+    // (cost is groups per unit of weight: the launch is as long as its most loaded slot)
+    uint64_t wsum = 0;
+    for (uint32_t k = 0; k < 8; k++)
+      wsum += weights[k];
+    worst = std::max(worst, best_cost);
+    mean_num += (double)mem.chain_start[nc];
+    mean_den += (double)n[m] * (waves / 4) * wsum;
+    wg0 += n[m];
+  }
+  out.imbalance = mean_num > 0 && mean_den > 0 ? worst / (mean_num / mean_den) : 1.0;
+  return out;
+}
+
+} // namespace hsrans
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------------------
+struct hsrans_batch
+{
+  hsrans_ctx *ctx = nullptr;
+  std::vector<hsrans_dplan *> members;
+  struct DirectLaunch
+  {
+    std::vector<uint32_t> member_idx; // batch member of launch-local member i
+    BatchShape shape{};
+    const BatchMember *d_members = nullptr;
+    const BatchSlot *d_slots = nullptr;
+    double imbalance = 1.0;
+  };
+  std::vector<DirectLaunch> direct;
+  std::vector<uint32_t> solo; // members that take a launch of their own (hsrans_decode_device's)
+  uint8_t *d_arena = nullptr;
+  uint64_t *d_finish = nullptr; // diagnostics (HSRANS_BATCH_STAMPS=1): per-wave finish times of the first direct launch
+  uint32_t finish_slots = 0;
+  std::vector<uint32_t> order_run; // per member: the slot order its chains were dealt with (diagnostics)
+};
+
+namespace
+{
+// a plan the one-chain-per-wave batch kernel can take: raw, mergeable, 64 states, the 8-byte host-built table (bits <= 12), one chain per wave
+bool direct_eligible(const hsrans_dplan *d)
+{
+  return d->pa.pieces != nullptr && d->pa.table != nullptr && d->pa.table_mode == 3 && d->pa.dual == 0 && d->hdr.states == 64 && d->hdr.bits <= 12 &&
+         (d->hdr.flags & kPlanMergeable) != 0 && d->hdr.container == HSRANS_RAW && d->hdr.n_chains >= 1;
+}
+} // namespace
+
+extern "C"
+{
+
+void hsrans_dplan_batch_destroy(hsrans_batch *b)
+{
+  if (b == nullptr)
+    return;
+  if (b->ctx)
+    (void)hipSetDevice(b->ctx->device);
+  if (b->d_arena)
+    (void)hipFree(b->d_arena);
+  if (b->d_finish)
+    (void)hipFree(b->d_finish);
+  delete b;
+}
+
+int hsrans_dplan_batch_create(hsrans_ctx *ctx, hsrans_dplan *const *dplans, uint32_t count, hsrans_batch **out_batch)
+try
+{
+  if (ctx == nullptr || dplans == nullptr || out_batch == nullptr || count == 0)
+    return HSRANS_E_ARG;
+  *out_batch = nullptr;
+  for (uint32_t k = 0; k < count; k++)
+  {
+    if (dplans[k] == nullptr || dplans[k]->ctx != ctx)
+      return HSRANS_E_ARG;
+    for (uint32_t j = 0; j < k; j++) // (a plan's status word and ticket counters belong to one member)
+      if (dplans[j] == dplans[k])
+        return HSRANS_E_ARG;
+  }
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return HSRANS_E_HIP;
+  hsrans_batch *b = new (std::nothrow) hsrans_batch;
+  if (b == nullptr)
+    return HSRANS_E_HIP;
+  b->ctx = ctx;
+  b->members.assign(dplans, dplans + count);
+  b->order_run.assign(count, 0);
+  std::vector<uint32_t> eligible;
+  for (uint32_t k = 0; k < count; k++)
+    (direct_eligible(dplans[k]) ? eligible : b->solo).push_back(k);
+  if (eligible.size() == 1) // a launch of its own is the same thing, with the plan's own dealing
+  {
+    b->solo.push_back(eligible[0]);
+    eligible.clear();
+    std::sort(b->solo.begin(), b->solo.end());
+  }
+  const size_t n_launches = (eligible.size() + kBatchMax - 1) / kBatchMax;
+  // one allocation: per launch its member records and its slot table
+  auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t arena = 0;
+  std::vector<std::vector<uint8_t>> host_blobs;
+  for (size_t l = 0; l < n_launches; l++)
+  {
+    hsrans_batch::DirectLaunch L;
+    // (launches of nearly equal member counts rather than 32 + the rest)
+    const size_t lo = eligible.size() * l / n_launches, hi = eligible.size() * (l + 1) / n_launches;
+    L.member_idx.assign(eligible.begin() + lo, eligible.begin() + hi);
+    uint32_t max_bits = 0;
+    for (uint32_t k : L.member_idx)
+      max_bits = std::max(max_bits, dplans[k]->hdr.bits);
+    L.shape = batch_direct_shape(ctx->geom, max_bits);
+    // the members' chain starts (in groups) and word offsets, from the device copies of their plans
+    std::vector<std::vector<uint64_t>> starts(L.member_idx.size());
+    std::vector<BatchDealMember> deal_in(L.member_idx.size());
+    std::vector<std::vector<Piece>> pieces(L.member_idx.size());
+    for (size_t i = 0; i < L.member_idx.size(); i++)
+    {
+      const hsrans_dplan *d = dplans[L.member_idx[i]];
+      const uint32_t nc = d->hdr.n_chains;
+      pieces[i].resize(nc);
+      if (hipMemcpy(pieces[i].data(), d->pa.pieces, (size_t)nc * sizeof(Piece), hipMemcpyDeviceToHost) != hipSuccess)
+      {
+        hsrans_dplan_batch_destroy(b);
+        return HSRANS_E_HIP;
+      }
+      starts[i].resize(nc + 1);
+      uint64_t g = 0;
+      for (uint32_t c = 0; c < nc; c++)
+      {
+        starts[i][c] = g;
+        g += pieces[i][c].steps;
+      }
+      starts[i][nc] = g;
+      deal_in[i].chain_start = starts[i].data();
+      deal_in[i].n_chains = nc;
+      deal_in[i].total_groups = g;
+    }
+    const BatchDeal deal = batch_deal(deal_in, L.shape.grid, L.shape.waves, L.shape.weights);
+    // a wave reads its run through one 32-bit window of the stream (run_direct_span: win_open)
+    for (const BatchSlot &s : deal.slots)
+    {
+      const hsrans_dplan *d = dplans[L.member_idx[s.member]];
+      if (s.begin >= s.end || s.end > d->hdr.n_chains)
+        continue;
+      const std::vector<Piece> &pc = pieces[s.member];
+      const uint64_t w_end = s.end < d->hdr.n_chains ? pc[s.end].words_off : d->hdr.stream_len;
+      if (w_end - pc[s.begin].words_off >= 0xFFFF0000ull)
+      {
+        hsrans_dplan_batch_destroy(b);
+        return HSRANS_E_FORMAT;
+      }
+    }
+    L.imbalance = deal.imbalance;
+    for (size_t i = 0; i < L.member_idx.size(); i++)
+      b->order_run[L.member_idx[i]] = deal.order_run[i];
+    // blobs to upload: members, then slots
+    std::vector<uint8_t> blob(up256(L.member_idx.size() * sizeof(BatchMember)) + up256(deal.slots.size() * sizeof(BatchSlot)));
+    BatchMember *bm = (BatchMember *)blob.data();
+    for (size_t i = 0; i < L.member_idx.size(); i++)
+    {
+      const hsrans_dplan *d = dplans[L.member_idx[i]];
+      bm[i] = BatchMember{};
+      bm[i].pieces = d->pa.pieces;
+      bm[i].states = d->pa.states;
+      bm[i].table = d->pa.table;
+      bm[i].hist_copy = d->pa.hist_copy;
+      bm[i].status = d->d_status;
+      bm[i].hist_off = d->pa.hist_off;
+      bm[i].n_chains = d->hdr.n_chains;
+      bm[i].bits = d->hdr.bits;
+      bm[i].S = d->hdr.states;
+    }
+    memcpy(blob.data() + up256(L.member_idx.size() * sizeof(BatchMember)), deal.slots.data(), deal.slots.size() * sizeof(BatchSlot));
+    arena += blob.size();
+    host_blobs.push_back(std::move(blob));
+    b->direct.push_back(std::move(L));
+  }
+  if (arena != 0)
+  {
+    if (hipMalloc((void **)&b->d_arena, arena) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      hsrans_dplan_batch_destroy(b);
+      return HSRANS_E_HIP;
+    }
+    size_t off = 0;
+    for (size_t l = 0; l < n_launches; l++)
+    {
+      if (hipMemcpy(b->d_arena + off, host_blobs[l].data(), host_blobs[l].size(), hipMemcpyHostToDevice) != hipSuccess)
+      {
+        hsrans_dplan_batch_destroy(b);
+        return HSRANS_E_HIP;
+      }
+      b->direct[l].d_members = (const BatchMember *)(b->d_arena + off);
+      b->direct[l].d_slots = (const BatchSlot *)(b->d_arena + off + up256(b->direct[l].member_idx.size() * sizeof(BatchMember)));
+      off += host_blobs[l].size();
+    }
+  }
+  if (getenv("HSRANS_BATCH_STAMPS") != nullptr && !b->direct.empty())
+  {
+    b->finish_slots = b->direct[0].shape.grid * b->direct[0].shape.waves;
+    if (hipMalloc((void **)&b->d_finish, ((size_t)b->finish_slots + 1) * 8) != hipSuccess)
+      b->d_finish = nullptr, b->finish_slots = 0;
+    else
+      (void)hipMemset(b->d_finish, 0, ((size_t)b->finish_slots + 1) * 8);
+  }
+  *out_batch = b;
+  return HSRANS_OK;
+}
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return HSRANS_E_HIP;
+}
+
+int hsrans_decode_device_batch(hsrans_ctx *ctx, hsrans_batch *b, const void *const *d_streams, const size_t *stream_lengths, void *const *d_outs,
+                               const size_t *out_capacities, void *hip_stream)
+{
+  if (ctx == nullptr || b == nullptr || b->ctx != ctx || d_streams == nullptr || stream_lengths == nullptr || d_outs == nullptr || out_capacities == nullptr)
+    return HSRANS_E_ARG;
+  const uint32_t count = (uint32_t)b->members.size();
+  // everything is checked before anything is launched: a batch decodes as a whole or not at all
+  for (uint32_t k = 0; k < count; k++)
+  {
+    const hsrans_dplan *d = b->members[k];
+    if (d_streams[k] == nullptr || d_outs[k] == nullptr || ((uintptr_t)d_streams[k] & 15) != 0 || ((uintptr_t)d_outs[k] & 3) != 0)
+      return HSRANS_E_ARG;
+    if (stream_lengths[k] < d->hdr.stream_len || out_capacities[k] < d->hdr.decoded_len)
+      return HSRANS_E_FORMAT;
+  }
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return HSRANS_E_HIP;
+  hipStream_t s = (hipStream_t)hip_stream;
+  bool first = true;
+  for (const hsrans_batch::DirectLaunch &L : b->direct)
+  {
+    BatchParams bp{};
+    for (size_t i = 0; i < L.member_idx.size(); i++)
+    {
+      const uint32_t k = L.member_idx[i];
+      bp.io[i].stream = (const uint8_t *)d_streams[k];
+      bp.io[i].stream_len = stream_lengths[k];
+      bp.io[i].out = (uint8_t *)d_outs[k];
+      bp.io[i].out_cap = out_capacities[k];
+    }
+    bp.members = L.d_members;
+    bp.slots = L.d_slots;
+    bp.finish = first ? b->d_finish : nullptr;
+    first = false;
+    if (launch_batch_direct(bp, L.shape, s) != hipSuccess)
+      return HSRANS_E_HIP;
+  }
+  for (uint32_t k : b->solo)
+  {
+    const int rc = dplan_launch(b->members[k], d_streams[k], stream_lengths[k], d_outs[k], out_capacities[k], s);
+    if (rc != HSRANS_OK)
+      return rc;
+  }
+  return HSRANS_OK;
+}
+
+int hsrans_dplan_batch_status(hsrans_ctx *ctx, hsrans_batch *b, void *hip_stream, int *member_status)
+{
+  if (ctx == nullptr || b == nullptr || b->ctx != ctx)
+    return HSRANS_E_ARG;
+  int worst = HSRANS_OK;
+  for (size_t k = 0; k < b->members.size(); k++)
+  {
+    const int rc = hsrans_dplan_status(ctx, b->members[k], hip_stream);
+    if (member_status != nullptr)
+      member_status[k] = rc;
+    if (rc != HSRANS_OK && worst == HSRANS_OK)
+      worst = rc;
+  }
+  return worst;
+}
+
+int hsrans_dplan_batch_info(const hsrans_batch *b, hsrans_batch_info *info)
+{
+  if (b == nullptr || info == nullptr)
+    return HSRANS_E_ARG;
+  memset(info, 0, sizeof(*info));
+  info->members = (uint32_t)b->members.size();
+  info->launches = (uint32_t)(b->direct.size() + b->solo.size());
+  info->solo_members = (uint32_t)b->solo.size();
+  for (const hsrans_batch::DirectLaunch &L : b->direct)
+  {
+    info->direct_members += (uint32_t)L.member_idx.size();
+    info->imbalance = std::max(info->imbalance, L.imbalance);
+  }
+  if (!b->direct.empty())
+  {
+    info->grid = b->direct[0].shape.grid;
+    info->block = b->direct[0].shape.waves * 64;
+    info->lds_bytes = b->direct[0].shape.lds;
+    for (int k = 0; k < 8; k++)
+      info->class_weights[k] = b->direct[0].shape.weights[k];
+  }
+  return HSRANS_OK;
+}
+
+double hsrans_batch_deal(const uint64_t *const *chain_starts, const uint32_t *n_chains, uint32_t members, uint32_t grid, uint32_t waves, const uint32_t *weights,
+                         uint32_t *slots_out)
+try
+{
+  if (chain_starts == nullptr || n_chains == nullptr || slots_out == nullptr || members == 0 || grid < 2 || waves == 0 || (uint64_t)grid * waves > (1u << 24))
+    return -1.0;
+  std::vector<BatchDealMember> in(members);
+  for (uint32_t m = 0; m < members; m++)
+  {
+    if (chain_starts[m] == nullptr || n_chains[m] == 0)
+      return -1.0;
+    for (uint32_t c = 0; c < n_chains[m]; c++)
+      if (chain_starts[m][c] > chain_starts[m][c + 1])
+        return -1.0;
+    in[m].chain_start = chain_starts[m];
+    in[m].n_chains = n_chains[m];
+    in[m].total_groups = chain_starts[m][n_chains[m]];
+  }
+  uint32_t w8[8];
+  if (weights == nullptr)
+  {
+    const BatchShape shape = batch_direct_shape(default_geom(), 11);
+    memcpy(w8, shape.weights, sizeof(w8));
+  }
+  else
+    memcpy(w8, weights, sizeof(w8));
+  const BatchDeal deal = batch_deal(in, grid, waves, w8);
+  memcpy(slots_out, deal.slots.data(), deal.slots.size() * sizeof(BatchSlot));
+  return deal.imbalance;
+}
+catch (...)
+{
+  return -1.0;
+}
+
+size_t hsrans_dplan_batch_read_finish(hsrans_batch *b, uint64_t *out, size_t capacity_u64)
+{
+  if (b == nullptr || b->d_finish == nullptr || out == nullptr)
+    return 0;
+  const size_t n = std::min<size_t>(capacity_u64, (size_t)b->finish_slots + 1);
+  return hipMemcpy(out, b->d_finish, n * 8, hipMemcpyDeviceToHost) == hipSuccess ? n : 0;
+}
+
+} // extern "C"

@@ -21,127 +21,8 @@
 
 using namespace hsrans;
 
-struct hsrans_dplan;
-struct hsrans_hpipe;
+#include "hsrans_internal.h"
 
-struct hsrans_ctx
-{
-  int device = 0;
-  char name[256] = {};
-  DeviceGeom geom{};     // CU count / LDS of THIS context's device (nothing about a device is process-global)
-  bool enc_prepared = false;
-  bool enc_raw_prepared = false;
-  std::mutex lock; // guards the staging buffers of the host-pointer entries
-  std::mutex stream_lock; // creation of pipe_streams (hsrans_hpipe_create may run under `lock` or without it)
-  hipStream_t stream = nullptr;
-  hsrans_dplan *host_dplan = nullptr; // device plan of the host-pointer entries, refilled per call (buffers are kept)
-  // hsrans_decode_host without a plan (the plain decodeFunc): the index the first decode of a stream recorded, kept for the next
-  // call on the same stream — {host address, length, codec, 64-bit fingerprint of all its bytes (computed on the device)}
-  hsrans_dplan *host_index = nullptr;
-  uint64_t host_index_key[4] = {};
-  hsrans_hpipe *cached_pipe = nullptr; // hsrans_decode_host_pipelined: the pipeline of the plan used last
-  uint64_t cached_pipe_key[3] = {};
-  uint8_t *d_in = nullptr;
-  size_t d_in_cap = 0;
-  uint8_t *d_out = nullptr;
-  size_t d_out_cap = 0;
-  uint8_t *d_plan = nullptr;
-  size_t d_plan_cap = 0;
-  uint32_t *d_status = nullptr;
-  uint8_t *d_enc_scratch = nullptr; // hsrans_encode_device: block images, then {image_bytes, image_off, result}
-  size_t d_enc_scratch_cap = 0;
-  uint8_t *d_enc_meta = nullptr;
-  size_t d_enc_meta_cap = 0;
-  uint8_t *d_enc_ck = nullptr; // checkpoint states / cursors of the blocks being encoded
-  size_t d_enc_ck_cap = 0;
-  // the three streams of the host pipelines (upload / decode / download): created once and shared by every hsrans_hpipe of the
-  // context.  Streams made per pipe were a trap: the second pipe of a process got streams on ONE hardware queue, its uploads and
-  // kernels ran one after the other, and every codec after the first in the harness read 24-26 instead of 33 GiB/s.
-  hipStream_t pipe_streams[3] = {nullptr, nullptr, nullptr};
-  uint8_t *h_pin = nullptr; // page-locked staging of hsrans_decode_device_indexing (checkpoints down, plan blob up); under `lock`
-  size_t h_pin_cap = 0;
-};
-
-struct hsrans_dplan
-{
-  hsrans_ctx *ctx = nullptr;
-  PlanHeader hdr{};
-  uint8_t *d_plan = nullptr;
-  size_t d_plan_cap = 0;
-  uint32_t *d_status = nullptr;
-  size_t plan_bytes = 0;
-  // dplan_fill puts status word, ticket counters, plan blob, host-built table and group list into ONE device allocation (a
-  // device plan used to cost up to five hipMalloc calls and three synchronisations: 3.2 ms for a 2.5 MB index): the pointers
-  // below then point into d_arena and are not freed one by one.  Plans written on the device (K2, the GPU encoder) still own theirs.
-  uint8_t *d_arena = nullptr;
-  size_t d_arena_cap = 0, arena_used = 0;
-  uint64_t *d_stamps = nullptr; // diagnostics (HSRANS_DEBUG_STAMPS=1)
-  uint64_t *d_finish = nullptr; // hsrans_ctx_calibrate: per-wave finish times of the plan's launches (owned by the calibration)
-  unsigned long long *d_counters = nullptr; // uniform persistent launches: kCounterSets sets of monotonic queue heads
-  std::atomic<uint32_t> epoch{0};           // launches so far: launch k uses counter set k % kCounterSets
-  uint8_t *d_table = nullptr;               // host-built decode table (plans that carry their histogram)
-  size_t d_table_cap = 0;
-  uint8_t *d_groups = nullptr;              // grouped launches (block_/mt_ plans with checkpoints)
-  size_t d_groups_cap = 0;
-  uint32_t n_groups = 0;
-  bool groups_lean = false; // 64 states, every group a mergeable run or fills only
-  uint32_t spread_min_block = 0; // plans k_decode_spread can take (single-piece chains, mergeable / fill groups): the fewest chains of a coded block that is not the last; else 0
-  PersistentArgs pa{};
-  SingleArgs single{};
-  LaunchInfo info{};
-  // what the plan's chains touch, recorded by dplan_fill: the lowest stream byte any of them reads (its own words, its
-  // histogram / header, the shared histogram when the plan carries no copy of it) and the output bytes they write
-  uint64_t body_lo = 0, out_lo = 0, out_hi = 0;
-};
-
-namespace
-{
-constexpr size_t kStampWaves = 16384;
-
-bool grow(uint8_t **p, size_t *cap, size_t need)
-{
-  if (need <= *cap)
-    return true;
-  if (*p)
-    (void)hipFree(*p);
-  *p = nullptr;
-  *cap = 0;
-  const size_t want = need + need / 8 + 4096;
-  if (hipMalloc((void **)p, want) != hipSuccess)
-  {
-    (void)hipGetLastError(); // (consumed here: the runtime's last error is sticky per thread and would surface at an unrelated launch)
-    return false;
-  }
-  *cap = want;
-  return true;
-}
-
-bool grow_pinned(uint8_t **p, size_t *cap, size_t need)
-{
-  if (need <= *cap)
-    return true;
-  if (*p)
-    (void)hipHostFree(*p);
-  *p = nullptr;
-  *cap = 0;
-  const size_t want = need + need / 4 + 65536;
-  if (hipHostMalloc((void **)p, want, hipHostMallocDefault) != hipSuccess)
-  {
-    (void)hipGetLastError();
-    return false;
-  }
-  *cap = want;
-  return true;
-}
-
-bool read_header(const uint8_t *plan, size_t size, PlanHeader *h)
-{
-  if (plan == nullptr || size < sizeof(PlanHeader))
-    return false;
-  memcpy(h, plan, sizeof(PlanHeader));
-  return memcmp(h->magic, "HSRPLAN1", 8) == 0;
-}
-} // namespace
 
 extern "C"
 {
@@ -371,7 +252,7 @@ uint32_t hsrans_ctx_host_index_chains(hsrans_ctx *ctx)
 // kind needs (persistent arguments + host-built table, or the group list).  Device buffers are kept and grown, so a plan
 // object can be refilled per call without allocations (the host-pointer entries do that).  The device must be current.
 
-static int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, const PlanHeader &h, hipStream_t s)
+extern "C++" int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, const PlanHeader &h, hipStream_t s)
 {
   hsrans_ctx *ctx = d->ctx;
   d->hdr = h;
@@ -666,7 +547,7 @@ static uint8_t *device_view_of_host(const void *ptr, size_t bytes)
 }
 
 // one launch of a filled device plan (asynchronous on s; the device must be current)
-static int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity, hipStream_t s, uint64_t stream_lo = 0)
+extern "C++" int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity, hipStream_t s, uint64_t stream_lo)
 {
   KParams kp{};
   kp.stream = (const uint8_t *)d_stream;

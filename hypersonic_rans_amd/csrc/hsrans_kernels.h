@@ -109,6 +109,49 @@ struct KParams
   uint32_t private_pair;
 };
 
+// ---- K independent streams in one launch (kernels_batch.h, hsrans_batch.cpp) -----------------------------------------------
+// what is fixed when the batch is made: a member's plan, table and status word (device memory, read through the scalar cache)
+struct BatchMember
+{
+  const Piece *pieces;
+  const uint32_t *states;
+  const uint2 *table;        // host-built decode table (MODE 3)
+  const uint16_t *hist_copy; // the 256 counts it was built from
+  uint32_t *status;          // the member's own status word (its device plan's)
+  uint64_t hist_off;
+  uint32_t n_chains, bits, S, reserved;
+};
+static_assert(sizeof(BatchMember) == 64, "BatchMember layout");
+// one per wave of the launch: chains [begin, end) of member `member` are the wave's run (begin == end == n_chains: none)
+struct BatchSlot
+{
+  uint32_t member, begin, end, flags;
+};
+constexpr uint32_t kBatchSlotCheckHist = 1; // the member's first workgroup: compares the table's histogram with the stream's
+// what changes from launch to launch: where the member's stream and output are.  Passed as kernel arguments (no copy in front of
+// the launch, graph-capturable), which bounds a launch at kBatchMax members; larger batches take several launches.
+struct BatchIO
+{
+  const uint8_t *stream;
+  uint64_t stream_len;
+  uint8_t *out;
+  uint64_t out_cap;
+};
+constexpr uint32_t kBatchMax = 32;
+struct BatchParams
+{
+  BatchIO io[kBatchMax];
+  const BatchMember *members;
+  const BatchSlot *slots;
+  uint64_t *finish; // diagnostics (batch stamps): wave w's finish time, [n_slots] = the first wave's entry; null otherwise
+  uint64_t *stamps;
+};
+struct BatchShape
+{
+  uint32_t grid, waves, lds;
+  uint32_t weights[8]; // per-mille run lengths of the 8 wave classes (class = (workgroup in the grid's second half) * 4 + wave / 4)
+};
+
 struct LaunchInfo
 {
   uint32_t grid, block, lds_bytes, waves_per_block, chains, shared_table, walk, two_level, table_mode, chains_per_wave;
@@ -126,6 +169,10 @@ struct DeviceGeom
   uint32_t have_direct_weights;
   uint32_t direct_weights[8];
 };
+
+// the launch all members of a batch of 64-state plans with 8-byte tables (bits <= 12) share; max_bits = the widest member
+BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits);
+hipError_t launch_batch_direct(const BatchParams &bp, const BatchShape &shape, hipStream_t stream);
 
 // a launch's shape as it follows from plan header + device (launch_shape)
 struct LaunchShape

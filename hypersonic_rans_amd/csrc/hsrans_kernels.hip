@@ -25,6 +25,7 @@
 //   kernels_common.h    ring, table build, group step + hand-scheduled groups, output path, generic chain runner
 //   kernels_persist.h   k_decode_persist   uniform-interval raw plans (static runs + ticket queues)
 //   kernels_direct.h    k_decode_direct    one chain (run of chains) per wave: the headline; k_calibrate
+//   kernels_batch.h     k_decode_batch     K independent streams in one launch of the one-chain-per-wave form
 //   kernels_grouped.h   k_decode_grouped   block_/mt_ plans with checkpoints (BASELINE config 4)
 //   kernels_spread.h    k_decode_spread    the same plans with few, large blocks: the chains dealt out evenly, two tables per workgroup
 //   kernels_generic.h   k_decode           mt_ without index, block_ header walk, index-build passes
@@ -44,6 +45,7 @@
 #include "kernels_common.h"
 #include "kernels_persist.h"
 #include "kernels_direct.h"
+#include "kernels_batch.h"
 #include "kernels_grouped.h"
 #include "kernels_spread.h"
 #include "kernels_generic.h"
@@ -301,6 +303,11 @@ hipError_t prepare_kernels(DeviceGeom *geom)
     if (e != hipSuccess)
       return e;
   }
+  {
+    const hipError_t e = hipFuncSetAttribute((const void *)k_decode_batch<kModePack64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
+    if (e != hipSuccess)
+      return e;
+  }
   return hipSuccess;
 }
 
@@ -489,6 +496,32 @@ size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, u
     prev = b;
   }
   return n + 1;
+}
+
+// The batch launch of 64-state plans with 8-byte tables: the one-chain-per-wave launch's own shape (two 16-wave workgroups per CU,
+// LDS = 16 rings + the widest member's table) and its age-class weights (the device's own once calibrated).
+BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits)
+{
+  PlanHeader h{};
+  h.states = 64;
+  h.bits = max_bits;
+  h.shared_hist = 1;
+  h.n_chains = 1u << 30; // "many": the full machine
+  const LaunchShape L = launch_shape(h, dg, true, kModePack64, 0, false, true, false);
+  BatchShape b{};
+  b.grid = L.grid;
+  b.waves = L.waves;
+  b.lds = L.lds;
+  for (uint32_t k = 0; k < 8; k++)
+    b.weights[k] = L.weights[k];
+  return b;
+}
+
+hipError_t launch_batch_direct(const BatchParams &bp, const BatchShape &shape, hipStream_t stream)
+{
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(k_decode_batch<kModePack64>, dim3(shape.grid), dim3(shape.waves * 64), shape.lds, stream, bp);
+  return hipGetLastError();
 }
 
 hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const DeviceGeom &dg, hipStream_t stream, LaunchInfo *info)

@@ -45,8 +45,10 @@ __device__ __forceinline__ DirectPiece direct_piece(const WaveCtx &c, const Pers
   return d;
 }
 
+// `w`: the wave's index in the launch (stamps, finish times); chains [ch, end) of kp.pa's plan are its run (ch >= n_chains: none);
+// `check_hist`: this workgroup compares the host-built table's histogram with the one in the stream
 template <int MODE>
-__device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, uint32_t w)
+__device__ __forceinline__ void run_direct_span(const WaveCtx &c, const KParams &kp, uint32_t waves, uint32_t w, uint32_t ch, uint32_t end, bool check_hist)
 {
   const PersistentArgs &pa = kp.pa;
   const uint32_t W = gridDim.x * waves;
@@ -72,7 +74,7 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
       for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
         *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
     }
-    if (blockIdx.x == 0 && threadIdx.x < 64)
+    if (check_hist && threadIdx.x < 64)
     {
       bool same = HSRANS_HIST_IN_RANGE(c, pa.hist_off) || pa.hist_off + 512 <= c.stream_lo; // (a window launch may lack the histogram: nothing to compare)
       if (same && pa.hist_off >= c.stream_lo)
@@ -92,9 +94,6 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
       t_table = __builtin_amdgcn_s_memrealtime();
   };
   const uint32_t n = pa.n_chains;
-  const uint32_t R = pa.run_chains ? pa.run_chains : 1; // launch_decode: W * R >= n
-  const uint32_t ch = w * R;                            // this wave's run: chains [ch, end)
-  const uint32_t end = ch + R < n ? ch + R : n;
   if (ch < n)
   {
     StreamWin sw;
@@ -156,6 +155,15 @@ __device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, 
     st[7] = (uint64_t)diag_wait | ((uint64_t)diag_store << 32); // shader clocks waiting at chunk crossings | issuing stores (-DHSRANS_DIAG_STORE_TIME)
 #endif
   }
+}
+
+template <int MODE>
+__device__ void run_direct(const WaveCtx &c, const KParams &kp, uint32_t waves, uint32_t w)
+{
+  const uint32_t n = kp.pa.n_chains;
+  const uint32_t R = kp.pa.run_chains ? kp.pa.run_chains : 1; // launch_decode: W * R >= n
+  const uint32_t ch = w * R;                                  // this wave's run: chains [ch, end)
+  run_direct_span<MODE>(c, kp, waves, w, ch, ch + R < n ? ch + R : n, blockIdx.x == 0);
 }
 
 // Direct launch of a 32-state plan: wave w decodes chains 2w and 2w + 1 side by side (lanes 0..31 / 32..63, group_step_pair);

@@ -205,6 +205,46 @@ size_t hsrans_dplan_read_plan(hsrans_dplan *dplan, uint8_t *out, size_t capacity
 /* synchronises `hip_stream` and returns HSRANS_OK or HSRANS_E_DEVICE (kernel found a bad histogram/header) */
 int hsrans_dplan_status(hsrans_ctx *ctx, hsrans_dplan *dplan, void *hip_stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * K independent streams, ONE launch.  The reference decodes independent work from one pool — a task per mt_ block on its
+ * thread pool (src/mt_rANS32x64_16w_decode.cpp:182-224), file after file in its benchmark loop (src/main.cpp:841-898); on the
+ * GPU the pool is the device's resident wave slots.  One launch per stream pays the launch's prologue, tail and kernel boundary
+ * (~11 of ~41 us for a 100 MB stream) K times, and launches put on several HIP streams cannot co-reside (every plan is shaped
+ * to fill the device).  A batch deals the wave slots of ONE launch to its members — whole workgroups (a workgroup holds one
+ * decode table), in proportion to the members' sizes, each member's chains cut into runs sized by the slots' scheduling
+ * class — so the three are paid once.  Members keep their own device plans, status words and results; a member whose plan
+ * the shared kernels do not take (an un-indexed raw stream, 13-15 bits, ...) gets its own launch behind them, in the same call.
+ * Best served: raw streams of 64 states, <= 12 bits, with the one-chain-per-wavefront index (hsrans_index_boundaries) when the
+ * members are 1, 2 or 4 of about one size, or with a uniform index (hsrans_encode_opts::index_interval) for any mix.
+ * The dplans must outlive the batch and must not be refilled while it exists; a dplan belongs to at most one member.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct hsrans_batch hsrans_batch;
+int hsrans_dplan_batch_create(hsrans_ctx *ctx, hsrans_dplan *const *dplans, uint32_t count, hsrans_batch **out_batch);
+void hsrans_dplan_batch_destroy(hsrans_batch *batch);
+/* member k: stream d_streams[k] (16-byte aligned, stream_lengths[k] bytes) -> d_outs[k] (4-byte aligned, out_capacities[k]).
+ * Asynchronous on `hip_stream`, no allocation, no synchronisation; nothing is launched unless every member's arguments pass. */
+int hsrans_decode_device_batch(hsrans_ctx *ctx, hsrans_batch *batch, const void *const *d_streams, const size_t *stream_lengths, void *const *d_outs,
+                               const size_t *out_capacities, void *hip_stream);
+/* synchronises `hip_stream`; member_status[k] (may be NULL) = hsrans_dplan_status of member k; returns the first failure or HSRANS_OK */
+int hsrans_dplan_batch_status(hsrans_ctx *ctx, hsrans_batch *batch, void *hip_stream, int *member_status);
+typedef struct hsrans_batch_info
+{
+  uint32_t members, launches;            /* kernel launches one hsrans_decode_device_batch call makes */
+  uint32_t direct_members, solo_members; /* members in the shared one-chain-per-wave launch(es) / with a launch of their own */
+  uint32_t grid, block, lds_bytes;       /* the (first) shared launch */
+  uint32_t class_weights[8];             /* per-mille run lengths of the 8 wave scheduling classes it was dealt with */
+  double imbalance;                      /* its most loaded wave slot (groups / class weight) over the mean: 1.0 = all waves end together */
+} hsrans_batch_info;
+int hsrans_dplan_batch_info(const hsrans_batch *batch, hsrans_batch_info *info);
+/* The dealing alone, without a device (tests, planning): members' chain starts in groups (chain_starts[m][0 .. n_chains[m]], the last
+ * entry = all the member's groups) -> slots_out[4 * (wg * waves + wave)] = {member, first chain, end chain, flags}; returns the
+ * imbalance (see above), < 0 on bad arguments.  weights NULL = the MI355X defaults of the 64-state launch. */
+double hsrans_batch_deal(const uint64_t *const *chain_starts, const uint32_t *n_chains, uint32_t members, uint32_t grid, uint32_t waves, const uint32_t *weights,
+                         uint32_t *slots_out);
+/* diagnostics: with HSRANS_BATCH_STAMPS=1 in the environment when the batch is made, every wave of its first shared launch leaves
+ * its finish time (100 MHz) in slot wg * waves + wave, the launch's first wave its entry time in the slot after the last */
+size_t hsrans_dplan_batch_read_finish(hsrans_batch *batch, uint64_t *out, size_t capacity_u64);
+
 /* First decode of a stream that came WITHOUT an index (e.g. a reference-emitted mt_ stream: one chain per block,
  * src/mt_rANS32x64_16w_decode.cpp:137-265 decodes it with one thread per block): decodes like hsrans_decode_device with
  * `dplan` (from hsrans_plan_build + hsrans_dplan_create, or from hsrans_dplan_create_from_device_stream; HSRANS_RAW and

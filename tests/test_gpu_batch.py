@@ -1,0 +1,176 @@
+"""K independent streams decoded by ONE launch (include/hsrans_hip.h: hsrans_dplan_batch_*, hsrans_decode_device_batch) — the
+counterpart of the reference's pool of independent work items (src/mt_rANS32x64_16w_decode.cpp:182-224: a task per block;
+src/main.cpp:841-898: file after file).  Every member's output is compared with the scalar CPU oracle's decode of the same
+stream; the dealing of the wave slots is checked on the host without a GPU."""
+import numpy as np
+import pytest
+
+import hypersonic_rans_amd as H
+from hypersonic_rans_amd import synth
+from oracle_lib import BLOCK, MT, RAW
+
+GRID, WAVES = 512, 16
+
+
+def _starts_wave(n, states=64, bits=11):
+    g = H.index_boundaries(states, bits, n, None)
+    return np.concatenate([[0], g, [n // states]]).astype(np.uint64)
+
+
+def _starts_uniform(n, interval, states=64):
+    total = n // states
+    s = np.arange(0, total, interval, dtype=np.uint64)
+    return np.concatenate([s, [total]]).astype(np.uint64)
+
+
+@pytest.mark.parametrize("members", (
+    [("wave", 100_000_000)],
+    [("wave", 100_000_000)] * 2,
+    [("wave", 100_000_000)] * 4,
+    [("wave", 100_000_000)] * 5,
+    [(32, 100_000_000)] * 3,
+    [("wave", 100_000_000), (32, 100_000_000), (16, 3_000_000), ("wave", 1_000_000), (64, 64 * 1024)],
+    [(8, 1 << 20)] * 32,
+))
+def test_dealing_covers_every_chain_once_and_never_mixes_members_in_a_workgroup(members):
+    """hsrans_batch_deal (no device): every member's chains are dealt exactly once, in contiguous runs; a workgroup's 16 slots
+    name one member (a workgroup holds one decode table); exactly one workgroup per member checks the histogram."""
+    starts = [_starts_wave(n) if kind == "wave" else _starts_uniform(n, kind) for kind, n in members]
+    imbalance, slots = H.batch_deal(starts, GRID, WAVES)
+    assert slots.shape == (GRID * WAVES, 4) and imbalance >= 0.99
+    per_wg_member = slots[:, 0].reshape(GRID, WAVES)
+    assert (per_wg_member == per_wg_member[:, :1]).all(), "a workgroup mixes members"
+    for m, st in enumerate(starts):
+        nc = st.size - 1
+        mine = slots[slots[:, 0] == m]
+        runs = mine[mine[:, 1] < mine[:, 2]]
+        order = np.argsort(runs[:, 1], kind="stable")
+        runs = runs[order]
+        assert runs.shape[0] >= 1 and runs[0, 1] == 0 and runs[-1, 2] == nc
+        assert (runs[1:, 1] == runs[:-1, 2]).all(), "runs overlap or leave a gap"
+        idle = mine[mine[:, 1] >= mine[:, 2]]
+        assert (idle[:, 1] == nc).all() and (idle[:, 2] == nc).all()
+        wgs_checking = np.unique(np.nonzero((slots[:, 0] == m) & (slots[:, 3] & 1 != 0))[0] // WAVES)
+        assert wgs_checking.size == 1, "exactly one workgroup per member compares the histograms"
+    # members of one size and the one-chain-per-wave index at 1, 1/2, 1/4 of the device: an exact fit
+    if all(kind == "wave" for kind, _ in members) and len(members) in (1, 2, 4) and len({n for _, n in members}) == 1:
+        assert imbalance < 1.05, imbalance
+
+
+def test_dealing_rejects_bad_arguments():
+    st = _starts_uniform(1 << 20, 32)
+    with pytest.raises(H.HsransError):
+        H.batch_deal([st], 1, 16)
+    with pytest.raises(H.HsransError):
+        H.batch_deal([st[::-1].copy()], GRID, WAVES)
+
+
+# ---- on the GPU ---------------------------------------------------------------------------------------------------------------
+def _member(ctx, oracle, container, states, bits, n, seed, index):
+    """(stream, plan, expected bytes per the oracle, device tensors, device plan)"""
+    import torch
+
+    data = synth.enwik8_shaped(n, seed=seed)
+    if index == "wave":
+        stream, plan = H.encode(container, states, bits, data, index_groups=H.index_boundaries(states, bits, n, ctx))
+    elif index == "none":
+        stream = H.encode(container, states, bits, data)
+        plan = H.plan_build(container, states, bits, stream)
+    elif container == RAW:
+        stream, plan = H.encode(container, states, bits, data, index_interval=index)
+    else:
+        stream, plan = H.encode(container, states, bits, data, block_size=1 << 16, index_interval=index)
+    r, want = oracle.decode(container, states, bits, stream, n)
+    assert r == n and np.array_equal(want, data)
+    d_in = torch.from_numpy(np.concatenate([stream, np.zeros((-stream.size) % 16, np.uint8)])).cuda()
+    d_out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    return {"stream": stream, "plan": plan, "want": want, "d_in": d_in, "d_out": d_out, "dplan": ctx.make_device_plan(plan), "n": n}
+
+
+MIX = (  # container, states, bits, decoded bytes, index
+    (RAW, 64, 11, 3_000_001, "wave"),
+    (RAW, 64, 12, 1_000_000, 32),
+    (MT, 64, 11, 2_500_000, 32),
+    (RAW, 32, 11, 777_777, "wave"),
+    (RAW, 64, 14, 1_500_000, "wave"),
+    (RAW, 64, 10, 5_000_000, 16),
+    (BLOCK, 64, 12, 600_000, 64),
+    (RAW, 64, 11, 200_000, "none"),
+)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", (1, 2, 5, 8))
+def test_batch_of_mixed_streams_matches_the_oracle_per_stream(gpu_ctx, oracle, k):
+    """K = 1, 2, 5, 8 members of mixed container / width / state count / length / index kind in one call: every member's output
+    equals the oracle's decode of its stream, its status word is clean, and the members the shared launch takes are counted."""
+    import torch
+
+    ms = [_member(gpu_ctx, oracle, MIX[i][0], MIX[i][1], MIX[i][2], MIX[i][3], 100 + i, MIX[i][4]) for i in range(k)]
+    batch = gpu_ctx.make_batch([m["dplan"] for m in ms])
+    info = batch.info()
+    assert info["members"] == k
+    eligible = sum(1 for i in range(k) if MIX[i][0] == RAW and MIX[i][1] == 64 and MIX[i][2] <= 12 and MIX[i][4] != "none")
+    assert info["direct_members"] == (eligible if eligible >= 2 else 0)
+    assert info["direct_members"] + info["solo_members"] == k
+    for rep in range(2):  # (a batch is launched again and again)
+        for m in ms:
+            m["d_out"].zero_()
+        gpu_ctx.decode_device_batch(batch, [m["d_in"] for m in ms], [m["d_out"] for m in ms], stream_lengths=[m["stream"].size for m in ms])
+        torch.cuda.synchronize()
+        assert gpu_ctx.batch_status(batch) == [0] * k
+        for i, m in enumerate(ms):
+            assert np.array_equal(m["d_out"].cpu().numpy(), m["want"]), f"member {i} {MIX[i]} differs from the oracle (repeat {rep})"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,index", ((4, "wave"), (2, "wave"), (3, 32), (4, 32)))
+def test_batch_of_equal_streams_one_launch(gpu_ctx, oracle, k, index):
+    """The benchmark's shape at a size the oracle decodes in seconds: K streams of one size share ONE launch; bit-exact per stream."""
+    import torch
+
+    ms = [_member(gpu_ctx, oracle, RAW, 64, 11, 16_000_000, 7 + i, index) for i in range(k)]
+    batch = gpu_ctx.make_batch([m["dplan"] for m in ms])
+    info = batch.info()
+    assert info["launches"] == 1 and info["direct_members"] == k and info["solo_members"] == 0
+    if index == "wave" and k in (2, 4):
+        assert info["imbalance"] < 1.06, info
+    gpu_ctx.decode_device_batch(batch, [m["d_in"] for m in ms], [m["d_out"] for m in ms], stream_lengths=[m["stream"].size for m in ms])
+    torch.cuda.synchronize()
+    assert gpu_ctx.batch_status(batch) == [0] * k
+    for i, m in enumerate(ms):
+        assert np.array_equal(m["d_out"].cpu().numpy(), m["want"]), f"member {i} differs from the oracle"
+
+
+@pytest.mark.gpu
+def test_batch_reports_a_members_bad_histogram_and_decodes_the_others(gpu_ctx, oracle):
+    """A member whose stream does not carry the histogram its plan's table was built from (the reference's sum check, hist.cpp:308-324,
+    returns false -> its decoder returns 0): that member's status says so, the other members' outputs and statuses are untouched."""
+    import torch
+
+    ms = [_member(gpu_ctx, oracle, RAW, 64, 11, 2_000_000, 40 + i, 32) for i in range(3)]
+    bad = ms[1]["d_in"].clone()
+    bad[16 + 40] ^= 0x5A  # one count of the stream's histogram (raw header: [n][total][counts...])
+    batch = gpu_ctx.make_batch([m["dplan"] for m in ms])
+    gpu_ctx.decode_device_batch(batch, [ms[0]["d_in"], bad, ms[2]["d_in"]], [m["d_out"] for m in ms], stream_lengths=[m["stream"].size for m in ms])
+    torch.cuda.synchronize()
+    codes = gpu_ctx.batch_status(batch)
+    assert codes[0] == 0 and codes[2] == 0 and codes[1] != 0, codes
+    for i in (0, 2):
+        assert np.array_equal(ms[i]["d_out"].cpu().numpy(), ms[i]["want"])
+    assert gpu_ctx.batch_status(batch) == [0, 0, 0]  # (reported once, then cleared, like hsrans_dplan_status)
+
+
+@pytest.mark.gpu
+def test_batch_argument_checks(gpu_ctx, oracle):
+    import torch
+
+    ms = [_member(gpu_ctx, oracle, RAW, 64, 11, 300_000, 60 + i, 32) for i in range(2)]
+    with pytest.raises(H.HsransError):
+        gpu_ctx.make_batch([ms[0]["dplan"], ms[0]["dplan"]])  # a plan belongs to one member
+    batch = gpu_ctx.make_batch([m["dplan"] for m in ms])
+    small = torch.zeros(100, dtype=torch.uint8, device="cuda")
+    with pytest.raises(H.HsransError):
+        gpu_ctx.decode_device_batch(batch, [m["d_in"] for m in ms], [ms[0]["d_out"], small], stream_lengths=[m["stream"].size for m in ms])
+    torch.cuda.synchronize()
+    assert int(ms[0]["d_out"].sum().item()) == 0, "nothing may have been launched when one member's arguments fail"
