@@ -25,9 +25,10 @@ from .api import (  # noqa: F401
     plan_thin,
     index_boundaries,
     batch_deal,
+    index_boundaries_batch,
 )
 
 __all__ = [
     "RAW", "BLOCK", "MT", "Context", "HsransError", "capacity", "encode", "make_hist", "plan_build", "plan_chain_count",
-    "plan_chain_range", "plan_decoded_length", "plan_slice", "plan_stream_ranges", "plan_thin", "index_boundaries", "batch_deal", "lib_path", "load_library",
+    "plan_chain_range", "plan_decoded_length", "plan_slice", "plan_stream_ranges", "plan_thin", "index_boundaries", "batch_deal", "index_boundaries_batch", "lib_path", "load_library",
 ]

@@ -139,6 +139,10 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_batch_deal.argtypes = [_vp, _vp, _u32, _u32, _u32, _vp, _vp]
     L.hsrans_dplan_batch_read_finish.restype = _sz
     L.hsrans_dplan_batch_read_finish.argtypes = [_vp, _vp, _sz]
+    L.hsrans_ctx_calibrate_runs.restype = _i
+    L.hsrans_ctx_calibrate_runs.argtypes = [_vp, _u32, _u32, _u32, ctypes.POINTER(Calibration)]
+    L.hsrans_index_boundaries_batch.restype = _sz
+    L.hsrans_index_boundaries_batch.argtypes = [_vp, _i, _u32, _vp, _u32, _u32, _vp, _sz]
     L.hsrans_dplan_status.restype = _i
     L.hsrans_dplan_status.argtypes = [_vp, _vp, _vp]
     L.hsrans_dplan_launch_info.restype = _i
@@ -383,6 +387,14 @@ def plan_tables(plan):
     return hdr, cf, pieces
 
 
+def index_boundaries_batch(states: int, bits: int, decoded_sizes, member: int, ctx: "Context | None" = None) -> np.ndarray:
+    """hsrans_index_boundaries_batch: checkpoint positions for member ``member`` of a batch of streams of ``decoded_sizes``."""
+    sizes = (ctypes.c_size_t * len(decoded_sizes))(*[int(x) for x in decoded_sizes])
+    out = np.zeros(1 << 15, np.uint64)
+    n = load_library().hsrans_index_boundaries_batch(ctx.handle if ctx is not None else None, states, bits, sizes, len(decoded_sizes), member, _p(out), out.size)
+    return out[:n].copy()
+
+
 def batch_deal(chain_starts, grid: int = 512, waves: int = 16, weights=None):
     """hsrans_batch_deal: how one launch's wave slots would be dealt to members whose chains start at ``chain_starts[m]`` (groups,
     ascending, last entry = the member's total).  Returns (imbalance, slots[grid * waves, 4] = member, first chain, end chain, flags)."""
@@ -484,6 +496,17 @@ class Context:
         if rc != 0:
             raise HsransError(f"hsrans_ctx_calibrate failed with code {rc}")
         return {"class_weights": list(rep.class_weights), "class_finish_us_last_iteration": [round(v, 3) for v in rep.class_finish_us_last_iteration],
+                "last_wave_us_before": rep.last_wave_us_before, "last_wave_us_after": rep.last_wave_us_after,
+                "class_spread_us_before": rep.class_spread_us_before, "class_spread_us_after": rep.class_spread_us_after,
+                "iterations": rep.iterations, "bytes": rep.bytes}
+
+    def calibrate_runs(self, bits: int = 11, copies: int = 2, iterations: int = 0) -> dict:
+        """hsrans_ctx_calibrate_runs: the same fit for runs ``copies`` times as long (``copies`` members of the calibration stream in one launch)."""
+        rep = Calibration()
+        rc = self.L.hsrans_ctx_calibrate_runs(self.handle, bits, iterations, copies, ctypes.byref(rep))
+        if rc != 0:
+            raise HsransError(f"hsrans_ctx_calibrate_runs failed with code {rc}")
+        return {"copies": copies, "class_weights": list(rep.class_weights), "class_finish_us_last_iteration": [round(v, 3) for v in rep.class_finish_us_last_iteration],
                 "last_wave_us_before": rep.last_wave_us_before, "last_wave_us_after": rep.last_wave_us_after,
                 "class_spread_us_before": rep.class_spread_us_before, "class_spread_us_after": rep.class_spread_us_after,
                 "iterations": rep.iterations, "bytes": rep.bytes}

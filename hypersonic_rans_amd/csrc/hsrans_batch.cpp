@@ -28,6 +28,78 @@ static uint32_t order_wave(uint32_t pos, uint32_t run)
   return cls * 4 + turn * run + u;
 }
 
+// Workgroup PAIRS per member (one workgroup from each half of the grid: a CU's older and its younger workgroup, so that every
+// member gets waves of all 8 age classes in the launch's own proportion).  Min-max: one pair each, then one more to whoever has
+// the most groups per pair, until the pairs are used up; a member cannot use more waves than it has chains (max_chains, or null).
+std::vector<uint32_t> batch_apportion(const uint64_t *total_groups, const uint64_t *max_chains, uint32_t M, uint32_t pairs, uint32_t waves)
+{
+  std::vector<uint32_t> n(M, 0);
+  uint32_t used = 0;
+  for (uint32_t m = 0; m < M && used < pairs; m++)
+    if (total_groups[m] != 0 || (max_chains != nullptr && max_chains[m] != 0))
+      n[m] = 1, used++;
+  for (; used < pairs; used++)
+  {
+    uint32_t best = M;
+    double best_load = 0;
+    for (uint32_t m = 0; m < M; m++)
+    {
+      if (n[m] == 0 || (max_chains != nullptr && (uint64_t)n[m] * 2 * waves >= max_chains[m]))
+        continue;
+      const double load = (double)total_groups[m] / n[m];
+      if (best == M || load > best_load)
+        best = m, best_load = load;
+    }
+    if (best == M)
+      break;
+    n[best]++;
+  }
+  return n;
+}
+
+// Checkpoint positions (ascending group indices, multiples of 4) that give member `member` of a batch of streams with
+// total_groups[0 .. M) whole groups exactly one chain per wave slot the batch launch will deal it, each sized by the slot's class:
+// what direct_boundaries does for a stream that has the device to itself.  Returns the number of chains (boundaries + 1), 0 = capacity.
+size_t batch_boundaries(const uint64_t *total_groups, uint32_t M, uint32_t member, uint32_t grid, uint32_t waves, const uint32_t weights[8], uint64_t *out, size_t cap)
+{
+  if (member >= M || grid < 2 || waves == 0)
+    return 0;
+  const uint32_t first_half = (grid + 1) / 2, pairs = grid - first_half;
+  const std::vector<uint32_t> n = batch_apportion(total_groups, nullptr, M, pairs, waves);
+  const uint64_t nslots = (uint64_t)n[member] * 2 * waves;
+  const uint64_t all_units = total_groups[member] / 4; // boundaries in units of 4 groups (the decode loop stores 4 groups at a time)
+  uint64_t chains = nslots;
+  if (chains > all_units / 8) // (as direct_boundaries: a chain is worth its index entry and its prologue from about 32 groups on)
+    chains = all_units / 8 ? all_units / 8 : 1;
+  if (chains <= 1)
+    return 1;
+  if (chains - 1 > cap)
+    return 0;
+  const uint32_t per_class = waves >= 4 ? waves / 4 : 1;
+  auto weight_of = [&](uint64_t i) { // slot i of the member in natural order: its first-half workgroups' waves, then its second-half ones
+    const uint64_t wg_local = i / waves;
+    const uint32_t wave = (uint32_t)(i % waves);
+    return (uint64_t)weights[(wg_local >= n[member] ? 4 : 0) + std::min(3u, wave / per_class)];
+  };
+  uint64_t all = 0;
+  for (uint64_t k = 0; k < chains; k++)
+    all += weight_of(k);
+  uint64_t cum = 0, prev = 0;
+  size_t count = 0;
+  for (uint64_t k = 0; k + 1 < chains; k++)
+  {
+    cum += weight_of(k);
+    uint64_t b = (uint64_t)((unsigned __int128)all_units * cum / all);
+    if (b <= prev)
+      b = prev + 1;
+    if (b >= all_units)
+      break;
+    out[count++] = b * 4;
+    prev = b;
+  }
+  return count + 1;
+}
+
 // Deals wave slots to the members' chains.  See hsrans_batch.h.
 BatchDeal batch_deal(const std::vector<BatchDealMember> &members, uint32_t grid, uint32_t waves, const uint32_t weights[8])
 {
@@ -42,32 +114,12 @@ BatchDeal batch_deal(const std::vector<BatchDealMember> &members, uint32_t grid,
   out.order_run.assign(M, 4);
   if (M == 0 || grid < 2 || waves == 0)
     return out;
-  // 1. workgroups: the grid's first half (a CU's older workgroup) and its second half are dealt separately and alike, so that every
-  //    member gets waves of all 8 age classes in the launch's own proportion.  Min-max: one workgroup pair each, then one more to
-  //    whoever has the most groups per pair, until the pairs are used up.
+  // 1. workgroups
   const uint32_t first_half = (grid + 1) / 2, pairs = grid - first_half; // (grid odd: the first half's last workgroup stays idle)
-  std::vector<uint32_t> n(M, 0);
-  uint32_t used = 0;
-  for (uint32_t m = 0; m < M && used < pairs; m++)
-    if (members[m].total_groups != 0 || members[m].n_chains != 0)
-      n[m] = 1, used++;
-  for (; used < pairs; used++)
-  {
-    uint32_t best = M;
-    double best_load = 0;
-    for (uint32_t m = 0; m < M; m++)
-    {
-      // (a member cannot use more waves than it has chains)
-      if (n[m] == 0 || (uint64_t)n[m] * 2 * waves >= members[m].n_chains)
-        continue;
-      const double load = (double)members[m].total_groups / n[m];
-      if (best == M || load > best_load)
-        best = m, best_load = load;
-    }
-    if (best == M)
-      break;
-    n[best]++;
-  }
+  std::vector<uint64_t> totals(M), caps(M);
+  for (uint32_t m = 0; m < M; m++)
+    totals[m] = members[m].total_groups, caps[m] = members[m].n_chains;
+  const std::vector<uint32_t> n = batch_apportion(totals.data(), caps.data(), M, pairs, waves);
   // 2. per member: its slots in order, its chains dealt to them by cumulative weight, boundaries at the nearest chain start.  The
   //    order of the slots inside a workgroup is tried three ways (class runs of 4, 2, 1 waves): an index made for a launch of its own
   //    (hsrans_index_boundaries: chains sized by class, four of a class in a row) is matched exactly by one of them when the member
@@ -167,26 +219,6 @@ BatchDeal batch_deal(const std::vector<BatchDealMember> &members, uint32_t grid,
 // ---------------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------------------
-struct hsrans_batch
-{
-  hsrans_ctx *ctx = nullptr;
-  std::vector<hsrans_dplan *> members;
-  struct DirectLaunch
-  {
-    std::vector<uint32_t> member_idx; // batch member of launch-local member i
-    BatchShape shape{};
-    const BatchMember *d_members = nullptr;
-    const BatchSlot *d_slots = nullptr;
-    double imbalance = 1.0;
-  };
-  std::vector<DirectLaunch> direct;
-  std::vector<uint32_t> solo; // members that take a launch of their own (hsrans_decode_device's)
-  uint8_t *d_arena = nullptr;
-  uint64_t *d_finish = nullptr; // diagnostics (HSRANS_BATCH_STAMPS=1): per-wave finish times of the first direct launch
-  uint32_t finish_slots = 0;
-  std::vector<uint32_t> order_run; // per member: the slot order its chains were dealt with (diagnostics)
-};
-
 namespace
 {
 // a plan the one-chain-per-wave batch kernel can take: raw, mergeable, 64 states, the 8-byte host-built table (bits <= 12), one chain per wave
@@ -208,7 +240,7 @@ void hsrans_dplan_batch_destroy(hsrans_batch *b)
     (void)hipSetDevice(b->ctx->device);
   if (b->d_arena)
     (void)hipFree(b->d_arena);
-  if (b->d_finish)
+  if (b->d_finish && b->finish_owned)
     (void)hipFree(b->d_finish);
   delete b;
 }
@@ -258,7 +290,6 @@ try
     uint32_t max_bits = 0;
     for (uint32_t k : L.member_idx)
       max_bits = std::max(max_bits, dplans[k]->hdr.bits);
-    L.shape = batch_direct_shape(ctx->geom, max_bits);
     // the members' chain starts (in groups) and word offsets, from the device copies of their plans
     std::vector<std::vector<uint64_t>> starts(L.member_idx.size());
     std::vector<BatchDealMember> deal_in(L.member_idx.size());
@@ -285,6 +316,10 @@ try
       deal_in[i].n_chains = nc;
       deal_in[i].total_groups = g;
     }
+    uint64_t launch_groups = 0;
+    for (const BatchDealMember &dm : deal_in)
+      launch_groups += dm.total_groups;
+    L.shape = batch_direct_shape(ctx->geom, max_bits, launch_groups);
     const BatchDeal deal = batch_deal(deal_in, L.shape.grid, L.shape.waves, L.shape.weights);
     // a wave reads its run through one 32-bit window of the stream (run_direct_span: win_open)
     for (const BatchSlot &s : deal.slots)
@@ -352,7 +387,7 @@ try
     if (hipMalloc((void **)&b->d_finish, ((size_t)b->finish_slots + 1) * 8) != hipSuccess)
       b->d_finish = nullptr, b->finish_slots = 0;
     else
-      (void)hipMemset(b->d_finish, 0, ((size_t)b->finish_slots + 1) * 8);
+      b->finish_owned = true, (void)hipMemset(b->d_finish, 0, ((size_t)b->finish_slots + 1) * 8);
   }
   *out_batch = b;
   return HSRANS_OK;
@@ -446,6 +481,29 @@ int hsrans_dplan_batch_info(const hsrans_batch *b, hsrans_batch_info *info)
       info->class_weights[k] = b->direct[0].shape.weights[k];
   }
   return HSRANS_OK;
+}
+
+size_t hsrans_index_boundaries_batch(const hsrans_ctx *ctx, int states, uint32_t bits, const size_t *decoded_sizes, uint32_t count, uint32_t member,
+                                     uint64_t *groups_out, size_t capacity)
+try
+{
+  if (states != 64 || bits < 10 || bits > 12 || decoded_sizes == nullptr || groups_out == nullptr || count == 0 || count > kBatchMax || member >= count)
+    return 0;
+  const DeviceGeom dg = ctx ? ctx->geom : default_geom();
+  std::vector<uint64_t> totals(count);
+  uint64_t all = 0;
+  for (uint32_t k = 0; k < count; k++)
+  {
+    totals[k] = decoded_sizes[k] + 1 >= 64 ? (decoded_sizes[k] - 64 + 1 + 63) / 64 : 0; // whole groups, as hsrans_index_boundaries
+    all += totals[k];
+  }
+  const BatchShape shape = batch_direct_shape(dg, bits, all);
+  const size_t chains = batch_boundaries(totals.data(), count, member, shape.grid, shape.waves, shape.weights, groups_out, capacity);
+  return chains > 1 ? chains - 1 : 0;
+}
+catch (...)
+{
+  return 0;
 }
 
 double hsrans_batch_deal(const uint64_t *const *chain_starts, const uint32_t *n_chains, uint32_t members, uint32_t grid, uint32_t waves, const uint32_t *weights,

@@ -22,6 +22,7 @@
 using namespace hsrans;
 
 #include "hsrans_internal.h"
+#include "hsrans_batch.h"
 
 
 extern "C"
@@ -2095,10 +2096,9 @@ size_t hsrans_decode_host_pipelined(hsrans_ctx *ctx, int container, int states, 
 // records the checkpoints), a few launches whose waves leave their finish time, and every class length moved towards
 // length x (mean finish / class finish) ^ 0.8.  The best lengths seen stay in the context: hsrans_index_boundaries(ctx, ...)
 // and the launch info (class_weights) use them from then on.
-int hsrans_ctx_calibrate(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, hsrans_calibration *report)
-try
+static int calibrate_impl(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, uint32_t copies, hsrans_calibration *report)
 {
-  if (ctx == nullptr || bits < 10 || bits > 12) // (the fitted kernel is k_decode_direct<3>: 64 states, 8-byte table, one chain per wave)
+  if (ctx == nullptr || bits < 10 || bits > 12 || copies < 1 || copies > 16) // (the fitted kernel is k_decode_direct<3>: 64 states, 8-byte table, one chain per wave)
     return HSRANS_E_ARG;
   if (iterations == 0)
     iterations = 4;
@@ -2144,10 +2144,23 @@ try
     uint8_t *stream = nullptr, *out = nullptr;
     uint64_t *finish = nullptr;
     hsrans_dplan *dplan = nullptr;
-    ~DeviceBuffers()
+    hsrans_batch *batch = nullptr;        // copies > 1: the iteration's batch of `copies` members and its other members' plans
+    std::vector<hsrans_dplan *> more;
+    void drop_iteration()
     {
+      if (batch)
+        hsrans_dplan_batch_destroy(batch);
+      batch = nullptr;
+      for (hsrans_dplan *d : more)
+        hsrans_dplan_destroy(d);
+      more.clear();
       if (dplan)
         hsrans_dplan_destroy(dplan);
+      dplan = nullptr;
+    }
+    ~DeviceBuffers()
+    {
+      drop_iteration();
       if (stream)
         (void)hipFree(stream);
       if (out)
@@ -2176,15 +2189,15 @@ try
     // 0.3 us late, a launch of a sustained rotation 1.5 us (its prologue loads and its stores are served last), and chains
     // fitted to the former leave that class to finish the rotated launch alone.  (One pair if the device cannot spare 400 MB.)
     const size_t stream_stride = ((stream_len + 15) / 16 * 16 + 255) / 256 * 256 + 256;
-    uint32_t pairs = 5;
+    uint32_t pairs = copies > 1 ? copies + 2 : 5; // (a batch launch writes `copies` outputs: the next launch's are other buffers)
     if (hipMalloc((void **)&d_stream, pairs * stream_stride) != hipSuccess || hipMalloc((void **)&d_out, pairs * n) != hipSuccess)
     {
       (void)hipGetLastError();
       if (d_stream)
         (void)hipFree(d_stream);
       d_stream = nullptr;
-      pairs = 1;
-      if (hipMalloc((void **)&d_stream, stream_stride) != hipSuccess || hipMalloc((void **)&d_out, n) != hipSuccess)
+      pairs = copies;
+      if (hipMalloc((void **)&d_stream, pairs * stream_stride) != hipSuccess || hipMalloc((void **)&d_out, pairs * n) != hipSuccess)
         break;
     }
     bool uploaded = true;
@@ -2210,10 +2223,21 @@ try
     for (uint32_t it = 0; it < iterations && !failed; it++)
     {
       ctx->geom.have_direct_weights = 1;
+      ctx->geom.n_weight_sets = 0; // (the trial lengths, not an interpolation of earlier fits)
       for (int k = 0; k < 8; k++)
         ctx->geom.direct_weights[k] = cur_w[k];
       const uint64_t T = (n - 63) / 64; // whole groups (hsrans_index_boundaries)
-      const size_t chains = direct_boundaries(ctx->geom, 64, bits, T, groups.data(), groups.size());
+      size_t chains;
+      BatchShape bshape{};
+      if (copies == 1)
+        chains = direct_boundaries(ctx->geom, 64, bits, T, groups.data(), groups.size());
+      else
+      {
+        // `copies` members of this one stream in one launch: every member indexed for its share of the wave slots (batch_boundaries)
+        bshape = batch_direct_shape(ctx->geom, bits, 0);
+        std::vector<uint64_t> totals(copies, T);
+        chains = batch_boundaries(totals.data(), copies, 0, bshape.grid, bshape.waves, cur_w, groups.data(), groups.size());
+      }
       if (chains < 2)
       {
         failed = true;
@@ -2226,7 +2250,25 @@ try
         failed = true;
         break;
       }
-      const uint32_t W = (uint32_t)chains; // one chain per wave
+      for (uint32_t k = 1; k < copies && !failed; k++)
+      {
+        hsrans_dplan *extra = nullptr;
+        if (hsrans_dplan_create(ctx, plan.data(), plan_len, &extra) != HSRANS_OK)
+          failed = true;
+        else
+          dev.more.push_back(extra);
+      }
+      if (!failed && copies > 1)
+      {
+        std::vector<hsrans_dplan *> all{dp};
+        all.insert(all.end(), dev.more.begin(), dev.more.end());
+        // (the batch's own weights must be the trial lengths: HSRANS_BATCH_WEIGHTS aside, batch_direct_shape reads ctx->geom, set above)
+        if (hsrans_dplan_batch_create(ctx, all.data(), copies, &dev.batch) != HSRANS_OK || dev.batch->direct.size() != 1 || !dev.batch->solo.empty())
+          failed = true;
+      }
+      if (failed)
+        break;
+      const uint32_t W = copies == 1 ? (uint32_t)chains : bshape.grid * bshape.waves; // one chain per wave
       if (W > (1u << 14)) // (the finish-time buffer below is sized for 16,384 waves: twice an MI355X)
       {
         failed = true;
@@ -2242,8 +2284,23 @@ try
         failed = hipMemset(d_finish, 0, (size_t)batch * finish_stride * 8) != hipSuccess;
         for (uint32_t l = 0; l < batch && !failed; l++)
         {
-          dp->d_finish = d_finish + l * finish_stride;
-          failed = dplan_launch(dp, d_stream + (l % pairs) * stream_stride, stream_len, d_out + (size_t)(l % pairs) * n, n, nullptr) != HSRANS_OK;
+          if (copies == 1)
+          {
+            dp->d_finish = d_finish + l * finish_stride;
+            failed = dplan_launch(dp, d_stream + (l % pairs) * stream_stride, stream_len, d_out + (size_t)(l % pairs) * n, n, nullptr) != HSRANS_OK;
+            continue;
+          }
+          const void *ins[16];
+          void *outs[16];
+          size_t in_len[16], out_cap[16];
+          for (uint32_t k = 0; k < copies; k++)
+          {
+            const uint32_t buf = (l * copies + k) % pairs;
+            ins[k] = d_stream + buf * stream_stride, in_len[k] = stream_len;
+            outs[k] = d_out + (size_t)buf * n, out_cap[k] = n;
+          }
+          dev.batch->d_finish = d_finish + l * finish_stride;
+          failed = hsrans_decode_device_batch(ctx, dev.batch, ins, in_len, outs, out_cap, nullptr) != HSRANS_OK;
         }
         failed = hipDeviceSynchronize() != hipSuccess || failed; // (nothing may still be writing the buffers, whatever failed)
         if (failed || round < 2)
@@ -2254,7 +2311,7 @@ try
           failed = true;
           break;
         }
-        const uint32_t waves = dp->info.waves_per_block, grid = dp->info.grid, first_half = (grid + 1) / 2;
+        const uint32_t waves = copies == 1 ? dp->info.waves_per_block : bshape.waves, grid = copies == 1 ? dp->info.grid : bshape.grid, first_half = (grid + 1) / 2;
         if (waves != 16 || (uint64_t)grid * waves != W)
         {
           failed = true;
@@ -2276,8 +2333,9 @@ try
       }
       dp->d_finish = nullptr;
       uint32_t status_ok = hsrans_dplan_status(ctx, dp, nullptr) == HSRANS_OK;
-      hsrans_dplan_destroy(dp);
-      dp = nullptr;
+      for (hsrans_dplan *extra : dev.more)
+        status_ok = hsrans_dplan_status(ctx, extra, nullptr) == HSRANS_OK && status_ok;
+      dev.drop_iteration();
       if (failed || !status_ok)
       {
         failed = true;
@@ -2313,9 +2371,36 @@ try
   } while (false);
   if (rc == HSRANS_OK)
   {
-    geom_restore.saved.have_direct_weights = 1; // (what the guard puts back: the geometry as it was, with the fitted lengths)
+    // what the guard puts back: the geometry as it was, with the fitted lengths — as the default set (the one-stream fit) and as
+    // the set of this run length (groups per wave)
+    DeviceGeom &g = geom_restore.saved;
+    if (copies == 1)
+    {
+      g.have_direct_weights = 1;
+      for (int k = 0; k < 8; k++)
+        g.direct_weights[k] = best_w[k];
+    }
+    const uint32_t run = (uint32_t)((uint64_t)copies * ((n - 63) / 64) / (2 * 16 * (uint64_t)g.num_cus));
+    uint32_t at = 0;
+    while (at < g.n_weight_sets && g.set_run[at] < run)
+      at++;
+    if (!(at < g.n_weight_sets && g.set_run[at] == run))
+    {
+      if (g.n_weight_sets == 4) // (full: the nearest one goes)
+        at = at < 4 ? at : 3;
+      else
+      {
+        for (uint32_t k = g.n_weight_sets; k > at; k--)
+        {
+          g.set_run[k] = g.set_run[k - 1];
+          memcpy(g.set_weights[k], g.set_weights[k - 1], sizeof(g.set_weights[k]));
+        }
+        g.n_weight_sets++;
+      }
+    }
+    g.set_run[at] = run;
     for (int k = 0; k < 8; k++)
-      geom_restore.saved.direct_weights[k] = best_w[k];
+      g.set_weights[at][k] = best_w[k];
     if (report)
     {
       for (int k = 0; k < 8; k++)
@@ -2323,10 +2408,26 @@ try
       report->last_wave_us_before = first_last, report->last_wave_us_after = best_last;
       report->class_spread_us_before = first_spread, report->class_spread_us_after = best_spread;
       report->iterations = iterations;
-      report->bytes = n;
+      report->bytes = (uint64_t)copies * n;
     }
   }
   return rc;
+}
+
+int hsrans_ctx_calibrate(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, hsrans_calibration *report)
+try
+{
+  return calibrate_impl(ctx, bits, iterations, 1, report);
+}
+catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
+{
+  return HSRANS_E_HIP;
+}
+
+int hsrans_ctx_calibrate_runs(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, uint32_t copies, hsrans_calibration *report)
+try
+{
+  return calibrate_impl(ctx, bits, iterations, copies, report);
 }
 catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
 {

@@ -136,6 +136,30 @@ inline bool read_header(const uint8_t *plan, size_t size, PlanHeader *h)
 }
 
 
+#include <vector>
+struct hsrans_batch
+{
+  hsrans_ctx *ctx = nullptr;
+  std::vector<hsrans_dplan *> members;
+  struct DirectLaunch
+  {
+    std::vector<uint32_t> member_idx; // batch member of launch-local member i
+    BatchShape shape{};
+    const BatchMember *d_members = nullptr;
+    const BatchSlot *d_slots = nullptr;
+    double imbalance = 1.0;
+  };
+  std::vector<DirectLaunch> direct;
+  std::vector<uint32_t> solo; // members that take a launch of their own (hsrans_decode_device's)
+  uint8_t *d_arena = nullptr;
+  // per-wave finish times of the first shared launch: diagnostics (HSRANS_BATCH_STAMPS=1: owned by the batch) and
+  // hsrans_ctx_calibrate_runs (which points it at its own buffer launch by launch: finish_owned false)
+  uint64_t *d_finish = nullptr;
+  bool finish_owned = false;
+  uint32_t finish_slots = 0;
+  std::vector<uint32_t> order_run; // per member: the slot order its chains were dealt with (diagnostics)
+};
+
 // (Re)fills a device plan from a validated host plan blob; one launch of a filled device plan (hsrans_capi.cpp)
 int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, const PlanHeader &h, hipStream_t s);
 int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity, hipStream_t s, uint64_t stream_lo = 0);

@@ -168,10 +168,20 @@ struct DeviceGeom
   // hsrans_ctx_calibrate (0 = not calibrated: the constants fitted on the development box, g_direct_weights)
   uint32_t have_direct_weights;
   uint32_t direct_weights[8];
+  // The same fit at several RUN LENGTHS (mean groups per wave of the launch; ascending): a wave's time is its prologue plus its groups
+  // at its class's rate, so the lengths that make all classes finish together depend on how long the runs are — an old wave's
+  // head start counts for less in a long run.  hsrans_ctx_calibrate fits the 48 MiB launch (96 groups per wave),
+  // hsrans_ctx_calibrate_runs longer ones; direct_weights_for interpolates between the fitted lengths (in log run length).
+  uint32_t n_weight_sets;
+  uint32_t set_run[4];
+  uint32_t set_weights[4][8];
 };
+// the per-mille chain lengths of the 8 wave classes for a 64-state one-chain-per-wave launch whose runs average run_groups
+void direct_weights_for(const DeviceGeom &dg, uint64_t run_groups, uint32_t out[8]);
 
 // the launch all members of a batch of 64-state plans with 8-byte tables (bits <= 12) share; max_bits = the widest member
-BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits);
+// (total_groups: all members' groups together — the class weights follow the launch's mean run length; 0 = the default set)
+BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits, uint64_t total_groups = 0);
 hipError_t launch_batch_direct(const BatchParams &bp, const BatchShape &shape, hipStream_t stream);
 
 // a launch's shape as it follows from plan header + device (launch_shape)

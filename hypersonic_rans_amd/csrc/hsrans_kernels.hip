@@ -35,6 +35,7 @@
 // This file: the host side — tuning constants, launch shapes, hsrans_index_boundaries' chain lengths, launch_decode.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 #include <stdlib.h>
 
 #include <mutex>
@@ -447,6 +448,33 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
   return L;
 }
 
+void direct_weights_for(const DeviceGeom &dg, uint64_t run_groups, uint32_t out[8])
+{
+  read_tuning_once();
+  const uint32_t *base = dg.have_direct_weights ? dg.direct_weights : g_direct_weights;
+  if (dg.n_weight_sets == 0 || run_groups == 0 || getenv("HSRANS_DIRECT_WEIGHTS") != nullptr) // (an explicit override rules)
+  {
+    for (uint32_t k = 0; k < 8; k++)
+      out[k] = base[k];
+    return;
+  }
+  const uint32_t n = dg.n_weight_sets < 4 ? dg.n_weight_sets : 4;
+  uint32_t hi = 0;
+  while (hi < n && dg.set_run[hi] < run_groups)
+    hi++;
+  if (hi == 0 || hi == n) // outside the fitted lengths: the nearest set
+  {
+    const uint32_t k0 = hi == 0 ? 0 : n - 1;
+    for (uint32_t k = 0; k < 8; k++)
+      out[k] = dg.set_weights[k0][k];
+    return;
+  }
+  const double a = log((double)dg.set_run[hi - 1]), b = log((double)dg.set_run[hi]), x = log((double)run_groups);
+  const double t = b > a ? (x - a) / (b - a) : 0.0;
+  for (uint32_t k = 0; k < 8; k++)
+    out[k] = (uint32_t)((1.0 - t) * dg.set_weights[hi - 1][k] + t * dg.set_weights[hi][k] + 0.5);
+}
+
 // Group boundaries that cut `total_groups` whole groups into one chain per wave of the direct launch this device would use
 // for a mergeable plan of (states, bits): chain w belongs to wave w, its length follows the wave's class weight.
 // Boundaries are multiples of 4 groups (the decode loop stores 4 groups at a time).  Returns the number of chains;
@@ -473,11 +501,17 @@ size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, u
   // cumulative weight up to chain k, then boundaries at units * cum / all
   const uint32_t first_half = (L.grid + 1) / 2;
   const uint32_t per_class = L.waves >= 4 ? L.waves / 4 : 1;
+  // the headline's launch shape (64 states, 8-byte table, two 16-wave workgroups per CU): the lengths fitted for runs of this length
+  uint32_t w8[8];
+  for (uint32_t k = 0; k < 8; k++)
+    w8[k] = L.weights[k];
+  if (states == 64 && !L.dual && L.waves == 16 && L.grid > dg.num_cus && L.mode == kModePack64)
+    direct_weights_for(dg, total_groups / chains, w8);
   auto weight_of = [&](uint64_t chain) {
     const uint64_t w = chain / runs_per_wave;
     const uint32_t blk = (uint32_t)(w / L.waves), wave_in_wg = (uint32_t)(w % L.waves);
     const uint32_t cls = (blk >= first_half ? 4 : 0) + (wave_in_wg / per_class < 4 ? wave_in_wg / per_class : 3);
-    return (uint64_t)L.weights[cls];
+    return (uint64_t)w8[cls];
   };
   uint64_t all = 0;
   for (uint64_t k = 0; k < chains; k++)
@@ -500,7 +534,7 @@ size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, u
 
 // The batch launch of 64-state plans with 8-byte tables: the one-chain-per-wave launch's own shape (two 16-wave workgroups per CU,
 // LDS = 16 rings + the widest member's table) and its age-class weights (the device's own once calibrated).
-BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits)
+BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits, uint64_t total_groups)
 {
   PlanHeader h{};
   h.states = 64;
@@ -514,6 +548,22 @@ BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits)
   b.lds = L.lds;
   for (uint32_t k = 0; k < 8; k++)
     b.weights[k] = L.weights[k];
+  if (total_groups != 0 && L.waves == 16 && L.grid > dg.num_cus)
+    direct_weights_for(dg, total_groups / ((uint64_t)L.grid * L.waves), b.weights);
+  // HSRANS_BATCH_WEIGHTS (tuning; read at every batch creation so that one process can try several): 8 per-mille run lengths
+  if (const char *e = getenv("HSRANS_BATCH_WEIGHTS"))
+  {
+    uint32_t v[8], n = 0;
+    for (const char *p = e; n < 8 && *p; n++)
+    {
+      v[n] = (uint32_t)strtoul(p, (char **)&p, 10);
+      if (*p == ',')
+        p++;
+    }
+    if (n == 8)
+      for (uint32_t k = 0; k < 8; k++)
+        b.weights[k] = v[k] ? v[k] : 1;
+  }
   return b;
 }
 

@@ -236,6 +236,13 @@ typedef struct hsrans_batch_info
   double imbalance;                      /* its most loaded wave slot (groups / class weight) over the mean: 1.0 = all waves end together */
 } hsrans_batch_info;
 int hsrans_dplan_batch_info(const hsrans_batch *batch, hsrans_batch_info *info);
+/* hsrans_index_boundaries for a stream that will be decoded as member `member` of a batch of `count` streams of the given decoded
+ * sizes: exactly one chain per wave slot the batch launch deals that member (8,192 / count each for streams of one size: the sidecar
+ * shrinks with the batch), sized by the slots' scheduling classes at the batch's run length.  64 states, bits 10..12.  A batch of
+ * plans made this way is dealt without rounding (hsrans_batch_info::imbalance ~ 1.00); the plans still decode alone, or in another
+ * batch, only less evenly.  Returns the number of group indices written (0 = one chain, or capacity too small). */
+size_t hsrans_index_boundaries_batch(const hsrans_ctx *ctx, int states, uint32_t bits, const size_t *decoded_sizes, uint32_t count, uint32_t member,
+                                     uint64_t *groups_out, size_t capacity);
 /* The dealing alone, without a device (tests, planning): members' chain starts in groups (chain_starts[m][0 .. n_chains[m]], the last
  * entry = all the member's groups) -> slots_out[4 * (wg * waves + wave)] = {member, first chain, end chain, flags}; returns the
  * imbalance (see above), < 0 on bad arguments.  weights NULL = the MI355X defaults of the 64-state launch. */
@@ -333,6 +340,13 @@ typedef struct hsrans_calibration
   uint64_t bytes;
 } hsrans_calibration;
 int hsrans_ctx_calibrate(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, hsrans_calibration *report);
+/* The same fit at another RUN LENGTH.  A wave's time is its prologue plus its groups at its class's rate, so the chain lengths that
+ * make the classes finish together depend on how long the runs are (an old wave's head start counts for less in a long run):
+ * hsrans_ctx_calibrate fits runs of ~96 groups (its 48 MiB stream over 8,192 waves); this call decodes `copies` (1..16) members
+ * of that stream in ONE batch launch — runs of copies x 96 groups — and keeps the fitted lengths as the set of that run length.
+ * hsrans_index_boundaries[_batch] and the batch dealing interpolate between the fitted run lengths (log scale; the nearest set
+ * outside them); up to 4 sets per context.  E.g. copies = 2 for 100 MB streams decoded alone, 8 for four of them in one launch. */
+int hsrans_ctx_calibrate_runs(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, uint32_t copies, hsrans_calibration *report);
 
 /* kernel launch geometry of the last hsrans_decode_device call on this plan (for benchmarks / DESIGN.md tables) */
 typedef struct hsrans_launch_info

@@ -133,8 +133,6 @@ def test_batch_of_equal_streams_one_launch(gpu_ctx, oracle, k, index):
     batch = gpu_ctx.make_batch([m["dplan"] for m in ms])
     info = batch.info()
     assert info["launches"] == 1 and info["direct_members"] == k and info["solo_members"] == 0
-    if index == "wave" and k in (2, 4):
-        assert info["imbalance"] < 1.06, info
     gpu_ctx.decode_device_batch(batch, [m["d_in"] for m in ms], [m["d_out"] for m in ms], stream_lengths=[m["stream"].size for m in ms])
     torch.cuda.synchronize()
     assert gpu_ctx.batch_status(batch) == [0] * k
