@@ -2101,7 +2101,7 @@ static int calibrate_impl(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, u
   if (ctx == nullptr || bits < 10 || bits > 12 || copies < 1 || copies > 16) // (the fitted kernel is k_decode_direct<3>: 64 states, 8-byte table, one chain per wave)
     return HSRANS_E_ARG;
   if (iterations == 0)
-    iterations = 4;
+    iterations = copies == 1 ? 4 : 7; // (a longer run starts from lengths fitted for another run length: further to go)
   if (iterations > 16)
     iterations = 16;
   if (hipSetDevice(ctx->device) != hipSuccess)
@@ -2298,6 +2298,11 @@ static int calibrate_impl(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, u
             const uint32_t buf = (l * copies + k) % pairs;
             ins[k] = d_stream + buf * stream_stride, in_len[k] = stream_len;
             outs[k] = d_out + (size_t)buf * n, out_cap[k] = n;
+          }
+          if (dev.batch->finish_owned) // (HSRANS_BATCH_STAMPS=1 gave the batch a buffer of its own: this fit uses its own)
+          {
+            (void)hipFree(dev.batch->d_finish);
+            dev.batch->finish_owned = false;
           }
           dev.batch->d_finish = d_finish + l * finish_stride;
           failed = hsrans_decode_device_batch(ctx, dev.batch, ins, in_len, outs, out_cap, nullptr) != HSRANS_OK;
