@@ -2279,8 +2279,17 @@ static int calibrate_impl(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, u
       if (d_finish == nullptr && hipMalloc((void **)&d_finish, (size_t)batch * finish_stride * 8) != hipSuccess)
         failed = true;
       double cls_t[8] = {}, cls_n[8] = {}, last = 0;
-      for (int round = 0; round < 3 && !failed; round++) // (two batches settle clocks and caches and are not counted)
+      // Rounds of back-to-back launches; only the last one is measured.  The ones before it run until the device has been busy for
+      // 20 ms (and at least twice): every iteration begins with host work (the index pass, the device plans) during which the GPU
+      // idles, and a GPU that wakes from idle runs the first ~12 ms at other clocks than it then keeps (tools/settle_probe.py,
+      // profiles/r04_settle.txt) — lengths fitted in that transient left the youngest class 4 % short on some boxes (round 5:
+      // the classes of a 4 x 100 MB batch finished 5 us apart after a fit whose own last round had them within 0.5 us).
+      const auto t_busy = std::chrono::steady_clock::now();
+      bool measured = false;
+      for (int round = 0; !measured && !failed; round++)
       {
+        const bool settle = round < 2 || std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_busy).count() < 20.0;
+        measured = !settle;
         failed = hipMemset(d_finish, 0, (size_t)batch * finish_stride * 8) != hipSuccess;
         for (uint32_t l = 0; l < batch && !failed; l++)
         {
@@ -2308,7 +2317,7 @@ static int calibrate_impl(hsrans_ctx *ctx, uint32_t bits, uint32_t iterations, u
           failed = hsrans_decode_device_batch(ctx, dev.batch, ins, in_len, outs, out_cap, nullptr) != HSRANS_OK;
         }
         failed = hipDeviceSynchronize() != hipSuccess || failed; // (nothing may still be writing the buffers, whatever failed)
-        if (failed || round < 2)
+        if (failed || settle)
           continue;
         finish.resize((size_t)batch * finish_stride);
         if (hipMemcpy(finish.data(), d_finish, finish.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
