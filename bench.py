@@ -137,7 +137,7 @@ def kernel_source_sha256() -> str:
     return h.hexdigest()
 
 
-def _pmc_profile(n: int, states: int, bits: int, index: str, pairs: int = 0):
+def _pmc_profile(n: int, states: int, bits: int, index: str, pairs: int = 0, units: int = 1):
     """The committed rocprofv3 PMC run of this very workload (profiles/*_pmc.json, written by tools/pmc_summary.py: FETCH_SIZE /
     WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  PMC counters cannot be collected
     from inside this process, so traffic is null unless such a run matches the workload AND was made with the kernels as they
@@ -149,7 +149,7 @@ def _pmc_profile(n: int, states: int, bits: int, index: str, pairs: int = 0):
         try:
             j = json.load(open(f))
             cfg = j["bench_line_under_trace"]["config"]
-            if (cfg["decoded_bytes"], cfg["states"], cfg["bits"], str(cfg.get("index", cfg.get("index_interval_groups")))) == (n, states, bits, index):
+            if (cfg["decoded_bytes"], cfg["states"], cfg["bits"], str(cfg.get("index", cfg.get("index_interval_groups"))), cfg.get("streams_per_launch", 1)) == (n, states, bits, index, units):
                 if cfg.get("kernel_source_sha256") != now:
                     stale = (os.path.relpath(f, ROOT), None)
                     continue
@@ -206,7 +206,23 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
     P = len(pairs)
     chains = H.plan_chain_count(pairs[0]["plan"])
 
+    # --one-launch: a step is ONE launch that decodes all P streams (hsrans_decode_device_batch; the streams' indexes shaped for that
+    # launch, hsrans_index_boundaries_batch) — the profiling form of mib_s.independent_streams_one_launch (tools/profile.sh r05_batch --one-launch)
+    units = 1
+    one_batch = None
+    if args.one_launch:
+        assert S == 64 and bits <= 12 and P >= 2, "--one-launch: 64 states, 10..12 bits, at least two streams"
+        shaped = [ctx.make_device_plan(ctx.index_build_at(H.RAW, S, bits, p["stream"], H.index_boundaries_batch(S, bits, [n] * P, k, ctx))) for k, p in enumerate(pairs)]
+        one_batch = ctx.make_batch(shaped)
+        units = P
+        for p, d in zip(pairs, shaped):
+            p["dplan"] = d
+        b_in0, b_out0, b_len0 = [p["d_in"] for p in pairs], [p["d_out"] for p in pairs], [p["stream"].size for p in pairs]
+
     def step(i):
+        if one_batch is not None:
+            ctx.decode_device_batch(one_batch, b_in0, b_out0, stream_lengths=b_len0)
+            return
         p = pairs[i % P]
         ctx.decode_device(p["dplan"], p["d_in"], p["d_out"], stream_length=p["stream"].size)
 
@@ -305,7 +321,7 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
     # + index"): the same K steps, launched alternately on two HIP streams, so that one launch's prologue and tail overlap its
     # neighbour's decode.  Not the headline: a step there is one launch with the GPU to itself.
     overlapped_ms = None
-    if not args.timed_only and world == 1:
+    if not args.timed_only and not args.one_launch and world == 1:
         side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         samples = []
         for _ in range(5):
@@ -321,7 +337,7 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
     # stream's chains cut into runs by the slots' age class — so that prologue, tail and kernel boundary are paid once for all P.
     # A step here is one launch that decodes all P streams (657 MB of stream + output: cold by construction).
     one_launch = None
-    if not args.timed_only and world == 1 and P >= 2 and S == 64 and bits <= 12:
+    if not args.timed_only and not args.one_launch and world == 1 and P >= 2 and S == 64 and bits <= 12:
         b_in, b_out, b_len = [p["d_in"] for p in pairs], [p["d_out"] for p in pairs], [p["stream"].size for p in pairs]
 
         def batch_leg(dplans):
@@ -378,11 +394,11 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
     stream, plan = pairs[0]["stream"], pairs[0]["plan"]
     ms_per_step = elapsed * 1e3 / args.steps
     k_avg = float(kernel_ms_span)
-    to_mib_s = lambda seconds: float(world * n / 2**20 / seconds * args.steps)
-    alg_bytes = int(np.mean([p["stream"].size for p in pairs])) + n  # compressed bytes read once + decoded bytes written once
+    to_mib_s = lambda seconds: float(world * units * n / 2**20 / seconds * args.steps)
+    alg_bytes = units * (int(np.mean([p["stream"].size for p in pairs])) + n)  # compressed bytes read once + decoded bytes written once (--one-launch: of all P streams)
     achieved = alg_bytes / (k_avg * 1e-3) / 1e9
-    groups_per_launch = n // S
-    prof = _pmc_profile(n, S, bits, args.index, P)
+    groups_per_launch = units * n // S
+    prof = _pmc_profile(n, S, bits, args.index, P, units)
     traffic, traffic_source, issue, traffic_stale = None, None, None, None
     if prof is not None and prof[1] is None:
         traffic_stale = prof[0]  # counters of this workload exist, but of kernels that have changed since: not reported
@@ -397,7 +413,7 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
                              "vector issue alone needs; counters from " + traffic_source}
     result = {
         "metric": "decode MiB/s (bit-exact) on 100 MB stream",
-        "value": world * n / 2**20 / elapsed * args.steps,
+        "value": world * units * n / 2**20 / elapsed * args.steps,
         "unit": "MiB/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -412,10 +428,11 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
             "workload": f"rANS32x{S} 16w {bits}-bit (raw + sidecar index) decode, {n} B enwik8-shaped synthetic (Zipf1.2/205 symbols, seed 20241008+rank), "
                         f"{P} distinct streams per GPU rotated through the timed loop ({P * (alg_bytes) / 2**20:.0f} MiB of stream + output: beyond the Infinity Cache), "
                         + ("index with one chain per resident wavefront" if args.index == "wave" else f"index with a checkpoint every {args.index} groups")
-                        + f" ({chains} chains)",
+                        + f" ({chains} chains)" + (f"; --one-launch: a step is ONE launch decoding all {P} streams (hsrans_decode_device_batch)" if args.one_launch else ""),
             "container": "raw", "states": S, "bits": bits, "decoded_bytes": n, "compressed_bytes": int(stream.size),
             "ratio": stream.size / n, "index": args.index, "plan_bytes": int(plan.size), "plan_over_compressed": plan.size / stream.size,
-            "effective_ratio_with_index": (stream.size + plan.size) / n, "chains": chains, "pairs": P,
+            "effective_ratio_with_index": (stream.size + plan.size) / n, "chains": chains, "pairs": P, "streams_per_launch": units,
+            "batch": one_batch.info() if one_batch is not None else None,
             "launch": info, "bit_exact": True, "sha256": shas[0], "host_encode_s": t_enc / P,
             # once per (stream, plan), outside the timed region: hsrans_dplan_create = plan validation + host-built table + upload of the index
             "plan_setup_ms": t_setup / P * 1e3,
@@ -429,8 +446,8 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
                   "p90": to_mib_s(np.percentile(region_s, 10)), "mean": to_mib_s(region_s.mean()), "repeats": int(region_s.size),
                   "per_repeat": [to_mib_s(x) for x in region_s], "ms_per_step_per_repeat": [float(x / args.steps * 1e3) for x in region_s],
                   "note": "each repeat = W warm-up steps + barrier/synchronize + K timed steps + synchronize/barrier; `value` is the median repeat",
-                  "best_single_launch": n / 2**20 / (float(np.min(kernel_ms)) * 1e-3),
-                  "warm_one_pair_replayed": n / 2**20 / (warm_ms * 1e-3), "launches_in_timed_region": args.steps,
+                  "best_single_launch": units * n / 2**20 / (float(np.min(kernel_ms)) * 1e-3),
+                  "warm_one_pair_replayed": units * n / 2**20 / (warm_ms * 1e-3), "launches_in_timed_region": args.steps,
                   # "1 stream, no index" = single_wavefront_no_plan below, "1 stream + index" = value, and "N independent streams":
                   "independent_streams_overlapped": None if overlapped_ms is None else
                   {"value": n / 2**20 / (overlapped_ms * 1e-3), "ms_per_stream": overlapped_ms, "frac_of_hbm_peak": alg_bytes / (overlapped_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -454,7 +471,7 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
             "warm": {"kernel_ms_avg": float(warm_ms), "frac": alg_bytes / (warm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms_per_pair": [float(x) for x in warm_each],
                      "cache_state": "one pair replayed back to back (Infinity-Cache resident, as BENCH_r01 measured)"},
             "issue_bound": issue,
-            "kernel": ("hsrans::k_decode_dual<%d>" % info["table_mode"]) if info["chains_per_wave"] == 2 else
+            "kernel": "hsrans::k_decode_batch<3>" if args.one_launch else ("hsrans::k_decode_dual<%d>" % info["table_mode"]) if info["chains_per_wave"] == 2 else
                       ("hsrans::k_decode_direct<%d>" % info["table_mode"]) if args.index == "wave" else
                       "hsrans::k_decode<%d, %s>" % (info["table_mode"], "true" if info["shared_table"] else "false"),
         },
@@ -846,6 +863,7 @@ def main() -> None:
     ap.add_argument("--no-calibrate", action="store_true", help="headline: shape the index with the compiled-in class lengths instead of fitting them to this device")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-single", action="store_true", help="skip the un-indexed single-wavefront and GPU-encoder legs")
+    ap.add_argument("--one-launch", action="store_true", help="a step = ONE launch that decodes all --pairs streams (hsrans_decode_device_batch), their indexes shaped for it")
     ap.add_argument("--timed-only", action="store_true", help="launch nothing but validation, warm-up and the timed rotation (profiling runs)")
     ap.add_argument("--rehearse", action="store_true",
                     help="NO GPU: ranks over gloo, sub-runs decoded by the library's host decoder — rehearses rank spawn, sharding and the pipelined "

@@ -305,7 +305,9 @@ hipError_t prepare_kernels(DeviceGeom *geom)
       return e;
   }
   {
-    const hipError_t e = hipFuncSetAttribute((const void *)k_decode_batch<kModePack64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
+    hipError_t e = hipFuncSetAttribute((const void *)k_decode_batch<kModePack64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)k_calibrate_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
     if (e != hipSuccess)
       return e;
   }
@@ -570,7 +572,10 @@ BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits, uint64_t 
 hipError_t launch_batch_direct(const BatchParams &bp, const BatchShape &shape, hipStream_t stream)
 {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(k_decode_batch<kModePack64>, dim3(shape.grid), dim3(shape.waves * 64), shape.lds, stream, bp);
+  if (bp.finish != nullptr)
+    hipLaunchKernelGGL(k_calibrate_batch, dim3(shape.grid), dim3(shape.waves * 64), shape.lds, stream, bp);
+  else
+    hipLaunchKernelGGL(k_decode_batch<kModePack64>, dim3(shape.grid), dim3(shape.waves * 64), shape.lds, stream, bp);
   return hipGetLastError();
 }
 

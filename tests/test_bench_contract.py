@@ -33,6 +33,8 @@ def test_bench_line_has_the_contract_keys():
     assert m["repeats"] >= 15 and len(m["per_repeat"]) == m["repeats"] and m["min"] <= m["p10"] <= m["median"] <= m["p90"] <= m["max"]
     assert abs(m["median"] - d["value"]) < 1e-6 * d["value"]
     assert m["independent_streams_overlapped"]["value"] > 0 and d["single_wavefront_no_plan"]["value"] > 0  # all three figures
+    one = m["independent_streams_one_launch"]  # K independent streams decoded by ONE launch, validated bit-exact inside bench.py
+    assert one["streams"] == 4 and one["batch"]["launches"] == 1 and one["batch"]["direct_members"] == 4 and one["value"] > 0 and 0 < one["frac_of_hbm_peak"] < 1
     # counters are only ever reported for the kernels as they are now
     assert len(d["config"]["kernel_source_sha256"]) == 64
     assert rf["traffic"] is None or rf["traffic_stale"] is None
