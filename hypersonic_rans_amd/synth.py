@@ -105,3 +105,20 @@ def two_symbol(n: int, seed: int = 5) -> np.ndarray:
     """Degenerate histogram: two symbols, 15:1."""
     u = splitmix64(seed, 0, n) >> np.uint64(60)
     return np.where(u == 0, np.uint8(0x41), np.uint8(0x7A)).astype(np.uint8)
+
+
+def zipf_bytes(n: int, exponent: float, symbols: int = 256, seed: int = 31, perm_seed: int = 7) -> np.ndarray:
+    """i.i.d. bytes over `symbols` symbols with weights 1 / rank^exponent (exponent 0 = uniform over the symbols).  The weights come
+    from floating point at run time: for sweeps that generate, encode and check in one process (tools/ratio_sweep.py), NOT for
+    fixtures that have to be regenerated identically elsewhere (those use the frozen table of enwik8_shaped)."""
+    w = np.floor(2.0**32 / np.arange(1, symbols + 1, dtype=np.float64) ** exponent).astype(np.uint64)
+    cdf = np.cumsum(w)
+    total = cdf[-1]
+    perm = _permutation(perm_seed)[:symbols]
+    out = np.empty(n, dtype=np.uint8)
+    for s0 in range(0, n, _CHUNK):
+        c = min(_CHUNK, n - s0)
+        u = splitmix64(seed, s0, c) >> np.uint64(40)
+        t = (u * total) >> np.uint64(24)
+        out[s0:s0 + c] = perm[np.searchsorted(cdf, t, side="right")]
+    return out
