@@ -642,8 +642,10 @@ def sharded_workload(args, world, rank, dv: _Dev, dist):
                 a = dv.mark()
                 dec.step(d_window, out, gather=False)
                 b = dv.mark()
-                if gather:
+                if gather and dv.rehearse:
                     sharded.gather_ranges(out, dec.ranges, None, dec.root, dec.out_base)
+                elif gather:
+                    dec.exchange(d_window, out)  # hsrans_decode_sharded(HSRANS_SHARD_EXCHANGE_ONLY): the same RCCL groups as the pipelined step's
                 c = dv.mark()
                 dv.sync()
                 dec_ms += dv.ms(a, b) / steps

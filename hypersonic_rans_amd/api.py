@@ -49,6 +49,19 @@ class BatchInfo(ctypes.Structure):
                [("class_weights", _u32 * 8), ("imbalance", ctypes.c_double)]
 
 
+class Shard(ctypes.Structure):
+    _fields_ = [("first_chain", _u32), ("chain_count", _u32), ("out_begin", ctypes.c_uint64), ("out_end", ctypes.c_uint64)]
+
+
+class ShardedInfo(ctypes.Structure):
+    _fields_ = [("world", _u32), ("rank", _u32), ("parts", _u32), ("root", ctypes.c_int32), ("window_begin", ctypes.c_uint64), ("window_end", ctypes.c_uint64),
+                ("out_base", ctypes.c_uint64), ("out_length", ctypes.c_uint64), ("decoded_length", ctypes.c_uint64), ("stream_length", ctypes.c_uint64)]
+
+
+COMM_ID_BYTES = 128
+SHARD_DECODE_ONLY, SHARD_DECODE_AND_EXCHANGE, SHARD_EXCHANGE_ONLY = 0, 1, 2
+
+
 def lib_path() -> str:
     # HSRANS_LIB: A/B a differently built libhsrans_hip.so in one process environment (kernel tuning only)
     if os.environ.get("HSRANS_LIB"):
@@ -143,6 +156,33 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_ctx_calibrate_runs.argtypes = [_vp, _u32, _u32, _u32, ctypes.POINTER(Calibration)]
     L.hsrans_index_boundaries_batch.restype = _sz
     L.hsrans_index_boundaries_batch.argtypes = [_vp, _i, _u32, _vp, _u32, _u32, _vp, _sz]
+    L.hsrans_comm_unique_id.restype = _i
+    L.hsrans_comm_unique_id.argtypes = [_vp]
+    L.hsrans_comm_create.restype = _i
+    L.hsrans_comm_create.argtypes = [_vp, _vp, _i, _i, ctypes.POINTER(_vp)]
+    L.hsrans_comm_destroy.restype = None
+    L.hsrans_comm_destroy.argtypes = [_vp]
+    L.hsrans_comm_rank.restype = _i
+    L.hsrans_comm_rank.argtypes = [_vp]
+    L.hsrans_comm_world.restype = _i
+    L.hsrans_comm_world.argtypes = [_vp]
+    L.hsrans_comm_rccl_version.restype = _i
+    L.hsrans_shard_layout.restype = _i
+    L.hsrans_shard_layout.argtypes = [_vp, _sz, _u32, _u32, _vp, _vp, _vp]
+    L.hsrans_sharded_create.restype = _i
+    L.hsrans_sharded_create.argtypes = [_vp, _vp, _vp, _sz, _u32, _vp, _i, ctypes.POINTER(_vp)]
+    L.hsrans_sharded_create_rank.restype = _i
+    L.hsrans_sharded_create_rank.argtypes = [_vp, _i, _i, _vp, _sz, _u32, _vp, _i, ctypes.POINTER(_vp)]
+    L.hsrans_sharded_destroy.restype = None
+    L.hsrans_sharded_destroy.argtypes = [_vp]
+    L.hsrans_sharded_info.restype = _i
+    L.hsrans_sharded_info.argtypes = [_vp, ctypes.POINTER(ShardedInfo), _vp, _sz]
+    L.hsrans_sharded_part_plan.restype = _vp
+    L.hsrans_sharded_part_plan.argtypes = [_vp, _u32]
+    L.hsrans_decode_sharded.restype = _i
+    L.hsrans_decode_sharded.argtypes = [_vp, _vp, _vp, _i, _vp]
+    L.hsrans_sharded_status.restype = _i
+    L.hsrans_sharded_status.argtypes = [_vp, _vp]
     L.hsrans_dplan_status.restype = _i
     L.hsrans_dplan_status.argtypes = [_vp, _vp, _vp]
     L.hsrans_dplan_launch_info.restype = _i
@@ -395,6 +435,23 @@ def index_boundaries_batch(states: int, bits: int, decoded_sizes, member: int, c
     return out[:n].copy()
 
 
+def shard_layout(plan, world: int, parts: int = 1, weights=None):
+    """hsrans_shard_layout: (shards[world][parts] as (first_chain, chain_count, out_begin, out_end), windows[world] as (begin, end)).
+    Pure host arithmetic in the C library — what every rank of a sharded decode computes identically."""
+    plan = _u8(plan)
+    shards = (Shard * (world * parts))()
+    windows = np.zeros(2 * world, np.uint64)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+    if w is not None and w.size != world:
+        raise HsransError("shard_layout: one weight per rank")
+    rc = load_library().hsrans_shard_layout(_p(plan), plan.size, world, parts, None if w is None else _p(w), shards, _p(windows))
+    if rc != 0:
+        raise HsransError(f"hsrans_shard_layout failed with code {rc}")
+    out = [[(int(shards[r * parts + k].first_chain), int(shards[r * parts + k].chain_count), int(shards[r * parts + k].out_begin), int(shards[r * parts + k].out_end))
+            for k in range(parts)] for r in range(world)]
+    return out, [(int(windows[2 * r]), int(windows[2 * r + 1])) for r in range(world)]
+
+
 def batch_deal(chain_starts, grid: int = 512, waves: int = 16, weights=None):
     """hsrans_batch_deal: how one launch's wave slots would be dealt to members whose chains start at ``chain_starts[m]`` (groups,
     ascending, last entry = the member's total).  Returns (imbalance, slots[grid * waves, 4] = member, first chain, end chain, flags)."""
@@ -442,8 +499,8 @@ class Batch:
 
 
 class DevicePlan:
-    def __init__(self, ctx: "Context", handle):
-        self.ctx, self.handle = ctx, handle
+    def __init__(self, ctx: "Context", handle, owned: bool = True):
+        self.ctx, self.handle, self.owned = ctx, handle, owned  # (owned False: a view of a plan another object destroys, e.g. a Sharded's sub-run)
 
     def launch_info(self) -> dict:
         info = LaunchInfo()
@@ -451,8 +508,91 @@ class DevicePlan:
         return {n: (list(getattr(info, n)) if n == "class_weights" else getattr(info, n)) for n, _ in LaunchInfo._fields_}
 
     def close(self):
-        if self.handle:
+        if self.handle and self.owned:
             load_library().hsrans_dplan_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """hsrans_comm: this process's rank in a communicator over the GPUs of the node (RCCL, bound by the C library at run time)."""
+
+    def __init__(self, ctx: "Context", comm_id: bytes, rank: int, world: int):
+        assert len(comm_id) == COMM_ID_BYTES
+        self.ctx = ctx
+        buf = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(comm_id)
+        h = _vp()
+        rc = ctx.L.hsrans_comm_create(ctx.handle, buf, rank, world, ctypes.byref(h))
+        if rc != 0:
+            raise HsransError(f"hsrans_comm_create(rank {rank} of {world}) failed with code {rc}")
+        self.handle, self.rank, self.world = h, rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
+        rc = load_library().hsrans_comm_unique_id(buf)
+        if rc != 0:
+            raise HsransError(f"hsrans_comm_unique_id failed with code {rc} (no RCCL could be bound?)")
+        return bytes(buf)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.L.hsrans_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Sharded:
+    """hsrans_sharded: this rank's share of ONE stream decoded by all ranks of a communicator (or, without one, decode only)."""
+
+    def __init__(self, ctx: "Context", plan, parts: int = 1, weights=None, root: int | None = None, comm: Comm | None = None, rank: int | None = None,
+                 world: int | None = None):
+        plan = _u8(plan)
+        self.ctx, self.comm = ctx, comm
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        h = _vp()
+        r = -1 if root is None else int(root)
+        if comm is not None:
+            rc = ctx.L.hsrans_sharded_create(ctx.handle, comm.handle, _p(plan), plan.size, parts, None if w is None else _p(w), r, ctypes.byref(h))
+        else:
+            rc = ctx.L.hsrans_sharded_create_rank(ctx.handle, rank, world, _p(plan), plan.size, parts, None if w is None else _p(w), r, ctypes.byref(h))
+        if rc != 0:
+            raise HsransError(f"hsrans_sharded_create failed with code {rc}")
+        self.handle = h
+        info = ShardedInfo()
+        shards = (Shard * (int(world if comm is None else comm.world) * parts))()
+        ctx.L.hsrans_sharded_info(h, ctypes.byref(info), shards, len(shards))
+        self.info = {n: getattr(info, n) for n, _ in ShardedInfo._fields_}
+        self.shards = [[(int(shards[q * parts + k].first_chain), int(shards[q * parts + k].chain_count), int(shards[q * parts + k].out_begin), int(shards[q * parts + k].out_end))
+                        for k in range(parts)] for q in range(info.world)]
+
+    def part_plan(self, k: int) -> DevicePlan | None:
+        h = self.ctx.L.hsrans_sharded_part_plan(self.handle, k)
+        return DevicePlan(self.ctx, _vp(h), owned=False) if h else None
+
+    def decode(self, d_window: torch.Tensor, d_out: torch.Tensor, mode: int = SHARD_DECODE_AND_EXCHANGE, stream: torch.cuda.Stream | None = None):
+        s = stream if stream is not None else torch.cuda.current_stream(d_out.device)
+        rc = self.ctx.L.hsrans_decode_sharded(self.handle, d_window.data_ptr(), d_out.data_ptr(), mode, ctypes.c_void_p(s.cuda_stream))
+        if rc != 0:
+            raise HsransError(f"hsrans_decode_sharded failed with code {rc}")
+
+    def status(self, stream: torch.cuda.Stream | None = None) -> int:
+        s = stream if stream is not None else torch.cuda.current_stream()
+        return self.ctx.L.hsrans_sharded_status(self.handle, ctypes.c_void_p(s.cuda_stream))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.L.hsrans_sharded_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

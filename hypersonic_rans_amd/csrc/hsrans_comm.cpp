@@ -1,0 +1,496 @@
+// hsrans_comm.cpp — ONE stream decoded by the GPUs of a node, behind the C ABI (include/hsrans_hip.h: hsrans_comm_*, hsrans_shard_layout,
+// hsrans_sharded_*, hsrans_decode_sharded): SURVEY.md §8(b) "what a C-ABI GPU replacement must add (3): context create/destroy (device id,
+// pinned staging, RCCL comm)".  The reference's counterpart is the fan-out of independent blocks to its thread pool behind the
+// `thread_pool *` argument of mt_rANS32x64_16w_decode_mt (src/mt_rANS32x64_16w.h:23-28, src/mt_rANS32x64_16w_decode.cpp:217-220) and the
+// join in thread_pool_await (:262); here a "thread" is a GPU (one process per GPU), a block is a chain of the decode plan, and the
+// join is a point-to-point exchange of the decoded ranges over xGMI (RCCL ncclSend / ncclRecv groups), pipelined behind the decode.
+//
+// RCCL is bound at run time (dlopen of the librccl the process already has, else the system's): libhsrans_hip.so itself has no
+// dependency on it, so single-GPU callers never load a collective library, and a process that already carries one (PyTorch ships
+// its own librccl.so) does not end up with two.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "hsrans_host.h"
+#include "hsrans_internal.h"
+
+namespace
+{
+
+struct Rccl
+{
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GetVersion)(int *) = nullptr;
+  bool ok = false;
+};
+
+const Rccl &rccl()
+{
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    // the library this process already has (RTLD_NOLOAD), then by name
+    for (const char *name : {"librccl.so", "librccl.so.1"})
+      if (r.lib == nullptr)
+        r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if (r.lib == nullptr)
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (r.lib == nullptr)
+      return;
+    auto sym = [&](const char *n) { return dlsym(r.lib, n); };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.Send = (decltype(r.Send))sym("ncclSend");
+    r.Recv = (decltype(r.Recv))sym("ncclRecv");
+    r.GetVersion = (decltype(r.GetVersion))sym("ncclGetVersion");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv;
+  });
+  return r;
+}
+
+// decoded bytes up to and including chain c (chains are in output order in every plan this library builds)
+bool chain_ends(const uint8_t *plan, size_t plan_size, PlanHeader *h, std::vector<uint64_t> *ends)
+{
+  if (!read_header(plan, plan_size, h) || !hsrans::plan_validate(plan, plan_size, h->stream_len, h->decoded_len))
+    return false;
+  const uint32_t *cf = (const uint32_t *)(plan + plan_chain_first_off());
+  const Piece *pc = (const Piece *)(plan + plan_pieces_off(h->n_chains));
+  ends->resize(h->n_chains);
+  uint64_t acc = 0;
+  uint32_t pi = 0;
+  for (uint32_t c = 0; c < h->n_chains; c++)
+  {
+    for (; pi < cf[c + 1]; pi++)
+      acc += (pc[pi].flags & kPieceFill) ? pc[pi].fill_len : (uint64_t)pc[pi].steps * h->states + pc[pi].tail;
+    (*ends)[c] = acc;
+  }
+  return true;
+}
+
+// Cuts chains [first, first + count) into n contiguous runs whose decoded bytes follow `shares` (null = equal): run r ends at the
+// first chain whose end lies beyond lo + (hi - lo) * (shares[0] + .. + shares[r]) / sum — sums taken in index order, in double.
+void cut(const std::vector<uint64_t> &ends, uint32_t first, uint32_t count, const double *shares, uint32_t n, uint32_t *run_first, uint32_t *run_count)
+{
+  const uint64_t lo = first > 0 ? ends[first - 1] : 0, hi = count ? ends[first + count - 1] : lo;
+  double sum = 0;
+  for (uint32_t r = 0; r < n; r++)
+    sum += shares ? shares[r] : 1.0;
+  double cum = 0;
+  uint32_t prev = first;
+  for (uint32_t r = 0; r < n; r++)
+  {
+    uint32_t b = first + count;
+    if (r + 1 < n)
+    {
+      cum += shares ? shares[r] : 1.0;
+      const uint64_t target = lo + (uint64_t)((double)(hi - lo) * (cum / sum));
+      b = first + (uint32_t)(std::upper_bound(ends.begin() + first, ends.begin() + first + count, target) - (ends.begin() + first));
+      b = std::min(std::max(b, prev), first + count);
+    }
+    run_first[r] = prev;
+    run_count[r] = b - prev;
+    prev = b;
+  }
+}
+
+} // namespace
+
+struct hsrans_comm
+{
+  hsrans_ctx *ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  hipStream_t stream = nullptr; // the exchange's own stream: transfers run beside the decode kernels of the caller's stream
+};
+
+struct hsrans_sharded
+{
+  hsrans_ctx *ctx = nullptr;
+  hsrans_comm *comm = nullptr;
+  uint32_t world = 1, rank = 0, parts = 1;
+  int root = -1;
+  std::vector<hsrans_shard> shards; // [world * parts]
+  std::vector<hsrans_dplan *> part_plans; // this rank's sub-runs (null: no chains)
+  uint64_t window_lo = 0, window_hi = 0, out_base = 0, out_len = 0, total = 0, stream_len = 0;
+  std::vector<hipEvent_t> part_done; // sub-run k's decode has been queued up to here (the exchange's stream waits for it)
+  hipEvent_t exchanged = nullptr;
+};
+
+extern "C"
+{
+
+int hsrans_comm_unique_id(uint8_t id[HSRANS_COMM_ID_BYTES])
+{
+  static_assert(HSRANS_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the id is RCCL's ncclUniqueId");
+  if (id == nullptr)
+    return HSRANS_E_ARG;
+  const Rccl &r = rccl();
+  if (!r.ok)
+    return HSRANS_E_NO_DEVICE;
+  ncclUniqueId u;
+  if (r.GetUniqueId(&u) != ncclSuccess)
+    return HSRANS_E_HIP;
+  memcpy(id, u.internal, HSRANS_COMM_ID_BYTES);
+  return HSRANS_OK;
+}
+
+int hsrans_comm_create(hsrans_ctx *ctx, const uint8_t id[HSRANS_COMM_ID_BYTES], int rank, int world, hsrans_comm **out_comm)
+{
+  if (ctx == nullptr || id == nullptr || out_comm == nullptr || world < 1 || rank < 0 || rank >= world)
+    return HSRANS_E_ARG;
+  *out_comm = nullptr;
+  const Rccl &r = rccl();
+  if (!r.ok)
+    return HSRANS_E_NO_DEVICE;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return HSRANS_E_HIP;
+  hsrans_comm *c = new (std::nothrow) hsrans_comm;
+  if (c == nullptr)
+    return HSRANS_E_HIP;
+  c->ctx = ctx;
+  c->rank = rank;
+  c->world = world;
+  ncclUniqueId u;
+  memcpy(u.internal, id, HSRANS_COMM_ID_BYTES);
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || r.CommInitRank(&c->comm, world, u, rank) != ncclSuccess)
+  {
+    hsrans_comm_destroy(c);
+    return HSRANS_E_HIP;
+  }
+  *out_comm = c;
+  return HSRANS_OK;
+}
+
+void hsrans_comm_destroy(hsrans_comm *c)
+{
+  if (c == nullptr)
+    return;
+  if (c->ctx)
+    (void)hipSetDevice(c->ctx->device);
+  if (c->stream)
+    (void)hipStreamSynchronize(c->stream);
+  if (c->comm && rccl().ok)
+    (void)rccl().CommDestroy(c->comm);
+  if (c->stream)
+    (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int hsrans_comm_rank(const hsrans_comm *c) { return c ? c->rank : -1; }
+int hsrans_comm_world(const hsrans_comm *c) { return c ? c->world : 0; }
+int hsrans_comm_rccl_version(void)
+{
+  int v = 0;
+  return rccl().ok && rccl().GetVersion && rccl().GetVersion(&v) == ncclSuccess ? v : 0;
+}
+
+int hsrans_shard_layout(const uint8_t *plan, size_t plan_size, uint32_t world, uint32_t parts, const double *weights, hsrans_shard *shards, uint64_t *windows)
+try
+{
+  if (plan == nullptr || shards == nullptr || world == 0 || world > 1024 || parts == 0 || parts > 64)
+    return HSRANS_E_ARG;
+  if (weights != nullptr)
+  {
+    double sum = 0;
+    for (uint32_t r = 0; r < world; r++)
+    {
+      if (!(weights[r] >= 0))
+        return HSRANS_E_ARG;
+      sum += weights[r];
+    }
+    if (!(sum > 0))
+      return HSRANS_E_ARG;
+  }
+  PlanHeader h;
+  std::vector<uint64_t> ends;
+  if (!chain_ends(plan, plan_size, &h, &ends))
+    return HSRANS_E_FORMAT;
+  std::vector<uint32_t> rf(world), rc(world), sf(parts), sc(parts);
+  cut(ends, 0, h.n_chains, weights, world, rf.data(), rc.data());
+  for (uint32_t r = 0; r < world; r++)
+  {
+    cut(ends, rf[r], rc[r], nullptr, parts, sf.data(), sc.data());
+    for (uint32_t k = 0; k < parts; k++)
+    {
+      hsrans_shard &s = shards[(size_t)r * parts + k];
+      s.first_chain = sf[k];
+      s.chain_count = sc[k];
+      s.out_begin = s.out_end = 0;
+      if (sc[k] != 0 && hsrans_plan_chain_range(plan, plan_size, sf[k], sc[k], &s.out_begin, &s.out_end) != 0)
+        return HSRANS_E_FORMAT;
+    }
+    if (windows != nullptr)
+    {
+      windows[2 * r] = windows[2 * r + 1] = 0;
+      if (rc[r] != 0)
+      {
+        uint64_t ranges[4];
+        if (hsrans_plan_stream_ranges(plan, plan_size, rf[r], rc[r], ranges) != 0)
+          return HSRANS_E_FORMAT;
+        windows[2 * r] = ranges[2] & ~(uint64_t)15; // 16-byte aligned start: hsrans_decode_device_window
+        windows[2 * r + 1] = ranges[3];
+      }
+    }
+  }
+  return HSRANS_OK;
+}
+catch (...)
+{
+  return HSRANS_E_HIP;
+}
+
+void hsrans_sharded_destroy(hsrans_sharded *s)
+{
+  if (s == nullptr)
+    return;
+  if (s->ctx)
+    (void)hipSetDevice(s->ctx->device);
+  for (hsrans_dplan *d : s->part_plans)
+    if (d)
+      hsrans_dplan_destroy(d);
+  for (hipEvent_t e : s->part_done)
+    if (e)
+      (void)hipEventDestroy(e);
+  if (s->exchanged)
+    (void)hipEventDestroy(s->exchanged);
+  delete s;
+}
+
+static int sharded_create_impl(hsrans_ctx *ctx, hsrans_comm *comm, int rank, int world, const uint8_t *plan, size_t plan_size, uint32_t parts, const double *weights,
+                               int root, hsrans_sharded **out)
+{
+  if (ctx == nullptr || out == nullptr || parts == 0 || parts > 64 || world < 1 || rank < 0 || rank >= world || root >= world)
+    return HSRANS_E_ARG;
+  *out = nullptr;
+  PlanHeader h;
+  if (!read_header(plan, plan_size, &h))
+    return HSRANS_E_FORMAT;
+  hsrans_sharded *s = new (std::nothrow) hsrans_sharded;
+  if (s == nullptr)
+    return HSRANS_E_HIP;
+  s->ctx = ctx;
+  s->comm = comm;
+  s->world = (uint32_t)world;
+  s->rank = (uint32_t)rank;
+  s->parts = parts;
+  s->root = root < 0 ? -1 : root;
+  s->total = h.decoded_len;
+  s->stream_len = h.stream_len;
+  s->shards.resize((size_t)s->world * parts);
+  std::vector<uint64_t> windows(2 * (size_t)s->world);
+  int rc = hsrans_shard_layout(plan, plan_size, s->world, parts, weights, s->shards.data(), windows.data());
+  if (rc == HSRANS_OK && hipSetDevice(ctx->device) != hipSuccess)
+    rc = HSRANS_E_HIP;
+  s->window_lo = windows[2 * s->rank];
+  s->window_hi = windows[2 * s->rank + 1];
+  // the output bytes this rank has to hold: everything, or (a gather to one rank, and this is another) its own range
+  s->out_base = 0;
+  s->out_len = s->total;
+  if (s->root >= 0 && (int)s->rank != s->root)
+  {
+    uint64_t b = ~(uint64_t)0, e = 0;
+    for (uint32_t k = 0; k < parts; k++)
+    {
+      const hsrans_shard &sh = s->shards[(size_t)s->rank * parts + k];
+      if (sh.chain_count == 0)
+        continue;
+      b = std::min(b, sh.out_begin);
+      e = std::max(e, sh.out_end);
+    }
+    s->out_base = e > b ? b : 0;
+    s->out_len = e > b ? e - b : 0;
+  }
+  s->part_plans.assign(parts, nullptr);
+  s->part_done.assign(parts, nullptr);
+  std::vector<uint8_t> slice(plan_size + 1024);
+  for (uint32_t k = 0; k < parts && rc == HSRANS_OK; k++)
+  {
+    const hsrans_shard &sh = s->shards[(size_t)s->rank * parts + k];
+    if (hipEventCreateWithFlags(&s->part_done[k], hipEventDisableTiming) != hipSuccess)
+      rc = HSRANS_E_HIP;
+    if (sh.chain_count == 0 || rc != HSRANS_OK)
+      continue;
+    const size_t n = hsrans_plan_slice(plan, plan_size, sh.first_chain, sh.chain_count, slice.data(), slice.size());
+    rc = n == 0 ? HSRANS_E_FORMAT : hsrans_dplan_create(ctx, slice.data(), n, &s->part_plans[k]);
+  }
+  if (rc == HSRANS_OK && hipEventCreateWithFlags(&s->exchanged, hipEventDisableTiming) != hipSuccess)
+    rc = HSRANS_E_HIP;
+  if (rc != HSRANS_OK)
+  {
+    hsrans_sharded_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return HSRANS_OK;
+}
+
+int hsrans_sharded_create(hsrans_ctx *ctx, hsrans_comm *comm, const uint8_t *plan, size_t plan_size, uint32_t parts, const double *weights, int root,
+                          hsrans_sharded **out)
+try
+{
+  if (comm == nullptr || comm->ctx != ctx)
+    return HSRANS_E_ARG;
+  return sharded_create_impl(ctx, comm, comm->rank, comm->world, plan, plan_size, parts, weights, root, out);
+}
+catch (...)
+{
+  return HSRANS_E_HIP;
+}
+
+int hsrans_sharded_create_rank(hsrans_ctx *ctx, int rank, int world, const uint8_t *plan, size_t plan_size, uint32_t parts, const double *weights, int root,
+                               hsrans_sharded **out)
+try
+{
+  return sharded_create_impl(ctx, nullptr, rank, world, plan, plan_size, parts, weights, root, out);
+}
+catch (...)
+{
+  return HSRANS_E_HIP;
+}
+
+int hsrans_sharded_info(const hsrans_sharded *s, hsrans_sharded_info_t *info, hsrans_shard *shards, size_t shard_capacity)
+{
+  if (s == nullptr || info == nullptr)
+    return HSRANS_E_ARG;
+  info->world = s->world;
+  info->rank = s->rank;
+  info->parts = s->parts;
+  info->root = s->root;
+  info->window_begin = s->window_lo;
+  info->window_end = s->window_hi;
+  info->out_base = s->out_base;
+  info->out_length = s->out_len;
+  info->decoded_length = s->total;
+  info->stream_length = s->stream_len;
+  if (shards != nullptr)
+  {
+    if (shard_capacity < s->shards.size())
+      return HSRANS_E_ARG;
+    memcpy(shards, s->shards.data(), s->shards.size() * sizeof(hsrans_shard));
+  }
+  return HSRANS_OK;
+}
+
+hsrans_dplan *hsrans_sharded_part_plan(hsrans_sharded *s, uint32_t part) { return s && part < s->parts ? s->part_plans[part] : nullptr; }
+
+// The exchange of sub-run k's ranges, queued on the communicator's own stream: one grouped batch of point-to-point operations —
+// every rank that owns bytes of part k sends them to every peer that wants them (all peers, or the root only), straight from its
+// output buffer into the same bytes of the receiver's; every byte crosses exactly one xGMI link.
+static int post_part(hsrans_sharded *s, uint32_t k, uint8_t *out)
+{
+  const Rccl &r = rccl();
+  hsrans_comm *c = s->comm;
+  const hsrans_shard &mine = s->shards[(size_t)s->rank * s->parts + k];
+  bool any = false;
+  for (uint32_t peer = 0; peer < s->world && !any; peer++)
+  {
+    if (peer == s->rank)
+      continue;
+    const hsrans_shard &theirs = s->shards[(size_t)peer * s->parts + k];
+    any = (mine.out_end > mine.out_begin && (s->root < 0 || s->root == (int)peer)) || (theirs.out_end > theirs.out_begin && (s->root < 0 || s->root == (int)s->rank));
+  }
+  if (!any)
+    return HSRANS_OK;
+  bool ok = r.GroupStart() == ncclSuccess;
+  for (uint32_t peer = 0; peer < s->world && ok; peer++)
+  {
+    if (peer == s->rank)
+      continue;
+    if (mine.out_end > mine.out_begin && (s->root < 0 || s->root == (int)peer))
+      ok = r.Send(out + (mine.out_begin - s->out_base), mine.out_end - mine.out_begin, ncclUint8, (int)peer, c->comm, c->stream) == ncclSuccess;
+    const hsrans_shard &theirs = s->shards[(size_t)peer * s->parts + k];
+    if (ok && theirs.out_end > theirs.out_begin && (s->root < 0 || s->root == (int)s->rank))
+      ok = r.Recv(out + (theirs.out_begin - s->out_base), theirs.out_end - theirs.out_begin, ncclUint8, (int)peer, c->comm, c->stream) == ncclSuccess;
+  }
+  ok = r.GroupEnd() == ncclSuccess && ok;
+  return ok ? HSRANS_OK : HSRANS_E_HIP;
+}
+
+int hsrans_decode_sharded(hsrans_sharded *s, const void *d_window, void *d_out, int gather, void *hip_stream)
+{
+  if (s == nullptr || d_out == nullptr || (d_window == nullptr && s->window_hi > s->window_lo))
+    return HSRANS_E_ARG;
+  hsrans_ctx *ctx = s->ctx;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return HSRANS_E_HIP;
+  if (gather != HSRANS_SHARD_DECODE_ONLY && gather != HSRANS_SHARD_DECODE_AND_EXCHANGE && gather != HSRANS_SHARD_EXCHANGE_ONLY)
+    return HSRANS_E_ARG;
+  if (gather != HSRANS_SHARD_DECODE_ONLY && s->comm == nullptr && s->world > 1) // (hsrans_sharded_create_rank: one rank's share, no communicator)
+    return HSRANS_E_ARG;
+  hipStream_t st = (hipStream_t)hip_stream;
+  hipStream_t xs = s->comm ? s->comm->stream : nullptr;
+  const bool exchange = gather != HSRANS_SHARD_DECODE_ONLY && s->world > 1;
+  const bool decode = gather != HSRANS_SHARD_EXCHANGE_ONLY;
+  const bool i_am_root = s->root >= 0 && (int)s->rank == s->root;
+  if (exchange)
+  {
+    // the exchange's stream starts behind whatever the caller's stream holds (the previous step may still be reading `d_out`)
+    if (hipEventRecord(s->exchanged, st) != hipSuccess || hipStreamWaitEvent(xs, s->exchanged, 0) != hipSuccess)
+      return HSRANS_E_HIP;
+    // a receiving root posts all its receives first: none of them depends on its own decode
+    if (i_am_root)
+      for (uint32_t k = 0; k < s->parts; k++)
+      {
+        const int rc = post_part(s, k, (uint8_t *)d_out);
+        if (rc != HSRANS_OK)
+          return rc;
+      }
+  }
+  for (uint32_t k = 0; k < s->parts; k++)
+  {
+    if (decode && s->part_plans[k] != nullptr)
+    {
+      const int rc = hsrans_decode_device_ranges(ctx, s->part_plans[k], d_window, s->window_lo, s->window_hi - s->window_lo, d_out, s->out_base, s->out_len, st);
+      if (rc != HSRANS_OK)
+        return rc;
+    }
+    if (!exchange || i_am_root)
+      continue;
+    // sub-run k's ranges go onto the links as soon as its decode is done, while sub-run k + 1 decodes
+    if (hipEventRecord(s->part_done[k], st) != hipSuccess || hipStreamWaitEvent(xs, s->part_done[k], 0) != hipSuccess)
+      return HSRANS_E_HIP;
+    const int rc = post_part(s, k, (uint8_t *)d_out);
+    if (rc != HSRANS_OK)
+      return rc;
+  }
+  if (exchange) // the caller's stream continues when the transfers are done
+    if (hipEventRecord(s->exchanged, xs) != hipSuccess || hipStreamWaitEvent(st, s->exchanged, 0) != hipSuccess)
+      return HSRANS_E_HIP;
+  return HSRANS_OK;
+}
+
+int hsrans_sharded_status(hsrans_sharded *s, void *hip_stream)
+{
+  if (s == nullptr)
+    return HSRANS_E_ARG;
+  int worst = HSRANS_OK;
+  for (hsrans_dplan *d : s->part_plans)
+    if (d != nullptr)
+    {
+      const int rc = hsrans_dplan_status(s->ctx, d, hip_stream);
+      if (rc != HSRANS_OK && worst == HSRANS_OK)
+        worst = rc;
+    }
+  return worst;
+}
+
+} // extern "C"

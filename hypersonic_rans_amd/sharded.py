@@ -27,37 +27,17 @@ import torch.distributed as dist
 from . import api
 
 
-def _chain_ends(plan) -> tuple[np.ndarray, int]:
-    """decoded bytes up to and including chain c (chains are in output order in every plan this library builds)"""
-    hdr, cf, pieces = api.plan_tables(plan)
-    n, S = hdr["n_chains"], hdr["states"]
-    size = np.where(pieces["flags"] & 2, pieces["fill_len"], pieces["steps"].astype(np.uint64) * S + pieces["tail"]).astype(np.uint64)
-    per_piece_end = np.cumsum(size)
-    return per_piece_end[cf[1:].astype(np.int64) - 1], n
-
-
-def _cut(chain_end: np.ndarray, first: int, count: int, shares) -> list[tuple[int, int]]:
-    """Cuts chains [first, first+count) into len(shares) contiguous runs whose decoded bytes follow `shares` (any positive
-    numbers).  Runs may be empty when there are fewer chains than runs."""
-    shares = np.asarray(shares, dtype=np.float64)
-    assert shares.ndim == 1 and shares.size >= 1 and (shares >= 0).all() and shares.sum() > 0
-    lo = int(chain_end[first - 1]) if first > 0 else 0
-    hi = int(chain_end[first + count - 1]) if count else lo
-    cum = np.cumsum(shares) / shares.sum()
-    bounds = [first]
-    for r in range(shares.size - 1):
-        target = lo + int((hi - lo) * cum[r])
-        b = first + int(np.searchsorted(chain_end[first:first + count], target, side="right"))
-        bounds.append(min(max(bounds[-1], b), first + count))
-    bounds.append(first + count)
-    return [(bounds[r], bounds[r + 1] - bounds[r]) for r in range(shares.size)]
-
-
 def shard_chains(plan, world_size: int, weights=None) -> list[tuple[int, int]]:
     """Splits the plan's chains into `world_size` contiguous runs [(first, count), ...] of (nearly) equal decoded bytes, or
-    of decoded bytes proportional to `weights[r]`.  Runs may be empty (count == 0) when there are fewer chains than ranks."""
-    chain_end, n = _chain_ends(plan)
-    return _cut(chain_end, 0, n, np.ones(world_size) if weights is None else weights)
+    of decoded bytes proportional to `weights[r]` (hsrans_shard_layout with one sub-run per rank).  Runs may be empty
+    (count == 0) when there are fewer chains than ranks."""
+    shards, _ = api.shard_layout(plan, world_size, 1, weights)
+    out, nxt = [], 0
+    for r in range(world_size):
+        f, c, _, _ = shards[r][0]
+        out.append((f if c else nxt, c))
+        nxt = out[-1][0] + c
+    return out
 
 
 def local_range(plan, first: int, count: int) -> tuple[int, int]:
@@ -82,26 +62,23 @@ def balanced_root_share(world_size: int, decode_bytes_per_s: float, inbound_byte
 
 
 class ShardLayout:
-    """Pure host arithmetic, identical on every rank: which chains / output bytes / stream bytes each rank owns and how each
-    rank's run is cut into `parts` sub-runs for the pipelined exchange."""
+    """Which chains / output bytes / stream bytes each rank owns and how each rank's run is cut into `parts` sub-runs for the
+    pipelined exchange: hsrans_shard_layout (pure host arithmetic in the C library, identical on every rank)."""
 
     def __init__(self, plan, world_size: int, parts: int = 1, weights=None):
         self.world, self.parts = world_size, max(1, parts)
-        chain_end, n = _chain_ends(plan)
-        self.runs = _cut(chain_end, 0, n, np.ones(world_size) if weights is None else weights)
-        self.ranges = [local_range(plan, f, c) for f, c in self.runs]
-        self.sub_runs = [_cut(chain_end, f, c, np.ones(self.parts)) for f, c in self.runs]
-        self.sub_ranges = [[local_range(plan, f, c) for f, c in subs] for subs in self.sub_runs]
+        shards, windows = api.shard_layout(plan, world_size, self.parts, weights)
+        self.sub_runs = [[(f, c) for f, c, _, _ in subs] for subs in shards]
+        self.sub_ranges = [[(b, e) if c else (0, 0) for _, c, b, e in subs] for subs in shards]
+        self.runs, self.ranges = [], []
+        for subs in shards:
+            live = [x for x in subs if x[1]]
+            self.runs.append((live[0][0], sum(x[1] for x in live)) if live else (subs[0][0], 0))
+            self.ranges.append((live[0][2], live[-1][3]) if live else (0, 0))
         self.total = api.plan_decoded_length(plan)
         hdr, _, _ = api.plan_tables(plan)
         self.stream_len = int(hdr["stream_len"])
-        self.windows = []
-        for f, c in self.runs:
-            if c:
-                (_hb, _he), (bb, be) = api.plan_stream_ranges(plan, f, c)
-                self.windows.append((bb & ~15, be))  # 16-byte aligned start: hsrans_decode_device_window
-            else:
-                self.windows.append((0, 0))
+        self.windows = windows
 
 
 def post_exchange(out: torch.Tensor, ranges: list[tuple[int, int]], group=None, root: int | None = None, out_base: int = 0) -> list:
@@ -158,46 +135,58 @@ def pipelined_gather(out: torch.Tensor, layout: ShardLayout, decode_part, group=
     return out
 
 
+def comm_for(ctx: "api.Context", group=None) -> "api.Comm":
+    """The RCCL communicator of the C library (hsrans_comm) for this process's rank in `group`: made once per (context, group) and
+    kept by the context; rank 0's hsrans_comm_unique_id travels through the process group — the only thing torch.distributed
+    does for the GPU path besides launching the ranks."""
+    comms = ctx.__dict__.setdefault("_comms", {})
+    key = id(group)
+    if key not in comms:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ids = [api.Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        comms[key] = api.Comm(ctx, ids[0], rank, world)
+    return comms[key]
+
+
 class ShardedDecoder:
-    """Everything that does not change between decodes of one (plan, world) pair, prepared once: this rank's chain run, its
-    sub-runs and their device plans, its output range and the stream bytes it needs.  A step is then `parts` kernel launches
-    + the exchange.
+    """This rank's share of ONE stream decoded by all ranks — a thin wrapper over the C ABI's hsrans_sharded (hsrans_comm.cpp): the
+    layout, the sub-runs' device plans, the pipelined point-to-point exchange on RCCL all live in the library; this class only
+    holds the tensors' lifetimes and the handful of views tests and bench.py read.
 
     `parts`   sub-runs per rank for the pipelined exchange (1 = decode, then exchange).
     `weights` decoded-byte shares of the ranks (None = equal; root_weights() for a gather to one rank).
     `root`    the rank the output is gathered to (None = every rank): a rank that is not the root then needs only ITS OWN
-              range of the output in HBM (`alloc_out`), decoded through hsrans_decode_device_ranges."""
+              range of the output in HBM (`alloc_out`).
+    `world` / `rank` given explicitly: one rank's share WITHOUT a communicator (hsrans_sharded_create_rank; decode only) —
+              tests run every rank's GPU side on one GPU that way."""
+
+    uses_c_abi = True
 
     def __init__(self, ctx: "api.Context", plan, group=None, parts: int = 1, weights=None, root: int | None = None, world: int | None = None,
                  rank: int | None = None):
-        # (world / rank given explicitly: one rank's share without a process group — tests run every rank's GPU side on one GPU)
         self.ctx, self.group, self.root = ctx, group, root
-        self.world = dist.get_world_size(group) if world is None else world
-        self.rank = dist.get_rank(group) if rank is None else rank
-        self.layout = ShardLayout(plan, self.world, parts, weights)
+        explicit = world is not None
+        self.world = world if explicit else dist.get_world_size(group)
+        self.rank = rank if explicit else dist.get_rank(group)
+        self.comm = None if explicit else comm_for(ctx, group)
+        self.c = api.Sharded(ctx, plan, max(1, parts), weights, root, comm=self.comm, rank=self.rank, world=self.world)
+        self.layout = ShardLayout(plan, self.world, parts, weights)  # (the same C arithmetic, as Python lists)
+        assert self.layout.sub_runs == [[(f, c) for f, c, _, _ in subs] for subs in self.c.shards]
         self.runs, self.ranges = self.layout.runs, self.layout.ranges
-        self.total, self.stream_len = self.layout.total, self.layout.stream_len
+        info = self.c.info
+        self.total, self.stream_len = int(info["decoded_length"]), int(info["stream_length"])
         self.first, self.count = self.runs[self.rank]
-        self.window = self.layout.windows[self.rank]
-        # device plans: one per sub-run (what step() launches); the plan of the rank's WHOLE run is only made when decode() /
-        # decode_window() ask for it (with parts > 1 nothing launches it: building and uploading it would cost HBM and set-up time)
+        self.window = (int(info["window_begin"]), int(info["window_end"]))
+        self.out_base, self.out_len = int(info["out_base"]), int(info["out_length"])
+        self.part_dplans = [self.c.part_plan(k) for k in range(self.layout.parts)]
         self._plan = plan
         self._dplan = None
-        if self.count and self.layout.parts > 1:
-            self.part_dplans = [ctx.make_device_plan(api.plan_slice(plan, f, c)) if c else None for f, c in self.layout.sub_runs[self.rank]]
-        elif self.count:
-            self.part_dplans = [self.dplan]
-        else:
-            self.part_dplans = [None] * self.layout.parts
-        # the output bytes this rank has to hold: everything, or (root gathers, this rank is not the root) its own range
-        self.out_base, self.out_len = 0, self.total
-        if root is not None and self.rank != root:
-            b, e = self.ranges[self.rank]
-            self.out_base, self.out_len = b, e - b
 
     @property
     def dplan(self):
-        """Device plan of this rank's whole chain run (None for a rank without chains), made on first use."""
+        """Device plan of this rank's whole chain run (None for a rank without chains), made on first use (decode_window)."""
         if self._dplan is None and self.count:
             self._dplan = self.ctx.make_device_plan(api.plan_slice(self._plan, self.first, self.count))
         return self._dplan
@@ -210,16 +199,9 @@ class ShardedDecoder:
     def alloc_out(self, device) -> torch.Tensor:
         return torch.zeros(max(self.out_len, 4), dtype=torch.uint8, device=device)
 
-    # -- the stream is already in this rank's HBM, whole --------------------------------------------------------------
-    def decode(self, d_stream: torch.Tensor, out: torch.Tensor, gather: bool = True, root: int | None = None) -> torch.Tensor:
-        if self.dplan is not None:
-            self.ctx.decode_device(self.dplan, d_stream, out, stream_length=self.stream_len)
-        return gather_ranges(out, self.ranges, self.group, root) if gather else out
-
-    # -- the stream is in host memory: upload only what this rank's chains read ---------------------------------------
     def upload_window(self, host_stream, device, side_stream: "torch.cuda.Stream | None" = None) -> torch.Tensor:
-        """Device copy of this rank's window of the stream (hsrans_plan_stream_ranges body, aligned down to 16 bytes) — the
-        buffer is as long as the window, not as the stream.  The copy goes through `side_stream` when given."""
+        """Device copy of this rank's window of the stream (hsrans_sharded_info: window_begin .. window_end) — the buffer is as
+        long as the window, not as the stream.  The copy goes through `side_stream` when given."""
         lo, hi = self.window
         host = host_stream if isinstance(host_stream, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(host_stream, dtype=np.uint8))
         d = torch.empty(max(hi - lo, 16) + 16, dtype=torch.uint8, device=device)
@@ -231,48 +213,46 @@ class ShardedDecoder:
                 d[: hi - lo].copy_(host[lo:hi], non_blocking=True)
         return d
 
-    def decode_window(self, d_window: torch.Tensor, out: torch.Tensor, gather: bool = True, root: int | None = None) -> torch.Tensor:
-        if self.dplan is not None:
-            lo, hi = self.window
-            self.ctx.decode_device_window(self.dplan, d_window, lo, hi - lo, out)
-        return gather_ranges(out, self.ranges, self.group, root) if gather else out
-
-    def launch_part(self, k: int, d_window: torch.Tensor, out: torch.Tensor) -> None:
-        """Sub-run k of this rank, asynchronous on the current stream; `out` = alloc_out()'s buffer (output bytes
-        [out_base, out_base + out_len))."""
-        dp = self.part_dplans[k]
-        if dp is not None:
-            lo, hi = self.window
-            self.ctx.decode_device_ranges(dp, d_window, lo, hi - lo, out, self.out_base, self.out_len)
-
     def step(self, d_window: torch.Tensor, out: torch.Tensor, gather: bool = True) -> torch.Tensor:
-        """One decode of the stream: this rank's sub-runs, their ranges exchanged (to `root`, or to everyone) behind the
-        decode of the next sub-run."""
-        if not gather:
-            for k in range(self.layout.parts):
-                self.launch_part(k, d_window, out)
-            return out
-        return pipelined_gather(out, self.layout, lambda k: self.launch_part(k, d_window, out), self.group, self.root, self.out_base)
+        """One decode of the stream (hsrans_decode_sharded): this rank's sub-runs, their ranges exchanged (to `root`, or to everyone)
+        behind the decode of the next sub-run.  `out` = alloc_out()'s buffer."""
+        assert out.numel() >= self.out_len
+        self.c.decode(d_window, out, api.SHARD_DECODE_AND_EXCHANGE if gather else api.SHARD_DECODE_ONLY)
+        return out
+
+    def exchange(self, d_window: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """The exchange alone, of ranges an earlier step(gather=False) decoded (bench.py times the two legs apart)."""
+        self.c.decode(d_window, out, api.SHARD_EXCHANGE_ONLY)
+        return out
+
+    # -- the stream is already in this rank's HBM, whole --------------------------------------------------------------
+    def decode(self, d_stream: torch.Tensor, out: torch.Tensor, gather: bool = True) -> torch.Tensor:
+        lo, _hi = self.window
+        return self.step(d_stream[lo:], out, gather)  # (window_begin is a multiple of 16: the slice keeps the alignment)
+
+    def decode_window(self, d_window: torch.Tensor, out: torch.Tensor, gather: bool = True) -> torch.Tensor:
+        return self.step(d_window, out, gather)
 
     def status_tensor(self, device) -> torch.Tensor:
-        """This rank's device status words OR-ed into one int32 tensor on `device` (no host round trip beyond the per-plan reads)."""
-        st = 0
-        for dp in {id(p): p for p in [self._dplan, *self.part_dplans] if p is not None}.values():
-            st |= 1 if self.ctx.status(dp) else 0
+        """This rank's device status (hsrans_sharded_status) as one int32 tensor on `device`."""
+        st = 1 if self.c.status() else 0
+        if self._dplan is not None:
+            st |= 1 if self.ctx.status(self._dplan) else 0
         return torch.tensor([st], dtype=torch.int32, device=device)
 
     def global_status(self) -> int:
         """The launches' device status OR-ed over all ranks (one small all-reduce): every rank learns whether any rank's kernel
         met a malformed histogram / block header.  Synchronises; call it once after a batch of steps, not per step."""
+        if self.comm is None:
+            return int(self.status_tensor(torch.device("cpu")).item())
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
         t = self.status_tensor(dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
 
     def check(self) -> None:
-        for dp in [self._dplan, *self.part_dplans]:
-            if dp is not None and self.ctx.status(dp) != 0:
-                raise api.HsransError("device reported a malformed histogram / block header")
+        if self.c.status() != 0 or (self._dplan is not None and self.ctx.status(self._dplan) != 0):
+            raise api.HsransError("device reported a malformed histogram / block header")
 
 
 class HostRehearsalDecoder:
@@ -338,6 +318,7 @@ def decode_sharded(ctx: "api.Context", d_stream: torch.Tensor, stream_length: in
     dec = ShardedDecoder(ctx, plan, group)
     out = torch.empty(dec.total, dtype=torch.uint8, device=d_stream.device)
     dec.decode(d_stream, out, gather=gather)
+    torch.cuda.synchronize()
     dec.check()
     return out
 

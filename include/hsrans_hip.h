@@ -252,6 +252,69 @@ double hsrans_batch_deal(const uint64_t *const *chain_starts, const uint32_t *n_
  * its finish time (100 MHz) in slot wg * waves + wave, the launch's first wave its entry time in the slot after the last */
 size_t hsrans_dplan_batch_read_finish(hsrans_batch *batch, uint64_t *out, size_t capacity_u64);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * ONE stream over the GPUs of a node: one process per GPU, the plan's chains cut into one contiguous run per rank, the decoded
+ * ranges exchanged point to point over xGMI (RCCL ncclSend / ncclRecv groups on the communicator's own HIP stream), pipelined behind
+ * the decode in `parts` sub-runs.  This is the C form of the reference's thread-pool fan-out behind the `thread_pool *` argument of
+ * mt_rANS32x64_16w_decode_mt_N (src/mt_rANS32x64_16w.h:23-28): blocks handed to workers (src/mt_rANS32x64_16w_decode.cpp:217-220),
+ * joined by thread_pool_await (:262) — a worker is a GPU, a block a chain, the join the exchange.  RCCL is bound at run time
+ * (the librccl the process already carries, else the system's); without one these entries return HSRANS_E_NO_DEVICE.
+ * Rendezvous: rank 0 calls hsrans_comm_unique_id and ships the 128 bytes to the other ranks by whatever it has (MPI, a file, a
+ * socket); every rank then calls hsrans_comm_create with the same bytes (collective: returns when all `world` ranks have called).
+ * ---------------------------------------------------------------------------------------------------------- */
+#define HSRANS_COMM_ID_BYTES 128
+typedef struct hsrans_comm hsrans_comm;
+int hsrans_comm_unique_id(uint8_t id[HSRANS_COMM_ID_BYTES]);
+int hsrans_comm_create(hsrans_ctx *ctx, const uint8_t id[HSRANS_COMM_ID_BYTES], int rank, int world, hsrans_comm **out_comm);
+void hsrans_comm_destroy(hsrans_comm *comm);
+int hsrans_comm_rank(const hsrans_comm *comm);
+int hsrans_comm_world(const hsrans_comm *comm);
+int hsrans_comm_rccl_version(void); /* 0: no RCCL could be bound */
+
+/* Which chains / output bytes / stream bytes each rank owns, and how each rank's run is cut into `parts` sub-runs: pure host
+ * arithmetic, identical on every rank, no GPU and no RCCL involved.  The chains are cut into `world` contiguous runs whose decoded
+ * bytes follow `weights` (NULL = equal shares; e.g. a larger share for the rank a gather goes to, which sends nothing), every run
+ * into `parts` sub-runs of equal decoded bytes.  shards[rank * parts + k] = sub-run k of `rank`; windows (may be NULL) receives
+ * {begin, end} of the stream bytes each rank's chains read (begin aligned down to 16: hsrans_decode_device_window). */
+typedef struct hsrans_shard
+{
+  uint32_t first_chain, chain_count; /* chain_count 0: nothing (fewer chains than sub-runs) */
+  uint64_t out_begin, out_end;       /* decoded bytes [out_begin, out_end) */
+} hsrans_shard;
+int hsrans_shard_layout(const uint8_t *plan, size_t plan_size, uint32_t world, uint32_t parts, const double *weights, hsrans_shard *shards /* [world * parts] */,
+                        uint64_t *windows /* [2 * world] or NULL */);
+
+/* Everything that does not change between decodes of one (plan, communicator) pair, prepared once: this rank's sub-runs as device
+ * plans, its stream window, the output bytes it holds.  root < 0: every rank ends with the whole output; root >= 0: that rank only
+ * (the others then hold just their own range: out_base / out_length below). */
+typedef struct hsrans_sharded hsrans_sharded;
+int hsrans_sharded_create(hsrans_ctx *ctx, hsrans_comm *comm, const uint8_t *plan, size_t plan_size, uint32_t parts, const double *weights, int root,
+                          hsrans_sharded **out_sharded);
+/* one rank's share WITHOUT a communicator (decode only: hsrans_decode_sharded with HSRANS_SHARD_DECODE_ONLY) — a consumer that is
+ * sharded like the decode, or tests that run every rank's GPU side on one GPU */
+int hsrans_sharded_create_rank(hsrans_ctx *ctx, int rank, int world, const uint8_t *plan, size_t plan_size, uint32_t parts, const double *weights, int root,
+                               hsrans_sharded **out_sharded);
+void hsrans_sharded_destroy(hsrans_sharded *sharded);
+typedef struct hsrans_sharded_info_t
+{
+  uint32_t world, rank, parts;
+  int32_t root;
+  uint64_t window_begin, window_end; /* stream bytes this rank must hold at d_window (d_window[0] = stream byte window_begin) */
+  uint64_t out_base, out_length;     /* output bytes this rank's d_out holds (d_out[0] = output byte out_base) */
+  uint64_t decoded_length, stream_length;
+} hsrans_sharded_info_t;
+int hsrans_sharded_info(const hsrans_sharded *sharded, hsrans_sharded_info_t *info, hsrans_shard *shards /* [world * parts] or NULL */, size_t shard_capacity);
+hsrans_dplan *hsrans_sharded_part_plan(hsrans_sharded *sharded, uint32_t part); /* this rank's sub-run `part` (launch info, status); NULL: no chains */
+/* One decode of the stream: this rank's sub-runs are queued on `hip_stream`; with gather != 0 sub-run k's ranges go onto the links
+ * (the communicator's stream waits for exactly that sub-run's kernel) while sub-run k + 1 decodes, and `hip_stream` continues when
+ * the transfers are done.  A receiving root posts all its receives first.  Asynchronous; collective when gather != 0 (every rank
+ * of the communicator must make the same call). */
+#define HSRANS_SHARD_DECODE_ONLY 0         /* every rank keeps its range */
+#define HSRANS_SHARD_DECODE_AND_EXCHANGE 1 /* the step: decode, ranges exchanged behind it */
+#define HSRANS_SHARD_EXCHANGE_ONLY 2       /* the ranges of an earlier decode-only call (to time the two legs apart) */
+int hsrans_decode_sharded(hsrans_sharded *sharded, const void *d_window, void *d_out, int gather, void *hip_stream);
+int hsrans_sharded_status(hsrans_sharded *sharded, void *hip_stream); /* as hsrans_dplan_status, over this rank's sub-runs */
+
 /* First decode of a stream that came WITHOUT an index (e.g. a reference-emitted mt_ stream: one chain per block,
  * src/mt_rANS32x64_16w_decode.cpp:137-265 decodes it with one thread per block): decodes like hsrans_decode_device with
  * `dplan` (from hsrans_plan_build + hsrans_dplan_create, or from hsrans_dplan_create_from_device_stream; HSRANS_RAW and

@@ -1,8 +1,9 @@
 """One rank of tests/test_sharded_rccl.py (started by `python -m torch.distributed.run`, one process per GPU, backend nccl = RCCL).
 
-Every rank builds the same stream, takes its shard through hypersonic_rans_amd.sharded.ShardedDecoder — the decode kernels on its
-own GPU, the decoded ranges exchanged point-to-point over RCCL exactly as bench.py's legs do — and compares what it ends up
-holding with the CPU oracle's bytes.  Legs: gather none / all / root, each with parts 1 and 4 (4 = the exchange of sub-run k
+Every rank builds the same stream, takes its shard through hypersonic_rans_amd.sharded.ShardedDecoder — since round 5 a thin wrapper
+over the C ABI's hsrans_comm_create / hsrans_sharded_create / hsrans_decode_sharded (csrc/hsrans_comm.cpp: the communicator, the
+layout, the grouped ncclSend / ncclRecv on RCCL's own stream all live in the library; torch.distributed only starts the ranks and
+carries rank 0's ncclUniqueId) — and compares what it ends up holding with the CPU oracle's bytes.  Legs: gather none / all / root, each with parts 1 and 4 (4 = the exchange of sub-run k
 is posted behind its decode and travels while sub-run k + 1 decodes: sharded.pipelined_gather's stream-ordering assumption,
 which gloo cannot check).  Fan-out this replaces: /root/reference/src/mt_rANS32x64_16w_decode.cpp:182-224.
 Exit code != 0 on any mismatch; rank 0 prints one JSON line."""
@@ -41,6 +42,7 @@ def main():
             for parts in (1, 4):
                 weights = sharded.root_weights(world, root, 0.5) if root is not None else None  # an uneven split too
                 dec = sharded.ShardedDecoder(ctx, plan, parts=parts, weights=weights, root=root)
+                assert dec.uses_c_abi and dec.comm is not None and dec.comm.world == world and H.load_library().hsrans_comm_rccl_version() > 0
                 d_window = dec.upload_window(stream, dev)
                 out = dec.alloc_out(dev)
                 for rep in range(3):  # repeated: the exchange must also be right when the buffers already hold the right bytes of the previous step ...
