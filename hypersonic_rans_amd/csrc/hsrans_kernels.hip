@@ -414,10 +414,6 @@ LaunchShape launch_shape(const PlanHeader &h, const DeviceGeom &dg, bool persist
     while (waves > 1 && (waves / 2 >= h.n_chains || waves * ring + table_bytes > dg.max_lds))
       waves /= 2;
     lds = waves * ring + table_bytes + (grouped ? 64 + 1024 : 0); // (run_grouped's two next-group words and its table-build scratch)
-#if defined(HSRANS_STAGE_SYMBOLS) && HSRANS_STAGE_SYMBOLS
-    if (direct && L.mode == kModePack64)
-      lds += waves * 1024; // experiment: a KiB of symbol staging per wave (run_groups_stage)
-#endif
     grid = (h.n_chains + waves - 1) / waves;
     if (grouped)
       grid = n_groups;

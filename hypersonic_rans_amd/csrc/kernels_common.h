@@ -131,9 +131,6 @@ struct WaveCtx
   const uint2 *gtable;   // kModeSpill: the table in global memory
   uint16_t *scratch_cnt; // LDS, 512 B each, only live during table builds: they alias a ring that has no request in
   uint16_t *scratch_cum; // flight (build_table is always called before the ring is begun)
-#if defined(HSRANS_STAGE_SYMBOLS) && HSRANS_STAGE_SYMBOLS
-  uint8_t *stage = nullptr; // experiment: this wave's KiB of LDS for 16 groups of symbols (run_groups_stage)
-#endif
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -894,123 +891,11 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
   r.vm = r.seq1 = r.seq2 = r.seq3 = 0; // (not kept here; zero only makes the waits of the few groups behind this loop stricter)
 }
 
-#if defined(HSRANS_STAGE_SYMBOLS) && HSRANS_STAGE_SYMBOLS
-// EXPERIMENT (profiles/r05_stage_symbols_ab.txt; not compiled into the shipped library): the symbols go through
-// LDS — one ds_write_b8 per lane and group at byte idx2idx(lane) of the group's 64-byte row — and every 16 groups the wave reads its
-// KiB back with one ds_read_b128 per lane and stores it with one global_store_dwordx4: no v_perm packing, no quad transpose (7 of the
-// loop's 11 vector instructions per group are the state step; the other 1.75 + one shift here), 4x fewer store instructions, 1 KiB
-// contiguous per wave-store.  The price is LDS: one more write per group on a unit that is already busy three quarters of the time.
-#define HSRANS_STAGE_GROUP(P0, P1, OFF)                                                                                                              \
-  "v_and_b32 %[t], %[x], %[vmask]\n\t"                                                                                                               \
-  "v_lshl_add_u32 %[t], %[t], 3, %[stab]\n\t"                                                                                                        \
-  "ds_read_b64 v[" #P0 ":" #P1 "], %[t]\n\t"                                                                                                         \
-  "v_lshrrev_b32 %[x], %[vbits], %[x]\n\t"                                                                                                           \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
-  "v_mad_u32_u24 %[x], v" #P0 ", %[x], v" #P1 "\n\t"                                                                                                 \
-  "v_lshrrev_b32 v" #P1 ", 24, v" #P0 "\n\t"                                                                                                         \
-  "ds_write_b8 %[vst], v" #P1 " offset:" #OFF "\n\t"                                                                                                 \
-  "v_cmpx_gt_u32 vcc, %[lim], %[x]\n\t"                                                                                                              \
-  "s_nop 1\n\t"                                                                                                                                      \
-  "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"                                                                                                           \
-  "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"                                                                                                        \
-  "v_lshl_add_u32 %[t], %[t], 1, %[sa]\n\t"                                                                                                          \
-  "ds_read_u16 %[t], %[t]\n\t"                                                                                                                       \
-  "s_bcnt1_i32_b64 %[st], vcc\n\t"                                                                                                                   \
-  "s_lshl1_add_u32 %[sa], %[st], %[sa]\n\t"                                                                                                          \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
-  "v_lshl_or_b32 %[x], %[x], 16, %[t]\n\t"                                                                                                           \
-  "s_mov_b64 exec, -1\n\t"
-
-template <int Q> // the groups 4Q .. 4Q + 3 of a 16-group tile
-__device__ __forceinline__ void stage_groups4(uint32_t &x, uint32_t &s_addr, const WaveCtx &c, uint32_t s_table, uint32_t v_stage)
-{
-  uint32_t t, st;
-  if (Q == 0)
-    asm volatile(HSRANS_STAGE_GROUP(52, 53, 0) HSRANS_STAGE_GROUP(54, 55, 64) HSRANS_STAGE_GROUP(56, 57, 128) HSRANS_STAGE_GROUP(58, 59, 192)
-                 : [x] "+v"(x), [sa] "+s"(s_addr), [t] "=&v"(t), [st] "=&s"(st)
-                 : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [stab] "s"(s_table), [lim] "s"(kConsume), [vst] "v"(v_stage)
-                 : "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "vcc", "scc", "memory");
-  if (Q == 1)
-    asm volatile(HSRANS_STAGE_GROUP(52, 53, 256) HSRANS_STAGE_GROUP(54, 55, 320) HSRANS_STAGE_GROUP(56, 57, 384) HSRANS_STAGE_GROUP(58, 59, 448)
-                 : [x] "+v"(x), [sa] "+s"(s_addr), [t] "=&v"(t), [st] "=&s"(st)
-                 : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [stab] "s"(s_table), [lim] "s"(kConsume), [vst] "v"(v_stage)
-                 : "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "vcc", "scc", "memory");
-  if (Q == 2)
-    asm volatile(HSRANS_STAGE_GROUP(52, 53, 512) HSRANS_STAGE_GROUP(54, 55, 576) HSRANS_STAGE_GROUP(56, 57, 640) HSRANS_STAGE_GROUP(58, 59, 704)
-                 : [x] "+v"(x), [sa] "+s"(s_addr), [t] "=&v"(t), [st] "=&s"(st)
-                 : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [stab] "s"(s_table), [lim] "s"(kConsume), [vst] "v"(v_stage)
-                 : "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "vcc", "scc", "memory");
-  if (Q == 3)
-    asm volatile(HSRANS_STAGE_GROUP(52, 53, 768) HSRANS_STAGE_GROUP(54, 55, 832) HSRANS_STAGE_GROUP(56, 57, 896) HSRANS_STAGE_GROUP(58, 59, 960)
-                 : [x] "+v"(x), [sa] "+s"(s_addr), [t] "=&v"(t), [st] "=&s"(st)
-                 : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [stab] "s"(s_table), [lim] "s"(kConsume), [vst] "v"(v_stage)
-                 : "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "vcc", "scc", "memory");
-}
-
-// `steps` whole groups in tiles of 16 (what is left goes to the ordinary hand-scheduled loop); c.stage = this wave's KiB of LDS
-__device__ __forceinline__ void run_groups_stage(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o_ref, uint32_t &steps, uint8_t *stage)
-{
-  const uint32_t s_table = uni(lds_address(c.table));
-  uint32_t s_addr = uni(r.lds + ((r.cur << 1) & (kRingBytes - 1)));
-  uint32_t next_cross = uni(r.lds + (((r.k + 1) & (kRingSlots - 1)) << 9));
-  if (next_cross == r.lds)
-    next_cross += kRingBytes;
-  const uint32_t words0 = r.cur, s_addr0 = s_addr;
-  uint32_t moved = 0;
-  uint8_t *outp = (uint8_t *)uni64((uint64_t)(uintptr_t)(c.out + uni64(o_ref)));
-  uint32_t tiles = steps >> 4;
-  steps &= 15;
-  o_ref += (uint64_t)tiles * 1024;
-  const uint32_t v_stage = lds_address(stage) + lane_to_byte(c.lane);
-  const uint32_t v_read = lds_address(stage) + c.lane * 16;
-  auto cross = [&]() {
-    if (s_addr >= next_cross)
-    {
-      r.k++;
-      next_cross += kChunkBytes;
-      if (s_addr >= r.lds + kRingBytes)
-      {
-        s_addr -= kRingBytes;
-        next_cross -= kRingBytes;
-        moved += kRingBytes;
-      }
-      ring_request(sw, r, c, r.k + HSRANS_RING_AHEAD);
-      // (chunk k + 1 must have landed; younger than its request are at least the requests for k + 2 and k + 3: "at most 2 outstanding" is
-      // always enough, and stricter than the shipped loop's counted wait by the stores issued in between — here one per 16 groups)
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    }
-  };
-  for (; tiles != 0; tiles--)
-  {
-    stage_groups4<0>(x, s_addr, c, s_table, v_stage);
-    cross();
-    stage_groups4<1>(x, s_addr, c, s_table, v_stage);
-    cross();
-    stage_groups4<2>(x, s_addr, c, s_table, v_stage);
-    cross();
-    stage_groups4<3>(x, s_addr, c, s_table, v_stage);
-    u32x4 row;
-    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(row) : "v"(v_read) : "memory");
-    asm volatile("global_store_dwordx4 %0, %1, %2" HSRANS_STORE_POLICY_DIRECT : : "v"(c.lane * 16), "v"(row), "s"(outp) : "memory");
-    outp += 1024;
-    cross();
-  }
-  r.cur = words0 + ((s_addr + moved - s_addr0) >> 1);
-  r.st1 = r.st2 = 0;
-  r.vm = r.seq1 = r.seq2 = r.seq3 = 0;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the loop that takes the remainder counts from a clean slate)
-}
-#endif
-
 // FAST: the call sites that carry the bulk of a launch's groups (every inlined copy of the hand-scheduled loop pins v52-v59 and
 // costs the big multi-path kernel registers: with it at every call site k_decode<3, true> went to 97 VGPRs and spilled)
 template <int MODE, bool FAST = false, bool STRICT = false, bool WT = false> // STRICT: the constant wait of run_groups_fast (the grouped launches); WT: write-through stores
 __device__ __forceinline__ void run_groups(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps)
 {
-#if defined(HSRANS_STAGE_SYMBOLS) && HSRANS_STAGE_SYMBOLS
-  if (FAST && WT && MODE == kModePack64 && c.S == 64 && r.mirror_lanes == 0xFFFFFFFFu && c.stage != nullptr)
-    run_groups_stage(x, sw, r, c, o, steps, c.stage); // (experiment: tiles of 16 groups through LDS; leaves < 16 groups)
-#endif
   if (FAST && MODE == kModePack64 && c.S == 64 && r.mirror_lanes == 0xFFFFFFFFu)
     run_groups_fast<STRICT, kModePack64, WT>(x, sw, r, c, o, steps); // the hand-scheduled loop; leaves < 4 groups
   if (FAST && MODE == kModeRank && c.S == 64 && r.mirror_lanes == 0xFFFFFFFFu && uni(lds_address(c.table)) == 0)

@@ -298,10 +298,6 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.gtable = kp.pa.table;
   c.scratch_cnt = (uint16_t *)ring0; // wave 0's ring (no request in flight while a table is built)
   c.scratch_cum = (uint16_t *)(ring0 + 512);
-#if defined(HSRANS_STAGE_SYMBOLS) && HSRANS_STAGE_SYMBOLS
-  if (MODE == kModePack64)
-    c.stage = smem + waves * ring_stride + table_bytes_for(MODE, c.bits) + wave * 1024; // (launch_shape adds waves KiB under the same flag)
-#endif
   const uint32_t chain = blockIdx.x * waves + wave;
   if (c.S == 32)
     run_direct_pair<MODE>(c, kp, waves, chain);
@@ -337,9 +333,6 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_c
   c.gtable = kp.pa.table;
   c.scratch_cnt = (uint16_t *)smem;
   c.scratch_cum = (uint16_t *)(smem + 512);
-#if defined(HSRANS_STAGE_SYMBOLS) && HSRANS_STAGE_SYMBOLS
-  c.stage = smem + waves * kFastRingBytes + table_bytes_for(MODE, c.bits) + wave * 1024;
-#endif
   run_direct<MODE>(c, kp, waves, blockIdx.x * waves + wave);
 }
 
