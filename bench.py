@@ -268,6 +268,9 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
     # once — measured with this very kernel (tools/settle_probe.py, profiles/r04_settle.txt): the first ~1 ms after the idle
     # gap reads 41 us per decode, the next 5-8 ms read 47-52 us, and only after about 12 ms of back-to-back launches the time is at
     # the 40-43 us it then keeps.  A production decoder is in that last state; --settle-ms 0 measures the wake-up instead.
+    # (the method changed between rounds 3 and 4 — one region straight after the validation's idle gap then, a settled median of
+    # 15 regions now — so the old method's figure is taken too, first, and reported beside the headline: mib_s.old_method_one_region_no_settle)
+    old_method = timed_region(0) if (args.settle_ms > 0 and not args.timed_only) else None
     settle_launches = 0
     if args.settle_ms > 0:
         t_settle = time.perf_counter()
@@ -446,6 +449,9 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
                   "p90": to_mib_s(np.percentile(region_s, 10)), "mean": to_mib_s(region_s.mean()), "repeats": int(region_s.size),
                   "per_repeat": [to_mib_s(x) for x in region_s], "ms_per_step_per_repeat": [float(x / args.steps * 1e3) for x in region_s],
                   "note": "each repeat = W warm-up steps + barrier/synchronize + K timed steps + synchronize/barrier; `value` is the median repeat",
+                  "old_method_one_region_no_settle": None if old_method is None else
+                  {"value": to_mib_s(old_method[0]), "ms_per_step": old_method[0] / args.steps * 1e3,
+                   "note": "rounds 1-3 measured this: ONE region (W warm-up + K timed steps) straight after the validation's idle gap, no settling, no repeats"},
                   "best_single_launch": units * n / 2**20 / (float(np.min(kernel_ms)) * 1e-3),
                   "warm_one_pair_replayed": units * n / 2**20 / (warm_ms * 1e-3), "launches_in_timed_region": args.steps,
                   # "1 stream, no index" = single_wavefront_no_plan below, "1 stream + index" = value, and "N independent streams":

@@ -602,7 +602,10 @@ try
   {
     std::lock_guard<std::mutex> guard(ctx->lock);
     hsrans_dplan *ix = ctx->host_index;
+    // (the stream's first bytes — its header, the first block header or the histogram — are compared on the host before anything is
+    // launched; the fingerprint of ALL bytes is what the result then rests on)
     if (ix != nullptr && ctx->host_index_key[0] == (uint64_t)(uintptr_t)in && ctx->host_index_key[1] == in_length && ctx->host_index_key[2] == codec_key &&
+        ctx->host_index_head_len == std::min<size_t>(in_length, sizeof(ctx->host_index_head)) && memcmp(ctx->host_index_head, in, ctx->host_index_head_len) == 0 &&
         ix->hdr.decoded_len <= out_capacity && hipSetDevice(ctx->device) == hipSuccess)
     {
       const size_t n = (size_t)ix->hdr.decoded_len;
@@ -687,6 +690,7 @@ try
     bool have_index = launch_stream_checksum(ctx->d_in, in_length, (uint64_t *)ctx->d_enc_meta, s) == hipSuccess &&
                       hipMemcpyAsync(&sum, ctx->d_enc_meta, 8, hipMemcpyDeviceToHost, s) == hipSuccess;
     if (have_index && container == HSRANS_RAW)
+    try
     {
       // a raw stream is ONE chain: the pass that records its checkpoints is the host SIMD decoder's (2-4 GB/s on one core, while the
       // upload is on its way; one wavefront would need four times as long), at the one-chain-per-wavefront boundaries of this device;
@@ -709,6 +713,13 @@ try
         }
       }
     }
+    catch (...) // (bad_alloc from the vectors above: the upload of `in` and the fingerprint's copy are already queued — nothing queued
+    {           // may still read `in` or write this frame when the function returns)
+      (void)hipStreamSynchronize(s);
+      if (ix != nullptr)
+        hsrans_dplan_destroy(ix);
+      return 0;
+    }
     else if (have_index)
       have_index = decode_device_indexing_impl(ctx, d, ctx->d_in, in_length, ctx->d_out, (size_t)h.decoded_len, 64, s, &ix, true) == HSRANS_OK;
     if (have_index)
@@ -719,6 +730,8 @@ try
       ctx->host_index_key[1] = in_length;
       ctx->host_index_key[2] = codec_key;
       ctx->host_index_key[3] = sum;
+      ctx->host_index_head_len = (uint32_t)std::min<size_t>(in_length, sizeof(ctx->host_index_head));
+      memcpy(ctx->host_index_head, in, ctx->host_index_head_len);
     }
     else
       (void)hipGetLastError();

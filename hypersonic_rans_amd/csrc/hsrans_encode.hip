@@ -372,7 +372,11 @@ __device__ __forceinline__ void encode_group_fast(uint32_t &x, const uint4 &e, u
   // s_or around both (EXEC is all ones here: the loop runs in wave-uniform control flow of a 64-thread workgroup)
   const uint32_t off = p + 2 * rank;
   const uint32_t xs = x >> 16;
-  asm volatile("s_mov_b64 exec, %2\n\tglobal_store_short %0, %1, %3\n\ts_mov_b64 exec, -1" : : "v"(off), "v"(x), "s"(mask), "s"(slot) : "memory");
+  // (EXEC is saved and put back, not assumed to be all ones: one more scalar move per group, and the function stays right if it is ever
+  // inlined under a narrowed EXEC — a partial last workgroup, a divergent caller)
+  unsigned long long saved_exec;
+  asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, %3, exec\n\tglobal_store_short %1, %2, %4\n\ts_mov_b64 exec, %0"
+               : "=&s"(saved_exec) : "v"(off), "v"(x), "s"(mask), "s"(slot) : "memory", "scc");
   asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(x) : "v"(x), "v"(xs), "s"(mask));
 #else
   if (emit)

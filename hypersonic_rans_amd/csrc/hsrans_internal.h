@@ -34,6 +34,8 @@ struct hsrans_ctx
   // call on the same stream — {host address, length, codec, 64-bit fingerprint of all its bytes (computed on the device)}
   hsrans_dplan *host_index = nullptr;
   uint64_t host_index_key[4] = {};
+  uint8_t host_index_head[128] = {}; // ... and the stream's first bytes, compared on the host first
+  uint32_t host_index_head_len = 0;
   hsrans_hpipe *cached_pipe = nullptr; // hsrans_decode_host_pipelined: the pipeline of the plan used last
   uint64_t cached_pipe_key[3] = {};
   uint8_t *d_in = nullptr;

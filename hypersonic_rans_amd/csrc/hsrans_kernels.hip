@@ -37,6 +37,7 @@
 #include <stdint.h>
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 
@@ -341,13 +342,13 @@ static void spread_weights(const DeviceGeom &dg, uint16_t (*cum_out)[17])
   }
 }
 
-uint32_t spread_longest_share(const DeviceGeom &dg, uint64_t n_chains)
+// (`cum`: the weights the launch will hand the kernel — computed ONCE per launch, so that the check and the kernel cannot see two
+// different sets when hsrans_ctx_calibrate rewrites the context's geometry on another thread)
+static uint32_t spread_longest_share_of(const DeviceGeom &dg, uint64_t n_chains, const uint16_t (*cum)[17])
 {
   const uint32_t grid = spread_grid(dg);
   if (n_chains < (uint64_t)grid * kSpreadWaves || n_chains > (uint64_t)grid * kSpreadMaxShare) // (a chain per wave at least)
     return 0;
-  uint16_t cum[2][17];
-  spread_weights(dg, cum);
   uint32_t longest = 0;
   for (uint32_t b : {0u, (grid + 1) / 2 - 1, (grid + 1) / 2, grid - 1}) // (shares differ by rounding only within a half)
   {
@@ -357,6 +358,13 @@ uint32_t spread_longest_share(const DeviceGeom &dg, uint64_t n_chains)
   }
   longest += 1; // (rounding)
   return longest > kSpreadMaxShare ? 0 : longest;
+}
+
+uint32_t spread_longest_share(const DeviceGeom &dg, uint64_t n_chains)
+{
+  uint16_t cum[2][17];
+  spread_weights(dg, cum);
+  return spread_longest_share_of(dg, n_chains, cum);
 }
 
 // Everything about a launch that follows from the plan header and the device alone (no pointers): the table layout, the
@@ -690,7 +698,9 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
   bool spread = false;
   if (grouped && L.shared && kp.spread != 0 && kp.groups_lean && L.mode == kModePack64 && g_spread)
   {
-    const uint32_t longest = spread_longest_share(dg, h.n_chains);
+    uint16_t spread_cum[2][17];
+    spread_weights(dg, spread_cum); // one snapshot: the same weights for the check below and for the kernel
+    const uint32_t longest = spread_longest_share_of(dg, h.n_chains, spread_cum);
     const uint32_t slds = kSpreadWaves * kFastRingBytes + 2 * table_bytes_for(kModePack64, h.bits) + (kSpreadMaxShare + 1) * (uint32_t)sizeof(Piece);
     if (longest != 0 && longest < kp.spread && 2 * slds <= dg.max_lds) // (a share shorter than every block touches at most two)
     {
@@ -699,7 +709,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
       launch_grid = spread_grid(dg);
       launch_waves = kSpreadWaves;
       launch_lds = slds;
-      spread_weights(dg, kp.group_cum);
+      memcpy(kp.group_cum, spread_cum, sizeof(kp.group_cum));
       kp.pa.n_chains = h.n_chains; // (single-piece chains: n_pieces == n_chains)
       kp.pa.S = h.states;
       kp.pa.bits = h.bits;

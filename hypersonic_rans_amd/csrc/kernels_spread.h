@@ -27,6 +27,12 @@ __device__ void run_spread(WaveCtx &c, const PlanView &pv, const KParams &kp, ui
   const uint32_t c0 = spread_share_begin(N, blockIdx.x, gridDim.x, kp.group_cum[0][waves], kp.group_cum[1][waves]);
   const uint32_t c1 = spread_share_begin(N, blockIdx.x + 1, gridDim.x, kp.group_cum[0][waves], kp.group_cum[1][waves]);
   const uint32_t count = c1 - c0;           // <= kSpreadMaxShare (the launcher checks)
+  if (count > kSpreadMaxShare) // (the launcher checks the same weights it hands the kernel; a share that would overrun the LDS record area must never run)
+  {
+    if (threadIdx.x == 0)
+      atomicOr(c.status, kStatusOutOfRange);
+    return;
+  }
   const uint32_t n_rec = count + (c1 < N);  // + the chain behind the share: where the last run's words end
   uint8_t *const table0 = c.table;
   const uint32_t table_bytes = table_bytes_for(MODE, c.bits);

@@ -161,9 +161,12 @@ uint32_t hsrans_ctx_host_index_chains(hsrans_ctx *ctx);
  * Returns the decoded length, 0 on failure. `plan` may be NULL (derived from the stream).
  * With plan == NULL, mt_ and raw streams of >= 1 MiB leave an index behind: the first call's decode records checkpoints (as
  * hsrans_decode_device_indexing) and the context keeps the plan; a later call with the same `in`, in_length and codec launches it
- * — but only counts when a 64-bit fingerprint of ALL stream bytes, computed on the device beside the decode, equals the first
- * call's (otherwise the call starts over; other bytes at the same address cost one wasted launch, never a wrong result short of a
- * 2^-64 collision).  A loop over one file (src/main.cpp:860-889) thus runs the indexed kernels from its second iteration:
+ * — but only counts when the stream's first 128 bytes (compared on the host) and a 64-bit fingerprint of ALL stream bytes, computed on
+ * the device beside the decode, equal the first call's (otherwise the call starts over; other bytes at the same address cost one
+ * wasted launch).  The fingerprint is a mixing hash, not a MAC: it guards against ACCIDENTAL reuse of a buffer (another file read into
+ * the same allocation), where a false match needs a 2^-64 coincidence; bytes crafted to collide with it would decode with the previous
+ * stream's checkpoints — memory-safe (every read stays inside in_length) but wrong.  Callers that decode hostile streams through this
+ * entry switch the cache off (HSRANS_HOST_INDEX_CACHE_OFF=1) or pass their own plan.  A loop over one file (src/main.cpp:860-889) thus runs the indexed kernels from its second iteration:
  * 100 MB mt_: 0.24 -> 0.06 ms of kernel per call; raw: 125 ms -> 0.04 ms (a raw stream's index comes from the host SIMD decoder's
  * pass, ~30 ms for 100 MB, during the first call).  HSRANS_HOST_INDEX_CACHE_OFF=1 disables it. */
 size_t hsrans_decode_host(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out,
