@@ -166,4 +166,10 @@ struct hsrans_batch
 int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, const PlanHeader &h, hipStream_t s);
 int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity, hipStream_t s, uint64_t stream_lo = 0);
 
+// a page-locked, device-mapped host range: the address the GPU reaches it at, else null (hsrans_capi.cpp)
+uint8_t *device_view_of_host(const void *ptr, size_t bytes);
+// hsrans_decode_device_indexing's body; have_lock: the caller holds ctx->lock already (hsrans_capi_index.cpp)
+int decode_device_indexing_impl(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity,
+                                uint32_t index_interval, void *hip_stream, hsrans_dplan **indexed, bool have_lock);
+
 #endif // HSRANS_INTERNAL_H
