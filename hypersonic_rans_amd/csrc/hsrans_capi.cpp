@@ -656,8 +656,8 @@ try
   const size_t in_pad = (in_length + 15) / 16 * 16;
   // (Storing straight into a page-locked `out`, as hsrans_hpipe_decode does, was measured here too: with nothing to overlap it
   // only replaces a download copy at 55 GB/s by the kernel's own PCIe writes at 47 — 100 MB: 3.58 instead of 3.26 ms — so this
-  // one-shot entry stages its output and copies it down; HSRANS_HOST_DIRECT=1 switches the direct stores on.)
-  uint8_t *out_view = getenv("HSRANS_HOST_DIRECT") != nullptr && ((uintptr_t)out & 3) == 0 ? device_view_of_host(out, (size_t)h.decoded_len) : nullptr;
+  // one-shot entry stages its output and copies it down (the knob that switched the direct stores on here is gone: settled).)
+  uint8_t *out_view = nullptr;
   if (!grow(&ctx->d_in, &ctx->d_in_cap, in_pad) || (out_view == nullptr && !grow(&ctx->d_out, &ctx->d_out_cap, (size_t)h.decoded_len + 16)))
     return 0;
   hipStream_t s = ctx->stream;

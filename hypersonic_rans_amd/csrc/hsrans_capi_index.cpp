@@ -100,9 +100,9 @@ static size_t index_build_impl(hsrans_ctx *ctx, int container, int states, uint3
     return 0;
   // A raw stream is one dependent chain: one wavefront records its checkpoints at ~0.65 GB/s, one host core with this
   // library's SIMD decoder at 2-3 GB/s and without the upload — so raw streams are indexed on the host (same plan, byte for
-  // byte; HSRANS_INDEX_ON_GPU=1 keeps the wavefront pass).  mt_ blocks (one wavefront each, in parallel) and block_ streams
+  // byte).  mt_ blocks (one wavefront each, in parallel) and block_ streams
   // (the walk that also reports the inline headers) stay on the GPU.
-  if (container == HSRANS_RAW && getenv("HSRANS_INDEX_ON_GPU") == nullptr)
+  if (container == HSRANS_RAW)
   {
     std::vector<uint64_t> own;
     if (groups == nullptr)

@@ -96,10 +96,10 @@ hipError_t launch_mt_fill(const uint8_t *d_stream, uint64_t stream_len, uint32_t
 // host-side launcher
 // ---------------------------------------------------------------------------------------------------------------
 // tuning knobs (environment, read once per process; the defaults are the measured best)
-static uint32_t g_pack64_max_bits = 14; // HSRANS_PACK64_MAX_BITS: widest histogram decoded with the 8-byte-per-slot shared table
+static constexpr uint32_t g_pack64_max_bits = 14; // widest histogram decoded with the 8-byte-per-slot shared table (knob removed in round 5: settled)
 static uint32_t g_waves_per_wg = 16;    // HSRANS_WAVES_PER_WG: waves per workgroup of the shared-table launches
 static uint32_t g_spread = 1;           // HSRANS_SPREAD=0: grouped plans with few large blocks keep the one-block-per-workgroup launch
-static uint32_t g_static_percent = 100; // HSRANS_STATIC_PERCENT: share of the chains handed out statically (uniform persistent launches)
+static constexpr uint32_t g_static_percent = 100; // share of the chains handed out statically (uniform persistent launches; knob removed: settled)
 // HSRANS_SLOT_WEIGHTS: per-mille run length of the 8 wave classes, see PersistentArgs::run_len.  Measured on
 // MI355X at 8 waves per SIMD (bits <= 12): with equal runs the four age classes of a workgroup finish at 33/36/39/42 us,
 // with these weights all at 39 us (tools/stamps.py), 3-7 % less kernel time; at 4 waves per SIMD (bits >= 13) equal
@@ -127,16 +127,16 @@ static uint32_t g_direct_weights_pair[8] = {1662, 1550, 1365, 1142, 887, 656, 45
 // chains of 32-state plans in private-table launches.  Measured: 2^30 B in 16,384 blocks 1.40 -> 1.33 ms, but 100 MB in 1,526
 // blocks 0.25 -> 0.30 ms (everything is latency-bound there and half as many waves are in flight)
 static uint32_t g_private_pair = 1;
-static bool g_weights_two_level = false; // HSRANS_WEIGHTS_TWO_LEVEL: apply the weights to the two-level table mode as well
+static constexpr bool g_weights_two_level = false; // (the class weights are not applied to the two-level table mode: measured, knob removed)
 static bool g_table_spill = false;       // HSRANS_TABLE_SPILL: host-built tables stay in global memory (kModeSpill; comparison only)
 // one-chain-per-wave plans (hsrans_index_boundaries): share of the stream (per mille) left to short chains that the ticket
 // queues hand to waves that are done early, and the length of those chains in groups
 
 static void read_tuning_once();
-static uint32_t g_persist_kernel = 1; // HSRANS_PERSIST_KERNEL: 0 = uniform-interval plans on k_decode<3, true> (A/B)
+static constexpr uint32_t g_persist_kernel = 1; // uniform-interval plans run k_decode_persist (the A/B against k_decode<3, true> is settled: knob removed)
 static uint32_t g_single_fast = 1; // HSRANS_SINGLE_FAST: 0 = un-indexed raw streams on the general kernel (one wave, two LDS round trips per group)
-static bool g_rank_table = true;      // HSRANS_NO_RANK_TABLE: the wide histograms fall back to the 8-byte-per-slot / two-level tables (comparison)
-static uint32_t g_dual_waves = 16; // HSRANS_DUAL_WAVES: waves per workgroup of k_decode_dual (12: two workgroups per CU fit beside a 16 KiB table)
+static constexpr bool g_rank_table = true; // wide histograms use the rank table (the comparison knob is gone: 52 against 57-63 us, CHANGELOG round 2-3)
+static constexpr uint32_t g_dual_waves = 16; // waves per workgroup of k_decode_dual (12 — two workgroups per CU beside a 16 KiB table — measured slower again in round 5: profiles/r05_table_at_zero_ab.txt; knob removed)
 static uint32_t g_dual = 1; // HSRANS_DUAL: 0 = never run two chains per wave (k_decode_dual), 1 = where it pays (default), 2 = for every width (experiment)
 // the one-chain-per-wave weights of the dual kernel's launches (one 16-wave workgroup per CU, two chains per wave)
 static uint32_t g_dual_weights[8] = {1232, 1112, 934, 722, 1232, 1112, 934, 722};        // 13 bits (8-byte table)
@@ -227,11 +227,6 @@ static void read_tuning_once() // contexts may be created from several threads
 }
 static void read_tuning_impl()
 {
-  if (const char *e = getenv("HSRANS_STATIC_PERCENT"))
-    g_static_percent = (uint32_t)atoi(e) > 100 ? 100 : (uint32_t)atoi(e);
-  if (const char *e = getenv("HSRANS_PACK64_MAX_BITS"))
-    if (atoi(e) >= 9 && atoi(e) <= 14)
-      g_pack64_max_bits = (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_SPREAD"))
     g_spread = atoi(e) != 0;
   if (const char *e = getenv("HSRANS_WAVES_PER_WG"))
@@ -261,22 +256,15 @@ static void read_tuning_impl()
   read_weights("HSRANS_DIRECT_WEIGHTS6", g_direct_weights6);
   read_weights("HSRANS_DIRECT_WEIGHTS3", g_direct_weights3);
   read_weights("HSRANS_DIRECT_WEIGHTS_PAIR", g_direct_weights_pair);
-  g_weights_two_level = getenv("HSRANS_WEIGHTS_TWO_LEVEL") != nullptr;
   g_table_spill = getenv("HSRANS_TABLE_SPILL") != nullptr;
   if (const char *e = getenv("HSRANS_PRIVATE_PAIR"))
     g_private_pair = (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_DUAL"))
     g_dual = (uint32_t)atoi(e);
-  if (const char *e = getenv("HSRANS_DUAL_WAVES"))
-    if (atoi(e) == 8 || atoi(e) == 12 || atoi(e) == 16)
-      g_dual_waves = (uint32_t)atoi(e);
-  if (const char *e = getenv("HSRANS_PERSIST_KERNEL"))
-    g_persist_kernel = (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_SINGLE_FAST"))
     g_single_fast = (uint32_t)atoi(e);
   read_weights("HSRANS_DUAL_WEIGHTS", g_dual_weights);               // 13 bits (8-byte table)
   read_weights("HSRANS_DUAL_WEIGHTS_WIDE", g_dual_weights_wide); // 14 / 15 bits (rank table)
-  g_rank_table = getenv("HSRANS_NO_RANK_TABLE") == nullptr;
 }
 
 // per device (the CURRENT device): dynamic-LDS limit of every kernel variant, CU count
