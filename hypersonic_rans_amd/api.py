@@ -45,7 +45,7 @@ class LaunchInfo(ctypes.Structure):
 
 
 class BatchInfo(ctypes.Structure):
-    _fields_ = [(n, _u32) for n in ("members", "launches", "direct_members", "solo_members", "grid", "block", "lds_bytes")] + \
+    _fields_ = [(n, _u32) for n in ("members", "launches", "direct_members", "solo_members", "grouped_members", "reserved", "grid", "block", "lds_bytes")] + \
                [("class_weights", _u32 * 8), ("imbalance", ctypes.c_double)]
 
 

@@ -227,6 +227,11 @@ bool direct_eligible(const hsrans_dplan *d)
   return d->pa.pieces != nullptr && d->pa.table != nullptr && d->pa.table_mode == 3 && d->pa.dual == 0 && d->hdr.states == 64 && d->hdr.bits <= 12 &&
          (d->hdr.flags & kPlanMergeable) != 0 && d->hdr.container == HSRANS_RAW && d->hdr.n_chains >= 1;
 }
+// a plan the grouped batch kernel can take: block_/mt_ with checkpoints whose groups are all mergeable runs or fills, 64 states, <= 12 bits
+bool grouped_eligible(const hsrans_dplan *d)
+{
+  return d->n_groups != 0 && d->groups_lean && d->d_groups != nullptr && d->hdr.states == 64 && d->hdr.bits <= 12 && d->hdr.n_pieces != 0;
+}
 } // namespace
 
 extern "C"
@@ -242,6 +247,12 @@ void hsrans_dplan_batch_destroy(hsrans_batch *b)
     (void)hipFree(b->d_arena);
   if (b->d_finish && b->finish_owned)
     (void)hipFree(b->d_finish);
+  for (hsrans_batch::GroupedLaunch &g : b->grouped)
+  {
+    if (g.d_members)
+      (void)hipFree((void *)g.d_members); // (members, groups and tickets are one allocation)
+    delete g.epoch;
+  }
   delete b;
 }
 
@@ -267,9 +278,78 @@ try
   b->ctx = ctx;
   b->members.assign(dplans, dplans + count);
   b->order_run.assign(count, 0);
-  std::vector<uint32_t> eligible;
+  std::vector<uint32_t> eligible, gr_eligible;
   for (uint32_t k = 0; k < count; k++)
-    (direct_eligible(dplans[k]) ? eligible : b->solo).push_back(k);
+    (direct_eligible(dplans[k]) ? eligible : grouped_eligible(dplans[k]) ? gr_eligible : b->solo).push_back(k);
+  // grouped members: one launch per histogram width (the LDS layout follows the width), at most kBatchMax members each; a lone member
+  // of its width keeps its own launch (its own dealing, incl. k_decode_spread)
+  for (uint32_t bits = 10; bits <= 12; bits++)
+  {
+    std::vector<uint32_t> of_width;
+    for (uint32_t k : gr_eligible)
+      if (dplans[k]->hdr.bits == bits)
+        of_width.push_back(k);
+    if (of_width.size() == 1)
+      b->solo.push_back(of_width[0]);
+    if (of_width.size() < 2)
+      continue;
+    const size_t n_gl = (of_width.size() + kBatchMax - 1) / kBatchMax;
+    for (size_t l = 0; l < n_gl; l++)
+    {
+      hsrans_batch::GroupedLaunch G;
+      G.member_idx.assign(of_width.begin() + of_width.size() * l / n_gl, of_width.begin() + of_width.size() * (l + 1) / n_gl);
+      G.bits = bits;
+      std::vector<Group> all;
+      std::vector<GroupMember> gm(G.member_idx.size());
+      uint64_t chains = 0;
+      for (size_t i = 0; i < G.member_idx.size(); i++)
+      {
+        const hsrans_dplan *d = dplans[G.member_idx[i]];
+        std::vector<Group> mine(d->n_groups);
+        if (hipMemcpy(mine.data(), d->d_groups, (size_t)d->n_groups * sizeof(Group), hipMemcpyDeviceToHost) != hipSuccess)
+        {
+          hsrans_dplan_batch_destroy(b);
+          return HSRANS_E_HIP;
+        }
+        for (Group &g : mine)
+          g.flags = (g.flags & ((1u << kGroupMemberShift) - 1)) | ((uint32_t)i << kGroupMemberShift);
+        all.insert(all.end(), mine.begin(), mine.end());
+        chains += d->hdr.n_chains;
+        gm[i].chain_first = (const uint32_t *)(d->d_plan + plan_chain_first_off());
+        gm[i].pieces = (const Piece *)(d->d_plan + plan_pieces_off(d->hdr.n_chains));
+        gm[i].states = (const uint32_t *)(d->d_plan + plan_states_off(d->hdr.n_chains, d->hdr.n_pieces));
+        gm[i].status = d->d_status;
+      }
+      // longest groups first: the launch hands groups out in list order (the first `grid` statically, the rest by ticket), and it
+      // finishes evenly when what is handed out last is short
+      std::stable_sort(all.begin(), all.end(), [](const Group &x, const Group &y) { return x.count > y.count; });
+      G.n_groups = (uint32_t)all.size();
+      G.shape = batch_grouped_shape(ctx->geom, bits, G.n_groups, chains);
+      const size_t counter_bytes = (size_t)kCounterSets * kDynQueueStride * 8;
+      auto up256g = [](size_t v) { return (v + 255) & ~(size_t)255; };
+      const size_t bytes = up256g(gm.size() * sizeof(GroupMember)) + up256g(all.size() * sizeof(Group)) + counter_bytes;
+      uint8_t *dev = nullptr;
+      if (hipMalloc((void **)&dev, bytes) != hipSuccess)
+      {
+        (void)hipGetLastError();
+        hsrans_dplan_batch_destroy(b);
+        return HSRANS_E_HIP;
+      }
+      G.d_members = (const GroupMember *)dev;
+      G.d_groups = (const Group *)(dev + up256g(gm.size() * sizeof(GroupMember)));
+      G.d_tickets = (unsigned long long *)(dev + up256g(gm.size() * sizeof(GroupMember)) + up256g(all.size() * sizeof(Group)));
+      G.epoch = new (std::nothrow) std::atomic<uint32_t>(0);
+      const bool ok = G.epoch != nullptr && hipMemset(dev, 0, bytes) == hipSuccess && hipMemcpy(dev, gm.data(), gm.size() * sizeof(GroupMember), hipMemcpyHostToDevice) == hipSuccess &&
+                      hipMemcpy((void *)G.d_groups, all.data(), all.size() * sizeof(Group), hipMemcpyHostToDevice) == hipSuccess;
+      b->grouped.push_back(std::move(G)); // (owned by the batch from here: destroyed with it)
+      if (!ok)
+      {
+        hsrans_dplan_batch_destroy(b);
+        return HSRANS_E_HIP;
+      }
+    }
+  }
+  std::sort(b->solo.begin(), b->solo.end());
   if (eligible.size() == 1) // a launch of its own is the same thing, with the plan's own dealing
   {
     b->solo.push_back(eligible[0]);
@@ -434,6 +514,27 @@ int hsrans_decode_device_batch(hsrans_ctx *ctx, hsrans_batch *b, const void *con
     if (launch_batch_direct(bp, L.shape, s) != hipSuccess)
       return HSRANS_E_HIP;
   }
+  for (const hsrans_batch::GroupedLaunch &G : b->grouped)
+  {
+    BatchGroupParams gp{};
+    for (size_t i = 0; i < G.member_idx.size(); i++)
+    {
+      const uint32_t k = G.member_idx[i];
+      gp.io[i].stream = (const uint8_t *)d_streams[k];
+      gp.io[i].stream_len = std::min<uint64_t>(stream_lengths[k], b->members[k]->hdr.stream_len);
+      gp.io[i].out = (uint8_t *)d_outs[k];
+      gp.io[i].out_cap = std::min<uint64_t>(out_capacities[k], b->members[k]->hdr.decoded_len);
+    }
+    gp.members = G.d_members;
+    gp.groups = G.d_groups;
+    gp.n_groups = G.n_groups;
+    gp.bits = G.bits;
+    gp.group_prio = 350; // (run_grouped: the share of its run the younger half of a workgroup decodes at raised priority; dplan_launch's default)
+    gp.tickets = G.d_tickets + (size_t)(G.epoch->fetch_add(1, std::memory_order_relaxed) % kCounterSets) * kDynQueueStride;
+    memcpy(gp.group_cum, G.shape.group_cum, sizeof(gp.group_cum));
+    if (launch_batch_grouped(gp, G.shape, s) != hipSuccess)
+      return HSRANS_E_HIP;
+  }
   for (uint32_t k : b->solo)
   {
     const int rc = dplan_launch(b->members[k], d_streams[k], stream_lengths[k], d_outs[k], out_capacities[k], s);
@@ -465,7 +566,9 @@ int hsrans_dplan_batch_info(const hsrans_batch *b, hsrans_batch_info *info)
     return HSRANS_E_ARG;
   memset(info, 0, sizeof(*info));
   info->members = (uint32_t)b->members.size();
-  info->launches = (uint32_t)(b->direct.size() + b->solo.size());
+  info->launches = (uint32_t)(b->direct.size() + b->grouped.size() + b->solo.size());
+  for (const hsrans_batch::GroupedLaunch &G : b->grouped)
+    info->grouped_members += (uint32_t)G.member_idx.size();
   info->solo_members = (uint32_t)b->solo.size();
   for (const hsrans_batch::DirectLaunch &L : b->direct)
   {

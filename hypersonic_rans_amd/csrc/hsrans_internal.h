@@ -152,6 +152,18 @@ struct hsrans_batch
     double imbalance = 1.0;
   };
   std::vector<DirectLaunch> direct;
+  // block_/mt_ members with checkpoints (64 states, one width <= 12 bits per launch): all their groups in ONE k_decode_grouped_batch launch
+  struct GroupedLaunch
+  {
+    std::vector<uint32_t> member_idx;
+    BatchGroupShape shape{};
+    const GroupMember *d_members = nullptr;
+    const Group *d_groups = nullptr;
+    unsigned long long *d_tickets = nullptr; // kCounterSets monotonic ticket counters, one per launch in flight (as a device plan's)
+    uint32_t n_groups = 0, bits = 0;
+    std::atomic<uint32_t> *epoch = nullptr; // (heap: the struct must stay movable)
+  };
+  std::vector<GroupedLaunch> grouped;
   std::vector<uint32_t> solo; // members that take a launch of their own (hsrans_decode_device's)
   uint8_t *d_arena = nullptr;
   // per-wave finish times of the first shared launch: diagnostics (HSRANS_BATCH_STAMPS=1: owned by the batch) and

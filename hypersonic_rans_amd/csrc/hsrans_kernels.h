@@ -146,6 +146,32 @@ struct BatchParams
   uint64_t *finish; // diagnostics (batch stamps): wave w's finish time, [n_slots] = the first wave's entry; null otherwise
   uint64_t *stamps;
 };
+// the grouped form (block_/mt_ members with checkpoints): Group::flags carries the member from bit kGroupMemberShift up
+constexpr uint32_t kGroupMemberShift = 16;
+struct GroupMember
+{
+  const uint32_t *chain_first;
+  const Piece *pieces;
+  const uint32_t *states;
+  uint32_t *status;
+};
+struct BatchGroupParams
+{
+  BatchIO io[kBatchMax];
+  const GroupMember *members;
+  const Group *groups; // all members' groups, flags |= member << kGroupMemberShift
+  unsigned long long *tickets;
+  uint32_t n_groups, bits, group_prio, reserved;
+  uint16_t group_cum[2][17];
+};
+struct BatchGroupShape
+{
+  uint32_t grid, waves, lds;
+  uint16_t group_cum[2][17];
+};
+BatchGroupShape batch_grouped_shape(const struct DeviceGeom &dg, uint32_t bits, uint32_t n_groups, uint64_t n_chains);
+hipError_t launch_batch_grouped(const BatchGroupParams &bp, const BatchGroupShape &shape, hipStream_t stream);
+
 struct BatchShape
 {
   uint32_t grid, waves, lds;

@@ -296,6 +296,8 @@ hipError_t prepare_kernels(DeviceGeom *geom)
   {
     hipError_t e = hipFuncSetAttribute((const void *)k_decode_batch<kModePack64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
     if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)k_decode_grouped_batch<kModePack64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
+    if (e == hipSuccess)
       e = hipFuncSetAttribute((const void *)k_calibrate_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
     if (e != hipSuccess)
       return e;
@@ -575,6 +577,46 @@ hipError_t launch_batch_direct(const BatchParams &bp, const BatchShape &shape, h
   return hipGetLastError();
 }
 
+// the per-wave shares of a group's chains as cumulative class weights (run_grouped: kp.group_cum)
+static void group_cum_of(const LaunchShape &L, uint16_t (*cum_out)[17])
+{
+  const uint32_t per_class = L.waves >= 4 ? L.waves / 4 : 1;
+  for (uint32_t hf = 0; hf < 2; hf++)
+  {
+    uint32_t cum = 0;
+    for (uint32_t k = 0; k <= 16; k++)
+    {
+      cum_out[hf][k] = (uint16_t)cum;
+      const uint32_t cls = k / per_class < 4 ? k / per_class : 3;
+      cum += k < L.waves ? L.weights[hf * 4 + cls] / 10 : 0;
+    }
+  }
+}
+
+// The grouped batch launch (64-state members, bits <= 12: the 8-byte table built per group): the shape k_decode_grouped would get for a
+// plan with all the members' groups and chains
+BatchGroupShape batch_grouped_shape(const DeviceGeom &dg, uint32_t bits, uint32_t n_groups, uint64_t n_chains)
+{
+  PlanHeader h{};
+  h.states = 64;
+  h.bits = bits;
+  h.n_chains = n_chains > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_chains;
+  const LaunchShape L = launch_shape(h, dg, false, 0, n_groups, false, false, false);
+  BatchGroupShape b{};
+  b.grid = L.grid;
+  b.waves = L.waves;
+  b.lds = L.lds;
+  group_cum_of(L, b.group_cum);
+  return b;
+}
+
+hipError_t launch_batch_grouped(const BatchGroupParams &bp, const BatchGroupShape &shape, hipStream_t stream)
+{
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(k_decode_grouped_batch<kModePack64>, dim3(shape.grid), dim3(shape.waves * 64), shape.lds, stream, bp);
+  return hipGetLastError();
+}
+
 hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const DeviceGeom &dg, hipStream_t stream, LaunchInfo *info)
 {
   KParams kp = kp_in;
@@ -586,19 +628,7 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
   kp.private_pair = L.private_pair;
 
   if (grouped)
-  {
-    const uint32_t per_class = waves >= 4 ? waves / 4 : 1;
-    for (uint32_t hf = 0; hf < 2; hf++)
-    {
-      uint32_t cum = 0;
-      for (uint32_t k = 0; k <= 16; k++)
-      {
-        kp.group_cum[hf][k] = (uint16_t)cum;
-        const uint32_t cls = k / per_class < 4 ? k / per_class : 3;
-        cum += k < waves ? L.weights[hf * 4 + cls] / 10 : 0;
-      }
-    }
-  }
+    group_cum_of(L, kp.group_cum);
   if (persistent && kp.pa.interval != 0)
   {
     // static share: a fixed fraction of the chains, split over the waves by class weight; the rest goes through the queues

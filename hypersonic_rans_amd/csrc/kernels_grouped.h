@@ -11,9 +11,22 @@ namespace hsrans
 // LEAN: the host promises a 64-state plan whose groups are all mergeable runs or fills (every block_/mt_ stream with checkpoints
 // this library's encoders or index builders make): the 32-state pair path and the general chain runner are left out of the
 // kernel, which is what keeps it at 8 waves per SIMD
-template <int MODE, bool LEAN = false, bool FAST = false> // FAST: the hand-scheduled 32-state pair loop too (measured in a kernel of its own: 71 VGPRs, 7 waves per SIMD — not used)
-__device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams &kp, uint32_t waves, uint32_t wave)
+// BATCH (round 5, k_decode_grouped_batch): the group list spans several member streams; bits 16.. of Group::flags name the group's
+// member, whose plan arrays, stream, output and status word are picked up at the start of every round (a handful of scalar loads
+// beside the group record's own): many small block_/mt_ streams then share the rounds of ONE launch instead of each launching a
+// mostly empty device (the reference's pool of per-block tasks over several files: mt_rANS32x64_16w_decode.cpp:182-224, main.cpp:841-898).
+template <int MODE, bool LEAN = false, bool FAST = false, bool BATCH = false> // FAST: the hand-scheduled 32-state pair loop too (measured in a kernel of its own: 71 VGPRs, 7 waves per SIMD — not used)
+__device__ void run_grouped(const WaveCtx &c_in, const PlanView &pv_in, const KParams &kp, uint32_t waves, uint32_t wave, const BatchGroupParams *bg = nullptr)
 {
+  WaveCtx c = c_in;   // (BATCH: stream / output / status change with the group's member; otherwise these are the caller's, unchanged)
+  PlanView pv = pv_in;
+  // the launch's group list and shares: kernel arguments either way (read through the scalar cache; a local copy of the share table
+  // would be indexed dynamically and land in scratch)
+  const Group *const groups = BATCH ? bg->groups : kp.groups;
+  const uint32_t n_groups = BATCH ? bg->n_groups : kp.n_groups;
+  unsigned long long *const group_tickets = BATCH ? bg->tickets : kp.group_tickets;
+  const uint32_t group_prio = BATCH ? bg->group_prio : kp.group_prio;
+  const uint16_t(*const group_cum)[17] = BATCH ? bg->group_cum : kp.group_cum;
   // -DHSRANS_GROUP_STAMPS=1 builds (tools/stamps_grouped.py; needs HSRANS_DEBUG_STAMPS=1 at run time): where a wave's time goes,
   // summed over its rounds: [0] first entry, [1] waiting at the round's barrier, [2] table build, [3] plan records + first chunks
   // (until the decode loop starts), [4] decode, [5] rounds, [6] last exit.  Compile-time because even switched off the extra
@@ -39,12 +52,12 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
   // alternating by round: round r's word is written before barrier r and read behind it; the next write to it comes behind
   // barrier r + 1.  Every workgroup draws once at the end of every round it runs, the launch as a whole exactly n_groups times:
   // ticket mod n_groups is the launch-local order whatever the counter has seen before (it is never reset).
-  const bool dynamic = kp.group_tickets != nullptr && kp.n_groups > gridDim.x;
+  const bool dynamic = group_tickets != nullptr && n_groups > gridDim.x;
   volatile uint32_t *lds_next = (volatile uint32_t *)(c.table + table_bytes_for(MODE, c.bits)); // 2 words: launch_shape reserves 64 bytes behind the table
   uint32_t gi = blockIdx.x;
   for (uint32_t round = 0;; round++)
   {
-    if (!(dynamic && round >= 1) && gi >= kp.n_groups) // (dynamic rounds: decided below, from the published group)
+    if (!(dynamic && round >= 1) && gi >= n_groups) // (dynamic rounds: decided below, from the published group)
       break;
     // `advance` runs at the end of the round (every path of the loop body ends in it)
     auto advance = [&]() {
@@ -52,8 +65,8 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
         gi += gridDim.x;
       else if (wave == 0 && c.lane == 0)
       {
-        const uint32_t j = (uint32_t)(atomicAdd(kp.group_tickets, 1ull) % kp.n_groups);
-        lds_next[(round + 1) & 1] = j < kp.n_groups - gridDim.x ? gridDim.x + j : 0xFFFFFFFFu;
+        const uint32_t j = (uint32_t)(atomicAdd(group_tickets, 1ull) % n_groups);
+        lds_next[(round + 1) & 1] = j < n_groups - gridDim.x ? gridDim.x + j : 0xFFFFFFFFu;
       }
     };
     HSRANS_GS(const uint64_t t0 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;)
@@ -62,11 +75,24 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
     if (dynamic && round >= 1)
     {
       gi = uni(lds_next[round & 1]);
-      if (gi >= kp.n_groups) // (the same in every wave)
+      if (gi >= n_groups) // (the same in every wave)
         break;
     }
-    const Group *G = kp.groups + gi;
+    const Group *G = groups + gi;
     const uint32_t begin = uni(G->begin), count = uni(G->count), flags = uni(G->flags);
+    if (BATCH)
+    {
+      const uint32_t member = flags >> kGroupMemberShift;
+      const __attribute__((address_space(4))) GroupMember *mp = (const __attribute__((address_space(4))) GroupMember *)(uintptr_t)(bg->members + member);
+      pv.chain_first = mp->chain_first;
+      pv.pieces = mp->pieces;
+      pv.states = mp->states;
+      c.status = mp->status;
+      c.stream = bg->io[member].stream;
+      c.stream_len = bg->io[member].stream_len;
+      c.out = bg->io[member].out;
+      c.out_cap = bg->io[member].out_cap;
+    }
     // mergeable groups: chain `begin + i` is piece `piece0 + i` and its start states are states[begin + i] (the host checks this
     // when it marks a group mergeable), so a wave's records come straight from the group record: one level of loads, not three
     const uint32_t piece0 = uni(G->piece0);
@@ -96,9 +122,9 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
     const uint32_t half = blockIdx.x >= (gridDim.x + 1) / 2 ? 1 : 0;
     // age-class weights only where a wave gets enough chains for them to mean something (else an even split)
     const bool weighted = count >= 8 * waves;
-    const uint32_t cum_all = weighted ? kp.group_cum[half][waves] : waves;
-    const uint32_t first = begin + (uint32_t)((uint64_t)(weighted ? kp.group_cum[half][wave] : wave) * count / cum_all);
-    const uint32_t last = begin + (uint32_t)((uint64_t)(weighted ? kp.group_cum[half][wave + 1] : wave + 1) * count / cum_all);
+    const uint32_t cum_all = weighted ? group_cum[half][waves] : waves;
+    const uint32_t first = begin + (uint32_t)((uint64_t)(weighted ? group_cum[half][wave] : wave) * count / cum_all);
+    const uint32_t last = begin + (uint32_t)((uint64_t)(weighted ? group_cum[half][wave + 1] : wave + 1) * count / cum_all);
     // the wave's run of a mergeable 64-state group: chains [first, last) as one chain
     StreamWin sw;
     Ring r;
@@ -170,7 +196,7 @@ __device__ void run_grouped(const WaveCtx &c, const PlanView &pv, const KParams 
       // done 8 us before the younger one and waits at the round's barrier.  Unlike the one-chain-per-wave launch, whose index
       // gives the classes chains of different lengths, a block's checkpoints are where the encoder put them.
       // (not where the wave's share was already sized by its age class: 100 MB in 256 KiB blocks + G=32: 0.359 -> 0.340 with both)
-      const uint32_t prio_steps = kp.group_prio != 0 && !weighted && wave >= waves / 2 ? (uint32_t)(run_steps * kp.group_prio / 1000) & ~3u : 0;
+      const uint32_t prio_steps = group_prio != 0 && !weighted && wave >= waves / 2 ? (uint32_t)(run_steps * group_prio / 1000) & ~3u : 0;
       if (prio_steps != 0)
       {
         __builtin_amdgcn_s_setprio(1);
@@ -232,6 +258,39 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.scratch_cnt = (uint16_t *)(c.table + table_bytes_for(MODE, c.bits) + 64);
   c.scratch_cum = c.scratch_cnt + 256;
   run_grouped<MODE, LEAN>(c, pv, kp, waves, wave);
+}
+
+// K member streams' groups in one launch (hsrans_decode_device_batch: members that are block_/mt_ plans with checkpoints, 64 states,
+// bits <= 12): k_decode_grouped<kModePack64, true>'s body with the member picked up per round.  LDS as k_decode_grouped.
+template <int MODE>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_decode_grouped_batch(BatchGroupParams bp)
+{
+  extern __shared__ u32x4 smem_v[];
+  uint8_t *smem = (uint8_t *)smem_v;
+  const uint32_t waves = blockDim.x >> 6;
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  WaveCtx c;
+  c.stream = nullptr; // (set per round from the group's member)
+  c.stream_len = 0;
+  c.stream_lo = 0;
+  c.out = nullptr;
+  c.out_cap = 0;
+  c.status = nullptr;
+  c.bits = bp.bits;
+  c.S = 64;
+  c.lane = threadIdx.x & 63;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
+  const uint32_t ring_stride = fast_ring_mode(MODE) ? kFastRingBytes : kWaveRingBytes;
+  c.rings = smem + wave * ring_stride;
+  c.table = smem + waves * ring_stride;
+  c.table_b = c.table;
+  c.gtable = nullptr;
+  c.scratch_cnt = (uint16_t *)(c.table + table_bytes_for(MODE, c.bits) + 64);
+  c.scratch_cum = c.scratch_cnt + 256;
+  KParams kp{}; // (nothing of it is read in the BATCH instantiation but the stamps pointer: null)
+  PlanView pv{};
+  run_grouped<MODE, true, false, true>(c, pv, kp, waves, wave, &bp);
 }
 
 } // namespace hsrans

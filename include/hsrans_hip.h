@@ -215,8 +215,10 @@ int hsrans_dplan_status(hsrans_ctx *ctx, hsrans_dplan *dplan, void *hip_stream);
  * (~11 of ~41 us for a 100 MB stream) K times, and launches put on several HIP streams cannot co-reside (every plan is shaped
  * to fill the device).  A batch deals the wave slots of ONE launch to its members — whole workgroups (a workgroup holds one
  * decode table), in proportion to the members' sizes, each member's chains cut into runs sized by the slots' scheduling
- * class — so the three are paid once.  Members keep their own device plans, status words and results; a member whose plan
- * the shared kernels do not take (an un-indexed raw stream, 13-15 bits, ...) gets its own launch behind them, in the same call.
+ * class — so the three are paid once.  Members keep their own device plans, status words and results.  block_/mt_ members with
+ * checkpoints (64 states, <= 12 bits) share a launch of their own kind: all their blocks in one list, a workgroup per block and round —
+ * many small streams then fill the device together instead of each launching a mostly empty one.  A member whose plan neither
+ * shared kernel takes (an un-indexed stream, 13-15 bits, 32 states) gets its own launch behind them, in the same call.
  * Best served: raw streams of 64 states, <= 12 bits, with the one-chain-per-wavefront index (hsrans_index_boundaries) when the
  * members are 1, 2 or 4 of about one size, or with a uniform index (hsrans_encode_opts::index_interval) for any mix.
  * The dplans must outlive the batch and must not be refilled while it exists; a dplan belongs to at most one member.
@@ -234,6 +236,7 @@ typedef struct hsrans_batch_info
 {
   uint32_t members, launches;            /* kernel launches one hsrans_decode_device_batch call makes */
   uint32_t direct_members, solo_members; /* members in the shared one-chain-per-wave launch(es) / with a launch of their own */
+  uint32_t grouped_members, reserved;    /* block_/mt_ members with checkpoints sharing a grouped launch (one per histogram width) */
   uint32_t grid, block, lds_bytes;       /* the (first) shared launch */
   uint32_t class_weights[8];             /* per-mille run lengths of the 8 wave scheduling classes it was dealt with */
   double imbalance;                      /* its most loaded wave slot (groups / class weight) over the mean: 1.0 = all waves end together */

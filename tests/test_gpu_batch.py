@@ -96,14 +96,18 @@ MIX = (  # container, states, bits, decoded bytes, index
     (RAW, 64, 10, 5_000_000, 16),
     (BLOCK, 64, 12, 600_000, 64),
     (RAW, 64, 11, 200_000, "none"),
+    (MT, 64, 11, 1_200_000, 64),
+    (BLOCK, 64, 12, 2_000_000, 32),
 )
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", (1, 2, 5, 8))
+@pytest.mark.parametrize("k", (1, 2, 5, 8, 10))
 def test_batch_of_mixed_streams_matches_the_oracle_per_stream(gpu_ctx, oracle, k):
-    """K = 1, 2, 5, 8 members of mixed container / width / state count / length / index kind in one call: every member's output
-    equals the oracle's decode of its stream, its status word is clean, and the members the shared launch takes are counted."""
+    """K = 1, 2, 5, 8, 10 members of mixed container / width / state count / length / index kind in one call: every member's output
+    equals the oracle's decode of its stream, its status word is clean, and the members the shared launches take are counted
+    (raw 64-state <= 12 bits with an index: the one-chain-per-wave launch; block_/mt_ 64-state with checkpoints, two or more of one
+    width: the grouped launch; everything else a launch of its own)."""
     import torch
 
     ms = [_member(gpu_ctx, oracle, MIX[i][0], MIX[i][1], MIX[i][2], MIX[i][3], 100 + i, MIX[i][4]) for i in range(k)]
@@ -112,7 +116,12 @@ def test_batch_of_mixed_streams_matches_the_oracle_per_stream(gpu_ctx, oracle, k
     assert info["members"] == k
     eligible = sum(1 for i in range(k) if MIX[i][0] == RAW and MIX[i][1] == 64 and MIX[i][2] <= 12 and MIX[i][4] != "none")
     assert info["direct_members"] == (eligible if eligible >= 2 else 0)
-    assert info["direct_members"] + info["solo_members"] == k
+    grouped = 0
+    for bits in (10, 11, 12):
+        of_width = sum(1 for i in range(k) if MIX[i][0] in (MT, BLOCK) and MIX[i][1] == 64 and MIX[i][2] == bits and MIX[i][4] != "none")
+        grouped += of_width if of_width >= 2 else 0
+    assert info["grouped_members"] == grouped
+    assert info["direct_members"] + info["grouped_members"] + info["solo_members"] == k
     for rep in range(2):  # (a batch is launched again and again)
         for m in ms:
             m["d_out"].zero_()
@@ -138,6 +147,46 @@ def test_batch_of_equal_streams_one_launch(gpu_ctx, oracle, k, index):
     assert gpu_ctx.batch_status(batch) == [0] * k
     for i, m in enumerate(ms):
         assert np.array_equal(m["d_out"].cpu().numpy(), m["want"]), f"member {i} differs from the oracle"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("container", (MT, BLOCK))
+def test_many_small_block_streams_share_one_launch(gpu_ctx, oracle, container):
+    """The many-small-files case: 12 block_/mt_ streams of 0.3 .. 3 MB (block sizes 32 .. 256 KiB, non-stationary data with single-symbol
+    blocks among them) decoded by ONE grouped launch — a workgroup per block and round over all members' blocks — each against the oracle;
+    then one member's block header is corrupted: that member alone reports it."""
+    import torch
+
+    ms = []
+    for i in range(12):
+        n = 300_000 + i * 233_333
+        data = synth.nonstationary(n, seed=300 + i)
+        stream, plan = H.encode(container, 64, 11, data, block_size=(1 << 15) << (i % 4), index_interval=(16, 32, 64)[i % 3])
+        r, want = oracle.decode(container, 64, 11, stream, n)
+        assert r == n and np.array_equal(want, data)
+        d_in = torch.from_numpy(np.concatenate([stream, np.zeros((-stream.size) % 16, np.uint8)])).cuda()
+        ms.append({"stream": stream, "want": want, "d_in": d_in, "d_out": torch.zeros(n, dtype=torch.uint8, device="cuda"), "dplan": gpu_ctx.make_device_plan(plan)})
+    batch = gpu_ctx.make_batch([m["dplan"] for m in ms])
+    info = batch.info()
+    assert info["launches"] == 1 and info["grouped_members"] == 12 and info["solo_members"] == 0 and info["direct_members"] == 0
+    for rep in range(3):
+        for m in ms:
+            m["d_out"].fill_(0xEE if rep else 0)
+        gpu_ctx.decode_device_batch(batch, [m["d_in"] for m in ms], [m["d_out"] for m in ms], stream_lengths=[m["stream"].size for m in ms])
+        torch.cuda.synchronize()
+        assert gpu_ctx.batch_status(batch) == [0] * 12
+        for i, m in enumerate(ms):
+            assert np.array_equal(m["d_out"].cpu().numpy(), m["want"]), f"member {i} differs from the oracle (repeat {rep})"
+    # a histogram count of member 5's first block changed: its sum check fails (the reference's decoder returns 0), nobody else's
+    bad = ms[5]["d_in"].clone()
+    bad[400] ^= 0x11  # inside the first block's 256 uint16 counts (mt_: bytes 288..799 = [n][total] [size][skip][states] then counts; block_: 280..791)
+    gpu_ctx.decode_device_batch(batch, [bad if i == 5 else m["d_in"] for i, m in enumerate(ms)], [m["d_out"] for m in ms], stream_lengths=[m["stream"].size for m in ms])
+    torch.cuda.synchronize()
+    codes = gpu_ctx.batch_status(batch)
+    assert codes[5] != 0 and all(c == 0 for i, c in enumerate(codes) if i != 5), codes
+    for i, m in enumerate(ms):
+        if i != 5:
+            assert np.array_equal(m["d_out"].cpu().numpy(), m["want"])
 
 
 @pytest.mark.gpu
