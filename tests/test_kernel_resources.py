@@ -56,6 +56,11 @@ def test_shared_table_decode_occupancy():
     assert len(grouped) == 4
     for name, r in grouped.items():
         assert r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] == 8, (name, r)
+    # the batch launches (round 5): the one-chain-per-wave form, its calibration twin, the grouped form
+    batch = {name: r for name, r in kernels.items() if "k_decode_batch" in name or "k_calibrate_batch" in name or "k_decode_grouped_batch" in name}
+    assert len(batch) == 3, sorted(batch)
+    for name, r in batch.items():
+        assert r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] == 8, (name, r)
     persist = [r for name, r in kernels.items() if "k_decode_persist" in name]
     assert len(persist) == 2 and all(r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] == 8 for r in persist), persist  # 8-byte table and rank table
 

@@ -3,12 +3,13 @@
 #   bash tools/regen_round.sh r04
 # then, back in the container:  python tools/collect_round.py r04   (condenses gpurun_out/prof_<tag>*/ and copies gpurun_out/<tag>/* into profiles/)
 # ONE regeneration per round: the numbers are whatever this box gives.
-TAG=${1:-r04}
+TAG=${1:-r05}
 bash tools/profile.sh $TAG                                                                   # headline, 4 pairs rotated: trace + counters
 ONLY_TRACE=1 bash tools/profile.sh ${TAG}_warm --pairs 1                                     # one pair replayed: trace
 bash tools/profile.sh ${TAG}_b15 --bits 15                                                   # BASELINE config 3: 15-bit histogram (k_decode_dual<4>): trace + counters
 ONLY_TRACE=1 bash tools/profile.sh ${TAG}_b14 --bits 14
-ONLY_TRACE=1 bash tools/profile.sh ${TAG}_s32 --states 32                                    # rANS32x32: trace
-ONLY_TRACE=1 STEPS=20 bash tools/profile.sh ${TAG}_1gib --size 1073741824 --pairs 1          # BASELINE config 2 at 2^30 bytes
+bash tools/profile.sh ${TAG}_batch --one-launch                                              # the 4 streams decoded by ONE launch (k_decode_batch<3>): trace + counters
+bash tools/profile.sh ${TAG}_s32 --states 32                                                 # rANS32x32: trace + counters (r04's were empty)
+STEPS=20 bash tools/profile.sh ${TAG}_1gib --size 1073741824 --pairs 1                       # BASELINE config 2 at 2^30 bytes: trace + counters
 STEPS=10 bash tools/profile.sh ${TAG}_sharded --workload sharded                             # BASELINE config 4 shape (mt_, 1 GiB, 256 KiB blocks): trace + counters
 bash tools/round_measure.sh $TAG

@@ -2,13 +2,16 @@
 # Everything DESIGN.md §8 quotes, in one go on the GPU box:  bash tools/round_measure.sh <tag>   (outputs under gpurun_out/<tag>/)
 # (the two stamps files need the diagnostic library: make -C hypersonic_rans_amd/csrc stamps, before gpurun)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 python bench.py --workload sharded > $OUT/bench_sharded_line.json 2> $OUT/bench_sharded.err
 python bench.py --workload sharded --no-cpu --block 65536 --interval 64 > $OUT/bench_sharded_64k_line.json 2> $OUT/bench_sharded_64k.err
 python bench.py --workload sharded --no-cpu --size 100000000 --block 262144 --interval 32 > $OUT/bench_sharded_100mb_256k_line.json 2> $OUT/bench_sharded_100mb_256k.err   # few, large blocks: k_decode_spread
+python tools/batch_probe.py --batch-index --out $OUT/batch_probe.jsonl > /dev/null 2> $OUT/batch_probe.err
+python tools/small_streams_probe.py --out $OUT/small_streams.jsonl > /dev/null 2> $OUT/small_streams.err
+python tools/ratio_sweep.py --out $OUT/ratio_sweep.jsonl > /dev/null 2> $OUT/ratio_sweep.err
 python tools/first_decode_rate.py > $OUT/first_decode_100mb.jsonl 2> $OUT/first_decode.err
 python tools/host_loop_rate.py > $OUT/host_loop_index_cache.jsonl 2> $OUT/host_loop.err
 python tools/sweep_configs.py > $OUT/config_sweep.jsonl 2> $OUT/sweep.err
