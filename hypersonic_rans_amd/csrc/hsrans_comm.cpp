@@ -67,51 +67,6 @@ const Rccl &rccl()
   return r;
 }
 
-// decoded bytes up to and including chain c (chains are in output order in every plan this library builds)
-bool chain_ends(const uint8_t *plan, size_t plan_size, PlanHeader *h, std::vector<uint64_t> *ends)
-{
-  if (!read_header(plan, plan_size, h) || !hsrans::plan_validate(plan, plan_size, h->stream_len, h->decoded_len))
-    return false;
-  const uint32_t *cf = (const uint32_t *)(plan + plan_chain_first_off());
-  const Piece *pc = (const Piece *)(plan + plan_pieces_off(h->n_chains));
-  ends->resize(h->n_chains);
-  uint64_t acc = 0;
-  uint32_t pi = 0;
-  for (uint32_t c = 0; c < h->n_chains; c++)
-  {
-    for (; pi < cf[c + 1]; pi++)
-      acc += (pc[pi].flags & kPieceFill) ? pc[pi].fill_len : (uint64_t)pc[pi].steps * h->states + pc[pi].tail;
-    (*ends)[c] = acc;
-  }
-  return true;
-}
-
-// Cuts chains [first, first + count) into n contiguous runs whose decoded bytes follow `shares` (null = equal): run r ends at the
-// first chain whose end lies beyond lo + (hi - lo) * (shares[0] + .. + shares[r]) / sum — sums taken in index order, in double.
-void cut(const std::vector<uint64_t> &ends, uint32_t first, uint32_t count, const double *shares, uint32_t n, uint32_t *run_first, uint32_t *run_count)
-{
-  const uint64_t lo = first > 0 ? ends[first - 1] : 0, hi = count ? ends[first + count - 1] : lo;
-  double sum = 0;
-  for (uint32_t r = 0; r < n; r++)
-    sum += shares ? shares[r] : 1.0;
-  double cum = 0;
-  uint32_t prev = first;
-  for (uint32_t r = 0; r < n; r++)
-  {
-    uint32_t b = first + count;
-    if (r + 1 < n)
-    {
-      cum += shares ? shares[r] : 1.0;
-      const uint64_t target = lo + (uint64_t)((double)(hi - lo) * (cum / sum));
-      b = first + (uint32_t)(std::upper_bound(ends.begin() + first, ends.begin() + first + count, target) - (ends.begin() + first));
-      b = std::min(std::max(b, prev), first + count);
-    }
-    run_first[r] = prev;
-    run_count[r] = b - prev;
-    prev = b;
-  }
-}
-
 } // namespace
 
 struct hsrans_comm
@@ -206,52 +161,7 @@ int hsrans_comm_rccl_version(void)
 int hsrans_shard_layout(const uint8_t *plan, size_t plan_size, uint32_t world, uint32_t parts, const double *weights, hsrans_shard *shards, uint64_t *windows)
 try
 {
-  if (plan == nullptr || shards == nullptr || world == 0 || world > 1024 || parts == 0 || parts > 64)
-    return HSRANS_E_ARG;
-  if (weights != nullptr)
-  {
-    double sum = 0;
-    for (uint32_t r = 0; r < world; r++)
-    {
-      if (!(weights[r] >= 0))
-        return HSRANS_E_ARG;
-      sum += weights[r];
-    }
-    if (!(sum > 0))
-      return HSRANS_E_ARG;
-  }
-  PlanHeader h;
-  std::vector<uint64_t> ends;
-  if (!chain_ends(plan, plan_size, &h, &ends))
-    return HSRANS_E_FORMAT;
-  std::vector<uint32_t> rf(world), rc(world), sf(parts), sc(parts);
-  cut(ends, 0, h.n_chains, weights, world, rf.data(), rc.data());
-  for (uint32_t r = 0; r < world; r++)
-  {
-    cut(ends, rf[r], rc[r], nullptr, parts, sf.data(), sc.data());
-    for (uint32_t k = 0; k < parts; k++)
-    {
-      hsrans_shard &s = shards[(size_t)r * parts + k];
-      s.first_chain = sf[k];
-      s.chain_count = sc[k];
-      s.out_begin = s.out_end = 0;
-      if (sc[k] != 0 && hsrans_plan_chain_range(plan, plan_size, sf[k], sc[k], &s.out_begin, &s.out_end) != 0)
-        return HSRANS_E_FORMAT;
-    }
-    if (windows != nullptr)
-    {
-      windows[2 * r] = windows[2 * r + 1] = 0;
-      if (rc[r] != 0)
-      {
-        uint64_t ranges[4];
-        if (hsrans_plan_stream_ranges(plan, plan_size, rf[r], rc[r], ranges) != 0)
-          return HSRANS_E_FORMAT;
-        windows[2 * r] = ranges[2] & ~(uint64_t)15; // 16-byte aligned start: hsrans_decode_device_window
-        windows[2 * r + 1] = ranges[3];
-      }
-    }
-  }
-  return HSRANS_OK;
+  return hsrans::shard_layout(plan, plan_size, world, parts, weights, shards, windows);
 }
 catch (...)
 {

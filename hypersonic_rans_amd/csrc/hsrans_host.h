@@ -62,6 +62,8 @@ bool plan_chain_range(const uint8_t *plan, size_t plan_size, uint32_t first, uin
 bool plan_stream_ranges(const uint8_t *plan, size_t plan_size, uint32_t first, uint32_t count, uint64_t out[4]);
 size_t plan_capacity(int container, int states, size_t decoded_size, uint32_t interval, uint32_t block_size);
 size_t plan_capacity_chains(int container, int states, size_t decoded_size, size_t extra_chains, uint32_t block_size);
+// hsrans_shard_layout's body (pure host arithmetic; see include/hsrans_hip.h)
+int shard_layout(const uint8_t *plan, size_t plan_size, uint32_t world, uint32_t parts, const double *weights, hsrans_shard *shards, uint64_t *windows);
 size_t plan_thin(const uint8_t *plan, size_t plan_size, const uint64_t *groups, size_t n_groups, uint8_t *out, size_t cap);
 
 } // namespace hsrans

@@ -13,7 +13,7 @@ for spec in "$@"; do
   flags=${spec#*=}
   eval "farr=($flags)" # (flags may carry quoted strings: -DHSRANS_STORE_POLICY='" nt"')
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter --offload-arch=gfx950 "${farr[@]}" -c "$C/hsrans_kernels.hip" -o "$C/build/variants/kernels_$name.o"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libhsrans_hip_$name.so" "$C/build/hsrans_host.o" "$C/build/hsrans_capi.o" "$C/build/hsrans_capi_encode.o" "$C/build/hsrans_capi_index.o" "$C/build/hsrans_capi_hpipe.o" "$C/build/hsrans_capi_calibrate.o" "$C/build/hsrans_batch.o" "$C/build/hsrans_comm.o" "$C/build/hsrans_dropin.o" \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libhsrans_hip_$name.so" "$C/build/hsrans_host.o" "$C/build/hsrans_capi.o" "$C/build/hsrans_capi_encode.o" "$C/build/hsrans_capi_index.o" "$C/build/hsrans_capi_hpipe.o" "$C/build/hsrans_capi_calibrate.o" "$C/build/hsrans_batch.o" "$C/build/hsrans_batch_deal.o" "$C/build/hsrans_comm.o" "$C/build/hsrans_dropin.o" \
     "$C/build/hsrans_cpu.o" "$C/build/variants/kernels_$name.o" "$C/build/hsrans_encode.o" -Wl,-rpath,/opt/rocm/lib -Wl,-soname,libhsrans_hip.so
   echo "built $OUT/libhsrans_hip_$name.so ($flags)"
 done

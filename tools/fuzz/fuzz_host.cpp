@@ -12,6 +12,7 @@
 
 #include <vector>
 
+#include "../../hypersonic_rans_amd/csrc/hsrans_batch.h"
 #include "../../hypersonic_rans_amd/csrc/hsrans_cpu.h"
 #include "../../hypersonic_rans_amd/csrc/hsrans_host.h"
 
@@ -151,6 +152,33 @@ int main(int argc, char **argv)
       (void)plan_chain_range(plan.data(), plan.size(), first, count, &b, &e);
       uint64_t groups[3] = {64, 256, 1024};
       (void)plan_thin(plan.data(), plan.size(), groups, 3, sl.data(), sl.size());
+      // the sharding arithmetic of the multi-GPU entries (hsrans_shard_layout): any world / sub-run count / weights, hostile ones too
+      {
+        const uint32_t world = 1 + (uint32_t)(rnd() % 9), parts = 1 + (uint32_t)(rnd() % 5);
+        std::vector<hsrans_shard> shards((size_t)world * parts);
+        std::vector<uint64_t> windows(2 * (size_t)world);
+        std::vector<double> w(world);
+        static const double odd[] = {0.0, 1.0, 1e-300, 1e300, -1.0, 0.5, 3.0};
+        for (double &x : w)
+          x = (rnd() & 3) ? (double)(rnd() % 1000) / 100.0 : odd[rnd() % 7];
+        if (rnd() % 16 == 0)
+          w[0] = 0.0 / (double)(rnd() % 2); // NaN (0/0) or 0/1
+        const int rc = shard_layout(plan.data(), plan.size(), world, parts, (rnd() & 1) ? w.data() : nullptr, shards.data(), (rnd() & 1) ? windows.data() : nullptr);
+        if (rc == HSRANS_OK)
+        {
+          // (a mutated plan that passes the validator may have chains whose outputs overlap: memory-safe, wrong bytes — so the ranges
+          // need not tile the output, but every one must lie inside it and the sub-runs must tile the CHAINS)
+          uint32_t next = 0;
+          for (const hsrans_shard &sh : shards)
+          {
+            if (sh.first_chain != next || sh.first_chain + sh.chain_count > h.n_chains || sh.out_end < sh.out_begin || sh.out_end > h.decoded_len)
+              return fprintf(stderr, "shard_layout: a sub-run is out of range\n"), 3;
+            next += sh.chain_count;
+          }
+          if (next != h.n_chains)
+            return fprintf(stderr, "shard_layout: %u of %u chains\n", next, h.n_chains), 3;
+        }
+      }
     }
     else
       (void)cpu::exec_plan(level, 1, plan.data(), plan.size(), stream.data(), stream.size(), out.data(), n); // must refuse, not crash
@@ -158,6 +186,50 @@ int main(int argc, char **argv)
     {
       uint64_t groups[4] = {8, 64, 512, 2000};
       (void)cpu::index_build(level, 1, c.container, c.states, c.bits, stream.data(), stream.size(), groups, 4, scratch.data(), scratch.size());
+    }
+    // the batch launch's dealing (hsrans_batch_deal / hsrans_index_boundaries_batch): random members, random chain lengths
+    if (rnd() % 8 == 0)
+    {
+      const uint32_t M = 1 + (uint32_t)(rnd() % 6), grid = 2 + (uint32_t)(rnd() % 40), waves = (rnd() & 1) ? 16 : 1 + (uint32_t)(rnd() % 16);
+      std::vector<std::vector<uint64_t>> starts(M);
+      std::vector<BatchDealMember> in(M);
+      std::vector<uint64_t> totals(M);
+      for (uint32_t m = 0; m < M; m++)
+      {
+        const uint32_t nc = 1 + (uint32_t)(rnd() % 3000);
+        starts[m].resize(nc + 1);
+        uint64_t g = 0;
+        for (uint32_t c2 = 0; c2 < nc; c2++)
+        {
+          starts[m][c2] = g;
+          g += (rnd() % 5 == 0) ? 0 : 1 + rnd() % ((rnd() & 7) ? 300 : 100000);
+        }
+        starts[m][nc] = g;
+        in[m] = BatchDealMember{starts[m].data(), nc, g};
+        totals[m] = g;
+      }
+      uint32_t w8[8];
+      for (uint32_t &x : w8)
+        x = (rnd() % 10 == 0) ? 1 : 200 + (uint32_t)(rnd() % 1500);
+      const BatchDeal deal = batch_deal(in, grid, waves, w8);
+      std::vector<uint32_t> covered(M, 0);
+      for (size_t wv = 0; wv < deal.slots.size(); wv++)
+      {
+        const BatchSlot &sl2 = deal.slots[wv];
+        if (sl2.member >= M || sl2.begin > sl2.end || sl2.end > in[sl2.member].n_chains)
+          return fprintf(stderr, "batch_deal: slot out of range\n"), 3;
+        if (sl2.member != deal.slots[wv / waves * waves].member)
+          return fprintf(stderr, "batch_deal: a workgroup mixes members\n"), 3;
+        covered[sl2.member] += sl2.end - sl2.begin;
+      }
+      for (uint32_t m = 0; m < M; m++)
+        if (deal.wg_count[m] != 0 && covered[m] != in[m].n_chains)
+          return fprintf(stderr, "batch_deal: member %u: %u of %u chains dealt\n", m, covered[m], in[m].n_chains), 3;
+      std::vector<uint64_t> bounds(1 << 16);
+      const size_t nb = batch_boundaries(totals.data(), M, (uint32_t)(rnd() % M), grid, waves, w8, bounds.data(), bounds.size());
+      for (size_t k = 1; k + 1 < nb; k++)
+        if (bounds[k] <= bounds[k - 1])
+          return fprintf(stderr, "batch_boundaries: not ascending\n"), 3;
     }
     iters++;
   }
