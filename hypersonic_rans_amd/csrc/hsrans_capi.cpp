@@ -510,42 +510,6 @@ extern "C++" int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_si
     // (Dynamic group order, run_grouped: the END of the list decides how evenly the launch finishes.  Cutting the last eighth /
     // quarter of the list into half-blocks was built and measured in round 3 at 2^30 bytes — 0.454-0.458 ms against 0.451-0.456
     // without: the extra table builds cost what the evener finish gains — and is gone.)
-    // A launch of only a FEW rounds is another matter (round 5): 100 MB in the reference's 64 KiB blocks are 1,525 groups for 1,024
-    // workgroup slots — one full round and half a round more, and the launch is as long as two.  The groups of the last, partial
-    // round are cut into k parts each (k * leftover <= slots, a chain per wave at least), so that the last round is 1 / k as long.
-    if (groups.size() < h.n_chains && getenv("HSRANS_GROUP_TAIL_SPLIT_OFF") == nullptr)
-    {
-      const LaunchShape shape = launch_shape(h, ctx->geom, false, 0, (uint32_t)groups.size(), false, false, false);
-      const size_t slots = shape.resident, n = groups.size();
-      const size_t leftover = slots ? n % slots : 0;
-      if (n > slots && n < 6 * slots && leftover != 0 && leftover * 2 <= slots)
-      {
-        std::vector<Group> cut(groups.begin(), groups.end() - leftover);
-        for (size_t gi = n - leftover; gi < n; gi++)
-        {
-          const Group &g = groups[gi];
-          uint32_t k = (g.flags & kGroupMergeable) ? (uint32_t)std::min<size_t>(slots / leftover, g.count / shape.waves) : 1;
-          k = std::min(k, 4u);
-          if (k < 2)
-          {
-            cut.push_back(g);
-            continue;
-          }
-          for (uint32_t part = 0; part < k; part++)
-          {
-            Group q = g;
-            const uint32_t lo = (uint32_t)((uint64_t)g.count * part / k), hi = (uint32_t)((uint64_t)g.count * (part + 1) / k);
-            q.begin = g.begin + lo;
-            q.piece0 = g.piece0 + lo;
-            q.count = hi - lo;
-            if (part + 1 < k)
-              q.words_end = pc[cf[g.begin + hi]].words_off;
-            cut.push_back(q);
-          }
-        }
-        groups.swap(cut);
-      }
-    }
     if (groups.size() < h.n_chains)
     {
       d->d_groups = carve(groups.size() * sizeof(Group)); // (the dynamic group order's ticket counters: d_counters, zeroed above)

@@ -367,21 +367,7 @@ try
     auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t plan_max = (size_t)plan_size(max_chains, max_chains, S, 0);
     const size_t counter_bytes = (size_t)kCounterSets * kDynQueues * kDynQueueStride * 8;
-    // a launch of few rounds: the blocks of its last, partial round in parts (the rule of dplan_fill; k_index_fill applies it per block)
-    uint32_t tail_start = nb, tail_parts = 1, tail_min_chains = 8;
-    if (group_split == 1 && getenv("HSRANS_GROUP_TAIL_SPLIT_OFF") == nullptr)
-    {
-      const LaunchShape shape = launch_shape(h, ctx->geom, false, 0, nb, false, false, false);
-      const size_t slots = shape.resident, leftover = slots ? nb % slots : 0;
-      if (nb > slots && nb < 6 * slots && leftover != 0 && leftover * 2 <= slots)
-      {
-        tail_start = nb - (uint32_t)leftover;
-        tail_parts = (uint32_t)std::min<size_t>(slots / leftover, 4);
-        tail_min_chains = shape.waves;
-      }
-    }
-    const size_t n_group_slots = group_split == 1 ? (size_t)tail_start + (size_t)(nb - tail_start) * tail_parts : (size_t)nb * group_split;
-    const size_t group_bytes = n_group_slots * sizeof(Group);
+    const size_t group_bytes = (size_t)nb * group_split * sizeof(Group);
     hsrans_dplan *nd = new (std::nothrow) hsrans_dplan;
     if (nd == nullptr)
       return HSRANS_E_HIP;
@@ -428,9 +414,6 @@ try
     ia.max_chains = max_chains;
     ia.groups = (Group *)nd->d_groups;
     ia.group_split = group_split;
-    ia.tail_start = tail_start;
-    ia.tail_parts = tail_parts;
-    ia.tail_min_chains = tail_min_chains;
     ia.stream_len = h.stream_len;
     uint32_t status = 0xFFFFFFFF;
     uint64_t counted[4] = {}; // chains in all, blocks with a histogram, the (one) histogram's offset, fewest chains of a coded block but the last
@@ -458,7 +441,7 @@ try
     nd->plan_bytes = (size_t)plan_size((uint32_t)total, (uint32_t)total, S, 0);
     nd->out_hi = h.decoded_len;
     const bool grouped = total > nb; // (no checkpoint fell inside any block: one chain per block, the ungrouped launch)
-    nd->n_groups = grouped ? (uint32_t)n_group_slots : 0;
+    nd->n_groups = grouped ? nb * group_split : 0;
     nd->groups_lean = grouped && S == 64;
     const uint64_t fewest = counted[3] == 0 ? ~0ull : ~counted[3]; // ([3]: ~(the fewest chains of a coded block that is not the last); 0 = there is none)
     nd->spread_min_block = nd->groups_lean ? (uint32_t)std::min<uint64_t>(fewest, 0xFFFFFFFFu) : 0;

@@ -276,9 +276,6 @@ struct IndexArgs
   Group *groups;             // [n_base * group_split] or null
   uint32_t group_split;
   uint64_t stream_len;
-  // group_split == 1 only: blocks from tail_start on (the launch's last, partial round) get tail_parts group slots each and are cut
-  // into min(tail_parts, chains / tail_min_chains) parts; tail_start = n_base, tail_parts = 1: no such blocks
-  uint32_t tail_start, tail_parts, tail_min_chains;
 };
 hipError_t launch_index_assemble(const IndexArgs &a, hipStream_t stream);
 // 64-bit fingerprint of d_stream[0, stream_len) into *d_sum (16-byte aligned stream; asynchronous: memset + one launch)

@@ -278,10 +278,7 @@ __global__ void __launch_bounds__(64) k_index_fill(IndexArgs a)
         v = k == 0 ? st0[(uint64_t)bp.state_idx * S + lane] : a.ck_states[((g_abs0 + (uint64_t)k * a.interval) / a.interval) * S + lane];
       states[(uint64_t)(c0 + k) * S + lane] = v;
     }
-  // (the blocks of a launch's last, partial round — ch >= a.tail_start, only when every block is one group — get a.tail_parts group
-  // slots each and are cut into as many parts as leave a chain per wave: the same rule as hsrans_capi.cpp dplan_fill's)
-  const bool in_tail = a.group_split == 1 && ch >= a.tail_start;
-  if (a.groups != nullptr && lane < (in_tail ? a.tail_parts : a.group_split))
+  if (a.groups != nullptr && lane < a.group_split)
   {
     // the block's words end at the next rANS block's histogram (as hsrans_capi.cpp dplan_fill has it), or at the stream's end
     uint64_t words_end = a.stream_len;
@@ -294,7 +291,7 @@ __global__ void __launch_bounds__(64) k_index_fill(IndexArgs a)
         break;
       }
     }
-    const uint32_t by_size = in_tail ? (count / a.tail_min_chains < a.tail_parts ? count / a.tail_min_chains : a.tail_parts) : group_parts_of(count, a.group_split);
+    const uint32_t by_size = group_parts_of(count, a.group_split);
     const uint32_t parts = fill || by_size < 1 ? 1 : by_size;
     Group g{};
     g.flags = fill ? kGroupFill : kGroupMergeable;
@@ -315,7 +312,7 @@ __global__ void __launch_bounds__(64) k_index_fill(IndexArgs a)
       g.flags = kGroupFill;
       g.words_end = words_end;
     }
-    a.groups[in_tail ? (uint64_t)a.tail_start + (uint64_t)(ch - a.tail_start) * a.tail_parts + lane : (uint64_t)ch * a.group_split + lane] = g;
+    a.groups[(uint64_t)ch * a.group_split + lane] = g;
   }
 }
 
