@@ -118,3 +118,51 @@ def test_mutated_streams_through_the_recording_first_decode_and_the_index_cache(
     buf[:stream.size] = stream
     r = L.hsrans_decode_host(ctx.handle, container, states, bits, H.api._p(buf), stream.size, H.api._p(out), n, None, 0)
     assert r == n and np.array_equal(out[:n], data)
+
+
+@pytest.mark.parametrize("form", ("one chain per wave (raw members)", "grouped (mt_ members)", "grouped (block_ members)"))
+def test_mutated_member_of_a_batch_never_disturbs_the_others(gpu_ctx, form):
+    """One launch, several member streams (hsrans_decode_device_batch): the bytes of ONE member are mutated (the plans stay the honest
+    ones: what changes under the kernel are histograms, headers and words), 60 times.  No fault, no hang, nothing written behind any
+    member's output, and every OTHER member decodes bit-exactly with a clean status word every time — a member is judged alone."""
+    rng = np.random.default_rng(777 + len(form))
+    container = H.RAW if "raw" in form else H.MT if "mt_" in form else H.BLOCK
+    ms = []
+    for i in range(4):
+        n = 400_000 + 150_001 * i
+        data = synth.nonstationary(n, seed=40 + i)
+        if container == H.RAW:
+            stream, plan = H.encode(H.RAW, 64, 11, data, index_interval=(16, 32)[i % 2])
+        else:
+            stream, plan = H.encode(container, 64, 11, data, block_size=(32768, 65536)[i % 2], index_interval=32)
+        ms.append({"n": n, "data": data, "stream": stream, "dplan": gpu_ctx.make_device_plan(plan),
+                   "d_in": torch.from_numpy(np.concatenate([stream, np.zeros((-stream.size) % 16 + 64, np.uint8)])).cuda(),
+                   "d_out": torch.full((n + 4096,), 0xCC, dtype=torch.uint8, device="cuda")})
+    batch = gpu_ctx.make_batch([m["dplan"] for m in ms])
+    info = batch.info()
+    assert info["launches"] == 1 and (info["direct_members"] == 4 if container == H.RAW else info["grouped_members"] == 4)
+    lens = [m["stream"].size for m in ms]
+    flagged = 0
+    for it in range(60):
+        victim = int(rng.integers(0, 4))
+        s = _mutate(rng, ms[victim]["stream"])
+        if s.size < ms[victim]["stream"].size:  # (a truncated member: the batch entry checks lengths before it launches; keep the length, junk the tail)
+            s = np.concatenate([s, rng.integers(0, 256, size=ms[victim]["stream"].size - s.size, dtype=np.uint8)])
+        bad = torch.from_numpy(np.concatenate([s, np.zeros((-s.size) % 16 + 64, np.uint8)])).cuda()
+        for m in ms:
+            m["d_out"].fill_(0xCC)
+        gpu_ctx.decode_device_batch(batch, [bad if k == victim else m["d_in"] for k, m in enumerate(ms)], [m["d_out"][:m["n"]] for m in ms], stream_lengths=lens)
+        torch.cuda.synchronize()
+        codes = gpu_ctx.batch_status(batch)
+        flagged += codes[victim] != 0
+        for k, m in enumerate(ms):
+            assert bool((m["d_out"][m["n"]:] == 0xCC).all()), f"member {k} wrote behind its output (iteration {it}, victim {victim})"
+            if k != victim:
+                assert codes[k] == 0, (it, victim, codes)
+                assert np.array_equal(m["d_out"][:m["n"]].cpu().numpy(), m["data"]), f"member {k} was disturbed by member {victim}'s bytes (iteration {it})"
+    # the unmodified members still decode after all that
+    gpu_ctx.decode_device_batch(batch, [m["d_in"] for m in ms], [m["d_out"][:m["n"]] for m in ms], stream_lengths=lens)
+    torch.cuda.synchronize()
+    assert gpu_ctx.batch_status(batch) == [0] * 4
+    for m in ms:
+        assert np.array_equal(m["d_out"][:m["n"]].cpu().numpy(), m["data"])
