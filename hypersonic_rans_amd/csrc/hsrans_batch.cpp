@@ -75,6 +75,16 @@ try
   hsrans_batch *b = new (std::nothrow) hsrans_batch;
   if (b == nullptr)
     return HSRANS_E_HIP;
+  struct Guard // (an exception on its way to the handler below — bad_alloc from one of the vectors — must not leak the batch and its device memory)
+  {
+    hsrans_batch *b;
+    bool armed = true;
+    ~Guard()
+    {
+      if (armed)
+        hsrans_dplan_batch_destroy(b);
+    }
+  } guard{b};
   b->ctx = ctx;
   b->members.assign(dplans, dplans + count);
   b->order_run.assign(count, 0);
@@ -96,7 +106,8 @@ try
     const size_t n_gl = (of_width.size() + kBatchMax - 1) / kBatchMax;
     for (size_t l = 0; l < n_gl; l++)
     {
-      hsrans_batch::GroupedLaunch G;
+      b->grouped.emplace_back(); // (owned by the batch from the start: whatever fails below, the batch's destructor frees it)
+      hsrans_batch::GroupedLaunch &G = b->grouped.back();
       G.member_idx.assign(of_width.begin() + of_width.size() * l / n_gl, of_width.begin() + of_width.size() * (l + 1) / n_gl);
       G.bits = bits;
       std::vector<Group> all;
@@ -108,7 +119,6 @@ try
         std::vector<Group> mine(d->n_groups);
         if (hipMemcpy(mine.data(), d->d_groups, (size_t)d->n_groups * sizeof(Group), hipMemcpyDeviceToHost) != hipSuccess)
         {
-          hsrans_dplan_batch_destroy(b);
           return HSRANS_E_HIP;
         }
         for (Group &g : mine)
@@ -132,7 +142,6 @@ try
       if (hipMalloc((void **)&dev, bytes) != hipSuccess)
       {
         (void)hipGetLastError();
-        hsrans_dplan_batch_destroy(b);
         return HSRANS_E_HIP;
       }
       G.d_members = (const GroupMember *)dev;
@@ -141,10 +150,8 @@ try
       G.epoch = new (std::nothrow) std::atomic<uint32_t>(0);
       const bool ok = G.epoch != nullptr && hipMemset(dev, 0, bytes) == hipSuccess && hipMemcpy(dev, gm.data(), gm.size() * sizeof(GroupMember), hipMemcpyHostToDevice) == hipSuccess &&
                       hipMemcpy((void *)G.d_groups, all.data(), all.size() * sizeof(Group), hipMemcpyHostToDevice) == hipSuccess;
-      b->grouped.push_back(std::move(G)); // (owned by the batch from here: destroyed with it)
       if (!ok)
       {
-        hsrans_dplan_batch_destroy(b);
         return HSRANS_E_HIP;
       }
     }
@@ -181,7 +188,6 @@ try
       pieces[i].resize(nc);
       if (hipMemcpy(pieces[i].data(), d->pa.pieces, (size_t)nc * sizeof(Piece), hipMemcpyDeviceToHost) != hipSuccess)
       {
-        hsrans_dplan_batch_destroy(b);
         return HSRANS_E_HIP;
       }
       starts[i].resize(nc + 1);
@@ -211,7 +217,6 @@ try
       const uint64_t w_end = s.end < d->hdr.n_chains ? pc[s.end].words_off : d->hdr.stream_len;
       if (w_end - pc[s.begin].words_off >= 0xFFFF0000ull)
       {
-        hsrans_dplan_batch_destroy(b);
         return HSRANS_E_FORMAT;
       }
     }
@@ -245,7 +250,6 @@ try
     if (hipMalloc((void **)&b->d_arena, arena) != hipSuccess)
     {
       (void)hipGetLastError();
-      hsrans_dplan_batch_destroy(b);
       return HSRANS_E_HIP;
     }
     size_t off = 0;
@@ -253,7 +257,6 @@ try
     {
       if (hipMemcpy(b->d_arena + off, host_blobs[l].data(), host_blobs[l].size(), hipMemcpyHostToDevice) != hipSuccess)
       {
-        hsrans_dplan_batch_destroy(b);
         return HSRANS_E_HIP;
       }
       b->direct[l].d_members = (const BatchMember *)(b->d_arena + off);
@@ -269,6 +272,7 @@ try
     else
       b->finish_owned = true, (void)hipMemset(b->d_finish, 0, ((size_t)b->finish_slots + 1) * 8);
   }
+  guard.armed = false;
   *out_batch = b;
   return HSRANS_OK;
 }
