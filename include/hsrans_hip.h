@@ -32,6 +32,10 @@ extern "C" {
 #define HSRANS_BLOCK 1 /* histogram swapped per block, inline: src/block_rANS32x64_16w_{encode,decode}.cpp         */
 #define HSRANS_MT 2    /* independent blocks:                  src/mt_rANS32x64_16w_{encode,decode}.cpp            */
 
+/* opaque handles of the GPU side (declared up here so that the host-side prototypes below that take a context are valid C as well) */
+typedef struct hsrans_ctx hsrans_ctx;     /* device id, staging buffers, HIP streams/events */
+typedef struct hsrans_dplan hsrans_dplan; /* a plan resident in device memory + its status word */
+
 /* = reference hist_t (src/hist.h:16-20) */
 typedef struct hsrans_hist
 {
@@ -83,7 +87,7 @@ typedef struct hsrans_encode_opts
  * encoded.  Writes ascending group indices (multiples of 4) to groups_out and returns their count (0 = one chain is all
  * the stream is good for, or capacity too small); pass them as hsrans_encode_opts::index_groups, to hsrans_index_build_at,
  * or to hsrans_plan_thin.  A plan built for another geometry still decodes correctly, only less evenly. */
-size_t hsrans_index_boundaries(const struct hsrans_ctx *ctx, int states, uint32_t bits, size_t decoded_size, uint64_t *groups_out, size_t capacity);
+size_t hsrans_index_boundaries(const hsrans_ctx *ctx, int states, uint32_t bits, size_t decoded_size, uint64_t *groups_out, size_t capacity);
 
 /* same as hsrans_encode, additionally emitting the sidecar decode plan; the stream bytes are unchanged by it */
 size_t hsrans_encode_ex(int container, int states, uint32_t bits, const uint8_t *in, size_t length, uint8_t *out, size_t out_capacity,
@@ -140,9 +144,6 @@ size_t hsrans_index_build_host(int level, uint32_t threads, int container, int s
 /* ------------------------------------------------------------------------------------------------------------
  * GPU side
  * ---------------------------------------------------------------------------------------------------------- */
-typedef struct hsrans_ctx hsrans_ctx;     /* device id, staging buffers, HIP streams/events */
-typedef struct hsrans_dplan hsrans_dplan; /* a plan resident in device memory + its status word */
-
 #define HSRANS_OK 0
 #define HSRANS_E_NO_DEVICE 1
 #define HSRANS_E_ARG 2
