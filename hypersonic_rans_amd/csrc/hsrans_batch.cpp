@@ -24,7 +24,7 @@ namespace
 // a plan the one-chain-per-wave batch kernel can take: raw, mergeable, 64 states, the 8-byte host-built table (bits <= 12), one chain per wave
 bool direct_eligible(const hsrans_dplan *d)
 {
-  return d->pa.pieces != nullptr && d->pa.table != nullptr && d->pa.table_mode == 3 && d->pa.dual == 0 && d->hdr.states == 64 && d->hdr.bits <= 12 &&
+  return d->pa.pieces != nullptr && d->pa.table != nullptr && d->pa.table_mode == 3 && d->pa.dual == 0 && (d->hdr.states == 64 || d->hdr.states == 32) && d->hdr.bits <= 12 &&
          (d->hdr.flags & kPlanMergeable) != 0 && d->hdr.container == HSRANS_RAW && d->hdr.n_chains >= 1;
 }
 // a plan the grouped batch kernel can take: block_/mt_ with checkpoints whose groups are all mergeable runs or fills, 64 states, <= 12 bits
@@ -157,13 +157,25 @@ try
     }
   }
   std::sort(b->solo.begin(), b->solo.end());
-  if (eligible.size() == 1) // a launch of its own is the same thing, with the plan's own dealing
+  // 64- and 32-state members take launches of their own kind (k_decode_batch / k_decode_batch_pair); a lone member of its kind keeps a
+  // launch of its own: the same thing, with the plan's own dealing
+  std::vector<std::vector<uint32_t>> launch_members;
+  for (uint32_t states : {64u, 32u})
   {
-    b->solo.push_back(eligible[0]);
-    eligible.clear();
-    std::sort(b->solo.begin(), b->solo.end());
+    std::vector<uint32_t> of_kind;
+    for (uint32_t k : eligible)
+      if (dplans[k]->hdr.states == states)
+        of_kind.push_back(k);
+    if (of_kind.size() == 1)
+      b->solo.push_back(of_kind[0]);
+    if (of_kind.size() < 2)
+      continue;
+    const size_t n_l = (of_kind.size() + kBatchMax - 1) / kBatchMax;
+    for (size_t l = 0; l < n_l; l++) // (launches of nearly equal member counts rather than 32 + the rest)
+      launch_members.emplace_back(of_kind.begin() + of_kind.size() * l / n_l, of_kind.begin() + of_kind.size() * (l + 1) / n_l);
   }
-  const size_t n_launches = (eligible.size() + kBatchMax - 1) / kBatchMax;
+  std::sort(b->solo.begin(), b->solo.end());
+  const size_t n_launches = launch_members.size();
   // one allocation: per launch its member records and its slot table
   auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t arena = 0;
@@ -171,9 +183,8 @@ try
   for (size_t l = 0; l < n_launches; l++)
   {
     hsrans_batch::DirectLaunch L;
-    // (launches of nearly equal member counts rather than 32 + the rest)
-    const size_t lo = eligible.size() * l / n_launches, hi = eligible.size() * (l + 1) / n_launches;
-    L.member_idx.assign(eligible.begin() + lo, eligible.begin() + hi);
+    L.member_idx = launch_members[l];
+    const uint32_t launch_states = dplans[L.member_idx[0]]->hdr.states;
     uint32_t max_bits = 0;
     for (uint32_t k : L.member_idx)
       max_bits = std::max(max_bits, dplans[k]->hdr.bits);
@@ -205,8 +216,8 @@ try
     uint64_t launch_groups = 0;
     for (const BatchDealMember &dm : deal_in)
       launch_groups += dm.total_groups;
-    L.shape = batch_direct_shape(ctx->geom, max_bits, launch_groups);
-    const BatchDeal deal = batch_deal(deal_in, L.shape.grid, L.shape.waves, L.shape.weights);
+    L.shape = batch_direct_shape(ctx->geom, max_bits, launch_groups, launch_states);
+    const BatchDeal deal = batch_deal(deal_in, L.shape.grid, L.shape.waves, L.shape.weights, launch_states == 32 ? 2 : 1);
     // a wave reads its run through one 32-bit window of the stream (run_direct_span: win_open)
     for (const BatchSlot &s : deal.slots)
     {
@@ -394,18 +405,19 @@ size_t hsrans_index_boundaries_batch(const hsrans_ctx *ctx, int states, uint32_t
                                      uint64_t *groups_out, size_t capacity)
 try
 {
-  if (states != 64 || bits < 10 || bits > 12 || decoded_sizes == nullptr || groups_out == nullptr || count == 0 || count > kBatchMax || member >= count)
+  if ((states != 64 && states != 32) || bits < 10 || bits > 12 || decoded_sizes == nullptr || groups_out == nullptr || count == 0 || count > kBatchMax || member >= count)
     return 0;
   const DeviceGeom dg = ctx ? ctx->geom : default_geom();
   std::vector<uint64_t> totals(count);
   uint64_t all = 0;
   for (uint32_t k = 0; k < count; k++)
   {
-    totals[k] = decoded_sizes[k] + 1 >= 64 ? (decoded_sizes[k] - 64 + 1 + 63) / 64 : 0; // whole groups, as hsrans_index_boundaries
+    totals[k] = decoded_sizes[k] + 1 >= (size_t)states ? (decoded_sizes[k] - states + 1 + states - 1) / states : 0; // whole groups, as hsrans_index_boundaries
     all += totals[k];
   }
-  const BatchShape shape = batch_direct_shape(dg, bits, all);
-  const size_t chains = batch_boundaries(totals.data(), count, member, shape.grid, shape.waves, shape.weights, groups_out, capacity);
+  const BatchShape shape = batch_direct_shape(dg, bits, all, (uint32_t)states);
+  // (32 states: two chains per wave slot, one per wave half — run_batch_pair)
+  const size_t chains = batch_boundaries(totals.data(), count, member, shape.grid, shape.waves, shape.weights, groups_out, capacity, states == 32 ? 2 : 1);
   return chains > 1 ? chains - 1 : 0;
 }
 catch (...)

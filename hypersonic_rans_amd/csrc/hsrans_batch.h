@@ -30,9 +30,11 @@ struct BatchDeal
 // Deals the launch's workgroups to the members (whole workgroups: one decode table each; the same number from each half of the grid,
 // so that every member sees all 8 age classes) in proportion to their groups, then every member's chains to its wave slots as runs of
 // consecutive chains whose lengths follow the slots' class weights.
-std::vector<uint32_t> batch_apportion(const uint64_t *total_groups, const uint64_t *max_chains, uint32_t M, uint32_t pairs, uint32_t waves);
-size_t batch_boundaries(const uint64_t *total_groups, uint32_t M, uint32_t member, uint32_t grid, uint32_t waves, const uint32_t weights[8], uint64_t *out, size_t cap);
-BatchDeal batch_deal(const std::vector<BatchDealMember> &members, uint32_t grid, uint32_t waves, const uint32_t weights[8]);
+std::vector<uint32_t> batch_apportion(const uint64_t *total_groups, const uint64_t *max_chains, uint32_t M, uint32_t pairs, uint32_t waves, uint32_t chains_per_slot = 1);
+size_t batch_boundaries(const uint64_t *total_groups, uint32_t M, uint32_t member, uint32_t grid, uint32_t waves, const uint32_t weights[8], uint64_t *out, size_t cap,
+                        uint32_t chains_per_slot = 1);
+// (chains_per_slot: 2 for 32-state members — a slot's run is decoded as two halves side by side, so a member can use twice as many chains as slots)
+BatchDeal batch_deal(const std::vector<BatchDealMember> &members, uint32_t grid, uint32_t waves, const uint32_t weights[8], uint32_t chains_per_slot = 1);
 
 } // namespace hsrans
 

@@ -24,7 +24,7 @@ static uint32_t order_wave(uint32_t pos, uint32_t run)
 // Workgroup PAIRS per member (one workgroup from each half of the grid: a CU's older and its younger workgroup, so that every
 // member gets waves of all 8 age classes in the launch's own proportion).  Min-max: one pair each, then one more to whoever has
 // the most groups per pair, until the pairs are used up; a member cannot use more waves than it has chains (max_chains, or null).
-std::vector<uint32_t> batch_apportion(const uint64_t *total_groups, const uint64_t *max_chains, uint32_t M, uint32_t pairs, uint32_t waves)
+std::vector<uint32_t> batch_apportion(const uint64_t *total_groups, const uint64_t *max_chains, uint32_t M, uint32_t pairs, uint32_t waves, uint32_t chains_per_slot)
 {
   std::vector<uint32_t> n(M, 0);
   uint32_t used = 0;
@@ -37,7 +37,7 @@ std::vector<uint32_t> batch_apportion(const uint64_t *total_groups, const uint64
     double best_load = 0;
     for (uint32_t m = 0; m < M; m++)
     {
-      if (n[m] == 0 || (max_chains != nullptr && (uint64_t)n[m] * 2 * waves >= max_chains[m]))
+      if (n[m] == 0 || (max_chains != nullptr && (uint64_t)n[m] * 2 * waves * chains_per_slot >= max_chains[m]))
         continue;
       const double load = (double)total_groups[m] / n[m];
       if (best == M || load > best_load)
@@ -53,13 +53,16 @@ std::vector<uint32_t> batch_apportion(const uint64_t *total_groups, const uint64
 // Checkpoint positions (ascending group indices, multiples of 4) that give member `member` of a batch of streams with
 // total_groups[0 .. M) whole groups exactly one chain per wave slot the batch launch will deal it, each sized by the slot's class:
 // what direct_boundaries does for a stream that has the device to itself.  Returns the number of chains (boundaries + 1), 0 = capacity.
-size_t batch_boundaries(const uint64_t *total_groups, uint32_t M, uint32_t member, uint32_t grid, uint32_t waves, const uint32_t weights[8], uint64_t *out, size_t cap)
+size_t batch_boundaries(const uint64_t *total_groups, uint32_t M, uint32_t member, uint32_t grid, uint32_t waves, const uint32_t weights[8], uint64_t *out, size_t cap,
+                        uint32_t chains_per_slot)
 {
+  if (chains_per_slot == 0)
+    return 0;
   if (member >= M || grid < 2 || waves == 0)
     return 0;
   const uint32_t first_half = (grid + 1) / 2, pairs = grid - first_half;
-  const std::vector<uint32_t> n = batch_apportion(total_groups, nullptr, M, pairs, waves);
-  const uint64_t nslots = (uint64_t)n[member] * 2 * waves;
+  const std::vector<uint32_t> n = batch_apportion(total_groups, nullptr, M, pairs, waves, chains_per_slot);
+  const uint64_t nslots = (uint64_t)n[member] * 2 * waves * chains_per_slot; // (in chains: a slot's chains share its weight)
   const uint64_t all_units = total_groups[member] / 4; // boundaries in units of 4 groups (the decode loop stores 4 groups at a time)
   uint64_t chains = nslots;
   if (chains > all_units / 8) // (as direct_boundaries: a chain is worth its index entry and its prologue from about 32 groups on)
@@ -70,8 +73,8 @@ size_t batch_boundaries(const uint64_t *total_groups, uint32_t M, uint32_t membe
     return 0;
   const uint32_t per_class = waves >= 4 ? waves / 4 : 1;
   auto weight_of = [&](uint64_t i) { // slot i of the member in natural order: its first-half workgroups' waves, then its second-half ones
-    const uint64_t wg_local = i / waves;
-    const uint32_t wave = (uint32_t)(i % waves);
+    const uint64_t slot = i / chains_per_slot, wg_local = slot / waves;
+    const uint32_t wave = (uint32_t)(slot % waves);
     return (uint64_t)weights[(wg_local >= n[member] ? 4 : 0) + std::min(3u, wave / per_class)];
   };
   uint64_t all = 0;
@@ -94,7 +97,7 @@ size_t batch_boundaries(const uint64_t *total_groups, uint32_t M, uint32_t membe
 }
 
 // Deals wave slots to the members' chains.  See hsrans_batch.h.
-BatchDeal batch_deal(const std::vector<BatchDealMember> &members, uint32_t grid, uint32_t waves, const uint32_t weights[8])
+BatchDeal batch_deal(const std::vector<BatchDealMember> &members, uint32_t grid, uint32_t waves, const uint32_t weights[8], uint32_t chains_per_slot)
 {
   BatchDeal out;
   const uint32_t M = (uint32_t)members.size();
@@ -112,7 +115,7 @@ BatchDeal batch_deal(const std::vector<BatchDealMember> &members, uint32_t grid,
   std::vector<uint64_t> totals(M), caps(M);
   for (uint32_t m = 0; m < M; m++)
     totals[m] = members[m].total_groups, caps[m] = members[m].n_chains;
-  const std::vector<uint32_t> n = batch_apportion(totals.data(), caps.data(), M, pairs, waves);
+  const std::vector<uint32_t> n = batch_apportion(totals.data(), caps.data(), M, pairs, waves, chains_per_slot ? chains_per_slot : 1);
   // 2. per member: its slots in order, its chains dealt to them by cumulative weight, boundaries at the nearest chain start.  The
   //    order of the slots inside a workgroup is tried three ways (class runs of 4, 2, 1 waves): an index made for a launch of its own
   //    (hsrans_index_boundaries: chains sized by class, four of a class in a row) is matched exactly by one of them when the member

@@ -174,7 +174,7 @@ hipError_t launch_batch_grouped(const BatchGroupParams &bp, const BatchGroupShap
 
 struct BatchShape
 {
-  uint32_t grid, waves, lds;
+  uint32_t grid, waves, lds, states;
   uint32_t weights[8]; // per-mille run lengths of the 8 wave classes (class = (workgroup in the grid's second half) * 4 + wave / 4)
 };
 
@@ -207,7 +207,7 @@ void direct_weights_for(const DeviceGeom &dg, uint64_t run_groups, uint32_t out[
 
 // the launch all members of a batch of 64-state plans with 8-byte tables (bits <= 12) share; max_bits = the widest member
 // (total_groups: all members' groups together — the class weights follow the launch's mean run length; 0 = the default set)
-BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits, uint64_t total_groups = 0);
+BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits, uint64_t total_groups = 0, uint32_t states = 64);
 hipError_t launch_batch_direct(const BatchParams &bp, const BatchShape &shape, hipStream_t stream);
 
 // a launch's shape as it follows from plan header + device (launch_shape)

@@ -298,6 +298,8 @@ hipError_t prepare_kernels(DeviceGeom *geom)
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void *)k_decode_grouped_batch<kModePack64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
     if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)k_decode_batch_pair<kModePack64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
+    if (e == hipSuccess)
       e = hipFuncSetAttribute((const void *)k_calibrate_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
     if (e != hipSuccess)
       return e;
@@ -534,10 +536,10 @@ size_t direct_boundaries(const DeviceGeom &dg, uint32_t states, uint32_t bits, u
 
 // The batch launch of 64-state plans with 8-byte tables: the one-chain-per-wave launch's own shape (two 16-wave workgroups per CU,
 // LDS = 16 rings + the widest member's table) and its age-class weights (the device's own once calibrated).
-BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits, uint64_t total_groups)
+BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits, uint64_t total_groups, uint32_t states)
 {
   PlanHeader h{};
-  h.states = 64;
+  h.states = states;
   h.bits = max_bits;
   h.shared_hist = 1;
   h.n_chains = 1u << 30; // "many": the full machine
@@ -546,9 +548,10 @@ BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits, uint64_t 
   b.grid = L.grid;
   b.waves = L.waves;
   b.lds = L.lds;
+  b.states = states;
   for (uint32_t k = 0; k < 8; k++)
-    b.weights[k] = L.weights[k];
-  if (total_groups != 0 && L.waves == 16 && L.grid > dg.num_cus)
+    b.weights[k] = L.weights[k]; // (32 states: the pair loop's own class lengths, g_direct_weights_pair)
+  if (states == 64 && total_groups != 0 && L.waves == 16 && L.grid > dg.num_cus)
     direct_weights_for(dg, total_groups / ((uint64_t)L.grid * L.waves), b.weights);
   // HSRANS_BATCH_WEIGHTS (tuning; read at every batch creation so that one process can try several): 8 per-mille run lengths
   if (const char *e = getenv("HSRANS_BATCH_WEIGHTS"))
@@ -570,7 +573,9 @@ BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits, uint64_t 
 hipError_t launch_batch_direct(const BatchParams &bp, const BatchShape &shape, hipStream_t stream)
 {
   (void)hipGetLastError();
-  if (bp.finish != nullptr)
+  if (shape.states == 32)
+    hipLaunchKernelGGL(k_decode_batch_pair<kModePack64>, dim3(shape.grid), dim3(shape.waves * 64), shape.lds, stream, bp);
+  else if (bp.finish != nullptr)
     hipLaunchKernelGGL(k_calibrate_batch, dim3(shape.grid), dim3(shape.waves * 64), shape.lds, stream, bp);
   else
     hipLaunchKernelGGL(k_decode_batch<kModePack64>, dim3(shape.grid), dim3(shape.waves * 64), shape.lds, stream, bp);

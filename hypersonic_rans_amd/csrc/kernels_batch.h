@@ -19,7 +19,87 @@ namespace hsrans
 typedef const __attribute__((address_space(4))) BatchSlot *kslot_ptr;
 typedef const __attribute__((address_space(4))) BatchMember *kmember_ptr;
 
+// The run [first, last) of a member's chains as ONE chain (back to back in stream and output: a mergeable plan): where its words and
+// its output start, where its words end, its whole groups and the final partial group's symbols
+__device__ __forceinline__ DirectPiece direct_run(const WaveCtx &c, const PersistentArgs &pa, uint32_t first, uint32_t last)
+{
+  const kptr64 p0 = (kptr64)(uintptr_t)(pa.pieces + first);
+  const kptr64 p1 = (kptr64)(uintptr_t)(pa.pieces + (last - 1));
+  DirectPiece d;
+  d.words = p0[0];
+  d.out = p0[1];
+  d.steps = (uint32_t)((p1[1] - d.out) / c.S) + ((kptr32)p1)[8];
+  d.tail = ((kptr32)p1)[9] & 0xFFFFu;
+  d.limit = last < pa.n_chains ? p1[6] : c.stream_len; // the piece behind the run's last one (Piece is 48 bytes), or the stream's end
+  return d;
+}
+
+// A slot of a 32-state member: its run [ch, end) is cut in two halves that are decoded side by side — A on lanes 0..31, B on lanes
+// 32..63, run_pair_groups — as k_decode_direct does with the chains 2w and 2w + 1 of a stream that has the device to itself
+// (run_direct_pair); what the pair loop leaves (unequal halves, < 4 groups, the stream's final partial group) is finished one at a time.
 template <int MODE>
+__device__ __forceinline__ void run_batch_pair(const WaveCtx &c, const KParams &kp, uint32_t ch, uint32_t end, bool check_hist)
+{
+  const PersistentArgs &pa = kp.pa;
+  StreamWin sw;
+  Ring ra, rb;
+  pair_bind<MODE>(ra, rb, c);
+  if (check_hist && threadIdx.x < 64)
+  {
+    bool same = HSRANS_HIST_IN_RANGE(c, pa.hist_off);
+    if (same)
+    {
+      const uint64_t mine = *(const uint64_t *)(pa.hist_copy + 4 * c.lane);
+      uint64_t theirs = 0;
+      for (int b = 3; b >= 0; b--)
+        theirs = (theirs << 16) | *(const uint16_t *)(c.stream + pa.hist_off + 8 * c.lane + 2 * b);
+      same = mine == theirs;
+    }
+    if (__builtin_amdgcn_ballot_w64(!same) != 0 && c.lane == 0)
+      atomicOr(c.status, kStatusBadHist);
+  }
+  auto copy_table = [&]() {
+    const uint32_t entries = table_bytes_for(MODE, c.bits) / 8;
+    for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
+      *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
+    __syncthreads();
+  };
+  if (ch >= end || ch >= pa.n_chains)
+  {
+    copy_table(); // a wave without chains still takes part in the workgroup's table copy
+    return;
+  }
+  const uint32_t mid = ch + (end - ch + 1) / 2;
+  const bool have_b = mid < end;
+  const DirectPiece da = direct_run(c, pa, ch, mid);
+  const DirectPiece db = have_b ? direct_run(c, pa, mid, end) : da;
+  win_open(sw, c, da.words, have_b ? db.limit : da.limit);
+  ring_begin(sw, ra, c, da.words, true, true);
+  if (have_b)
+    ring_begin(sw, rb, c, db.words, true, true);
+  uint32_t x = pa.states[(uint64_t)((c.lane < 32 || !have_b) ? ch : mid) * 32 + (c.lane & 31)];
+  copy_table();
+  ring_begin_rest(sw, ra, c);
+  if (have_b)
+    ring_begin_rest(sw, rb, c);
+  if (have_b)
+    asm volatile("s_waitcnt vmcnt(6)" : "+v"(x)::"memory"); // (the six requests just made are the only younger ones)
+  else
+    asm volatile("s_waitcnt vmcnt(3)" : "+v"(x)::"memory");
+  uint64_t oa = da.out, ob = db.out;
+  uint32_t sa = da.steps, sb = have_b ? db.steps : 0;
+  const uint32_t both = have_b ? (sa < sb ? sa : sb) & ~3u : 0;
+  run_pair_groups<MODE, true, true>(x, sw, ra, rb, c, oa, ob, both);
+  sa -= both;
+  sb -= both;
+  uint32_t xb = __shfl(x, (c.lane & 31) + 32, 64); // B's states move down to lanes 0..31 and B is finished alone
+  run_groups<MODE>(xb, sw, rb, c, ob, sb);
+  run_tail<MODE>(xb, rb, c, ob, have_b ? db.tail : 0);
+  run_groups<MODE>(x, sw, ra, c, oa, sa);
+  run_tail<MODE>(x, ra, c, oa, da.tail);
+}
+
+template <int MODE, bool PAIR> // PAIR: the launch's members are 32-state plans (a kernel of its own: the 64-state launch keeps its register allocation)
 __device__ __forceinline__ void batch_body(const BatchParams &bp)
 {
   extern __shared__ u32x4 smem_v[];
@@ -40,7 +120,7 @@ __device__ __forceinline__ void batch_body(const BatchParams &bp)
   c.out_cap = io.out_cap;
   c.status = mp->status;
   c.bits = mp->bits;
-  c.S = 64;
+  c.S = PAIR ? 32 : 64; // (a launch's members share one state count: the host puts 64- and 32-state members into launches of their own)
   c.lane = threadIdx.x & 63;
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
   asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
@@ -60,20 +140,30 @@ __device__ __forceinline__ void batch_body(const BatchParams &bp)
   kp.pa.hist_copy = mp->hist_copy;
   kp.finish = bp.finish;
   kp.stamps = bp.stamps;
-  run_direct_span<MODE>(c, kp, waves, w, ch, end, (flags & kBatchSlotCheckHist) != 0);
+  if (PAIR)
+    run_batch_pair<MODE>(c, kp, ch, end, (flags & kBatchSlotCheckHist) != 0);
+  else
+    run_direct_span<MODE>(c, kp, waves, w, ch, end, (flags & kBatchSlotCheckHist) != 0);
 }
 
 template <int MODE>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_decode_batch(BatchParams bp)
 {
-  batch_body<MODE>(bp);
+  batch_body<MODE, false>(bp);
+}
+
+// the same launch for 32-state members (two runs per wave, one per half: run_batch_pair)
+template <int MODE>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_decode_batch_pair(BatchParams bp)
+{
+  batch_body<MODE, true>(bp);
 }
 
 // hsrans_ctx_calibrate_runs' launches (and HSRANS_BATCH_STAMPS' ones): the same kernel under a name of its own, so that a profile
 // of a run that calibrates first lists the calibration apart from the decodes it is there to measure (as k_calibrate does)
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_calibrate_batch(BatchParams bp)
 {
-  batch_body<kModePack64>(bp);
+  batch_body<kModePack64, false>(bp);
 }
 
 } // namespace hsrans

@@ -114,8 +114,11 @@ def test_batch_of_mixed_streams_matches_the_oracle_per_stream(gpu_ctx, oracle, k
     batch = gpu_ctx.make_batch([m["dplan"] for m in ms])
     info = batch.info()
     assert info["members"] == k
-    eligible = sum(1 for i in range(k) if MIX[i][0] == RAW and MIX[i][1] == 64 and MIX[i][2] <= 12 and MIX[i][4] != "none")
-    assert info["direct_members"] == (eligible if eligible >= 2 else 0)
+    direct = 0
+    for states in (64, 32):  # (a launch per state count; a lone member of its kind keeps its own launch)
+        of_kind = sum(1 for i in range(k) if MIX[i][0] == RAW and MIX[i][1] == states and MIX[i][2] <= 12 and MIX[i][4] != "none")
+        direct += of_kind if of_kind >= 2 else 0
+    assert info["direct_members"] == direct
     grouped = 0
     for bits in (10, 11, 12):
         of_width = sum(1 for i in range(k) if MIX[i][0] in (MT, BLOCK) and MIX[i][1] == 64 and MIX[i][2] == bits and MIX[i][4] != "none")
@@ -147,6 +150,54 @@ def test_batch_of_equal_streams_one_launch(gpu_ctx, oracle, k, index):
     assert gpu_ctx.batch_status(batch) == [0] * k
     for i, m in enumerate(ms):
         assert np.array_equal(m["d_out"].cpu().numpy(), m["want"]), f"member {i} differs from the oracle"
+
+
+@pytest.mark.gpu
+def test_batch_of_32_state_streams_and_both_state_counts_together(gpu_ctx, oracle):
+    """rANS32x32 members share a launch of their own kind (k_decode_batch_pair: a slot's run decoded as two halves side by side, lanes
+    0..31 / 32..63); together with rANS32x64 members a call makes two launches.  Index kinds: one chain per wave of a launch of its
+    own, uniform, and shaped for this batch (hsrans_index_boundaries_batch: two chains per wave slot); every member against the oracle."""
+    import torch
+
+    sizes32 = [4_000_000, 4_000_000, 2_500_003, 700_001]
+    ms = []
+    for i, n in enumerate(sizes32):
+        data = synth.enwik8_shaped(n, seed=500 + i)
+        if i == 0:
+            stream, plan = H.encode(RAW, 32, 11, data, index_groups=H.index_boundaries_batch(32, 11, sizes32, i, gpu_ctx))
+        elif i == 1:
+            stream, plan = H.encode(RAW, 32, 11, data, index_groups=H.index_boundaries(32, 11, n, gpu_ctx))
+        else:
+            stream, plan = H.encode(RAW, 32, (12, 10)[i % 2], data, index_interval=(16, 64)[i % 2])
+        bits = 11 if i < 2 else (12, 10)[i % 2]
+        r, want = oracle.decode(RAW, 32, bits, stream, n)
+        assert r == n and np.array_equal(want, data)
+        ms.append({"stream": stream, "want": want, "d_in": torch.from_numpy(np.concatenate([stream, np.zeros((-stream.size) % 16, np.uint8)])).cuda(),
+                   "d_out": torch.zeros(n, dtype=torch.uint8, device="cuda"), "dplan": gpu_ctx.make_device_plan(plan)})
+    only32 = gpu_ctx.make_batch([m["dplan"] for m in ms])
+    info = only32.info()
+    assert info["launches"] == 1 and info["direct_members"] == 4 and info["solo_members"] == 0
+    for rep in range(2):
+        for m in ms:
+            m["d_out"].fill_(0xA5 if rep else 0)
+        gpu_ctx.decode_device_batch(only32, [m["d_in"] for m in ms], [m["d_out"] for m in ms], stream_lengths=[m["stream"].size for m in ms])
+        torch.cuda.synchronize()
+        assert gpu_ctx.batch_status(only32) == [0] * 4
+        for i, m in enumerate(ms):
+            assert np.array_equal(m["d_out"].cpu().numpy(), m["want"]), f"32-state member {i} differs from the oracle (repeat {rep})"
+    only32.close()
+    # 64- and 32-state members in ONE call: a launch per state count
+    members = [_member(gpu_ctx, oracle, RAW, 64, 11, 3_000_000, 600 + i, ("wave", 32)[i]) for i in range(2)] + ms[:3]
+    two = gpu_ctx.make_batch([m["dplan"] for m in members])
+    info = two.info()
+    assert info["launches"] == 2 and info["direct_members"] == 5
+    for m in members:
+        m["d_out"].zero_()
+    gpu_ctx.decode_device_batch(two, [m["d_in"] for m in members], [m["d_out"] for m in members], stream_lengths=[m["stream"].size for m in members])
+    torch.cuda.synchronize()
+    assert gpu_ctx.batch_status(two) == [0] * 5
+    for i, m in enumerate(members):
+        assert np.array_equal(m["d_out"].cpu().numpy(), m["want"]), f"member {i} of the two-launch call differs from the oracle"
 
 
 @pytest.mark.gpu
