@@ -21,6 +21,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=100_000_000)
 ap.add_argument("--bits", type=int, default=11)
 ap.add_argument("--pairs", type=int, default=4)
+ap.add_argument("--states", type=int, default=64)
 ap.add_argument("--index", default="wave")
 ap.add_argument("--window", type=int, default=48, help="batch launches per window (serial windows run pairs x as many)")
 ap.add_argument("--windows", type=int, default=6)
@@ -29,7 +30,7 @@ ap.add_argument("--no-calibrate", action="store_true")
 ap.add_argument("--batch-index", action="store_true", help="index every stream for its share of the batch launch (hsrans_index_boundaries_batch) and fit the lengths at the batch's run length (hsrans_ctx_calibrate_runs)")
 ap.add_argument("--out", default="")
 a = ap.parse_args()
-n, S, bits, P = a.size, 64, a.bits, a.pairs
+n, S, bits, P = a.size, a.states, a.bits, a.pairs
 cache = f"/tmp/zipf_{n}_20241008.bin"
 if os.path.exists(cache):
     base = np.fromfile(cache, np.uint8)
@@ -37,8 +38,8 @@ else:
     base = synth.enwik8_shaped(n, seed=20241008)
     base.tofile(cache)
 ctx = H.Context(0)
-cal = None if a.no_calibrate else ctx.calibrate(bits=bits)
-if a.batch_index and not a.no_calibrate:
+cal = None if (a.no_calibrate or S != 64) else ctx.calibrate(bits=bits)
+if a.batch_index and cal is not None:
     run = n / S / 8192.0
     cal["runs"] = [ctx.calibrate_runs(bits=bits, copies=c) for c in sorted({min(16, max(2, round(run / 96))), min(16, max(2, round(P * run / 96)))})]
     print(json.dumps(cal), flush=True)
@@ -101,7 +102,7 @@ def class_finish(batch):
 for k in range(P):
     ctx.decode_device(dplans[k], d_in[k], d_out[k], stream_length=lens[k])
 check("serial")
-report = {"size": n, "pairs": P, "index": a.index, "calibration": cal, "rounds": []}
+report = {"size": n, "pairs": P, "states": S, "index": a.index, "batch_index": a.batch_index, "calibration": cal, "rounds": []}
 weights = None
 for it in range(a.fit + 1):
     if weights is not None:
