@@ -220,8 +220,9 @@ int hsrans_dplan_status(hsrans_ctx *ctx, hsrans_dplan *dplan, void *hip_stream);
  * checkpoints (64 states, <= 12 bits) share a launch of their own kind: all their blocks in one list, a workgroup per block and round —
  * many small streams then fill the device together instead of each launching a mostly empty one.  A member whose plan neither
  * shared kernel takes (an un-indexed stream, 13-15 bits, 32 states) gets its own launch behind them, in the same call.
- * Best served: raw streams of 64 states, <= 12 bits, with the one-chain-per-wavefront index (hsrans_index_boundaries) when the
- * members are 1, 2 or 4 of about one size, or with a uniform index (hsrans_encode_opts::index_interval) for any mix.
+ * Best served: raw streams of <= 12 bits (64 states, or 32: a launch per state count) with a uniform index
+ * (hsrans_encode_opts::index_interval: any mix of sizes), with the index shaped for the batch (hsrans_index_boundaries_batch), or with
+ * the one-chain-per-wavefront index of a launch of their own (hsrans_index_boundaries) when the members are 1, 2 or 4 of one size.
  * The dplans must outlive the batch and must not be refilled while it exists; a dplan belongs to at most one member.
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct hsrans_batch hsrans_batch;
@@ -245,9 +246,10 @@ typedef struct hsrans_batch_info
 int hsrans_dplan_batch_info(const hsrans_batch *batch, hsrans_batch_info *info);
 /* hsrans_index_boundaries for a stream that will be decoded as member `member` of a batch of `count` streams of the given decoded
  * sizes: exactly one chain per wave slot the batch launch deals that member (8,192 / count each for streams of one size: the sidecar
- * shrinks with the batch), sized by the slots' scheduling classes at the batch's run length.  64 states, bits 10..12.  A batch of
+ * shrinks with the batch), sized by the slots' scheduling classes at the batch's run length.  64 or 32 states, bits 10..12.  A batch of
  * plans made this way is dealt without rounding (hsrans_batch_info::imbalance ~ 1.00); the plans still decode alone, or in another
- * batch, only less evenly.  Returns the number of group indices written (0 = one chain, or capacity too small). */
+ * batch, only less evenly.  32 states: two chains per wave slot.  Returns the number of group indices written (0 = one chain, or
+ * capacity too small). */
 size_t hsrans_index_boundaries_batch(const hsrans_ctx *ctx, int states, uint32_t bits, const size_t *decoded_sizes, uint32_t count, uint32_t member,
                                      uint64_t *groups_out, size_t capacity);
 /* The dealing alone, without a device (tests, planning): members' chain starts in groups (chain_starts[m][0 .. n_chains[m]], the last
