@@ -24,8 +24,12 @@ namespace
 // a plan the one-chain-per-wave batch kernel can take: raw, mergeable, 64 states, the 8-byte host-built table (bits <= 12), one chain per wave
 bool direct_eligible(const hsrans_dplan *d)
 {
-  return d->pa.pieces != nullptr && d->pa.table != nullptr && d->pa.table_mode == 3 && d->pa.dual == 0 && (d->hdr.states == 64 || d->hdr.states == 32) && d->hdr.bits <= 12 &&
-         (d->hdr.flags & kPlanMergeable) != 0 && d->hdr.container == HSRANS_RAW && d->hdr.n_chains >= 1;
+  if (d->pa.pieces == nullptr || d->pa.table == nullptr || (d->hdr.flags & kPlanMergeable) == 0 || d->hdr.container != HSRANS_RAW || d->hdr.n_chains < 1)
+    return false;
+  if (d->hdr.bits <= 12) // the 8-byte table, one chain per wave (64 states) or two halves per wave (32 states)
+    return d->pa.table_mode == 3 && d->pa.dual == 0 && (d->hdr.states == 64 || d->hdr.states == 32);
+  // 13-15 bits, 64 states: k_decode_batch_dual takes the 8-byte table at 13 bits and the rank table at 14 / 15
+  return d->hdr.states == 64 && d->hdr.bits <= 15 && d->pa.table_mode == (d->hdr.bits == 13 ? 3u : 4u);
 }
 // a plan the grouped batch kernel can take: block_/mt_ with checkpoints whose groups are all mergeable runs or fills, 64 states, <= 12 bits
 bool grouped_eligible(const hsrans_dplan *d)
@@ -160,11 +164,15 @@ try
   // 64- and 32-state members take launches of their own kind (k_decode_batch / k_decode_batch_pair); a lone member of its kind keeps a
   // launch of its own: the same thing, with the plan's own dealing
   std::vector<std::vector<uint32_t>> launch_members;
-  for (uint32_t states : {64u, 32u})
+  auto kind_of = [&](uint32_t k) { // which shared kernel a member runs on (hsrans_kernels.h: kBatch*)
+    const PlanHeader &ph = dplans[k]->hdr;
+    return ph.states == 32 ? kBatchPair : ph.bits <= 12 ? kBatchDirect : ph.bits == 13 ? kBatchDualPack : kBatchDualRank;
+  };
+  for (uint32_t kind : {kBatchDirect, kBatchPair, kBatchDualPack, kBatchDualRank})
   {
     std::vector<uint32_t> of_kind;
     for (uint32_t k : eligible)
-      if (dplans[k]->hdr.states == states)
+      if (kind_of(k) == kind)
         of_kind.push_back(k);
     if (of_kind.size() == 1)
       b->solo.push_back(of_kind[0]);
@@ -217,7 +225,7 @@ try
     for (const BatchDealMember &dm : deal_in)
       launch_groups += dm.total_groups;
     L.shape = batch_direct_shape(ctx->geom, max_bits, launch_groups, launch_states);
-    const BatchDeal deal = batch_deal(deal_in, L.shape.grid, L.shape.waves, L.shape.weights, launch_states == 32 ? 2 : 1);
+    const BatchDeal deal = batch_deal(deal_in, L.shape.grid, L.shape.waves, L.shape.weights, L.shape.kind == kBatchDirect ? 1 : 2);
     // a wave reads its run through one 32-bit window of the stream (run_direct_span: win_open)
     for (const BatchSlot &s : deal.slots)
     {
@@ -405,7 +413,7 @@ size_t hsrans_index_boundaries_batch(const hsrans_ctx *ctx, int states, uint32_t
                                      uint64_t *groups_out, size_t capacity)
 try
 {
-  if ((states != 64 && states != 32) || bits < 10 || bits > 12 || decoded_sizes == nullptr || groups_out == nullptr || count == 0 || count > kBatchMax || member >= count)
+  if ((states != 64 && states != 32) || bits < 10 || bits > (states == 64 ? 15u : 12u) || decoded_sizes == nullptr || groups_out == nullptr || count == 0 || count > kBatchMax || member >= count)
     return 0;
   const DeviceGeom dg = ctx ? ctx->geom : default_geom();
   std::vector<uint64_t> totals(count);
@@ -417,7 +425,7 @@ try
   }
   const BatchShape shape = batch_direct_shape(dg, bits, all, (uint32_t)states);
   // (32 states: two chains per wave slot, one per wave half — run_batch_pair)
-  const size_t chains = batch_boundaries(totals.data(), count, member, shape.grid, shape.waves, shape.weights, groups_out, capacity, states == 32 ? 2 : 1);
+  const size_t chains = batch_boundaries(totals.data(), count, member, shape.grid, shape.waves, shape.weights, groups_out, capacity, shape.kind == kBatchDirect ? 1 : 2);
   return chains > 1 ? chains - 1 : 0;
 }
 catch (...)

@@ -172,9 +172,10 @@ struct BatchGroupShape
 BatchGroupShape batch_grouped_shape(const struct DeviceGeom &dg, uint32_t bits, uint32_t n_groups, uint64_t n_chains);
 hipError_t launch_batch_grouped(const BatchGroupParams &bp, const BatchGroupShape &shape, hipStream_t stream);
 
+constexpr uint32_t kBatchDirect = 0, kBatchPair = 1, kBatchDualPack = 2, kBatchDualRank = 3; // which kernel a shared launch runs
 struct BatchShape
 {
-  uint32_t grid, waves, lds, states;
+  uint32_t grid, waves, lds, states, kind;
   uint32_t weights[8]; // per-mille run lengths of the 8 wave classes (class = (workgroup in the grid's second half) * 4 + wave / 4)
 };
 

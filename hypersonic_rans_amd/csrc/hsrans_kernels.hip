@@ -47,11 +47,11 @@
 #include "kernels_common.h"
 #include "kernels_persist.h"
 #include "kernels_direct.h"
-#include "kernels_batch.h"
 #include "kernels_grouped.h"
 #include "kernels_spread.h"
 #include "kernels_generic.h"
 #include "kernels_dual.h"
+#include "kernels_batch.h"
 #include "kernels_single.h"
 #include "kernels_walk.h"
 
@@ -300,6 +300,10 @@ hipError_t prepare_kernels(DeviceGeom *geom)
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void *)k_decode_batch_pair<kModePack64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
     if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)k_decode_batch_dual<kModePack64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)k_decode_batch_dual<kModeRank>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
+    if (e == hipSuccess)
       e = hipFuncSetAttribute((const void *)k_calibrate_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
     if (e != hipSuccess)
       return e;
@@ -543,8 +547,12 @@ BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits, uint64_t 
   h.bits = max_bits;
   h.shared_hist = 1;
   h.n_chains = 1u << 30; // "many": the full machine
-  const LaunchShape L = launch_shape(h, dg, true, kModePack64, 0, false, true, false);
+  // 13-15 bits (64 states): k_decode_dual's shape — one 16-wave workgroup per CU, two chains per wave, the 8-byte table at 13 bits,
+  // the rank table at 14 / 15 — and its class lengths
+  const bool wide = states == 64 && max_bits >= 13;
+  const LaunchShape L = launch_shape(h, dg, true, wide && max_bits >= 14 ? kModeRank : kModePack64, 0, false, true, wide);
   BatchShape b{};
+  b.kind = states == 32 ? kBatchPair : !wide ? kBatchDirect : max_bits >= 14 ? kBatchDualRank : kBatchDualPack;
   b.grid = L.grid;
   b.waves = L.waves;
   b.lds = L.lds;
@@ -573,8 +581,12 @@ BatchShape batch_direct_shape(const DeviceGeom &dg, uint32_t max_bits, uint64_t 
 hipError_t launch_batch_direct(const BatchParams &bp, const BatchShape &shape, hipStream_t stream)
 {
   (void)hipGetLastError();
-  if (shape.states == 32)
+  if (shape.kind == kBatchPair)
     hipLaunchKernelGGL(k_decode_batch_pair<kModePack64>, dim3(shape.grid), dim3(shape.waves * 64), shape.lds, stream, bp);
+  else if (shape.kind == kBatchDualPack)
+    hipLaunchKernelGGL(k_decode_batch_dual<kModePack64>, dim3(shape.grid), dim3(shape.waves * 64), shape.lds, stream, bp);
+  else if (shape.kind == kBatchDualRank)
+    hipLaunchKernelGGL(k_decode_batch_dual<kModeRank>, dim3(shape.grid), dim3(shape.waves * 64), shape.lds, stream, bp);
   else if (bp.finish != nullptr)
     hipLaunchKernelGGL(k_calibrate_batch, dim3(shape.grid), dim3(shape.waves * 64), shape.lds, stream, bp);
   else

@@ -99,6 +99,144 @@ __device__ __forceinline__ void run_batch_pair(const WaveCtx &c, const KParams &
   run_tail<MODE>(x, ra, c, oa, da.tail);
 }
 
+// A slot of a 64-state member with a WIDE histogram (13-15 bits: k_decode_dual's launch shape — one 16-wave workgroup per CU, two rings
+// per wave, the 8-byte table at 13 bits, the rank table at LDS address 0 at 14 / 15): the slot's run [ch, end) cut in two halves that are
+// decoded as two chains in one instruction stream (run_dual_fast), as k_decode_dual does with chains 2w and 2w + 1.
+template <int MODE>
+__device__ __forceinline__ void run_batch_dual(const WaveCtx &c, const KParams &kp, uint32_t ch, uint32_t end, bool check_hist)
+{
+  const PersistentArgs &pa = kp.pa;
+  constexpr uint32_t kDualRing = kFastRingBytes;
+  // the host-built table, the first workgroup of the member also checks the histogram it was built from against the stream's
+  {
+    const uint32_t entries = table_bytes_for(MODE, c.bits) / 8;
+    for (uint32_t i = threadIdx.x * 2; i < entries; i += blockDim.x * 2)
+      *(u32x4 *)(c.table + (uint64_t)i * 8) = *(const u32x4 *)(pa.table + i);
+    if (check_hist && threadIdx.x < 64)
+    {
+      bool same = HSRANS_HIST_IN_RANGE(c, pa.hist_off);
+      if (same)
+      {
+        const uint64_t mine = *(const uint64_t *)(pa.hist_copy + 4 * c.lane);
+        uint64_t theirs = 0;
+        for (int b = 3; b >= 0; b--)
+          theirs = (theirs << 16) | *(const uint16_t *)(c.stream + pa.hist_off + 8 * c.lane + 2 * b);
+        same = mine == theirs;
+      }
+      if (__builtin_amdgcn_ballot_w64(!same) != 0 && c.lane == 0)
+        atomicOr(c.status, kStatusBadHist);
+    }
+  }
+  if (ch >= end || ch >= pa.n_chains)
+  {
+    __syncthreads(); // (the table copy's barrier: every wave of the workgroup, with or without chains)
+    return;
+  }
+  const uint32_t mid = ch + (end - ch + 1) / 2;
+  const bool have_b = mid < end;
+  const DirectPiece da = direct_run(c, pa, ch, mid);
+  const DirectPiece db = have_b ? direct_run(c, pa, mid, end) : da;
+  uint32_t xa = pa.states[(uint64_t)ch * 64 + c.lane];
+  uint32_t xb = pa.states[(uint64_t)(have_b ? mid : ch) * 64 + c.lane];
+  StreamWin sw;
+  RingD ra, rb;
+  ring_bind(ra.r, c.rings, 9, true);
+  ring_bind(rb.r, c.rings + kDualRing, 9, true);
+  uint32_t vm = 0;
+  win_open(sw, c, da.words, have_b ? db.limit : da.limit); // the two halves are neighbours in the stream: one window
+  ring_begin_counted(sw, ra, c, da.words, vm, true);
+  if (have_b)
+    ring_begin_counted(sw, rb, c, db.words, vm, true);
+  __syncthreads(); // the table is in LDS
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa), "+v"(xb)::"memory"); // states, table and the first two chunks of both rings
+  ring_request_mirror0(sw, ra.r, c);
+  ring_request(sw, ra.r, c, 2);
+  if (have_b)
+  {
+    ring_request_mirror0(sw, rb.r, c);
+    ring_request(sw, rb.r, c, 2);
+  }
+  if (HSRANS_RING_AHEAD == 3)
+  {
+    ring_request(sw, ra.r, c, 3);
+    if (have_b)
+      ring_request(sw, rb.r, c, 3);
+  }
+  if (!have_b)
+    rb = ra;
+  vm = 0;
+  ra.seq1 = ra.seq2 = ra.seq3 = rb.seq1 = rb.seq2 = rb.seq3 = 0;
+  uint64_t oa = da.out, ob = db.out;
+  uint32_t sa = da.steps, sb = have_b ? db.steps : 0;
+  uint32_t both = have_b ? (sa < sb ? sa : sb) & ~3u : 0;
+  sa -= both;
+  sb -= both;
+  run_dual_fast<MODE>(xa, xb, sw, ra, rb, c, oa, ob, both, vm);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  run_groups<MODE>(xa, sw, ra.r, c, oa, sa);
+  if (have_b)
+    run_groups<MODE>(xb, sw, rb.r, c, ob, sb);
+  run_tail<MODE>(xa, ra.r, c, oa, da.tail);
+  if (have_b)
+    run_tail<MODE>(xb, rb.r, c, ob, db.tail);
+}
+
+// the launch of wide-histogram members: LDS as k_decode_dual ([table][16 x 2 rings] with the rank table first, [rings][table] with the 8-byte one)
+template <int MODE>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_decode_batch_dual(BatchParams bp)
+{
+  extern __shared__ u32x4 smem_v[];
+  uint8_t *smem = (uint8_t *)smem_v;
+  const uint32_t waves = blockDim.x >> 6;
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  const uint32_t w = blockIdx.x * waves + wave;
+  const kslot_ptr sp = (kslot_ptr)(uintptr_t)(bp.slots + w);
+  const uint32_t member = uni(sp->member), ch = uni(sp->begin), end = uni(sp->end), flags = uni(sp->flags);
+  const kmember_ptr mp = (kmember_ptr)(uintptr_t)(bp.members + member);
+  const BatchIO &io = bp.io[member];
+  WaveCtx c;
+  c.stream = io.stream;
+  c.stream_len = io.stream_len;
+  c.stream_lo = 0;
+  c.out = io.out;
+  c.out_cap = io.out_cap;
+  c.status = mp->status;
+  c.bits = mp->bits;
+  c.S = 64;
+  c.lane = threadIdx.x & 63;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << c.bits) - 1));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(c.bits));
+  constexpr uint32_t kDualRing = kFastRingBytes;
+  if (MODE == kModeRank)
+  {
+    if (uni(lds_address(smem)) != 0) // (the hand-scheduled group takes the slot as the rank byte's address)
+    {
+      if (threadIdx.x == 0)
+        atomicOr(c.status, kStatusOutOfRange);
+      return;
+    }
+    c.table = smem;
+    c.rings = smem + table_bytes_for(MODE, c.bits) + wave * 2 * kDualRing;
+  }
+  else
+  {
+    c.rings = smem + wave * 2 * kDualRing;
+    c.table = smem + waves * 2 * kDualRing;
+  }
+  c.table_b = c.table;
+  c.gtable = mp->table;
+  c.scratch_cnt = (uint16_t *)smem;
+  c.scratch_cum = (uint16_t *)(smem + 512);
+  KParams kp{};
+  kp.pa.pieces = mp->pieces;
+  kp.pa.states = mp->states;
+  kp.pa.n_chains = mp->n_chains;
+  kp.pa.hist_off = mp->hist_off;
+  kp.pa.table = mp->table;
+  kp.pa.hist_copy = mp->hist_copy;
+  run_batch_dual<MODE>(c, kp, ch, end, (flags & kBatchSlotCheckHist) != 0);
+}
+
 template <int MODE, bool PAIR> // PAIR: the launch's members are 32-state plans (a kernel of its own: the 64-state launch keeps its register allocation)
 __device__ __forceinline__ void batch_body(const BatchParams &bp)
 {

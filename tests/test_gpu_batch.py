@@ -201,6 +201,41 @@ def test_batch_of_32_state_streams_and_both_state_counts_together(gpu_ctx, oracl
 
 
 @pytest.mark.gpu
+def test_batch_of_wide_histogram_streams(gpu_ctx, oracle):
+    """13-15-bit members (BASELINE config 3's widths) share launches of k_decode_dual's kind — two chains per wave in one instruction
+    stream, the 8-byte table at 13 bits, the rank table at 14 / 15 (a launch for each of the two table kinds; 14- and 15-bit members
+    together in one).  Index kinds: one chain per wave of a launch of their own, uniform, shaped for the batch; each against the oracle."""
+    import torch
+
+    spec = [(14, 5_000_000, "batch"), (15, 5_000_000, "wave"), (14, 1_200_007, 16), (15, 2_000_000, 64), (13, 3_000_000, "wave"), (13, 999_999, 32)]
+    rank_sizes = [n for b, n, _ in spec if b >= 14]
+    ms = []
+    for i, (bits, n, index) in enumerate(spec):
+        data = synth.enwik8_shaped(n, seed=700 + i)
+        if index == "batch":
+            stream, plan = H.encode(RAW, 64, bits, data, index_groups=H.index_boundaries_batch(64, bits, rank_sizes, 0, gpu_ctx))
+        elif index == "wave":
+            stream, plan = H.encode(RAW, 64, bits, data, index_groups=H.index_boundaries(64, bits, n, gpu_ctx))
+        else:
+            stream, plan = H.encode(RAW, 64, bits, data, index_interval=index)
+        r, want = oracle.decode(RAW, 64, bits, stream, n)
+        assert r == n and np.array_equal(want, data)
+        ms.append({"stream": stream, "want": want, "d_in": torch.from_numpy(np.concatenate([stream, np.zeros((-stream.size) % 16, np.uint8)])).cuda(),
+                   "d_out": torch.zeros(n, dtype=torch.uint8, device="cuda"), "dplan": gpu_ctx.make_device_plan(plan)})
+    batch = gpu_ctx.make_batch([m["dplan"] for m in ms])
+    info = batch.info()
+    assert info["launches"] == 2 and info["direct_members"] == 6 and info["solo_members"] == 0, info
+    for rep in range(2):
+        for m in ms:
+            m["d_out"].fill_(0x5A if rep else 0)
+        gpu_ctx.decode_device_batch(batch, [m["d_in"] for m in ms], [m["d_out"] for m in ms], stream_lengths=[m["stream"].size for m in ms])
+        torch.cuda.synchronize()
+        assert gpu_ctx.batch_status(batch) == [0] * 6
+        for i, m in enumerate(ms):
+            assert np.array_equal(m["d_out"].cpu().numpy(), m["want"]), f"wide member {i} {spec[i]} differs from the oracle (repeat {rep})"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("container", (MT, BLOCK))
 def test_many_small_block_streams_share_one_launch(gpu_ctx, oracle, container):
     """The many-small-files case: 12 block_/mt_ streams of 0.3 .. 3 MB (block sizes 32 .. 256 KiB, non-stationary data with single-symbol
