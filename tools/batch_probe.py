@@ -38,7 +38,7 @@ else:
     base = synth.enwik8_shaped(n, seed=20241008)
     base.tofile(cache)
 ctx = H.Context(0)
-cal = None if (a.no_calibrate or S != 64) else ctx.calibrate(bits=bits)
+cal = None if (a.no_calibrate or S != 64 or bits > 12) else ctx.calibrate(bits=bits)
 if a.batch_index and cal is not None:
     run = n / S / 8192.0
     cal["runs"] = [ctx.calibrate_runs(bits=bits, copies=c) for c in sorted({min(16, max(2, round(run / 96))), min(16, max(2, round(P * run / 96)))})]
@@ -102,7 +102,7 @@ def class_finish(batch):
 for k in range(P):
     ctx.decode_device(dplans[k], d_in[k], d_out[k], stream_length=lens[k])
 check("serial")
-report = {"size": n, "pairs": P, "states": S, "index": a.index, "batch_index": a.batch_index, "calibration": cal, "rounds": []}
+report = {"size": n, "pairs": P, "states": S, "bits": bits, "index": a.index, "batch_index": a.batch_index, "calibration": cal, "rounds": []}
 weights = None
 for it in range(a.fit + 1):
     if weights is not None:
