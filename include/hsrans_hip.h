@@ -218,8 +218,10 @@ int hsrans_dplan_status(hsrans_ctx *ctx, hsrans_dplan *dplan, void *hip_stream);
  * decode table), in proportion to the members' sizes, each member's chains cut into runs sized by the slots' scheduling
  * class — so the three are paid once.  Members keep their own device plans, status words and results.  block_/mt_ members with
  * checkpoints (64 states, <= 12 bits) share a launch of their own kind: all their blocks in one list, a workgroup per block and round —
- * many small streams then fill the device together instead of each launching a mostly empty one.  A member whose plan neither
- * shared kernel takes (an un-indexed stream, 13-15 bits, 32 states) gets its own launch behind them, in the same call.
+ * many small streams then fill the device together instead of each launching a mostly empty one.  Raw members come in four kinds
+ * with a shared kernel each (64 states <= 12 bits; 32 states <= 12 bits; 64 states 13 bits; 64 states 14-15 bits): a call makes one
+ * launch per kind present.  A member no shared kernel takes (an un-indexed stream, a lone member of its kind) gets its own launch
+ * behind them, in the same call.
  * Best served: raw streams of <= 12 bits (64 states, or 32: a launch per state count) with a uniform index
  * (hsrans_encode_opts::index_interval: any mix of sizes), with the index shaped for the batch (hsrans_index_boundaries_batch), or with
  * the one-chain-per-wavefront index of a launch of their own (hsrans_index_boundaries) when the members are 1, 2 or 4 of one size.
@@ -246,7 +248,8 @@ typedef struct hsrans_batch_info
 int hsrans_dplan_batch_info(const hsrans_batch *batch, hsrans_batch_info *info);
 /* hsrans_index_boundaries for a stream that will be decoded as member `member` of a batch of `count` streams of the given decoded
  * sizes: exactly one chain per wave slot the batch launch deals that member (8,192 / count each for streams of one size: the sidecar
- * shrinks with the batch), sized by the slots' scheduling classes at the batch's run length.  64 or 32 states, bits 10..12.  A batch of
+ * shrinks with the batch), sized by the slots' scheduling classes at the batch's run length.  64 states, bits 10..15, or 32 states, bits
+ * 10..12 (the sizes given are those of the members of the same kind: see hsrans_dplan_batch_create).  A batch of
  * plans made this way is dealt without rounding (hsrans_batch_info::imbalance ~ 1.00); the plans still decode alone, or in another
  * batch, only less evenly.  32 states: two chains per wave slot.  Returns the number of group indices written (0 = one chain, or
  * capacity too small). */
