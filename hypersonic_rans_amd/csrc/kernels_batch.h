@@ -37,6 +37,18 @@ __device__ __forceinline__ DirectPiece direct_run(const WaveCtx &c, const Persis
 // A slot of a 32-state member: its run [ch, end) is cut in two halves that are decoded side by side — A on lanes 0..31, B on lanes
 // 32..63, run_pair_groups — as k_decode_direct does with the chains 2w and 2w + 1 of a stream that has the device to itself
 // (run_direct_pair); what the pair loop leaves (unequal halves, < 4 groups, the stream's final partial group) is finished one at a time.
+// (diagnostics, HSRANS_BATCH_STAMPS: wave w's finish time in finish[w], the launch's first wave's entry in finish[n_waves] — as run_direct_span)
+__device__ __forceinline__ void batch_stamp_entry(uint64_t *finish, uint32_t w, uint32_t n_waves, uint32_t lane)
+{
+  if (finish != nullptr && w == 0 && lane == 0)
+    finish[n_waves] = __builtin_amdgcn_s_memrealtime();
+}
+__device__ __forceinline__ void batch_stamp_done(uint64_t *finish, uint32_t w, uint32_t lane)
+{
+  if (finish != nullptr && lane == 0)
+    finish[w] = __builtin_amdgcn_s_memrealtime();
+}
+
 template <int MODE>
 __device__ __forceinline__ void run_batch_pair(const WaveCtx &c, const KParams &kp, uint32_t ch, uint32_t end, bool check_hist)
 {
@@ -234,7 +246,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(102))) k_
   kp.pa.hist_off = mp->hist_off;
   kp.pa.table = mp->table;
   kp.pa.hist_copy = mp->hist_copy;
+  batch_stamp_entry(bp.finish, w, gridDim.x * waves, c.lane);
   run_batch_dual<MODE>(c, kp, ch, end, (flags & kBatchSlotCheckHist) != 0);
+  batch_stamp_done(bp.finish, w, c.lane);
 }
 
 template <int MODE, bool PAIR> // PAIR: the launch's members are 32-state plans (a kernel of its own: the 64-state launch keeps its register allocation)
@@ -279,7 +293,11 @@ __device__ __forceinline__ void batch_body(const BatchParams &bp)
   kp.finish = bp.finish;
   kp.stamps = bp.stamps;
   if (PAIR)
+  {
+    batch_stamp_entry(bp.finish, w, gridDim.x * waves, c.lane);
     run_batch_pair<MODE>(c, kp, ch, end, (flags & kBatchSlotCheckHist) != 0);
+    batch_stamp_done(bp.finish, w, c.lane);
+  }
   else
     run_direct_span<MODE>(c, kp, waves, w, ch, end, (flags & kBatchSlotCheckHist) != 0);
 }
