@@ -24,11 +24,16 @@ namespace hsrans
 namespace
 {
 
-constexpr uint32_t kWavesPerWG = 4;
+constexpr uint32_t kWavesPerWG = 1;       // one wavefront per workgroup: its LDS starts at address 0, so every LDS address of the pass is a constant plus the lane's part
 constexpr uint32_t kChunk = 4096;        // input bytes fetched per step of the rANS pass
 constexpr uint32_t kRing = 2 * kChunk;   // LDS staging ring: two chunks resident, a third on its way in registers
 constexpr uint32_t kSubHists = 8;        // histogram copies (lane & 7) that keep equal bytes of one load off one LDS address
 constexpr uint32_t kSubStride = 257;     // dwords between copies: copy c of symbol s sits in bank (c + s) % 32, not all in bank s % 32
+// The emitted words of the rANS pass go through an LDS ring and leave it in whole segments (one 8-byte store per lane) instead of
+// one masked 2-byte global store per group: a group emits at most 128 bytes, a set of four groups at most one segment, so with a
+// check after every set two segments are all the ring needs (byte o of the block's slot sits at ring offset o mod kOutRing)
+constexpr uint32_t kOutSeg = 512;
+constexpr uint32_t kOutRing = 2 * kOutSeg;
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)); }
 __device__ __forceinline__ uint32_t enc_lane_to_byte(uint32_t j) { return (j & 0x23u) | ((j & 0x04u) << 2) | ((j & 0x18u) >> 1); }
@@ -50,11 +55,14 @@ struct __attribute__((packed, aligned(2))) U32a2
 
 struct WaveLds
 {
-  uint32_t order[256];  // count << 8 | symbol in heap-sort order
+  uint32_t order[256];  // count << 8 | symbol in heap-sort order; after the normalisation: the kOutRing bytes of the emitted-word ring
   uint4 table[256];     // {x_max, bias, rcp, cmpl | shift << 24}
   uint8_t stage[kRing]; // (table and stage double as the kSubHists histogram copies before the table exists)
+  uint32_t sink[64];    // where the lanes that emit nothing in a group put their write (a select of the address is cheaper than two writes of EXEC)
 };
+
 static_assert(sizeof(uint4) * 256 + kRing >= kSubHists * kSubStride * 4, "histogram copies must fit");
+static_assert(kOutRing == sizeof(uint32_t) * 256, "the emitted-word ring is the sort's order array");
 
 // ---- hist.cpp:16-215: the heap sort ---------------------------------------------------------------------------------
 // The reference sorts the symbols by count with a textbook heap sort; the order of EQUAL counts that sort happens to
@@ -336,8 +344,7 @@ __device__ __forceinline__ void chunk_to_lds(WaveLds &L, const Chunk &r, uint32_
 
 // one group, general form: lanes whose byte does not exist (the file's last, partial group) keep their state
 template <uint32_t S>
-__device__ __forceinline__ void encode_group_slow(uint32_t &x, const WaveLds &L, uint32_t group_off, uint32_t valid, uint8_t *slot, uint32_t &p, uint32_t lane,
-                                                  uint32_t byte_in_group)
+__device__ __forceinline__ void encode_group_slow(uint32_t &x, WaveLds &L, uint32_t group_off, uint32_t valid, uint32_t &p, uint32_t lane, uint32_t byte_in_group)
 {
   const bool active = lane < S && byte_in_group < valid;
   const uint32_t sym = L.stage[(group_off + byte_in_group) & (kRing - 1)];
@@ -349,7 +356,7 @@ __device__ __forceinline__ void encode_group_slow(uint32_t &x, const WaveLds &L,
   uint32_t v = x;
   if (emit)
   {
-    *(uint16_t *)(slot + (p + 2 * rank)) = (uint16_t)x; // lane S-1's word goes last in memory (rANS32x64_16w.cpp:65-99)
+    *(uint16_t *)((uint8_t *)L.order + ((p + 2 * rank) & (kOutRing - 1))) = (uint16_t)x; // lane S-1's word goes last in memory (rANS32x64_16w.cpp:65-99)
     v = x >> 16;
   }
   const uint32_t q = __umulhi(v, e.z) >> (e.w >> 24);
@@ -357,37 +364,62 @@ __device__ __forceinline__ void encode_group_slow(uint32_t &x, const WaveLds &L,
   x = active ? nx : x;
 }
 
-// one whole group with its table entries already in registers; lanes >= S (32-state codec) carry garbage states that
-// never emit
+// Four whole groups (a set: groups 4t+3 ... 4t, coded in that order) with their table entries already in registers.
+//
+// ONE wavefront codes a block and every state is one dependent chain, so the wavefront is alone on its issue port and pays about
+// 2.1-2.4 ns for EVERY instruction, whatever it is (tools/microbench/lone_wave.hip: dependent or independent VALU, SALU, s_nop and
+// s_waitcnt alike) — the pass costs its instruction count.  Hence one asm statement per set (nothing of the compiler's between the
+// groups) and per group the 14 instructions below: the cursor counts words (no shift of the popcount), the ring address is an
+// add-shift and an and-or, lanes that emit nothing write to their own sink word through a select of the ADDRESS (two writes of
+// EXEC around the store cost three instructions and their hazards), the renormalisation shift is the select itself
+// (v_cndmask_b32_sdwa with src1_sel:WORD_1), the table's shift count is read out of byte 3 of its word by the shift.
+// `pw`: word offset (from the slot) of the lowest word written; `ring`: LDS address of the emitted-word ring (kOutRing-aligned);
+// `sink`: this lane's sink address.  S == 32: only lanes 0..31 hold states; EXEC is narrowed to them for the set.
+#define HSRANS_ENC_GROUP(EX, EY, EZ, EW)                                                                                                  \
+  "v_cmp_ge_u32 vcc, %[x], " EX "\n\t"                                                                                                    \
+  "s_bcnt1_i32_b64 %[n], vcc\n\t" /* (also the wait state a VALU read of VCC as an operand needs after a VALU write of it) */            \
+  "v_mbcnt_lo_u32_b32 %[r], vcc_lo, 0\n\t"                                                                                                \
+  "v_mbcnt_hi_u32_b32 %[r], vcc_hi, %[r]\n\t"                                                                                             \
+  "s_sub_u32 %[pw], %[pw], %[n]\n\t"                                                                                                      \
+  "v_add_lshl_u32 %[r], %[r], %[pw], 1\n\t"                                                                                               \
+  "v_and_or_b32 %[r], %[r], %[mask], %[ring]\n\t"                                                                                         \
+  "v_cndmask_b32 %[r], %[sink], %[r], vcc\n\t"                                                                                            \
+  "ds_write_b16 %[r], %[x]\n\t"                                                                                                           \
+  "v_cndmask_b32_sdwa %[x], %[x], %[x], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"                       \
+  "v_mul_hi_u32 %[q], %[x], " EZ "\n\t"                                                                                                   \
+  "v_lshrrev_b32_sdwa %[q], " EW ", %[q] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"                          \
+  "v_mul_u32_u24 %[q], %[q], " EW "\n\t"                                                                                                  \
+  "v_add3_u32 %[x], %[x], " EY ", %[q]\n\t"
 template <uint32_t S>
-__device__ __forceinline__ void encode_group_fast(uint32_t &x, const uint4 &e, uint8_t *slot, uint32_t &p) // p: byte offset of the lowest word written, from `slot`
+__device__ __forceinline__ void encode_set_fast(uint32_t &x, const uint4 (&e)[4], uint32_t ring, uint32_t sink, uint32_t &pw)
 {
-  const bool emit = S == 64 ? x >= e.x : (x >= e.x && lane_id() < 32);
-  const unsigned long long mask = __builtin_amdgcn_ballot_w64(emit);
-  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-  p -= 2 * (uint32_t)__builtin_popcountll(mask);
-#if !defined(HSRANS_ENC_BRANCHY) || !HSRANS_ENC_BRANCHY
-  // One wavefront, in order: every instruction of the group is on the clock.  The renormalisation as straight-line code — the
-  // masked store between two writes of EXEC, the shift as a select — instead of the compiler's s_and_saveexec / s_cbranch_execz /
-  // s_or around both (EXEC is all ones here: the loop runs in wave-uniform control flow of a 64-thread workgroup)
-  const uint32_t off = p + 2 * rank;
-  const uint32_t xs = x >> 16;
-  // (EXEC is saved and put back, not assumed to be all ones: one more scalar move per group, and the function stays right if it is ever
-  // inlined under a narrowed EXEC — a partial last workgroup, a divergent caller)
-  unsigned long long saved_exec;
-  asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, %3, exec\n\tglobal_store_short %1, %2, %4\n\ts_mov_b64 exec, %0"
-               : "=&s"(saved_exec) : "v"(off), "v"(x), "s"(mask), "s"(slot) : "memory", "scc");
-  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(x) : "v"(x), "v"(xs), "s"(mask));
-#else
-  if (emit)
-  {
-    *(uint16_t *)(slot + (p + 2 * rank)) = (uint16_t)x;
-    x >>= 16;
-  }
-#endif
-  const uint32_t q = __umulhi(x, e.z) >> (e.w >> 24);
-  x = __umul24(q, e.w) + x + e.y; // x + bias + q * (2^bits - freq)
+  uint32_t r, q, n;
+  unsigned long long saved_exec = 0;
+  if constexpr (S == 64)
+    asm volatile(HSRANS_ENC_GROUP("%[x3]", "%[y3]", "%[z3]", "%[w3]") HSRANS_ENC_GROUP("%[x2]", "%[y2]", "%[z2]", "%[w2]")
+                 HSRANS_ENC_GROUP("%[x1]", "%[y1]", "%[z1]", "%[w1]") HSRANS_ENC_GROUP("%[x0]", "%[y0]", "%[z0]", "%[w0]")
+                 : [x] "+v"(x), [pw] "+s"(pw), [r] "=&v"(r), [q] "=&v"(q), [n] "=&s"(n)
+                 : [x0] "v"(e[0].x), [y0] "v"(e[0].y), [z0] "v"(e[0].z), [w0] "v"(e[0].w), [x1] "v"(e[1].x), [y1] "v"(e[1].y), [z1] "v"(e[1].z), [w1] "v"(e[1].w),
+                   [x2] "v"(e[2].x), [y2] "v"(e[2].y), [z2] "v"(e[2].z), [w2] "v"(e[2].w), [x3] "v"(e[3].x), [y3] "v"(e[3].y), [z3] "v"(e[3].z), [w3] "v"(e[3].w),
+                   [ring] "v"(ring), [sink] "v"(sink), [mask] "s"(kOutRing - 1)
+                 : "vcc", "scc", "memory");
+  else
+    asm volatile("s_mov_b64 %[ex], exec\n\ts_and_b64 exec, exec, %[lanes]\n\t" //
+                 HSRANS_ENC_GROUP("%[x3]", "%[y3]", "%[z3]", "%[w3]") HSRANS_ENC_GROUP("%[x2]", "%[y2]", "%[z2]", "%[w2]")
+                 HSRANS_ENC_GROUP("%[x1]", "%[y1]", "%[z1]", "%[w1]") HSRANS_ENC_GROUP("%[x0]", "%[y0]", "%[z0]", "%[w0]") //
+                 "s_mov_b64 exec, %[ex]"
+                 : [x] "+v"(x), [pw] "+s"(pw), [r] "=&v"(r), [q] "=&v"(q), [n] "=&s"(n), [ex] "=&s"(saved_exec)
+                 : [x0] "v"(e[0].x), [y0] "v"(e[0].y), [z0] "v"(e[0].z), [w0] "v"(e[0].w), [x1] "v"(e[1].x), [y1] "v"(e[1].y), [z1] "v"(e[1].z), [w1] "v"(e[1].w),
+                   [x2] "v"(e[2].x), [y2] "v"(e[2].y), [z2] "v"(e[2].z), [w2] "v"(e[2].w), [x3] "v"(e[3].x), [y3] "v"(e[3].y), [z3] "v"(e[3].z), [w3] "v"(e[3].w),
+                   [ring] "v"(ring), [sink] "v"(sink), [mask] "s"(kOutRing - 1), [lanes] "s"(0xFFFFFFFFull)
+                 : "vcc", "scc", "memory");
+  // (an asm statement with several outputs returns a struct; when a member of it lives across basic blocks the instruction selector
+  // exports the WHOLE struct in registers of one kind — scalar ones here, and the states cannot be copied into those.  These two empty
+  // statements, one output each, give the states and the cursor values of their own inside the block.  No instructions.)
+  asm volatile("" : "+v"(x));
+  asm volatile("" : "+s"(pw));
 }
+#undef HSRANS_ENC_GROUP
 
 // One wavefront's job.  RAW = false: block b of an mt_ stream with independent blocks (own histogram, own header).
 // RAW = true: a whole raw stream (rANS32x64_16w.cpp:34-166 is ONE dependent chain per coder state, so one wavefront is all the
@@ -593,17 +625,30 @@ __device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t 
     ck_want = ck_left ? ep.ck_groups[ck_left - 1] : 0;
   };
 
+  // emitted words: [p, flushed_to) of the slot is still in the LDS ring only; a whole segment leaves with one 8-byte store per lane
+  const uint32_t out_ring = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)L.order;
+  const uint32_t sink = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)L.sink + 4 * lane;
+  uint32_t flushed_to = (uint32_t)ep.slot_bytes; // (a multiple of kOutSeg: encode_slot_bytes)
+  auto flush_segment = [&]() {
+    flushed_to -= kOutSeg;
+    const uint2 v = *(const uint2 *)((const uint8_t *)L.order + ((flushed_to & (kOutRing - 1)) + lane * 8));
+    *(uint2 *)(slot + flushed_to + lane * 8) = v;
+  };
+
   uint32_t g = (size + S - 1) / S; // groups of the block still to code; group i covers bytes [i*S, i*S+S)
   if (size % S != 0)               // only the file's last group can be partial
   {
     g--;
-    encode_group_slow<S>(x, L, g * S, size - g * S, slot, p, lane, byte_in_group);
+    encode_group_slow<S>(x, L, g * S, size - g * S, p, lane, byte_in_group);
   }
   while (g % 4 != 0)
   {
     g--;
-    encode_group_slow<S>(x, L, g * S, S, slot, p, lane, byte_in_group);
+    encode_group_slow<S>(x, L, g * S, S, p, lane, byte_in_group);
   }
+  wave_sync();
+  if (p + kOutSeg <= flushed_to) // (at most four groups so far: at most one segment)
+    flush_segment();
 
   if (ep.interval != 0 && g != 0 && g % ep.interval == 0 && g < whole_groups)
     checkpoint(g);
@@ -624,11 +669,6 @@ __device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t 
     for (uint32_t k = 0; k < 4; k++)
       e[k] = L.table[s[k]];
   };
-  auto code_set = [&](const uint4(&e)[4]) {
-#pragma unroll
-    for (int k = 3; k >= 0; k--)
-      encode_group_fast<S>(x, e[k], slot, p);
-  };
   auto chunk_finished = [&](uint32_t c) { // every group of chunk c is coded: its ring half takes the chunk two further down
     if (c < 2)
       return;
@@ -637,36 +677,91 @@ __device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t 
       pre = chunk_load(in, begin, end, c - 3, lane);
     wave_sync();
   };
-  auto chunk_done = [&](int32_t t) { // set t (groups 4t .. 4t+3) is coded
-    if (ep.interval != 0 && t != 0 && (uint32_t)(4 * t) % ep.interval == 0)
-      checkpoint((uint32_t)(4 * t));
-    listed((uint32_t)(4 * t));
-    if ((uint32_t)t % kSetsPerChunk == 0)
-      chunk_finished((uint32_t)t / kSetsPerChunk);
-  };
   if ((uint64_t)g * S <= (uint64_t)(n_chunks - 1) * kChunk) // the groups coded one by one above were all of the last chunk
     chunk_finished(n_chunks - 1);
 
+  // What else happens after a set — a checkpoint, a chunk of input used up — happens at sets known in advance: `event` is the next
+  // such set below, and the loop pays one compare per set for all of it (the wavefront pays for every instruction, see above)
+  const uint32_t ck_sets = ep.interval != 0 ? ep.interval / (ep.interval % 4 == 0 ? 4 : ep.interval % 2 == 0 ? 2 : 1) : 0; // 4 t % interval == 0  <=>  t % ck_sets == 0
+  uint32_t pw = __builtin_amdgcn_readfirstlane(p >> 1); // the cursor in words
   int32_t t = (int32_t)(g / 4) - 1;
+  // the next set (<= t) that ends a chunk whose ring half is wanted / that a checkpoint follows / that a listed checkpoint follows; -1: none
+  int32_t ev_chunk = t >= (int32_t)(2 * kSetsPerChunk) ? (int32_t)((uint32_t)t / kSetsPerChunk * kSetsPerChunk) : -1;
+  int32_t ev_ck = ck_sets != 0 && t >= (int32_t)ck_sets ? (int32_t)((uint32_t)t / ck_sets * ck_sets) : -1;
+  auto listed_set = [&]() { return RAW && ck_want != 0 && (int32_t)(ck_want / 4) <= t ? (int32_t)(ck_want / 4) : -1; };
+  int32_t ev_listed = listed_set();
+  auto max3 = [](int32_t a, int32_t b, int32_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); };
+  int32_t event = max3(ev_chunk, ev_ck, ev_listed);
+  auto set_events = [&]() { // set t (groups 4t .. 4t+3) is coded and something is due after it
+    p = pw << 1;
+    if (t == ev_ck)
+    {
+      checkpoint((uint32_t)(4 * t));
+      ev_ck = t > (int32_t)ck_sets ? t - (int32_t)ck_sets : -1; // (never after set 0: group 0 starts no chain of its own)
+    }
+    if (RAW && t == ev_listed)
+    {
+      listed((uint32_t)(4 * t));
+      ev_listed = listed_set();
+      if (ev_listed == t)
+        ev_listed = -1;
+    }
+    if (t == ev_chunk)
+    {
+      chunk_finished((uint32_t)t / kSetsPerChunk);
+      ev_chunk = t >= (int32_t)(3 * kSetsPerChunk) ? t - (int32_t)kSetsPerChunk : -1;
+    }
+    event = max3(ev_chunk, ev_ck, ev_listed);
+  };
+
+  uint32_t flush_at = (flushed_to - kOutSeg) >> 1; // a segment is complete when the cursor is at or below this word
   uint32_t sa[4], sb[4];
   uint4 ea[4], eb[4];
   read_syms(t, sa);
   read_entries(sa, ea);
   read_syms(t - 1, sb);
-  while (t >= 0)
+  // one wait per set: everything fetched during the last set (this set's entries, the next set's symbols) has had a whole set to arrive;
+  // said here, the compiler drops the five finer waits it would spread over the set (each a slot of the wavefront's issue port)
+  auto lds_arrived = [] {
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);  // (nothing moves above it: a use scheduled ahead of it would get a wait of its own)
+  };
+  auto after_set = [&]() { // (both unlikely: a taken branch costs the lone wavefront a refill of its instruction buffer, the straight path must be the common one)
+    if (__builtin_expect(pw <= flush_at, 0))
+    {
+      flush_segment();
+      flush_at -= kOutSeg >> 1;
+    }
+    if (__builtin_expect(t == event, 0))
+      set_events();
+  };
+  if (t >= 0 && (t & 1) == 0) // an odd number of sets: one set ahead of the loop, which then runs two sets a turn and never leaves in the middle
   {
+    lds_arrived();
     read_entries(sb, eb);
     read_syms(t - 2, sa);
-    code_set(ea);
-    chunk_done(t);
-    if (--t < 0)
-      break;
+    encode_set_fast<S>(x, ea, out_ring, sink, pw);
+    after_set();
+    --t;
+    for (uint32_t k = 0; k < 4; k++)
+      ea[k] = eb[k], sb[k] = sa[k];
+  }
+  while (t >= 0)
+  {
+    lds_arrived();
+    read_entries(sb, eb);
+    read_syms(t - 2, sa);
+    encode_set_fast<S>(x, ea, out_ring, sink, pw);
+    after_set();
+    --t;
+    lds_arrived();
     read_entries(sa, ea);
     read_syms(t - 2, sb);
-    code_set(eb);
-    chunk_done(t);
+    encode_set_fast<S>(x, eb, out_ring, sink, pw);
+    after_set();
     --t;
   }
+  p = pw << 1;
 
   const uint64_t t3 = __builtin_amdgcn_s_memrealtime();
   if (ep.stamps && lane == 0)
@@ -677,6 +772,9 @@ __device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t 
     ep.stamps[b * 4 + 3] = t3;
   }
   const uint32_t words_bytes = (uint32_t)ep.slot_bytes - p;
+  wave_sync();
+  for (uint32_t o = p + 2 * lane; o < flushed_to; o += 128) // the ring's rest (less than two segments), word by word
+    *(uint16_t *)(slot + o) = *(const uint16_t *)((const uint8_t *)L.order + (o & (kOutRing - 1)));
   if constexpr (RAW)
   {
     // ---- the stream's header in front of the words: [n u64][total u64][counts 256 x u16][states S x u32] (rANS32x64_16w.cpp:150-166) ----
@@ -722,7 +820,7 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   const uint32_t lane = lane_id();
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t wave = kWavesPerWG == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t b = blockIdx.x * kWavesPerWG + wave;
   if (b >= ep.n_blocks)
     return;
@@ -1033,7 +1131,7 @@ uint64_t encode_slot_bytes(uint64_t block, uint32_t S)
 {
   // every symbol emits at most one 16-bit word; the last block can be up to S-1 symbols longer
   const uint64_t need = 2 * (block + S) + 16 + 4 * (uint64_t)S + 512;
-  return (need + 255) / 256 * 256;
+  return (need + 511) / 512 * 512; // (a multiple of the encoder's flush segment)
 }
 
 hipError_t launch_encode(const EncParams &ep, hipStream_t stream, bool *prepared_flag)
