@@ -233,6 +233,8 @@ void hsrans_ctx_destroy(hsrans_ctx *ctx)
     (void)hipFree(ctx->d_status);
   if (ctx->h_pin)
     (void)hipHostFree(ctx->h_pin);
+  if (ctx->h_enc_result)
+    (void)hipHostFree(ctx->h_enc_result);
   for (hipStream_t st : ctx->pipe_streams)
     if (st)
       (void)hipStreamDestroy(st);

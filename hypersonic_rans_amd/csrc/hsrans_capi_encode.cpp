@@ -219,8 +219,18 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   ep.scratch = ctx->d_enc_scratch;
   ep.image_bytes = (uint64_t *)ctx->d_enc_meta;
   ep.image_off = ep.image_bytes + nb;
-  ep.result = ep.image_off + nb;
-  uint64_t *after = ep.result + kEncResultWords;
+  // the result words land in page-locked host memory the kernels write directly (the stream is synchronised before they are read)
+  if (ctx->h_enc_result == nullptr && hipHostMalloc((void **)&ctx->h_enc_result, kEncResultWords * 8, hipHostMallocMapped) != hipSuccess)
+  {
+    ctx->h_enc_result = nullptr;
+    return 0;
+  }
+  void *d_result = nullptr;
+  if (hipHostGetDevicePointer(&d_result, ctx->h_enc_result, 0) != hipSuccess)
+    return 0;
+  ep.result = (uint64_t *)d_result;
+  ep.fits = ep.image_off + nb;
+  uint64_t *after = ep.image_off + nb + kEncResultWords; // (the words' old place in the meta buffer stays reserved)
   ep.stamps = stamps ? after : nullptr;
   after += stamps ? nb * 4 : 0;
   ep.chain_count = (uint32_t *)after;
@@ -233,8 +243,9 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   uint64_t result[kEncResultWords] = {};
   if (launch_encode(ep, s, &ctx->enc_prepared) != hipSuccess)
     return 0;
-  if (hipMemcpyAsync(result, ep.result, sizeof(result), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+  if (hipStreamSynchronize(s) != hipSuccess)
     return 0;
+  memcpy(result, ctx->h_enc_result, sizeof(result));
   if (stamps) // printed, not returned: a tuning aid only
   {
     std::vector<uint64_t> st(nb * 4);
@@ -251,6 +262,15 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
       }
       fprintf(stderr, "[hsrans encode stamps] blocks %u  mean us: histogram %.1f  normalise+table %.1f  rANS pass %.1f   first start -> last end %.1f us\n", ep.n_blocks,
               ph[0] / ep.n_blocks / 100.0, ph[1] / ep.n_blocks / 100.0, ph[2] / ep.n_blocks / 100.0, (double)(hi - lo) / 100.0);
+      for (int k = 1; k < 3; k++) // the spread over the blocks: the kernel lasts as long as its slowest block
+      {
+        std::vector<uint64_t> d(ep.n_blocks);
+        for (uint32_t b = 0; b < ep.n_blocks; b++)
+          d[b] = st[b * 4 + k + 1] - st[b * 4 + k];
+        std::sort(d.begin(), d.end());
+        fprintf(stderr, "[hsrans encode stamps]   %s us: min %.1f  p10 %.1f  p25 %.1f  median %.1f  p75 %.1f  p90 %.1f  max %.1f\n", k == 1 ? "normalise+table" : "rANS pass      ",
+                d[0] / 100.0, d[d.size() / 10] / 100.0, d[d.size() / 4] / 100.0, d[d.size() / 2] / 100.0, d[d.size() * 3 / 4] / 100.0, d[d.size() * 9 / 10] / 100.0, d.back() / 100.0);
+      }
     }
   }
   if (result[1] != 1)

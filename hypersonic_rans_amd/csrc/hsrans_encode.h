@@ -18,6 +18,7 @@ struct EncParams
   uint64_t slot_bytes;   // encode_slot_bytes()
   uint64_t *image_bytes; // [n_blocks] bytes of block b's image (header + words, or the 8-byte single-symbol marker)
   uint64_t *image_off;   // [n_blocks] position of the image in the stream
+  uint64_t *fits;        // device memory: K_scan's copy of result[1] for K_gather (result may be page-locked host memory); unused up to kSelfScanBlocks blocks and by raw encodes
   uint64_t *result;      // [0] stream length, [1] 1 when it fits out_cap (else nothing is written to out), [2] chains,
                          // [3] blocks that are not single-symbol blocks, [4] position of the counts of the last such block
   uint64_t block;        // symbols per block (multiple of 64)

@@ -164,6 +164,152 @@ __device__ __forceinline__ uint32_t heap_extract(Heap &h, uint32_t i)
   return top;
 }
 
+// ---- the extraction as straight-line scalar code -----------------------------------------------------------------------------
+// One extraction is one sift of the heap's last entry down from the root, every step depends on the one before, and the wavefront
+// pays about 2.3 ns per instruction whatever it is (tools/microbench/lone_wave.hip) — so this is written for its instruction count
+// (the compiler's form of heap_sift<> above spends 22-24 instructions a level).  Bottom-up: walk down the path of the larger
+// children to its end WITHOUT looking at the entry to place (8 instructions a level: two v_readlane, "right wins only when its
+// count is strictly larger" as one s_or + s_cmp on count << 8 | symbol, two s_cselect), then find from the bottom where the entry
+// belongs (it came from the bottom: usually one compare), then move the path up by one (s_mov m0 + v_writelane per level).
+// Same heap as heap_sift<0>: the counts along the path never grow, so "the first node whose larger child is not larger than the
+// entry" is found from either end.  Lanes: A holds nodes 0..62 (lane = node), B nodes 63..126 (lane = node - 63), C 127..190,
+// D 191..254; cK = lane of the path's node on level K (level 7: 0..63 in C, 64..127 in D), bK = that node's entry.
+#define HSRANS_HEAP_PICK(REG, BN, CN) /* children at lanes %[l], %[r] of REG: the larger one's entry -> BN, its lane -> CN */                      \
+  "v_readlane_b32 %[sl], " REG ", %[l]\n\t"                                                                                                       \
+  "v_readlane_b32 %[sr], " REG ", %[r]\n\t"                                                                                                       \
+  "s_or_b32 " BN ", %[sl], 0xff\n\t"                                                                                                              \
+  "s_cmp_gt_u32 %[sr], " BN "\n\t"                                                                                                                \
+  "s_cselect_b32 " BN ", %[sr], %[sl]\n\t"                                                                                                        \
+  "s_cselect_b32 " CN ", %[r], %[l]\n\t"
+#define HSRANS_HEAP_DOWN_A(CK, BN, CN) /* node at lane CK of A (levels 1..4): children at lanes 2 CK + 1, 2 CK + 2 of A */                        \
+  "s_lshl1_add_u32 %[l], " CK ", 1\n\t"                                                                                                           \
+  "s_add_u32 %[r], %[l], 1\n\t" HSRANS_HEAP_PICK("%[A]", BN, CN)
+#define HSRANS_HEAP_HEAD /* the entry's compare key, levels 0..4 */                                                                           \
+  "s_or_b32 %[vmax], %[val], 0xff\n\t"                                                                                                            \
+  "s_mov_b32 %[l], 1\n\t"                                                                                                                         \
+  "s_mov_b32 %[r], 2\n\t" HSRANS_HEAP_PICK("%[A]", "%[b1]", "%[c1]") HSRANS_HEAP_DOWN_A("%[c1]", "%[b2]", "%[c2]")                                \
+      HSRANS_HEAP_DOWN_A("%[c2]", "%[b3]", "%[c3]") HSRANS_HEAP_DOWN_A("%[c3]", "%[b4]", "%[c4]") HSRANS_HEAP_DOWN_A("%[c4]", "%[b5]", "%[c5]")
+#define HSRANS_HEAP_CLIMB_FROM(K, BK, BNEXT, LOWER) /* the path ends on level K: does the entry go there? (else try level K - 1) */                \
+  "bottom" K "_%=:\n\t"                                                                                                                           \
+  "s_cmp_gt_u32 " BK ", %[vmax]\n\t"                                                                                                              \
+  "s_cbranch_scc0 " LOWER "_%=\n\t"                                                                                                               \
+  "s_mov_b32 " BNEXT ", %[val]\n\t"                                                                                                               \
+  "s_branch w" K "_%=\n\t"
+#define HSRANS_HEAP_WRITE_A(K, CK, BNEXT) "w" K "_%=:\n\ts_mov_b32 m0, " CK "\n\tv_writelane_b32 %[A], " BNEXT ", m0\n\t"
+#define HSRANS_HEAP_WRITES /* levels 5 .. 0 take the entry of the level below (or the entry to place) */                                          \
+  HSRANS_HEAP_WRITE_A("5", "%[c5]", "%[b6]") HSRANS_HEAP_WRITE_A("4", "%[c4]", "%[b5]") HSRANS_HEAP_WRITE_A("3", "%[c3]", "%[b4]")                \
+  HSRANS_HEAP_WRITE_A("2", "%[c2]", "%[b3]") HSRANS_HEAP_WRITE_A("1", "%[c1]", "%[b2]")                                                           \
+  "w0_%=:\n\tv_writelane_b32 %[A], %[b1], 0\n\t"                                                                                                  \
+  "s_branch done_%=\n\t"
+#define HSRANS_HEAP_CLIMBS /* the rarer ends of the climb */                                                                                       \
+  HSRANS_HEAP_CLIMB_FROM("5", "%[b5]", "%[b6]", "bottom4") HSRANS_HEAP_CLIMB_FROM("4", "%[b4]", "%[b5]", "bottom3")                               \
+  HSRANS_HEAP_CLIMB_FROM("3", "%[b3]", "%[b4]", "bottom2") HSRANS_HEAP_CLIMB_FROM("2", "%[b2]", "%[b3]", "bottom1")                               \
+  HSRANS_HEAP_CLIMB_FROM("1", "%[b1]", "%[b2]", "bottom0")                                                                                        \
+  "bottom0_%=:\n\t"                                                                                                                               \
+  "s_mov_b32 %[b1], %[val]\n\t"                                                                                                                   \
+  "s_branch w0_%=\n\t"                                                                                                                            \
+  "done_%=:"
+struct HeapScratch // (scalar temporaries of one extraction; the register allocator places them)
+{
+  uint32_t vmax, l, r, sl, sr, c1, c2, c3, c4, c5, c6, c7, b1, b2, b3, b4, b5, b6, b7;
+};
+#define HSRANS_HEAP_OPERANDS                                                                                                                       \
+  [A] "+v"(h.A), [B] "+v"(h.B), [C] "+v"(h.C), [D] "+v"(h.D), [vmax] "=&s"(t.vmax), [l] "=&s"(t.l), [r] "=&s"(t.r), [sl] "=&s"(t.sl), \
+      [sr] "=&s"(t.sr), [c1] "=&s"(t.c1), [c2] "=&s"(t.c2), [c3] "=&s"(t.c3), [c4] "=&s"(t.c4), [c5] "=&s"(t.c5), [c6] "=&s"(t.c6), [c7] "=&s"(t.c7),  \
+      [b1] "=&s"(t.b1), [b2] "=&s"(t.b2), [b3] "=&s"(t.b3), [b4] "=&s"(t.b4), [b5] "=&s"(t.b5), [b6] "=&s"(t.b6), [b7] "=&s"(t.b7)
+
+// heap of n entries, 127 <= n <= 255 (levels 0..6 whole, level 7 up to node n - 1): the maximum leaves, `val` (the entry that was at
+// node n) is sifted down from the root; returns the maximum
+__device__ __forceinline__ uint32_t heap_extract_high(Heap &h, uint32_t n, uint32_t val)
+{
+  const uint32_t top = __builtin_amdgcn_readlane(h.A, 0);
+  HeapScratch t;
+  const uint32_t n7 = n - 127; // nodes of level 7 in the heap: their lanes in C / D (as 0..127) are below this
+  asm volatile(HSRANS_HEAP_HEAD
+               // level 5 (A, nodes 31..62) -> level 6 (B): children at lanes 2 c - 62, 2 c - 61
+               "s_lshl1_add_u32 %[l], %[c5], -62\n\t"
+               "s_add_u32 %[r], %[l], 1\n\t" HSRANS_HEAP_PICK("%[B]", "%[b6]", "%[c6]")
+               // level 6 (B, lane c) -> level 7: children are level-7 entries 2 c and 2 c + 1 (C: 0..63, D: 64..127), if still in the heap
+               "s_lshl_b32 %[l], %[c6], 1\n\t"
+               "s_cmp_ge_u32 %[l], %[n7]\n\t"
+               "s_cbranch_scc1 bottom6_%=\n\t"
+               "s_add_u32 %[r], %[l], 1\n\t"
+               "s_cmp_lt_u32 %[c6], 32\n\t"
+               "s_cbranch_scc0 fromD_%=\n\t"
+               "v_readlane_b32 %[sl], %[C], %[l]\n\t"
+               "v_readlane_b32 %[sr], %[C], %[r]\n\t"
+               "s_branch pick7_%=\n\t"
+               "fromD_%=:\n\t"
+               "s_sub_u32 %[b7], %[l], 64\n\t"
+               "v_readlane_b32 %[sl], %[D], %[b7]\n\t"
+               "s_add_u32 %[b7], %[b7], 1\n\t"
+               "v_readlane_b32 %[sr], %[D], %[b7]\n\t"
+               "pick7_%=:\n\t"
+               "s_cmp_lt_u32 %[r], %[n7]\n\t" // the right child may already be out of the heap: then it never wins
+               "s_cselect_b32 %[sr], %[sr], 0\n\t"
+               "s_or_b32 %[b7], %[sl], 0xff\n\t"
+               "s_cmp_gt_u32 %[sr], %[b7]\n\t"
+               "s_cselect_b32 %[b7], %[sr], %[sl]\n\t"
+               "s_cselect_b32 %[c7], %[r], %[l]\n\t"
+               // the path ends on level 7: the common case first, straight down through the writes
+               "s_cmp_gt_u32 %[b7], %[vmax]\n\t"
+               "s_cbranch_scc0 bottom6_%=\n\t"
+               "s_cmp_lt_u32 %[c7], 64\n\t"
+               "s_cbranch_scc1 w7C_%=\n\t"
+               "s_sub_u32 m0, %[c7], 64\n\t"
+               "v_writelane_b32 %[D], %[val], m0\n\t"
+               "s_branch w6_%=\n\t"
+               "w7C_%=:\n\t"
+               "s_mov_b32 m0, %[c7]\n\t"
+               "v_writelane_b32 %[C], %[val], m0\n\t"
+               "w6_%=:\n\t"
+               "s_mov_b32 m0, %[c6]\n\t"
+               "v_writelane_b32 %[B], %[b7], m0\n\t" HSRANS_HEAP_WRITES HSRANS_HEAP_CLIMB_FROM("6", "%[b6]", "%[b7]", "bottom5") HSRANS_HEAP_CLIMBS
+               : HSRANS_HEAP_OPERANDS
+               : [val] "s"(val), [n7] "s"(n7)
+               : "scc");
+  return top;
+}
+
+// heap of n entries, 63 <= n <= 126 (levels 0..5 whole, level 6 up to node n - 1)
+__device__ __forceinline__ uint32_t heap_extract_mid(Heap &h, uint32_t n, uint32_t val)
+{
+  const uint32_t top = __builtin_amdgcn_readlane(h.A, 0);
+  HeapScratch t;
+  const uint32_t n6 = n - 63; // nodes of level 6 in the heap: their lanes in B are below this
+  asm volatile(HSRANS_HEAP_HEAD
+               // level 5 (A, nodes 31..62) -> level 6 (B): children at lanes 2 c - 62, 2 c - 61, if still in the heap
+               "s_lshl1_add_u32 %[l], %[c5], -62\n\t"
+               "s_cmp_ge_u32 %[l], %[n6]\n\t"
+               "s_cbranch_scc1 bottom5_%=\n\t"
+               "s_add_u32 %[r], %[l], 1\n\t"
+               "v_readlane_b32 %[sl], %[B], %[l]\n\t"
+               "v_readlane_b32 %[sr], %[B], %[r]\n\t"
+               "s_cmp_lt_u32 %[r], %[n6]\n\t"
+               "s_cselect_b32 %[sr], %[sr], 0\n\t"
+               "s_or_b32 %[b6], %[sl], 0xff\n\t"
+               "s_cmp_gt_u32 %[sr], %[b6]\n\t"
+               "s_cselect_b32 %[b6], %[sr], %[sl]\n\t"
+               "s_cselect_b32 %[c6], %[r], %[l]\n\t"
+               "s_cmp_gt_u32 %[b6], %[vmax]\n\t"
+               "s_cbranch_scc0 bottom5_%=\n\t"
+               "s_mov_b32 %[b7], %[val]\n\t"
+               "s_mov_b32 m0, %[c6]\n\t"
+               "v_writelane_b32 %[B], %[b7], m0\n\t" HSRANS_HEAP_WRITES HSRANS_HEAP_CLIMBS
+               : HSRANS_HEAP_OPERANDS
+               : [val] "s"(val), [n6] "s"(n6)
+               : "scc");
+  return top;
+}
+#undef HSRANS_HEAP_PICK
+#undef HSRANS_HEAP_DOWN_A
+#undef HSRANS_HEAP_HEAD
+#undef HSRANS_HEAP_CLIMB_FROM
+#undef HSRANS_HEAP_WRITE_A
+#undef HSRANS_HEAP_WRITES
+#undef HSRANS_HEAP_CLIMBS
+#undef HSRANS_HEAP_OPERANDS
+
 __device__ __forceinline__ uint32_t ballot_count(bool pred) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pred)); }
 
 // Heap sort of L.order (count << 8 | symbol) as far as the adjustment needs it: the `take` largest entries in the order
@@ -232,24 +378,30 @@ __device__ __forceinline__ uint32_t heap_take_largest(WaveLds &L, uint32_t lane,
     heap_build_level<1>(h, 1, 2);
     heap_build_level<0>(h, 0, 0);
   }
-  uint32_t taken = 0;
+  // the extracted symbols are marked as bytes in LDS (the table's space, not yet in use): one store per extraction instead of a
+  // compare and a select on a register, and each lane collects its four at the end
+  uint8_t *marks = (uint8_t *)L.table;
+  ((uint32_t *)marks)[lane] = 0;
   auto mark = [&](uint32_t top) {
-    const uint32_t sym = top & 0xFF;
-    taken |= lane == (sym >> 2) ? 1u << (sym & 3) : 0;
+    marks[top & 0xFF] = 1; // (every lane stores the same byte to the same place)
     take--;
   };
+  uint32_t i = 255; // the heap's size before the next extraction is i + 1; its last entry, node i, is the one sifted down
   if (take != 0)
-    mark(heap_extract<8>(h, 255));
-  for (uint32_t i = 254; take != 0 && i >= 191; i--)
-    mark(heap_extract<7>(h, i));
-  for (uint32_t i = 190; take != 0 && i >= 127; i--)
-    mark(heap_extract<7>(h, i));
-  for (uint32_t i = 126; take != 0 && i >= 63; i--)
-    mark(heap_extract<6>(h, i));
-  for (uint32_t i = 62; take != 0 && i >= 1; i--)
+    mark(heap_extract_high(h, i, h.E)), i--;
+  for (; take != 0 && i >= 191; i--)
+    mark(heap_extract_high(h, i, __builtin_amdgcn_readlane(h.D, i - 191)));
+  for (; take != 0 && i >= 127; i--)
+    mark(heap_extract_high(h, i, __builtin_amdgcn_readlane(h.C, i - 127)));
+  for (; take != 0 && i >= 63; i--)
+    mark(heap_extract_mid(h, i, __builtin_amdgcn_readlane(h.B, i - 63)));
+  for (; take != 0 && i >= 1; i--) // (more than 192 of the 256 symbols: not seen on any input so far; the general form)
     mark(heap_extract<5>(h, i));
   if (take != 0)
     mark(__builtin_amdgcn_readlane(h.A, 0));
+  wave_sync();
+  const uint32_t m4 = ((const uint32_t *)marks)[lane];
+  const uint32_t taken = (m4 & 1) | ((m4 >> 7) & 2) | ((m4 >> 14) & 4) | ((m4 >> 21) & 8);
   return taken;
 }
 
@@ -309,7 +461,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
   for (int d = 32; d >= 1; d >>= 1)
     v += __shfl_xor(v, d, 64);
-  return v;
+  return __builtin_amdgcn_readfirstlane(v); // (every lane holds the total; said so, what is computed from it stays in scalar registers)
 }
 
 __device__ __forceinline__ uint4 load16_guarded(const uint8_t *in, uint64_t pos, uint64_t n)
@@ -858,36 +1010,55 @@ __global__ void __launch_bounds__(256) k_raw_histogram(const uint8_t *in, uint64
 // a few microseconds for the whole input, and the block is in L2 when the coding wavefront reads it again.
 __global__ void __launch_bounds__(256) k_block_histograms(EncParams ep, uint32_t *counts)
 {
-  // 32 copies of the histogram (copy = lane & 31): equal bytes of one load instruction — text has one symbol every fifth byte — then
-  // only meet in one LDS atomic from lanes 32 apart (8 copies: 38.9 us for 100 MB, 32: 31.7 us)
-  constexpr uint32_t kSubHists = 32;
-  __shared__ uint32_t sub[kSubHists * kSubStride];
+  // 32 copies of the histogram, copy = lane & 31, laid out [symbol][copy]: a lane's counter is ALWAYS in bank (lane & 31), whatever the
+  // symbol, so the 32 lanes the LDS serves at a time never meet in a bank (the [copy][symbol] layout of round 4, copies 257 dwords apart,
+  // put a counter in bank (copy + symbol) % 32: 64 random symbols per instruction, about five to a bank — 31.7 us per 100 MB); equal
+  // bytes only meet from lanes 32 apart, which the LDS serves one after the other anyway
+  // (23.7 us per 100 MB.  Fewer copies to fit more workgroups on a CU — 24: 6 per CU, all 1,526 blocks in one round — measured slower:
+  // 27.3 us with 24, 26.5 us with 16: it is the atomics, not the tail of the grid)
+  constexpr uint32_t kCopies = 32;
+  __shared__ uint32_t sub[256 * kCopies];
   const uint32_t b = blockIdx.x;
   const uint64_t begin = (uint64_t)b * ep.block;
   const uint64_t end = b + 1 == ep.n_blocks ? ep.n : begin + ep.block;
-  for (uint32_t k = threadIdx.x; k < kSubHists * kSubStride; k += 256)
+  for (uint32_t k = threadIdx.x; k < 256 * kCopies; k += 256)
     sub[k] = 0;
   __syncthreads();
-  uint32_t *mine = sub + (threadIdx.x & (kSubHists - 1)) * kSubStride;
-  for (uint64_t off = begin + threadIdx.x * 16; off < end; off += 4096)
+  uint32_t *mine = sub + (threadIdx.x & (kCopies - 1));
+  auto count16 = [&](const uint4 &d) {
+    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++)
+      atomicAdd(&mine[((w[k >> 2] >> (8 * (k & 3))) & 0xFF) * kCopies], 1u);
+  };
+  uint64_t off = begin + threadIdx.x * 16;
+  for (; off + 3 * 4096 + 16 <= end; off += 4 * 4096) // four loads in flight per thread
+  {
+    uint4 d[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++)
+      d[u] = *(const uint4 *)(ep.in + off + u * 4096);
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++)
+      count16(d[u]);
+  }
+  for (; off < end; off += 4096)
   {
     const uint4 d = load16_guarded(ep.in, off, end);
-    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
     const uint32_t have = end - off < 16 ? (uint32_t)(end - off) : 16;
     if (have == 16)
-    {
-#pragma unroll
-      for (uint32_t k = 0; k < 16; k++)
-        atomicAdd(&mine[(w[k >> 2] >> (8 * (k & 3))) & 0xFF], 1u);
-    }
+      count16(d);
     else
+    {
+      const uint32_t w[4] = {d.x, d.y, d.z, d.w};
       for (uint32_t k = 0; k < have; k++)
-        atomicAdd(&mine[(w[k >> 2] >> (8 * (k & 3))) & 0xFF], 1u);
+        atomicAdd(&mine[((w[k >> 2] >> (8 * (k & 3))) & 0xFF) * kCopies], 1u);
+    }
   }
   __syncthreads();
   uint32_t v = 0;
-  for (uint32_t c = 0; c < kSubHists; c++)
-    v += sub[c * kSubStride + threadIdx.x];
+  for (uint32_t c = 0; c < kCopies; c++) // (thread t sums symbol t's copies starting at copy t: the 32 lanes served together read 32 banks)
+    v += sub[threadIdx.x * kCopies + ((threadIdx.x + c) & (kCopies - 1))];
   counts[(uint64_t)b * 256 + threadIdx.x] = v;
 }
 
@@ -970,6 +1141,8 @@ __global__ void __launch_bounds__(1024) k_scan_images(EncParams ep)
     const uint64_t total = bytes_before;
     ep.result[0] = total;
     ep.result[1] = total <= ep.out_cap ? 1 : 0;
+    if (ep.fits)
+      *ep.fits = total <= ep.out_cap ? 1 : 0;
     ep.result[2] = chains_before;
     ep.result[3] = coded_blocks;
     ep.result[4] = last_hist;
@@ -1074,14 +1247,78 @@ struct __attribute__((packed, aligned(2))) U128a2
   uint32_t v[4];
 };
 
+// sum of `v` over the 256 threads of the workgroup (every thread gets it); `slot`: 4 words of LDS of the caller's
+__device__ __forceinline__ uint64_t wg_sum(uint64_t v, uint64_t *slot)
+{
+  for (int d = 32; d >= 1; d >>= 1)
+    v += __shfl_xor(v, d, 64);
+  if ((threadIdx.x & 63) == 0)
+    slot[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return slot[0] + slot[1] + slot[2] + slot[3];
+}
+
+// Up to this many blocks, every workgroup of K_gather adds up the image sizes in front of its own block itself (n / 256 loads per
+// thread out of L2, two reductions) and the scan kernel with its launch is not run at all: K_scan is one workgroup's worth of latency
+// (13.5 us at 1,526 blocks) on the path of every encode.  Beyond it the reads grow with the square of the block count: K_scan again.
+constexpr uint32_t kSelfScanBlocks = 4096;
+
 __global__ void __launch_bounds__(256) k_gather_images(EncParams ep)
 {
-  if (ep.result[1] == 0)
-    return;
   const uint32_t b = blockIdx.x;
   const uint64_t bytes = ep.image_bytes[b];
+  uint64_t off;
+  if (ep.n_blocks <= kSelfScanBlocks)
+  {
+    __shared__ uint64_t red[5][4];
+    uint64_t before = 0, total = 0, chains_before = 0, chains = 0, coded = 0;
+    for (uint32_t i = threadIdx.x; i < ep.n_blocks; i += 256)
+    {
+      const uint64_t by = ep.image_bytes[i];
+      const uint64_t ch = ep.chain_count[i];
+      total += by;
+      chains += ch;
+      coded += by != 8 ? 1 : 0;
+      before += i < b ? by : 0;
+      chains_before += i < b ? ch : 0;
+    }
+    before = wg_sum(before, red[0]);
+    total = 16 + wg_sum(total, red[1]); // (16: the file header)
+    chains_before = wg_sum(chains_before, red[2]);
+    chains = wg_sum(chains, red[3]);
+    coded = wg_sum(coded, red[4]);
+    off = 16 + before;
+    const bool fits = total <= ep.out_cap;
+    if (threadIdx.x == 0)
+    {
+      ep.image_off[b] = off;
+      ep.chain_off[b] = (uint32_t)chains_before;
+      if (bytes != 8 && coded == 1) // the one coded block of the stream says where its counts are (read in that case only)
+        ep.result[4] = off + 16 + 4 * (uint64_t)ep.S;
+      if (b + 1 == ep.n_blocks)
+      {
+        ep.result[0] = total;
+        ep.result[1] = fits ? 1 : 0;
+        ep.result[2] = chains;
+        ep.result[3] = coded;
+        if (fits)
+        {
+          ((uint64_t *)ep.out)[0] = ep.n;
+          ((uint64_t *)ep.out)[1] = total;
+        }
+      }
+    }
+    if (!fits)
+      return;
+  }
+  else
+  {
+    if (*ep.fits == 0)
+      return;
+    off = ep.image_off[b];
+  }
   const uint8_t *src = ep.scratch + (uint64_t)(b + 1) * ep.slot_bytes - bytes;
-  uint8_t *dst = ep.out + ep.image_off[b];
+  uint8_t *dst = ep.out + off;
   // head: up to the first 16-byte boundary of dst
   uint64_t head = (16 - ((uintptr_t)dst & 15)) & 15;
   if (head > bytes)
@@ -1156,7 +1393,8 @@ hipError_t launch_encode(const EncParams &ep, hipStream_t stream, bool *prepared
     hipLaunchKernelGGL(k_encode_blocks<64>, dim3(grid), dim3(64 * kWavesPerWG), lds, stream, ep);
   else
     hipLaunchKernelGGL(k_encode_blocks<32>, dim3(grid), dim3(64 * kWavesPerWG), lds, stream, ep);
-  hipLaunchKernelGGL(k_scan_images, dim3(1), dim3(1024), 0, stream, ep);
+  if (ep.n_blocks > kSelfScanBlocks)
+    hipLaunchKernelGGL(k_scan_images, dim3(1), dim3(1024), 0, stream, ep);
   hipLaunchKernelGGL(k_gather_images, dim3(ep.n_blocks), dim3(256), 0, stream, ep);
   return hipGetLastError();
 }

@@ -55,6 +55,7 @@ struct hsrans_ctx
   // context.  Streams made per pipe were a trap: the second pipe of a process got streams on ONE hardware queue, its uploads and
   // kernels ran one after the other, and every codec after the first in the harness read 24-26 instead of 33 GiB/s.
   hipStream_t pipe_streams[3] = {nullptr, nullptr, nullptr};
+  uint64_t *h_enc_result = nullptr; // page-locked, device-mapped: hsrans_encode_device's kernels write their result words straight into it (no copy kernel, no second launch gap); under `lock`
   uint8_t *h_pin = nullptr; // page-locked staging of hsrans_decode_device_indexing (checkpoints down, plan blob up); under `lock`
   size_t h_pin_cap = 0;
 };
