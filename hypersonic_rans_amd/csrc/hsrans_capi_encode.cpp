@@ -207,7 +207,7 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
     return 0;
   const bool stamps = getenv("HSRANS_DEBUG_STAMPS") != nullptr;
   const size_t nb = ep.n_blocks;
-  const bool wide_hist = true; // (false: the coding wavefront counts its own block, as in rounds 1-3 — 36 us slower per 100 MB; the knob is gone)
+  const bool wide_hist = true; // (false: the coding wavefront counts its own block, as in rounds 1-3: 29.5 us per 64 KiB block — one wavefront's LDS atomics — against 23.5 us for the whole input by K_hist; the knob is gone)
   const size_t meta_bytes = (nb * 2 + kEncResultWords) * 8 + nb * 2 * 4 + (stamps ? nb * 4 * 8 : 0) + 64 + (wide_hist ? nb * 1024 + 16 : 0);
   const size_t ck_slots = nb * (ep.max_ck ? ep.max_ck : 1);
   if (!grow(&ctx->d_enc_scratch, &ctx->d_enc_scratch_cap, nb * ep.slot_bytes) || !grow(&ctx->d_enc_meta, &ctx->d_enc_meta_cap, meta_bytes) ||

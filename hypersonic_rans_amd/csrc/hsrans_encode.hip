@@ -27,8 +27,7 @@ namespace
 constexpr uint32_t kWavesPerWG = 1;       // one wavefront per workgroup: its LDS starts at address 0, so every LDS address of the pass is a constant plus the lane's part
 constexpr uint32_t kChunk = 4096;        // input bytes fetched per step of the rANS pass
 constexpr uint32_t kRing = 2 * kChunk;   // LDS staging ring: two chunks resident, a third on its way in registers
-constexpr uint32_t kSubHists = 8;        // histogram copies (lane & 7) that keep equal bytes of one load off one LDS address
-constexpr uint32_t kSubStride = 257;     // dwords between copies: copy c of symbol s sits in bank (c + s) % 32, not all in bank s % 32
+constexpr uint32_t kSubHists = 8;        // histogram copies (lane & 7) of a wavefront that counts its own bytes, laid out [symbol][copy]
 // The emitted words of the rANS pass go through an LDS ring and leave it in whole segments (one 8-byte store per lane) instead of
 // one masked 2-byte global store per group: a group emits at most 128 bytes, a set of four groups at most one segment, so with a
 // check after every set two segments are all the ring needs (byte o of the block's slot sits at ring offset o mod kOutRing)
@@ -61,7 +60,7 @@ struct WaveLds
   uint32_t sink[64];    // where the lanes that emit nothing in a group put their write (a select of the address is cheaper than two writes of EXEC)
 };
 
-static_assert(sizeof(uint4) * 256 + kRing >= kSubHists * kSubStride * 4, "histogram copies must fit");
+static_assert(sizeof(uint4) * 256 + kRing >= kSubHists * 256 * 4, "histogram copies must fit");
 static_assert(kOutRing == sizeof(uint32_t) * 256, "the emitted-word ring is the sort's order array");
 
 // ---- hist.cpp:16-215: the heap sort ---------------------------------------------------------------------------------
@@ -625,39 +624,50 @@ __device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t 
   }
   else
   {
-  // ---- byte histogram: kSubHists copies, copy = lane & 7 ----
+  // ---- byte histogram by the coding wavefront itself: kSubHists copies laid out [symbol][copy], copy = lane & 7 ----
+  // (a lane's counter sits in bank 8 * (symbol % 4) + copy: lanes of different copies never meet in a bank)
   uint32_t *sub = (uint32_t *)L.table;
-  for (uint32_t k = lane; k < kSubHists * kSubStride; k += 64)
-    sub[k] = 0;
+  for (uint32_t k = lane; k < kSubHists * 256 / 4; k += 64)
+    ((uint4 *)sub)[k] = make_uint4(0, 0, 0, 0);
   wave_sync();
-  uint32_t *mine = sub + (lane & (kSubHists - 1)) * kSubStride;
-  for (uint32_t off = lane * 16; off < size; off += 4096)
+  uint32_t *mine = sub + (lane & (kSubHists - 1));
+  auto count16 = [&](const uint4 &d) {
+    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++)
+      atomicAdd(&mine[((w[k >> 2] >> (8 * (k & 3))) & 0xFF) * kSubHists], 1u);
+  };
+  uint32_t off = lane * 16;
+  for (; off + 3 * 1024 + 16 <= size; off += 4096) // four loads in flight
   {
     uint4 d[4];
 #pragma unroll
     for (uint32_t u = 0; u < 4; u++)
-      d[u] = off + u * 1024 < size ? load16_guarded(in, begin + off + u * 1024, end) : make_uint4(0, 0, 0, 0);
+      d[u] = *(const uint4 *)(in + begin + off + u * 1024);
 #pragma unroll
     for (uint32_t u = 0; u < 4; u++)
+      count16(d[u]);
+  }
+  for (; off < size; off += 1024)
+  {
+    const uint4 d = load16_guarded(in, begin + off, end);
+    const uint32_t have = size - off < 16 ? size - off : 16;
+    if (have == 16)
+      count16(d);
+    else
     {
-      const uint32_t w[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
-      const uint32_t o = off + u * 1024;
-      const uint32_t have = o >= size ? 0 : size - o < 16 ? size - o : 16;
-      if (have == 16)
-      {
-#pragma unroll
-        for (uint32_t k = 0; k < 16; k++)
-          atomicAdd(&mine[(w[k >> 2] >> (8 * (k & 3))) & 0xFF], 1u);
-      }
-      else
-        for (uint32_t k = 0; k < have; k++)
-          atomicAdd(&mine[(w[k >> 2] >> (8 * (k & 3))) & 0xFF], 1u);
+      const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+      for (uint32_t k = 0; k < have; k++)
+        atomicAdd(&mine[((w[k >> 2] >> (8 * (k & 3))) & 0xFF) * kSubHists], 1u);
     }
   }
   wave_sync();
-  for (uint32_t c = 0; c < kSubHists; c++)
-    for (uint32_t k = 0; k < 4; k++)
-      raw[k] += sub[c * kSubStride + lane * 4 + k];
+  for (uint32_t k = 0; k < 4; k++) // symbol 4 * lane + k: its kSubHists copies are 32 bytes in a row
+  {
+    const uint4 lo = ((const uint4 *)sub)[(lane * 4 + k) * 2], hi = ((const uint4 *)sub)[(lane * 4 + k) * 2 + 1];
+    raw[k] = lo.x + lo.y + lo.z + lo.w + hi.x + hi.y + hi.z + hi.w;
+  }
+  wave_sync();
   }
   uint32_t present = 0;
   for (uint32_t k = 0; k < 4; k++)
@@ -995,6 +1005,7 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
 // of the block encoder), one global atomic per symbol and workgroup
 __global__ void __launch_bounds__(256) k_raw_histogram(const uint8_t *in, uint64_t n, uint32_t *counts)
 {
+  constexpr uint32_t kSubStride = 257; // dwords between copies: copy c of symbol s sits in bank (c + s) % 32, not all in bank s % 32
   __shared__ uint32_t sub[kSubHists * kSubStride];
   for (uint32_t k = threadIdx.x; k < kSubHists * kSubStride; k += 256)
     sub[k] = 0;
