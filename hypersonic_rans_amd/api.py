@@ -70,6 +70,10 @@ def lib_path() -> str:
         stamps = os.path.join(_HERE, "lib", "libhsrans_hip_stamps.so")
         if not os.path.exists(stamps):
             raise HsransError("HSRANS_DEBUG_STAMPS needs the diagnostic library: make -C hypersonic_rans_amd/csrc stamps")
+        main = os.path.join(_HERE, "lib", "libhsrans_hip.so")
+        # (`make` alone does not rebuild it: numbers from a diagnostic library older than the product one are numbers of old code)
+        if os.path.exists(main) and os.path.getmtime(stamps) + 1 < os.path.getmtime(main):
+            raise HsransError("libhsrans_hip_stamps.so is older than libhsrans_hip.so: make -C hypersonic_rans_amd/csrc all stamps")
         return stamps
     return os.path.join(_HERE, "lib", "libhsrans_hip.so")
 
