@@ -747,7 +747,9 @@ __device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t 
     {
       const uint32_t shift = 32 - __clz(freq - 1); // smallest shift with freq <= 1 << shift
       e.y = cum;
-      e.z = (uint32_t)((((uint64_t)1 << (shift + 31)) + freq - 1) / freq);
+      // ceil(2^(shift + 31) / freq), in [2^31, 2^32): by one correctly rounded double division — the quotient is an integer or at least
+      // 2^-15 away from one (freq <= 2^15), the rounding error below 2^-21 — instead of a 64-bit integer division in software
+      e.z = (uint32_t)__builtin_ceil(__builtin_ldexp(1.0, (int)shift + 31) / (double)freq);
       e.w = (target - freq) | ((shift - 1) << 24);
     }
     L.table[lane * 4 + k] = e;
@@ -759,11 +761,12 @@ __device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t 
   // The block's bytes pass through an LDS ring of two chunks (byte r of the block at ring offset r mod kRing) with a third
   // chunk on its way in registers; symbols and their table entries are fetched one and two sets (of four groups) ahead of
   // the set being coded, so that the state update is the only dependent chain.
-  const uint32_t n_chunks = (size + kChunk - 1) / kChunk;
   const uint32_t byte_in_group = enc_lane_to_byte(lane) & (S - 1);
   uint32_t x = 1u << 15;
   uint8_t *slot = slot_end - ep.slot_bytes; // the block's scratch slot; words are written from its end downwards
   uint32_t p = (uint32_t)ep.slot_bytes;     // byte offset (from `slot`) of the lowest word written so far
+  // (asking for this first input ahead of the normalisation, which uses neither the ring nor these registers, was measured: nothing)
+  const uint32_t n_chunks = (size + kChunk - 1) / kChunk;
   chunk_to_lds(L, chunk_load(in, begin, end, n_chunks - 1, lane), n_chunks - 1, lane);
   if (n_chunks >= 2)
     chunk_to_lds(L, chunk_load(in, begin, end, n_chunks - 2, lane), n_chunks - 2, lane);
