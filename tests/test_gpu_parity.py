@@ -655,6 +655,66 @@ def test_gpu_encoder_round_trip_on_device_100mb(gpu_ctx):
     assert torch.equal(back.cpu(), torch.from_numpy(d))
 
 
+def _extractions_needed(block, bits):
+    """how many entries of the reference's heap sort the normalisation of `block` needs (the GPU encoder replays exactly that many
+    extractions: DESIGN 5b) — the host-side restatement of adjust_counts' arithmetic, used to pick inputs, not to check results"""
+    target = 1 << bits
+    raw = np.bincount(block, minlength=256).astype(np.int64)
+    factor = np.float32(target) / np.float32(block.size)
+    c = ((raw.astype(np.float32) * factor).astype(np.float32) + np.float32(0.5)).astype(np.uint16).astype(np.int64)
+    c[(c == 0) & (raw != 0)] = 1
+    s = int(c.sum())
+    if s == target:
+        return 0
+    m = int((c >= 2).sum())
+    if s > target:
+        e, j, mj = s - target, 1, m
+        while e > mj:
+            e -= mj
+            j += 1
+            mj = int((c >= j + 1).sum())
+        return mj - e
+    e = target - s
+    return e - (e - 1) // m * m
+
+
+@pytest.mark.parametrize("states", (32, 64))
+def test_gpu_encoder_every_depth_of_the_heap_sort_replay(gpu_ctx, oracle, states):
+    """The GPU encoder replays the reference's heap sort (hist.cpp:16-215) only as far as the normalisation needs it, with one piece of
+    straight-line code while the heap has >= 127 entries, another down to 63 and the general form below: blocks that need few, ~130,
+    ~160 and > 192 extractions, byte-identical to the host encoder (whose normalisation is pinned to the reference's make_hist)."""
+    seen = set()
+    for name, d, bits, block in (("text", synth.enwik8_shaped(1 << 18, seed=5), 11, 1 << 16), ("text15", synth.enwik8_shaped(1 << 18, seed=6), 15, 1 << 16),
+                                 ("uniform", synth.uniform_bytes(1 << 18, seed=7), 15, 1 << 16), ("uniform12", synth.uniform_bytes(1 << 17, seed=8), 12, 1 << 15),
+                                 ("zipf", synth.zipf_bytes(1 << 18, 1.05, seed=10), 14, 1 << 15)):
+        for b in range(0, d.size, block):
+            t = _extractions_needed(d[b:b + block], bits)
+            seen |= {"none"} if t == 0 else {"high"} | ({"mid"} if t > 129 else set()) | ({"general"} if t > 192 else set())  # (the first 129 extractions of any block are the high form's)
+        want = H.encode(H.MT, states, bits, d, block_size=block, independent_blocks=True)
+        got, _ = _gpu_encode(gpu_ctx, states, bits, d, block)
+        assert got.size == want.size and np.array_equal(got, want), (name, states, bits, block, int(np.argmax(got[:want.size] != want[:got.size])))
+        r, back = oracle.decode(MT, states, bits, got, d.size)
+        assert r == d.size and np.array_equal(back, d), (name, states, bits)
+    assert seen == {"none", "high", "mid", "general"}, seen  # (the inputs reach every form of the extraction)
+
+
+def test_gpu_encoder_placement_by_either_kernel(gpu_ctx, zipf):
+    """Up to 4,096 blocks every workgroup of the gather kernel adds up the image sizes in front of its block itself; beyond, the scan
+    kernel does: the same stream as the host encoder's on both sides of the limit; a too-small output buffer is refused and left untouched."""
+    import torch
+    src = synth.zipf_bytes(5000 * 4096 + 17, 1.1, seed=3)
+    for n, block in ((4096 * 4096, 4096), (4097 * 4096, 4096), (5000 * 4096 + 17, 4096), (300_000, 4096)):
+        d = src[:n]
+        want = H.encode(H.MT, 64, 11, d, block_size=block, independent_blocks=True)
+        got, _ = _gpu_encode(gpu_ctx, 64, 11, d, block)
+        assert got.size == want.size and np.array_equal(got, want), (n, block)
+        d_in = torch.from_numpy(d.copy()).cuda()
+        small = torch.full((want.size - 2,), 0xA5, dtype=torch.uint8, device="cuda")
+        with pytest.raises(H.HsransError):  # (the capacity contract of the host encoders: refused before anything is launched)
+            gpu_ctx.encode_device(H.MT, 64, 11, d_in, small, block_size=block)
+        assert bool((small == 0xA5).all()), (n, block)
+
+
 def test_gpu_encoder_rejects_bad_arguments(gpu_ctx, zipf):
     import torch
     d_in = torch.from_numpy(zipf[:4096].copy()).cuda()
