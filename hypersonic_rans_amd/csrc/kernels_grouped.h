@@ -40,6 +40,11 @@ __device__ void run_grouped(const WaveCtx &c_in, const PlanView &pv_in, const KP
   // (Measured and not kept, round 3: wave 0 pulling the NEXT group's record, piece records and start states through the caches at the
   // end of its round — LDS-DMA into the build scratch, so that the three dependent round trips behind the barrier hit L2: 64 KiB
   // blocks 537 / 542 / 534 us against 537 / 540 / 542 with it, 100 MB 0.368 against 0.369.  The other workgroups of the CU hide them.)
+  // (Round 5, the same idea in full: every wave, once its own share of a round is decoded, reads the NEXT group's record — published by
+  // wave 0 through a third LDS word — fetches its piece record, start states and its thread's histogram count and starts its ring
+  // before the round's barrier; the table build then reads nothing from memory.  Correct (the mt_/block_/batch suites pass), and
+  // slower: 100 MB in 64 KiB blocks, G = 16 / 32 / 64 / 128: 56.0 / 50.8 / 49.9 / 49.8 us against 53.8 / 49.1 / 47.9 / 47.9 without.
+  // The barrier wait grows by what the early fetch takes (0.75 -> 1.8 us a round), the decode gets that much company less.  Removed.)
   // (Round 2 had measured a ticket counter — drawn by everyone after the round's barrier — and checkpoints placed by wave class
   // inside the blocks, and found neither worth it; what changed the picture in round 3 is below: the draw hidden in wave 0's
   // barrier wait, four 8-wave workgroups per CU (launch_shape) and the younger waves' raised priority.)
