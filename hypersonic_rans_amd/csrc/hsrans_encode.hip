@@ -173,20 +173,19 @@ __device__ __forceinline__ uint32_t heap_extract(Heap &h, uint32_t i)
 // Same heap as heap_sift<0>: the counts along the path never grow, so "the first node whose larger child is not larger than the
 // entry" is found from either end.  Lanes: A holds nodes 0..62 (lane = node), B nodes 63..126 (lane = node - 63), C 127..190,
 // D 191..254; cK = lane of the path's node on level K (level 7: 0..63 in C, 64..127 in D), bK = that node's entry.
-#define HSRANS_HEAP_PICK(REG, BN, CN) /* children at lanes %[l], %[r] of REG: the larger one's entry -> BN, its lane -> CN */                      \
-  "v_readlane_b32 %[sl], " REG ", %[l]\n\t"                                                                                                       \
-  "v_readlane_b32 %[sr], " REG ", %[r]\n\t"                                                                                                       \
+#define HSRANS_HEAP_PICK_AT(REG, L, R, BN, CN) /* children at lanes L, R of REG: the larger one's entry -> BN, its lane -> CN */                    \
+  "v_readlane_b32 %[sl], " REG ", " L "\n\t"                                                                                                      \
+  "v_readlane_b32 %[sr], " REG ", " R "\n\t"                                                                                                      \
   "s_or_b32 " BN ", %[sl], 0xff\n\t"                                                                                                              \
   "s_cmp_gt_u32 %[sr], " BN "\n\t"                                                                                                                \
   "s_cselect_b32 " BN ", %[sr], %[sl]\n\t"                                                                                                        \
-  "s_cselect_b32 " CN ", %[r], %[l]\n\t"
+  "s_cselect_b32 " CN ", " R ", " L "\n\t"
+#define HSRANS_HEAP_PICK(REG, BN, CN) HSRANS_HEAP_PICK_AT(REG, "%[l]", "%[r]", BN, CN)
 #define HSRANS_HEAP_DOWN_A(CK, BN, CN) /* node at lane CK of A (levels 1..4): children at lanes 2 CK + 1, 2 CK + 2 of A */                        \
   "s_lshl1_add_u32 %[l], " CK ", 1\n\t"                                                                                                           \
   "s_add_u32 %[r], %[l], 1\n\t" HSRANS_HEAP_PICK("%[A]", BN, CN)
 #define HSRANS_HEAP_HEAD /* the entry's compare key, levels 0..4 */                                                                           \
-  "s_or_b32 %[vmax], %[val], 0xff\n\t"                                                                                                            \
-  "s_mov_b32 %[l], 1\n\t"                                                                                                                         \
-  "s_mov_b32 %[r], 2\n\t" HSRANS_HEAP_PICK("%[A]", "%[b1]", "%[c1]") HSRANS_HEAP_DOWN_A("%[c1]", "%[b2]", "%[c2]")                                \
+  "s_or_b32 %[vmax], %[val], 0xff\n\t" HSRANS_HEAP_PICK_AT("%[A]", "1", "2", "%[b1]", "%[c1]") HSRANS_HEAP_DOWN_A("%[c1]", "%[b2]", "%[c2]")         \
       HSRANS_HEAP_DOWN_A("%[c2]", "%[b3]", "%[c3]") HSRANS_HEAP_DOWN_A("%[c3]", "%[b4]", "%[c4]") HSRANS_HEAP_DOWN_A("%[c4]", "%[b5]", "%[c5]")
 #define HSRANS_HEAP_CLIMB_FROM(K, BK, BNEXT, LOWER) /* the path ends on level K: does the entry go there? (else try level K - 1) */                \
   "bottom" K "_%=:\n\t"                                                                                                                           \
@@ -218,10 +217,9 @@ struct HeapScratch // (scalar temporaries of one extraction; the register alloca
       [b1] "=&s"(t.b1), [b2] "=&s"(t.b2), [b3] "=&s"(t.b3), [b4] "=&s"(t.b4), [b5] "=&s"(t.b5), [b6] "=&s"(t.b6), [b7] "=&s"(t.b7)
 
 // heap of n entries, 127 <= n <= 255 (levels 0..6 whole, level 7 up to node n - 1): the maximum leaves, `val` (the entry that was at
-// node n) is sifted down from the root; returns the maximum
-__device__ __forceinline__ uint32_t heap_extract_high(Heap &h, uint32_t n, uint32_t val)
+// node n) is sifted down from the root
+__device__ __forceinline__ void heap_extract_high(Heap &h, uint32_t n, uint32_t val)
 {
-  const uint32_t top = __builtin_amdgcn_readlane(h.A, 0);
   HeapScratch t;
   const uint32_t n7 = n - 127; // nodes of level 7 in the heap: their lanes in C / D (as 0..127) are below this
   asm volatile(HSRANS_HEAP_HEAD
@@ -267,13 +265,11 @@ __device__ __forceinline__ uint32_t heap_extract_high(Heap &h, uint32_t n, uint3
                : HSRANS_HEAP_OPERANDS
                : [val] "s"(val), [n7] "s"(n7)
                : "scc");
-  return top;
 }
 
 // heap of n entries, 63 <= n <= 126 (levels 0..5 whole, level 6 up to node n - 1)
-__device__ __forceinline__ uint32_t heap_extract_mid(Heap &h, uint32_t n, uint32_t val)
+__device__ __forceinline__ void heap_extract_mid(Heap &h, uint32_t n, uint32_t val)
 {
-  const uint32_t top = __builtin_amdgcn_readlane(h.A, 0);
   HeapScratch t;
   const uint32_t n6 = n - 63; // nodes of level 6 in the heap: their lanes in B are below this
   asm volatile(HSRANS_HEAP_HEAD
@@ -298,8 +294,8 @@ __device__ __forceinline__ uint32_t heap_extract_mid(Heap &h, uint32_t n, uint32
                : HSRANS_HEAP_OPERANDS
                : [val] "s"(val), [n6] "s"(n6)
                : "scc");
-  return top;
 }
+#undef HSRANS_HEAP_PICK_AT
 #undef HSRANS_HEAP_PICK
 #undef HSRANS_HEAP_DOWN_A
 #undef HSRANS_HEAP_HEAD
@@ -377,30 +373,38 @@ __device__ __forceinline__ uint32_t heap_take_largest(WaveLds &L, uint32_t lane,
     heap_build_level<1>(h, 1, 2);
     heap_build_level<0>(h, 0, 0);
   }
-  // the extracted symbols are marked as bytes in LDS (the table's space, not yet in use): one store per extraction instead of a
-  // compare and a select on a register, and each lane collects its four at the end
-  uint8_t *marks = (uint8_t *)L.table;
-  ((uint32_t *)marks)[lane] = 0;
-  auto mark = [&](uint32_t top) {
-    marks[top & 0xFF] = 1; // (every lane stores the same byte to the same place)
-    take--;
+  if (take == 0)
+    return 0;
+  // `take` extractions; i + 1 = the heap's size before the next one, whose last entry (node i) is the one sifted down.  Nothing is
+  // recorded per extraction: what was taken is what is no longer among the heap's first i + 1 nodes (every symbol is in it once).
+  uint32_t i = 255;
+  heap_extract_high(h, i, h.E);
+  i--, take--;
+  auto run = [&](uint32_t lowest, auto &&extract) { // nodes i ... lowest leave the heap, as long as extractions are wanted
+    uint32_t todo = take < i + 1 - lowest ? take : i + 1 - lowest;
+    take -= todo;
+    for (; todo != 0; todo--, i--)
+      extract(i);
   };
-  uint32_t i = 255; // the heap's size before the next extraction is i + 1; its last entry, node i, is the one sifted down
-  if (take != 0)
-    mark(heap_extract_high(h, i, h.E)), i--;
-  for (; take != 0 && i >= 191; i--)
-    mark(heap_extract_high(h, i, __builtin_amdgcn_readlane(h.D, i - 191)));
-  for (; take != 0 && i >= 127; i--)
-    mark(heap_extract_high(h, i, __builtin_amdgcn_readlane(h.C, i - 127)));
-  for (; take != 0 && i >= 63; i--)
-    mark(heap_extract_mid(h, i, __builtin_amdgcn_readlane(h.B, i - 63)));
-  for (; take != 0 && i >= 1; i--) // (more than 192 of the 256 symbols: not seen on any input so far; the general form)
-    mark(heap_extract<5>(h, i));
-  if (take != 0)
-    mark(__builtin_amdgcn_readlane(h.A, 0));
+  run(191, [&](uint32_t k) { heap_extract_high(h, k, __builtin_amdgcn_readlane(h.D, k - 191)); });
+  run(127, [&](uint32_t k) { heap_extract_high(h, k, __builtin_amdgcn_readlane(h.C, k - 127)); });
+  run(63, [&](uint32_t k) { heap_extract_mid(h, k, __builtin_amdgcn_readlane(h.B, k - 63)); });
+  run(1, [&](uint32_t k) { (void)heap_extract<5>(h, k); }); // (more than 192 of the 256 symbols: uniform bytes at 12+ bits; the general form)
+  const uint32_t left = take != 0 ? 0 : i + 1; // (take still wanted with one node left: the root goes too)
+  uint8_t *rem = (uint8_t *)L.table;         // (the table's space, not yet in use)
+  ((uint32_t *)rem)[lane] = 0;
   wave_sync();
-  const uint32_t m4 = ((const uint32_t *)marks)[lane];
-  const uint32_t taken = (m4 & 1) | ((m4 >> 7) & 2) | ((m4 >> 14) & 4) | ((m4 >> 21) & 8);
+  if (lane < 63 && lane < left)
+    rem[h.A & 0xFF] = 1;
+  if (63 + lane < left)
+    rem[h.B & 0xFF] = 1;
+  if (127 + lane < left)
+    rem[h.C & 0xFF] = 1;
+  if (191 + lane < left) // (nodes 191 .. 254; node 255 left with the first extraction)
+    rem[h.D & 0xFF] = 1;
+  wave_sync();
+  const uint32_t m4 = ((const uint32_t *)rem)[lane];
+  const uint32_t taken = ~((m4 & 1) | ((m4 >> 7) & 2) | ((m4 >> 14) & 4) | ((m4 >> 21) & 8)) & 0xFu;
   return taken;
 }
 
