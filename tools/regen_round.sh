@@ -12,4 +12,7 @@ bash tools/profile.sh ${TAG}_batch --one-launch                                 
 bash tools/profile.sh ${TAG}_s32 --states 32                                                 # rANS32x32: trace + counters (r04's were empty)
 STEPS=20 bash tools/profile.sh ${TAG}_1gib --size 1073741824 --pairs 1                       # BASELINE config 2 at 2^30 bytes: trace + counters
 STEPS=10 bash tools/profile.sh ${TAG}_sharded --workload sharded                             # BASELINE config 4 shape (mt_, 1 GiB, 256 KiB blocks): trace + counters
+# the mt_ GPU encoder's kernels (100 MB, 64 KiB blocks): trace only
+mkdir -p gpurun_out/prof_${TAG}_enc; TMPDIR=/tmp timeout -k 5 150 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_enc/trace -- python3 tools/debug/enc_once.py > gpurun_out/prof_${TAG}_enc/trace.log 2>&1
+mkdir -p gpurun_out/$TAG; cp $(find gpurun_out/prof_${TAG}_enc -name "*kernel_stats.csv" | head -1) gpurun_out/$TAG/encode_kernel_stats.csv
 bash tools/round_measure.sh $TAG

@@ -29,6 +29,9 @@ HSRANS_HPIPE_DIRECT=1 python tools/host_pipeline_rate.py >> $OUT/host_pipeline_1
 python tools/host_decoder_vs_reference.py --size 100000000 --budget 2.0 --cases 32:11,32:12,32:13,32:14,32:15,64:11,64:12,64:13,64:14,64:15 > $OUT/host_decoder_vs_reference.jsonl 2> $OUT/host_decoder.err
 python tools/stamps_grouped.py 2>/dev/null | grep -v amdgpu > $OUT/stamps_grouped_1gib.txt
 python tools/encode_rate.py > $OUT/encode_rate_100mb.jsonl 2> $OUT/encode.err
+HSRANS_DEBUG_STAMPS=1 python tools/encode_phase_probe.py 2>&1 | grep -v amdgpu > $OUT/encode_phases.txt   # per-block phase stamps of k_encode_blocks by blocks in flight
+timeout 120 tools/microbench/lone_wave > $OUT/encoder_lone_wave.txt 2>&1                                  # what one wavefront alone on its SIMD pays per instruction
+python tools/spread_by_interval.py > $OUT/spread_by_interval.txt 2> $OUT/spread.err                        # mt_ decode against block size and index interval
 python tools/cold_cache.py > $OUT/cold_cache.jsonl 2> $OUT/cold.err
 timeout 300 tools/microbench/stream_pattern > $OUT/stream_pattern.txt 2>&1
 python tools/stamps.py --index wave 2>/dev/null | grep -v amdgpu > $OUT/stamps_wave_warm.txt
