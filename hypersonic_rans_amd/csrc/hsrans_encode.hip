@@ -4,11 +4,14 @@
 // between blocks is the coder state that is carried across block boundaries.  With HSRANS_ENC_INDEPENDENT_BLOCKS every
 // block starts from fresh states, so a block is one self-contained job:
 //
-//   K_enc    one wavefront per block: byte histogram (LDS atomics) -> normalisation identical to hist.cpp:16-215 ->
-//            backward rANS pass, lane j = coder state j, words stored top-down into the block's scratch slot, then the
-//            block header [size][skip][states][counts] is put in front of them: the slot ends with the block's image
-//   K_scan   exclusive scan of the image sizes -> position of every block in the stream, file header [n][total]
-//   K_gather copies every image to its place
+//   K_hist   byte counts of every block, a workgroup per block (32 LDS copies laid out [symbol][copy]: no bank conflicts)
+//   K_enc    one wavefront per block: normalisation identical to hist.cpp:16-215 (the heap sort's extractions as straight-line
+//            scalar code) -> backward rANS pass, lane j = coder state j, a set of four groups as one asm statement, words through an
+//            LDS ring into the block's scratch slot top-down, then the block header [size][skip][states][counts] in front of them:
+//            the slot ends with the block's image.  Written for its INSTRUCTION COUNT: a wavefront alone on its SIMD pays about
+//            2.3 ns per instruction, whatever it is (tools/microbench/lone_wave.hip)
+//   K_gather adds up the image sizes in front of its block (K_scan does beyond 4,096 blocks), copies the image to its place; the last
+//            workgroup writes the file header [n][total] and the result words (page-locked host memory)
 //
 // The result is byte-identical to the host encoder (hsrans_host.cpp encode(), same flag).
 #include <hip/hip_runtime.h>
