@@ -353,8 +353,11 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
             for p in pairs:
                 assert np.array_equal(p["d_out"].cpu().numpy(), p["data"]), "batch launch: GPU output is not bit-exact"
             launches = max(4, args.steps // P)
-            t_settle = time.perf_counter()  # (the checks above idled the GPU: the same settling as the headline's)
-            while (time.perf_counter() - t_settle) * 1e3 < max(args.settle_ms, 1.0):
+            # (the checks above idled the GPU: settled like the headline, but three times as long — this launch moves 657 MB and its samples
+            # kept falling through the first ~55 ms of sustained launches, 161 -> 142 us in profiles/r05_bench_line.json's first take, where
+            # the one-stream launch is steady after 30)
+            t_settle = time.perf_counter()
+            while (time.perf_counter() - t_settle) * 1e3 < max(3 * args.settle_ms, 1.0):
                 for _ in range(launches):
                     ctx.decode_device_batch(batch, b_in, b_out, stream_lengths=b_len)
                 torch.cuda.synchronize()
