@@ -155,17 +155,6 @@ __device__ __forceinline__ void heap_build_level(Heap &h, uint32_t first, uint32
     heap_sift<LEVEL>(h, i, 256, heap_get<LEVEL>(h, i));
 }
 
-// moves the maximum to node i (on level LEVEL), re-heapifies nodes [0, i) and returns the maximum (count << 8 | symbol)
-template <int LEVEL>
-__device__ __forceinline__ uint32_t heap_extract(Heap &h, uint32_t i)
-{
-  const uint32_t top = __builtin_amdgcn_readlane(h.A, 0);
-  const uint32_t last = heap_get<LEVEL>(h, i);
-  heap_set<LEVEL>(h, i, top);
-  heap_sift<0>(h, 0, i, last);
-  return top;
-}
-
 // ---- the extraction as straight-line scalar code -----------------------------------------------------------------------------
 // One extraction is one sift of the heap's last entry down from the root, every step depends on the one before, and the wavefront
 // pays about 2.3 ns per instruction whatever it is (tools/microbench/lone_wave.hip) — so this is written for its instruction count
@@ -298,6 +287,38 @@ __device__ __forceinline__ void heap_extract_mid(Heap &h, uint32_t n, uint32_t v
                : [val] "s"(val), [n6] "s"(n6)
                : "scc");
 }
+// heap of n entries, 1 <= n <= 62 (every node in A; more than 192 of the 256 symbols extracted: near-uniform bytes): every level
+// looks whether its children are still in the heap
+#define HSRANS_HEAP_DOWN_CHECKED(K, CK, BN, CN) /* node at lane CK of A on level K: children 2 CK + 1, 2 CK + 2 if below n */                    \
+  "s_lshl1_add_u32 %[l], " CK ", 1\n\t"                                                                                                           \
+  "s_cmp_ge_u32 %[l], %[n]\n\t"                                                                                                                   \
+  "s_cbranch_scc1 bottom" K "_%=\n\t"                                                                                                             \
+  "s_add_u32 %[r], %[l], 1\n\t"                                                                                                                   \
+  "v_readlane_b32 %[sl], %[A], %[l]\n\t"                                                                                                          \
+  "v_readlane_b32 %[sr], %[A], %[r]\n\t"                                                                                                          \
+  "s_cmp_lt_u32 %[r], %[n]\n\t"                                                                                                                   \
+  "s_cselect_b32 %[sr], %[sr], 0\n\t"                                                                                                             \
+  "s_or_b32 " BN ", %[sl], 0xff\n\t"                                                                                                              \
+  "s_cmp_gt_u32 %[sr], " BN "\n\t"                                                                                                                \
+  "s_cselect_b32 " BN ", %[sr], %[sl]\n\t"                                                                                                        \
+  "s_cselect_b32 " CN ", %[r], %[l]\n\t"
+__device__ __forceinline__ void heap_extract_low(Heap &h, uint32_t n, uint32_t val)
+{
+  HeapScratch t;
+  asm volatile("s_or_b32 %[vmax], %[val], 0xff\n\t"
+               "s_mov_b32 %[c1], 0\n\t" // (the root, as the lane the first step starts from)
+               HSRANS_HEAP_DOWN_CHECKED("0", "%[c1]", "%[b1]", "%[c1]") HSRANS_HEAP_DOWN_CHECKED("1", "%[c1]", "%[b2]", "%[c2]")
+               HSRANS_HEAP_DOWN_CHECKED("2", "%[c2]", "%[b3]", "%[c3]") HSRANS_HEAP_DOWN_CHECKED("3", "%[c3]", "%[b4]", "%[c4]")
+               HSRANS_HEAP_DOWN_CHECKED("4", "%[c4]", "%[b5]", "%[c5]")
+               // level 5 (nodes 31..62) has no children below 62: the path ends here at the latest
+               "s_cmp_gt_u32 %[b5], %[vmax]\n\t"
+               "s_cbranch_scc0 bottom4_%=\n\t"
+               "s_mov_b32 %[b6], %[val]\n\t" HSRANS_HEAP_WRITES HSRANS_HEAP_CLIMBS
+               : HSRANS_HEAP_OPERANDS
+               : [val] "s"(val), [n] "s"(n)
+               : "scc");
+}
+#undef HSRANS_HEAP_DOWN_CHECKED
 #undef HSRANS_HEAP_PICK_AT
 #undef HSRANS_HEAP_PICK
 #undef HSRANS_HEAP_DOWN_A
@@ -392,7 +413,7 @@ __device__ __forceinline__ uint32_t heap_take_largest(WaveLds &L, uint32_t lane,
   run(191, [&](uint32_t k) { heap_extract_high(h, k, __builtin_amdgcn_readlane(h.D, k - 191)); });
   run(127, [&](uint32_t k) { heap_extract_high(h, k, __builtin_amdgcn_readlane(h.C, k - 127)); });
   run(63, [&](uint32_t k) { heap_extract_mid(h, k, __builtin_amdgcn_readlane(h.B, k - 63)); });
-  run(1, [&](uint32_t k) { (void)heap_extract<5>(h, k); }); // (more than 192 of the 256 symbols: uniform bytes at 12+ bits; the general form)
+  run(1, [&](uint32_t k) { heap_extract_low(h, k, __builtin_amdgcn_readlane(h.A, k)); }); // (more than 192 of the 256 symbols: near-uniform bytes)
   const uint32_t left = take != 0 ? 0 : i + 1; // (take still wanted with one node left: the root goes too)
   uint8_t *rem = (uint8_t *)L.table;         // (the table's space, not yet in use)
   ((uint32_t *)rem)[lane] = 0;

@@ -681,7 +681,7 @@ def _extractions_needed(block, bits):
 @pytest.mark.parametrize("states", (32, 64))
 def test_gpu_encoder_every_depth_of_the_heap_sort_replay(gpu_ctx, oracle, states):
     """The GPU encoder replays the reference's heap sort (hist.cpp:16-215) only as far as the normalisation needs it, with one piece of
-    straight-line code while the heap has >= 127 entries, another down to 63 and the general form below: blocks that need few, ~130,
+    straight-line code while the heap has >= 127 entries, another down to 63 and a third below: blocks that need few, ~130,
     ~160 and > 192 extractions, byte-identical to the host encoder (whose normalisation is pinned to the reference's make_hist)."""
     seen = set()
     for name, d, bits, block in (("text", synth.enwik8_shaped(1 << 18, seed=5), 11, 1 << 16), ("text15", synth.enwik8_shaped(1 << 18, seed=6), 15, 1 << 16),
