@@ -28,7 +28,10 @@ namespace
 {
 
 constexpr uint32_t kWavesPerWG = 1;       // one wavefront per workgroup: its LDS starts at address 0, so every LDS address of the pass is a constant plus the lane's part
-constexpr uint32_t kChunk = 4096;        // input bytes fetched per step of the rANS pass
+// input bytes fetched per step of the rANS pass.  2 KiB since round 5 (4 KiB before): the staging ring is most of a wavefront's LDS,
+// and with 9.25 instead of 13.25 KiB a CU holds 17 wavefronts instead of 12 — nothing at 100 MB (1,526 blocks: 6 per CU either way),
+// 615 -> 680 GB/s at 256 MiB, 777 -> 826 GB/s at 2^30 bytes, where the blocks take turns
+constexpr uint32_t kChunk = 2048;
 constexpr uint32_t kRing = 2 * kChunk;   // LDS staging ring: two chunks resident, a third on its way in registers
 constexpr uint32_t kSubHists = 8;        // histogram copies (lane & 7) of a wavefront that counts its own bytes, laid out [symbol][copy]
 // The emitted words of the rANS pass go through an LDS ring and leave it in whole segments (one 8-byte store per lane) instead of
