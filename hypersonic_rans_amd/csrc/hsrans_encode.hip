@@ -28,11 +28,11 @@ namespace
 {
 
 constexpr uint32_t kWavesPerWG = 1;       // one wavefront per workgroup: its LDS starts at address 0, so every LDS address of the pass is a constant plus the lane's part
-// input bytes fetched per step of the rANS pass.  2 KiB since round 5 (4 KiB before): the staging ring is most of a wavefront's LDS,
-// and with 9.25 instead of 13.25 KiB a CU holds 17 wavefronts instead of 12 — nothing at 100 MB (1,526 blocks: 6 per CU either way),
-// 615 -> 680 GB/s at 256 MiB, 777 -> 826 GB/s at 2^30 bytes, where the blocks take turns
-constexpr uint32_t kChunk = 2048;
-constexpr uint32_t kRing = 2 * kChunk;   // LDS staging ring: two chunks resident, a third on its way in registers
+// Input bytes fetched per step of the rANS pass (CHUNK): the staging ring — two chunks — is most of a wavefront's LDS.  4 KiB chunks
+// (13.25 KiB a wavefront, 11 wavefronts per CU) while every block of the launch is resident at once anyway: a block is then alone with
+// its chain and pays for every chunk change; 2 KiB chunks (9.25 KiB, 17 per CU) beyond that: 100 MB in 32 KiB blocks 442 -> 501 GB/s
+// (3,052 blocks: one round instead of two), 256 MiB 615 -> 685, 2^30 bytes 777 -> 822 GB/s; 100 MB in 64 KiB blocks lose 1 % with them.
+constexpr uint32_t kChunkFew = 4096, kChunkMany = 2048;
 constexpr uint32_t kSubHists = 8;        // histogram copies (lane & 7) of a wavefront that counts its own bytes, laid out [symbol][copy]
 // The emitted words of the rANS pass go through an LDS ring and leave it in whole segments (one 8-byte store per lane) instead of
 // one masked 2-byte global store per group: a group emits at most 128 bytes, a set of four groups at most one segment, so with a
@@ -58,15 +58,15 @@ struct __attribute__((packed, aligned(2))) U32a2
   uint32_t v;
 };
 
-struct WaveLds
+template <uint32_t CHUNK>
+struct WaveLdsT
 {
-  uint32_t order[256];  // count << 8 | symbol in heap-sort order; after the normalisation: the kOutRing bytes of the emitted-word ring
-  uint4 table[256];     // {x_max, bias, rcp, cmpl | shift << 24}
-  uint8_t stage[kRing]; // (table and stage double as the kSubHists histogram copies before the table exists)
-  uint32_t sink[64];    // where the lanes that emit nothing in a group put their write (a select of the address is cheaper than two writes of EXEC)
+  uint32_t order[256];      // count << 8 | symbol in heap-sort order; after the normalisation: the kOutRing bytes of the emitted-word ring
+  uint4 table[256];         // {x_max, bias, rcp, cmpl | shift << 24}
+  uint8_t stage[2 * CHUNK]; // the input ring (table and stage double as the kSubHists histogram copies before the table exists)
+  uint32_t sink[64];        // where the lanes that emit nothing in a group put their write (a select of the address is cheaper than two writes of EXEC)
 };
-
-static_assert(sizeof(uint4) * 256 + kRing >= kSubHists * 256 * 4, "histogram copies must fit");
+static_assert(sizeof(uint4) * 256 + 2 * kChunkMany >= kSubHists * 256 * 4, "histogram copies must fit");
 static_assert(kOutRing == sizeof(uint32_t) * 256, "the emitted-word ring is the sort's order array");
 
 // ---- hist.cpp:16-215: the heap sort ---------------------------------------------------------------------------------
@@ -337,8 +337,8 @@ __device__ __forceinline__ uint32_t ballot_count(bool pred) { return (uint32_t)_
 // Heap sort of L.order (count << 8 | symbol) as far as the adjustment needs it: the `take` largest entries in the order
 // the reference's sort puts them at the top of its array.  Returns, per lane, a 4-bit mask of its symbols (4 * lane + k)
 // that are among them.
-template <bool PARALLEL_BUILD> // (the raw format's kernel keeps the register form: its one wavefront does this once per 100 MB, and the LDS form costs its pass 6 % through the register allocation)
-__device__ __forceinline__ uint32_t heap_take_largest(WaveLds &L, uint32_t lane, uint32_t take)
+template <bool PARALLEL_BUILD, class LDS> // (the raw format's kernel keeps the register form: its one wavefront does this once per 100 MB, and the LDS form costs its pass 6 % through the register allocation)
+__device__ __forceinline__ uint32_t heap_take_largest(LDS &L, uint32_t lane, uint32_t take)
 {
   Heap h;
   if constexpr (PARALLEL_BUILD)
@@ -447,8 +447,8 @@ __device__ __forceinline__ uint32_t heap_take_largest(WaveLds &L, uint32_t lane,
 //            e - F * m largest of the sort get one more.
 // So the heap sort only has to deliver its largest few entries (heap_take_largest), in exactly the order the reference's
 // sort would put them (ties!).  Counts stay in registers: sc[k] is symbol 4 * lane + k.
-template <bool PARALLEL_BUILD>
-__device__ __forceinline__ void adjust_counts(WaveLds &L, uint32_t lane, uint32_t (&sc)[4], uint32_t sum, uint32_t target)
+template <bool PARALLEL_BUILD, class LDS>
+__device__ __forceinline__ void adjust_counts(LDS &L, uint32_t lane, uint32_t (&sc)[4], uint32_t sum, uint32_t target)
 {
   auto count_ge = [&](uint32_t t) {
     uint32_t n = 0;
@@ -505,37 +505,41 @@ __device__ __forceinline__ uint4 load16_guarded(const uint8_t *in, uint64_t pos,
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-struct Chunk
+template <uint32_t CHUNK>
+struct ChunkT
 {
-  uint4 q[kChunk / 1024];
+  uint4 q[CHUNK / 1024];
 };
-__device__ __forceinline__ Chunk chunk_load(const uint8_t *in, uint64_t begin, uint64_t end, uint32_t c, uint32_t lane)
+template <uint32_t CHUNK>
+__device__ __forceinline__ ChunkT<CHUNK> chunk_load(const uint8_t *in, uint64_t begin, uint64_t end, uint32_t c, uint32_t lane)
 {
-  Chunk r;
-  const uint64_t at = begin + (uint64_t)c * kChunk;
-  if (at + kChunk <= end) // (wave-uniform; all but a block's last chunk: four plain loads instead of four guarded ones)
+  ChunkT<CHUNK> r;
+  const uint64_t at = begin + (uint64_t)c * CHUNK;
+  if (at + CHUNK <= end) // (wave-uniform; all but a block's last chunk: plain loads instead of guarded ones)
   {
 #pragma unroll
-    for (uint32_t k = 0; k < kChunk / 1024; k++)
+    for (uint32_t k = 0; k < CHUNK / 1024; k++)
       r.q[k] = *(const uint4 *)(in + at + k * 1024 + lane * 16);
     return r;
   }
 #pragma unroll
-  for (uint32_t k = 0; k < kChunk / 1024; k++)
+  for (uint32_t k = 0; k < CHUNK / 1024; k++)
     r.q[k] = load16_guarded(in, at + k * 1024 + lane * 16, end);
   return r;
 }
-__device__ __forceinline__ void chunk_to_lds(WaveLds &L, const Chunk &r, uint32_t c, uint32_t lane)
+template <uint32_t CHUNK>
+__device__ __forceinline__ void chunk_to_lds(WaveLdsT<CHUNK> &L, const ChunkT<CHUNK> &r, uint32_t c, uint32_t lane)
 {
 #pragma unroll
-  for (uint32_t k = 0; k < kChunk / 1024; k++)
-    *(uint4 *)(L.stage + (c & 1) * kChunk + k * 1024 + lane * 16) = r.q[k];
+  for (uint32_t k = 0; k < CHUNK / 1024; k++)
+    *(uint4 *)(L.stage + (c & 1) * CHUNK + k * 1024 + lane * 16) = r.q[k];
 }
 
 // one group, general form: lanes whose byte does not exist (the file's last, partial group) keep their state
-template <uint32_t S>
-__device__ __forceinline__ void encode_group_slow(uint32_t &x, WaveLds &L, uint32_t group_off, uint32_t valid, uint32_t &p, uint32_t lane, uint32_t byte_in_group)
+template <uint32_t S, uint32_t CHUNK>
+__device__ __forceinline__ void encode_group_slow(uint32_t &x, WaveLdsT<CHUNK> &L, uint32_t group_off, uint32_t valid, uint32_t &p, uint32_t lane, uint32_t byte_in_group)
 {
+  constexpr uint32_t kRing = 2 * CHUNK;
   const bool active = lane < S && byte_in_group < valid;
   const uint32_t sym = L.stage[(group_off + byte_in_group) & (kRing - 1)];
   const uint4 e = L.table[sym];
@@ -615,9 +619,11 @@ __device__ __forceinline__ void encode_set_fast(uint32_t &x, const uint4 (&e)[4]
 // RAW = true: a whole raw stream (rANS32x64_16w.cpp:34-166 is ONE dependent chain per coder state, so one wavefront is all the
 // format has work for): the counts come from the caller or from k_raw_histogram, checkpoints may sit at listed groups, and the
 // image in the slot is the finished stream [n][total][counts][states][words].
-template <uint32_t S, bool RAW>
-__device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t b, WaveLds &L, const uint32_t lane)
+template <uint32_t S, bool RAW, uint32_t CHUNK>
+__device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t b, WaveLdsT<CHUNK> &L, const uint32_t lane)
 {
+  constexpr uint32_t kChunk = CHUNK, kRing = 2 * CHUNK;
+  using Chunk = ChunkT<CHUNK>;
   const uint64_t begin = RAW ? 0 : (uint64_t)b * ep.block;
   const uint64_t end = RAW || b + 1 == ep.n_blocks ? ep.n : begin + ep.block;
   const uint32_t size = (uint32_t)(end - begin);
@@ -798,12 +804,12 @@ __device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t 
   uint32_t p = (uint32_t)ep.slot_bytes;     // byte offset (from `slot`) of the lowest word written so far
   // (asking for this first input ahead of the normalisation, which uses neither the ring nor these registers, was measured: nothing)
   const uint32_t n_chunks = (size + kChunk - 1) / kChunk;
-  chunk_to_lds(L, chunk_load(in, begin, end, n_chunks - 1, lane), n_chunks - 1, lane);
+  chunk_to_lds(L, chunk_load<CHUNK>(in, begin, end, n_chunks - 1, lane), n_chunks - 1, lane);
   if (n_chunks >= 2)
-    chunk_to_lds(L, chunk_load(in, begin, end, n_chunks - 2, lane), n_chunks - 2, lane);
+    chunk_to_lds(L, chunk_load<CHUNK>(in, begin, end, n_chunks - 2, lane), n_chunks - 2, lane);
   Chunk pre{};
   if (n_chunks >= 3)
-    pre = chunk_load(in, begin, end, n_chunks - 3, lane);
+    pre = chunk_load<CHUNK>(in, begin, end, n_chunks - 3, lane);
   wave_sync();
 
   // sidecar checkpoints (hsrans_host.cpp encode(): after group gr of the block is coded, gr % interval == 0, gr != 0, the
@@ -846,12 +852,12 @@ __device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t 
   if (size % S != 0)               // only the file's last group can be partial
   {
     g--;
-    encode_group_slow<S>(x, L, g * S, size - g * S, p, lane, byte_in_group);
+    encode_group_slow<S, CHUNK>(x, L, g * S, size - g * S, p, lane, byte_in_group);
   }
   while (g % 4 != 0)
   {
     g--;
-    encode_group_slow<S>(x, L, g * S, S, p, lane, byte_in_group);
+    encode_group_slow<S, CHUNK>(x, L, g * S, S, p, lane, byte_in_group);
   }
   wave_sync();
   if (p + kOutSeg <= flushed_to) // (at most four groups so far: at most one segment)
@@ -881,7 +887,7 @@ __device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t 
       return;
     chunk_to_lds(L, pre, c - 2, lane);
     if (c >= 3)
-      pre = chunk_load(in, begin, end, c - 3, lane);
+      pre = chunk_load<CHUNK>(in, begin, end, c - 3, lane);
     wave_sync();
   };
   if ((uint64_t)g * S <= (uint64_t)(n_chunks - 1) * kChunk) // the groups coded one by one above were all of the last chunk
@@ -1022,7 +1028,7 @@ __device__ __forceinline__ void encode_body(const EncParams &ep, const uint32_t 
     *(uint16_t *)(h + 16 + 4 * S + 2 * (lane * 4 + k)) = (uint16_t)sc[k];
 }
 
-template <uint32_t S>
+template <uint32_t S, uint32_t CHUNK>
 __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -1031,7 +1037,8 @@ __global__ void __launch_bounds__(64 * kWavesPerWG) k_encode_blocks(EncParams ep
   const uint32_t b = blockIdx.x * kWavesPerWG + wave;
   if (b >= ep.n_blocks)
     return;
-  encode_body<S, false>(ep, b, *(WaveLds *)(lds_raw + (size_t)wave * sizeof(WaveLds)), lane);
+  using WaveLds = WaveLdsT<CHUNK>;
+  encode_body<S, false, CHUNK>(ep, b, *(WaveLds *)(lds_raw + (size_t)wave * sizeof(WaveLds)), lane);
 }
 
 // ---- raw streams: K_hist (wide) -> K_raw (one wavefront) -> K_copy (wide) -----------------------------------------------
@@ -1122,7 +1129,7 @@ template <uint32_t S>
 __global__ void __launch_bounds__(64) k_encode_raw(EncParams ep)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-  encode_body<S, true>(ep, 0, *(WaveLds *)lds_raw, lane_id());
+  encode_body<S, true, kChunkFew>(ep, 0, *(WaveLdsT<kChunkFew> *)lds_raw, lane_id());
 }
 
 // (Round 4 also built single-pass placement — the coding wavefront learns its image's position by a decoupled look-back over status
@@ -1442,24 +1449,38 @@ hipError_t launch_encode(const EncParams &ep, hipStream_t stream, bool *prepared
 {
   bool local = false;
   bool &prepared = prepared_flag ? *prepared_flag : local;
-  const size_t lds = sizeof(WaveLds) * kWavesPerWG;
+  const size_t lds_few = sizeof(WaveLdsT<kChunkFew>) * kWavesPerWG, lds_many = sizeof(WaveLdsT<kChunkMany>) * kWavesPerWG;
   if (!prepared)
   {
-    hipError_t e = hipFuncSetAttribute((const void *)k_encode_blocks<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)k_encode_blocks<64, kChunkFew>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_few);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void *)k_encode_blocks<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e = hipFuncSetAttribute((const void *)k_encode_blocks<32, kChunkFew>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_few);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)k_encode_blocks<64, kChunkMany>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_many);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)k_encode_blocks<32, kChunkMany>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_many);
     if (e != hipSuccess)
       return e;
     prepared = true;
   }
+  // few blocks: all resident at once with the large chunks too (11 workgroups of 13.25 KiB per CU: the LDS is handed out in pieces)
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    cus = 1;
+  const bool few = ep.n_blocks <= 11u * (uint32_t)cus * kWavesPerWG;
+  const size_t lds = few ? lds_few : lds_many;
   const uint32_t grid = (ep.n_blocks + kWavesPerWG - 1) / kWavesPerWG;
   (void)hipGetLastError(); // (sticky per thread)
   if (ep.raw_counts != nullptr)
     hipLaunchKernelGGL(k_block_histograms, dim3(ep.n_blocks), dim3(256), 0, stream, ep, const_cast<uint32_t *>(ep.raw_counts));
-  if (ep.S == 64)
-    hipLaunchKernelGGL(k_encode_blocks<64>, dim3(grid), dim3(64 * kWavesPerWG), lds, stream, ep);
+  if (ep.S == 64 && few)
+    hipLaunchKernelGGL((k_encode_blocks<64, kChunkFew>), dim3(grid), dim3(64 * kWavesPerWG), lds, stream, ep);
+  else if (ep.S == 64)
+    hipLaunchKernelGGL((k_encode_blocks<64, kChunkMany>), dim3(grid), dim3(64 * kWavesPerWG), lds, stream, ep);
+  else if (few)
+    hipLaunchKernelGGL((k_encode_blocks<32, kChunkFew>), dim3(grid), dim3(64 * kWavesPerWG), lds, stream, ep);
   else
-    hipLaunchKernelGGL(k_encode_blocks<32>, dim3(grid), dim3(64 * kWavesPerWG), lds, stream, ep);
+    hipLaunchKernelGGL((k_encode_blocks<32, kChunkMany>), dim3(grid), dim3(64 * kWavesPerWG), lds, stream, ep);
   if (ep.n_blocks > kSelfScanBlocks)
     hipLaunchKernelGGL(k_scan_images, dim3(1), dim3(1024), 0, stream, ep);
   hipLaunchKernelGGL(k_gather_images, dim3(ep.n_blocks), dim3(256), 0, stream, ep);
@@ -1470,7 +1491,7 @@ hipError_t launch_encode_raw(const EncParams &ep, uint32_t *d_counts, hipStream_
 {
   bool local = false;
   bool &prepared = prepared_flag ? *prepared_flag : local;
-  const size_t lds = sizeof(WaveLds);
+  const size_t lds = sizeof(WaveLdsT<kChunkFew>);
   if (!prepared)
   {
     hipError_t e = hipFuncSetAttribute((const void *)k_encode_raw<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
