@@ -55,7 +55,8 @@ class Shard(ctypes.Structure):
 
 class ShardedInfo(ctypes.Structure):
     _fields_ = [("world", _u32), ("rank", _u32), ("parts", _u32), ("root", ctypes.c_int32), ("window_begin", ctypes.c_uint64), ("window_end", ctypes.c_uint64),
-                ("out_base", ctypes.c_uint64), ("out_length", ctypes.c_uint64), ("decoded_length", ctypes.c_uint64), ("stream_length", ctypes.c_uint64)]
+                ("out_base", ctypes.c_uint64), ("out_length", ctypes.c_uint64), ("decoded_length", ctypes.c_uint64), ("stream_length", ctypes.c_uint64),
+                ("one_launch", _u32), ("reserved", _u32)]
 
 
 COMM_ID_BYTES = 128
@@ -183,6 +184,10 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_sharded_info.argtypes = [_vp, ctypes.POINTER(ShardedInfo), _vp, _sz]
     L.hsrans_sharded_part_plan.restype = _vp
     L.hsrans_sharded_part_plan.argtypes = [_vp, _u32]
+    L.hsrans_sharded_wait_part.restype = _i
+    L.hsrans_sharded_wait_part.argtypes = [_vp, _u32, _vp]
+    L.hsrans_sharded_whole_plan.restype = _vp
+    L.hsrans_sharded_whole_plan.argtypes = [_vp]
     L.hsrans_decode_sharded.restype = _i
     L.hsrans_decode_sharded.argtypes = [_vp, _vp, _vp, _i, _vp]
     L.hsrans_sharded_status.restype = _i
@@ -582,6 +587,17 @@ class Sharded:
 
     def part_plan(self, k: int) -> DevicePlan | None:
         h = self.ctx.L.hsrans_sharded_part_plan(self.handle, k)
+        return DevicePlan(self.ctx, _vp(h), owned=False) if h else None
+
+    def wait_part(self, part: int, stream: torch.cuda.Stream):
+        """hsrans_sharded_wait_part: `stream` waits until sub-run `part` of the last decode() is complete and visible"""
+        rc = self.ctx.L.hsrans_sharded_wait_part(self.handle, part, ctypes.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise HsransError(f"hsrans_sharded_wait_part failed with code {rc}")
+
+    def whole_plan(self) -> DevicePlan | None:
+        """this rank's whole run when ONE launch decodes all its sub-runs (hsrans_sharded_info: one_launch), else None"""
+        h = self.ctx.L.hsrans_sharded_whole_plan(self.handle)
         return DevicePlan(self.ctx, _vp(h), owned=False) if h else None
 
     def decode(self, d_window: torch.Tensor, d_out: torch.Tensor, mode: int = SHARD_DECODE_AND_EXCHANGE, stream: torch.cuda.Stream | None = None):

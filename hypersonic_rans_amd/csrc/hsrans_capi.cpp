@@ -466,10 +466,15 @@ extern "C++" int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_si
     // chains of a coded block that is not the last
     {
       bool ok = h.states == 64 && h.n_pieces == h.n_chains && groups.size() < h.n_chains;
-      size_t last_coded = groups.size();
+      size_t last_coded = groups.size(), first_coded = groups.size();
       for (size_t k = groups.size(); k-- > 0 && last_coded == groups.size();)
         if (!(groups[k].flags & kGroupFill))
           last_coded = k;
+      for (size_t k = 0; k < groups.size() && first_coded == groups.size(); k++)
+        if (!(groups[k].flags & kGroupFill))
+          first_coded = k;
+      // (a share touches three coded blocks only when one lies wholly INSIDE it: neither the plan's first nor its last coded block can —
+      // a slice of a plan, e.g. a rank's run of a sharded decode, usually begins and ends with part of a block)
       uint32_t fewest = 0xFFFFFFFFu;
       for (size_t k = 0; k < groups.size() && ok; k++)
       {
@@ -477,7 +482,7 @@ extern "C++" int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_si
         if (g.flags & kGroupFill)
           continue;
         ok = (g.flags & kGroupMergeable) && g.piece0 == g.begin;
-        if (k != last_coded)
+        if (k != last_coded && k != first_coded)
           fewest = std::min(fewest, g.count);
       }
       d->spread_min_block = ok ? fewest : 0;
@@ -512,6 +517,21 @@ extern "C++" int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_si
     // (Dynamic group order, run_grouped: the END of the list decides how evenly the launch finishes.  Cutting the last eighth /
     // quarter of the list into half-blocks was built and measured in round 3 at 2^30 bytes — 0.454-0.458 ms against 0.451-0.456
     // without: the extra table builds cost what the evener finish gains — and is gone.)
+    if (!d->part_ends.empty() && d->part_ends.size() <= kMaxLaunchParts)
+    {
+      // the sub-runs of a sharded decode (hsrans_comm.cpp): which of them a group overlaps, and how many groups each will be counted by
+      const std::vector<uint32_t> &ends = d->part_ends;
+      auto part_of = [&](uint32_t chain) { return (uint32_t)(std::upper_bound(ends.begin(), ends.end(), chain) - ends.begin()); };
+      d->part_units.assign(ends.size(), 0);
+      d->part_cum.assign(ends.size(), 0);
+      for (Group &g : groups)
+      {
+        const uint32_t lo = std::min<uint32_t>(part_of(g.begin), (uint32_t)ends.size() - 1), hi = std::min<uint32_t>(part_of(g.begin + g.count - 1), (uint32_t)ends.size() - 1);
+        g.flags = (g.flags & ((1u << kGroupPartShift) - 1)) | (lo << kGroupPartShift) | (hi << (kGroupPartShift + 8));
+        for (uint32_t p = lo; p <= hi; p++)
+          d->part_units[p]++;
+      }
+    }
     if (groups.size() < h.n_chains)
     {
       d->d_groups = carve(groups.size() * sizeof(Group)); // (the dynamic group order's ticket counters: d_counters, zeroed above)
@@ -550,7 +570,8 @@ extern "C++" uint8_t *device_view_of_host(const void *ptr, size_t bytes)
 }
 
 // one launch of a filled device plan (asynchronous on s; the device must be current)
-extern "C++" int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity, hipStream_t s, uint64_t stream_lo)
+extern "C++" int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity, hipStream_t s, uint64_t stream_lo,
+                              const PartArgs *part_words)
 {
   KParams kp{};
   kp.stream = (const uint8_t *)d_stream;
@@ -580,6 +601,15 @@ extern "C++" int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stre
     // dynamic group order: this launch's own ticket counter (the counter sets of the persistent launches, one head of each used)
     if (d->d_counters != nullptr && getenv("HSRANS_GROUP_STATIC") == nullptr)
       kp.group_tickets = d->d_counters + (size_t)(d->epoch.fetch_add(1, std::memory_order_relaxed) % kCounterSets) * kDynQueues * kDynQueueStride;
+  }
+  if (part_words != nullptr)
+  {
+    // a rank's sub-runs in one launch: the caller's completion words and sequence number, this plan's parts and running totals
+    if (d->part_ends.empty() || d->part_units.size() != d->part_ends.size() || d->n_groups == 0)
+      return HSRANS_E_ARG;
+    kp.parts = *part_words;
+    PartPlan pp{(uint32_t)d->part_ends.size(), d->part_ends.data(), d->part_units.data(), d->part_cum.data()};
+    return launch_decode(kp, d->hdr, d->ctx->geom, s, &d->info, &pp) == hipSuccess ? HSRANS_OK : HSRANS_E_HIP;
   }
   return launch_decode(kp, d->hdr, d->ctx->geom, s, &d->info) == hipSuccess ? HSRANS_OK : HSRANS_E_HIP;
 }
@@ -783,6 +813,33 @@ catch (...) // (std::bad_alloc and friends: nothing is thrown across the C ABI)
   return HSRANS_E_HIP;
 }
 
+// hsrans_dplan_create for a plan whose chains [part_ends[k - 1], part_ends[k]) are the sub-runs of a sharded decode (hsrans_comm.cpp): the
+// group list is tagged with them.  *out_dplan's part_units is empty when the plan is of a kind no one-launch kernel takes.
+extern "C++" int dplan_create_with_parts(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, const std::vector<uint32_t> &part_ends, hsrans_dplan **out_dplan)
+{
+  *out_dplan = nullptr;
+  PlanHeader h;
+  if (!read_header(plan, plan_size, &h) || !plan_validate(plan, plan_size, h.stream_len, h.decoded_len))
+    return HSRANS_E_FORMAT;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return HSRANS_E_HIP;
+  hsrans_dplan *d = new (std::nothrow) hsrans_dplan;
+  if (d == nullptr)
+    return HSRANS_E_HIP;
+  d->ctx = ctx;
+  d->part_ends = part_ends;
+  int rc = dplan_fill(d, plan, plan_size, h, nullptr);
+  if (rc == HSRANS_OK && hipStreamSynchronize(nullptr) != hipSuccess)
+    rc = HSRANS_E_HIP;
+  if (rc != HSRANS_OK)
+  {
+    hsrans_dplan_destroy(d);
+    return rc;
+  }
+  *out_dplan = d;
+  return HSRANS_OK;
+}
+
 size_t hsrans_debug_read_stamps(hsrans_dplan *d, uint64_t *out, size_t capacity_u64)
 {
   if (d == nullptr || d->d_stamps == nullptr || out == nullptr)
@@ -935,8 +992,8 @@ int hsrans_decode_device(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_stream,
 }
 
 // the general launch: stream bytes [window_offset, +window_length) at d_window, output bytes [out_offset, +out_length) at d_out
-static int launch_ranges(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_window, size_t window_offset, size_t window_length, void *d_out, size_t out_offset,
-                         size_t out_length, void *hip_stream)
+extern "C++" int dplan_launch_ranges(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_window, size_t window_offset, size_t window_length, void *d_out, size_t out_offset,
+                                     size_t out_length, void *hip_stream, const PartArgs *part_words)
 {
   if (ctx == nullptr || d == nullptr || d_window == nullptr || d_out == nullptr || d->ctx != ctx)
     return HSRANS_E_ARG;
@@ -956,7 +1013,7 @@ static int launch_ranges(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_window,
   // (the kernels' own bound on the output is the end of the caller's window, not of the whole output: a path that rounded a store
   // up past a chain's end must not reach past a rank's smaller buffer either)
   const uint64_t out_end = std::min<uint64_t>((uint64_t)out_offset + out_length, d->hdr.decoded_len);
-  return dplan_launch(d, (const uint8_t *)d_window - window_offset, (size_t)end, (uint8_t *)d_out - out_offset, (size_t)out_end, (hipStream_t)hip_stream, window_offset);
+  return dplan_launch(d, (const uint8_t *)d_window - window_offset, (size_t)end, (uint8_t *)d_out - out_offset, (size_t)out_end, (hipStream_t)hip_stream, window_offset, part_words);
 }
 
 int hsrans_decode_device_window(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_window, size_t window_offset, size_t window_length, void *d_out,
@@ -964,13 +1021,13 @@ int hsrans_decode_device_window(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_
 {
   if (d == nullptr || out_capacity < d->hdr.decoded_len)
     return d == nullptr ? HSRANS_E_ARG : HSRANS_E_FORMAT;
-  return launch_ranges(ctx, d, d_window, window_offset, window_length, d_out, 0, out_capacity, hip_stream);
+  return dplan_launch_ranges(ctx, d, d_window, window_offset, window_length, d_out, 0, out_capacity, hip_stream, nullptr);
 }
 
 int hsrans_decode_device_ranges(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_window, size_t window_offset, size_t window_length, void *d_out_window,
                                 size_t out_offset, size_t out_length, void *hip_stream)
 {
-  return launch_ranges(ctx, d, d_window, window_offset, window_length, d_out_window, out_offset, out_length, hip_stream);
+  return dplan_launch_ranges(ctx, d, d_window, window_offset, window_length, d_out_window, out_offset, out_length, hip_stream, nullptr);
 }
 
 int hsrans_dplan_status(hsrans_ctx *ctx, hsrans_dplan *d, void *hip_stream)

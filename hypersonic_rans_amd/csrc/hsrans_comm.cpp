@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -88,7 +89,15 @@ struct hsrans_sharded
   uint64_t window_lo = 0, window_hi = 0, out_base = 0, out_len = 0, total = 0, stream_len = 0;
   std::vector<hipEvent_t> part_done; // sub-run k's decode has been queued up to here (the exchange's stream waits for it)
   hipEvent_t exchanged = nullptr;
+  // Round 6: the sub-runs as ONE launch.  `whole` = this rank's whole run as one device plan whose group list knows the sub-runs;
+  // the launch counts finished groups into d_words[0 .. parts) and publishes `seq` to sub-run k's completion word (d_words + 16 + 16 k,
+  // a cache line each) when its last group is in; the exchange's stream waits for the word (hipStreamWaitValue32) instead of for an
+  // event between launches.  The reference joins its pool once per stream too (mt_rANS32x64_16w_decode.cpp:262).
+  hsrans_dplan *whole = nullptr;
+  uint32_t *d_words = nullptr;
+  uint32_t seq = 0;
 };
+constexpr uint32_t kWordStride = 16; // uint32s between completion words
 
 extern "C"
 {
@@ -177,6 +186,10 @@ void hsrans_sharded_destroy(hsrans_sharded *s)
   for (hsrans_dplan *d : s->part_plans)
     if (d)
       hsrans_dplan_destroy(d);
+  if (s->whole)
+    hsrans_dplan_destroy(s->whole);
+  if (s->d_words)
+    (void)hipFree(s->d_words);
   for (hipEvent_t e : s->part_done)
     if (e)
       (void)hipEventDestroy(e);
@@ -232,12 +245,48 @@ static int sharded_create_impl(hsrans_ctx *ctx, hsrans_comm *comm, int rank, int
   s->part_plans.assign(parts, nullptr);
   s->part_done.assign(parts, nullptr);
   std::vector<uint8_t> slice(plan_size + 1024);
+  // the sub-runs as one launch: block_/mt_ plans with checkpoints (the grouped / spread kernels count their units into the sub-runs), where the
+  // device can make a stream wait for a word in memory; HSRANS_SHARD_ONE_LAUNCH=0 keeps a launch per sub-run (comparison: tools/shard_projection.py)
+  if (rc == HSRANS_OK && parts > 1 && parts <= kMaxLaunchParts && !(getenv("HSRANS_SHARD_ONE_LAUNCH") && atoi(getenv("HSRANS_SHARD_ONE_LAUNCH")) == 0))
+  {
+    int can_wait = 0;
+    (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, ctx->device);
+    uint32_t first = 0, count = 0;
+    std::vector<uint32_t> ends(parts, 0);
+    for (uint32_t k = 0; k < parts; k++)
+    {
+      const hsrans_shard &sh = s->shards[(size_t)s->rank * parts + k];
+      if (sh.chain_count != 0 && count == 0)
+        first = sh.first_chain;
+      if (sh.chain_count != 0 && sh.first_chain != first + count) // (sub-runs of a rank are back to back: hsrans_shard_layout)
+        can_wait = 0;
+      count += sh.chain_count;
+      ends[k] = count; // in the slice's own chain numbers
+    }
+    if (can_wait && count != 0)
+    {
+      const size_t n = hsrans_plan_slice(plan, plan_size, first, count, slice.data(), slice.size());
+      hsrans_dplan *w = nullptr;
+      if (n != 0 && dplan_create_with_parts(ctx, slice.data(), n, ends, &w) == HSRANS_OK && w->n_groups != 0 && w->groups_lean && w->part_units.size() == parts &&
+          hipMalloc((void **)&s->d_words, (size_t)(parts + 1) * kWordStride * 4) == hipSuccess && hipMemset(s->d_words, 0, (size_t)(parts + 1) * kWordStride * 4) == hipSuccess)
+        s->whole = w;
+      else
+      {
+        (void)hipGetLastError();
+        if (w)
+          hsrans_dplan_destroy(w);
+        if (s->d_words)
+          (void)hipFree(s->d_words);
+        s->d_words = nullptr;
+      }
+    }
+  }
   for (uint32_t k = 0; k < parts && rc == HSRANS_OK; k++)
   {
     const hsrans_shard &sh = s->shards[(size_t)s->rank * parts + k];
     if (hipEventCreateWithFlags(&s->part_done[k], hipEventDisableTiming) != hipSuccess)
       rc = HSRANS_E_HIP;
-    if (sh.chain_count == 0 || rc != HSRANS_OK)
+    if (sh.chain_count == 0 || rc != HSRANS_OK || s->whole != nullptr)
       continue;
     const size_t n = hsrans_plan_slice(plan, plan_size, sh.first_chain, sh.chain_count, slice.data(), slice.size());
     rc = n == 0 ? HSRANS_E_FORMAT : hsrans_dplan_create(ctx, slice.data(), n, &s->part_plans[k]);
@@ -291,6 +340,8 @@ int hsrans_sharded_info(const hsrans_sharded *s, hsrans_sharded_info_t *info, hs
   info->out_length = s->out_len;
   info->decoded_length = s->total;
   info->stream_length = s->stream_len;
+  info->one_launch = s->whole != nullptr ? 1 : 0;
+  info->reserved = 0;
   if (shards != nullptr)
   {
     if (shard_capacity < s->shards.size())
@@ -301,6 +352,7 @@ int hsrans_sharded_info(const hsrans_sharded *s, hsrans_sharded_info_t *info, hs
 }
 
 hsrans_dplan *hsrans_sharded_part_plan(hsrans_sharded *s, uint32_t part) { return s && part < s->parts ? s->part_plans[part] : nullptr; }
+hsrans_dplan *hsrans_sharded_whole_plan(hsrans_sharded *s) { return s ? s->whole : nullptr; }
 
 // The exchange of sub-run k's ranges, queued on the communicator's own stream: one grouped batch of point-to-point operations —
 // every rank that owns bytes of part k sends them to every peer that wants them (all peers, or the root only), straight from its
@@ -365,7 +417,32 @@ int hsrans_decode_sharded(hsrans_sharded *s, const void *d_window, void *d_out, 
           return rc;
       }
   }
-  for (uint32_t k = 0; k < s->parts; k++)
+  if (s->whole != nullptr)
+  {
+    // ONE launch for all sub-runs; sub-run k's ranges go onto the links when the launch publishes its completion word
+    if (decode)
+    {
+      PartArgs pw{};
+      pw.seq = ++s->seq;
+      pw.count = s->d_words;
+      for (uint32_t k = 0; k < s->parts; k++)
+        pw.done[k] = s->d_words + (size_t)(k + 1) * kWordStride;
+      const int rc = dplan_launch_ranges(ctx, s->whole, d_window, s->window_lo, s->window_hi - s->window_lo, d_out, s->out_base, s->out_len, st, &pw);
+      if (rc != HSRANS_OK)
+        return rc;
+    }
+    for (uint32_t k = 0; k < s->parts && exchange && !i_am_root; k++)
+    {
+      const hsrans_shard &mine = s->shards[(size_t)s->rank * s->parts + k];
+      if (decode && mine.chain_count != 0 &&
+          hipStreamWaitValue32(xs, s->d_words + (size_t)(k + 1) * kWordStride, s->seq, hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess)
+        return HSRANS_E_HIP;
+      const int rc = post_part(s, k, (uint8_t *)d_out);
+      if (rc != HSRANS_OK)
+        return rc;
+    }
+  }
+  for (uint32_t k = 0; k < s->parts && s->whole == nullptr; k++)
   {
     if (decode && s->part_plans[k] != nullptr)
     {
@@ -373,10 +450,12 @@ int hsrans_decode_sharded(hsrans_sharded *s, const void *d_window, void *d_out, 
       if (rc != HSRANS_OK)
         return rc;
     }
+    if (decode && hipEventRecord(s->part_done[k], st) != hipSuccess) // (also what hsrans_sharded_wait_part waits for)
+      return HSRANS_E_HIP;
     if (!exchange || i_am_root)
       continue;
     // sub-run k's ranges go onto the links as soon as its decode is done, while sub-run k + 1 decodes
-    if (hipEventRecord(s->part_done[k], st) != hipSuccess || hipStreamWaitEvent(xs, s->part_done[k], 0) != hipSuccess)
+    if ((!decode && hipEventRecord(s->part_done[k], st) != hipSuccess) || hipStreamWaitEvent(xs, s->part_done[k], 0) != hipSuccess)
       return HSRANS_E_HIP;
     const int rc = post_part(s, k, (uint8_t *)d_out);
     if (rc != HSRANS_OK)
@@ -388,11 +467,30 @@ int hsrans_decode_sharded(hsrans_sharded *s, const void *d_window, void *d_out, 
   return HSRANS_OK;
 }
 
+int hsrans_sharded_wait_part(hsrans_sharded *s, uint32_t part, void *hip_stream)
+{
+  if (s == nullptr || part >= s->parts)
+    return HSRANS_E_ARG;
+  if (hipSetDevice(s->ctx->device) != hipSuccess)
+    return HSRANS_E_HIP;
+  const hsrans_shard &mine = s->shards[(size_t)s->rank * s->parts + part];
+  if (mine.chain_count == 0) // nothing to wait for
+    return HSRANS_OK;
+  if (s->whole != nullptr)
+  {
+    if (s->seq == 0) // no decode queued yet
+      return HSRANS_E_ARG;
+    return hipStreamWaitValue32((hipStream_t)hip_stream, s->d_words + (size_t)(part + 1) * kWordStride, s->seq, hipStreamWaitValueGte, 0xFFFFFFFFu) == hipSuccess ? HSRANS_OK
+                                                                                                                                                                 : HSRANS_E_HIP;
+  }
+  return hipStreamWaitEvent((hipStream_t)hip_stream, s->part_done[part], 0) == hipSuccess ? HSRANS_OK : HSRANS_E_HIP;
+}
+
 int hsrans_sharded_status(hsrans_sharded *s, void *hip_stream)
 {
   if (s == nullptr)
     return HSRANS_E_ARG;
-  int worst = HSRANS_OK;
+  int worst = s->whole != nullptr ? hsrans_dplan_status(s->ctx, s->whole, hip_stream) : HSRANS_OK;
   for (hsrans_dplan *d : s->part_plans)
     if (d != nullptr)
     {

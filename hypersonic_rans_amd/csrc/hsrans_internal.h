@@ -10,6 +10,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <vector>
 
 #include "../../include/hsrans_hip.h"
 #include "hsrans_kernels.h"
@@ -90,6 +91,10 @@ struct hsrans_dplan
   // what the plan's chains touch, recorded by dplan_fill: the lowest stream byte any of them reads (its own words, its
   // histogram / header, the shared histogram when the plan carries no copy of it) and the output bytes they write
   uint64_t body_lo = 0, out_lo = 0, out_hi = 0;
+  // a rank's sub-runs decoded by ONE launch of this plan (hsrans_comm.cpp): part k = chains [part_ends[k - 1], part_ends[k]) — set before
+  // dplan_fill, which then tags every group with the parts it overlaps (Group::flags, kGroupPartShift) and counts them: part_units[k];
+  // part_cum[k] = units counted into part k by all launches so far (the device's counters are never reset: launch_decode, PartPlan)
+  std::vector<uint32_t> part_ends, part_units, part_cum;
 };
 
 constexpr size_t kStampWaves = 16384;
@@ -138,8 +143,6 @@ inline bool read_header(const uint8_t *plan, size_t size, PlanHeader *h)
   return memcmp(h->magic, "HSRPLAN1", 8) == 0;
 }
 
-
-#include <vector>
 struct hsrans_batch
 {
   hsrans_ctx *ctx = nullptr;
@@ -177,7 +180,15 @@ struct hsrans_batch
 
 // (Re)fills a device plan from a validated host plan blob; one launch of a filled device plan (hsrans_capi.cpp)
 int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_size, const PlanHeader &h, hipStream_t s);
-int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity, hipStream_t s, uint64_t stream_lo = 0);
+int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity, hipStream_t s, uint64_t stream_lo = 0,
+                 const PartArgs *part_words = nullptr);
+
+// hsrans_decode_device_ranges' body: stream bytes [window_offset, +window_length) at d_window, output bytes [out_offset, +out_length) at d_out;
+// part_words: a sharded decode's sub-runs in this one launch (completion words, sequence number; hsrans_comm.cpp)
+int dplan_launch_ranges(hsrans_ctx *ctx, hsrans_dplan *d, const void *d_window, size_t window_offset, size_t window_length, void *d_out, size_t out_offset,
+                        size_t out_length, void *hip_stream, const PartArgs *part_words);
+
+int dplan_create_with_parts(hsrans_ctx *ctx, const uint8_t *plan, size_t plan_size, const std::vector<uint32_t> &part_ends, hsrans_dplan **out_dplan);
 
 // a page-locked, device-mapped host range: the address the GPU reaches it at, else null (hsrans_capi.cpp)
 uint8_t *device_view_of_host(const void *ptr, size_t bytes);

@@ -54,6 +54,29 @@ struct Group
 constexpr uint32_t kGroupMergeable = 1;
 constexpr uint32_t kGroupFill = 2;
 
+// A rank's sub-runs as ONE launch (hsrans_decode_sharded, round 6).  The reference hands every block of a stream to its pool in one
+// pass and joins once (mt_rANS32x64_16w_decode.cpp:182-224, :262); a rank of a sharded decode used to queue one launch per sub-run
+// so that sub-run k's ranges could go onto the links while sub-run k + 1 decodes — at 8 ranks x 4 sub-runs each launch was 32 MiB
+// on a device that needs 100 MB to fill, and every one paid prologue, tail and kernel boundary.  Now the sub-runs ("parts":
+// contiguous chain ranges of the rank's plan) are decoded by one launch in list order, and the launch itself tells the exchange's
+// stream when a part is complete: a unit of work (a group of the grouped launch, a workgroup's share of the spread launch) that
+// is done makes its stores visible (release fence, device scope), then counts itself into every part it overlaps
+// (PartArgs::count, monotonic, never reset); the unit whose increment reaches `target` publishes `seq` to the part's completion
+// word, which hipStreamWaitValue32(..., Gte) on the exchange's stream is waiting for.
+constexpr uint32_t kMaxLaunchParts = 16;
+struct PartArgs
+{
+  uint32_t n;                           // 0: not such a launch
+  uint32_t seq;                         // what a completion word receives (one more with every launch of the sharded decode)
+  uint32_t *count;                      // [n] units seen so far, over all launches
+  uint32_t *done[kMaxLaunchParts];      // completion words (signal memory: the command processor polls them)
+  uint32_t target[kMaxLaunchParts];     // count[k] once this launch's last unit of part k is in
+  uint32_t chain_end[kMaxLaunchParts];  // part k = chains [chain_end[k - 1], chain_end[k]) of the launch's plan (the spread launch's units are chain ranges)
+};
+// grouped launches: Group::flags carries the first / last part a group overlaps in bits 16..23 / 24..31 (a group is a block or a
+// part of one; sub-runs are cut at chain boundaries, so a group can straddle two of them)
+constexpr uint32_t kGroupPartShift = 16;
+
 // k_decode_single: a plan of ONE chain of ONE rANS piece (a raw stream without an index), filled by the host from the plan
 struct SingleArgs
 {
@@ -107,6 +130,7 @@ struct KParams
   // private-table launches of 32-state plans: every wave takes TWO chains (2w, 2w+1), one per wave half, each with its own
   // table (run_private_pair); the LDS layout then holds two tables per wave
   uint32_t private_pair;
+  PartArgs parts; // a sharded decode's sub-runs in one launch (k_decode_grouped<.., true, true>, k_decode_spread<.., true>); n == 0 otherwise
 };
 
 // ---- K independent streams in one launch (kernels_batch.h, hsrans_batch.cpp) -----------------------------------------------
@@ -302,7 +326,19 @@ uint32_t pack64_max_bits();
 // (160 KiB) and report the device's geometry
 hipError_t prepare_kernels(DeviceGeom *geom);
 // asynchronous on `stream` of the current device; no allocation, no synchronisation (graph-capturable)
-hipError_t launch_decode(const KParams &kp, const PlanHeader &h, const DeviceGeom &dg, hipStream_t stream, LaunchInfo *info);
+// `parts` (may be null): the launch decodes a rank's sub-runs and publishes a completion word per sub-run (PartArgs).  In: n,
+// chain_end[], group_units[k] = groups of the plan's group list that overlap part k.  The launcher picks the kernel, works out how
+// many units of that kernel overlap each part, adds them to cum[k] (the running total over all launches of this plan: the
+// counters on the device are never reset) and hands the kernel cum[] as its targets.  Only plans the grouped (64 states, lean) or
+// the spread kernel takes: hipErrorNotSupported otherwise, nothing launched.
+struct PartPlan
+{
+  uint32_t n;
+  const uint32_t *chain_end;
+  const uint32_t *group_units;
+  uint32_t *cum;
+};
+hipError_t launch_decode(const KParams &kp, const PlanHeader &h, const DeviceGeom &dg, hipStream_t stream, LaunchInfo *info, const PartPlan *parts = nullptr);
 
 } // namespace hsrans
 

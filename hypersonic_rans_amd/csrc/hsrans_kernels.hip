@@ -287,7 +287,8 @@ hipError_t prepare_kernels(DeviceGeom *geom)
                       (KernelFn)k_decode_direct<kModeTwoLevel>, (KernelFn)k_decode_direct<kModePack64>, (KernelFn)k_decode_direct<kModeRank>, (KernelFn)k_decode_direct<kModeSpill>,
                       (KernelFn)k_decode_grouped<kModePack, false>, (KernelFn)k_decode_grouped<kModePackM1, false>, (KernelFn)k_decode_grouped<kModeTwoLevel, false>,
                       (KernelFn)k_decode_grouped<kModePack64, false>, (KernelFn)k_decode_grouped<kModeTwoLevel, true>, (KernelFn)k_decode_grouped<kModePack64, true>,
-                      (KernelFn)k_decode_grouped<kModeRank, false>, (KernelFn)k_decode_grouped<kModeRank, true>, (KernelFn)k_decode_spread<kModePack64>})
+                      (KernelFn)k_decode_grouped<kModeRank, false>, (KernelFn)k_decode_grouped<kModeRank, true>, (KernelFn)k_decode_spread<kModePack64>,
+                      (KernelFn)k_decode_grouped<kModePack64, true, true>, (KernelFn)k_decode_grouped<kModeRank, true, true>, (KernelFn)k_decode_spread<kModePack64, true>})
   {
     const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
     if (e != hipSuccess)
@@ -634,9 +635,11 @@ hipError_t launch_batch_grouped(const BatchGroupParams &bp, const BatchGroupShap
   return hipGetLastError();
 }
 
-hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const DeviceGeom &dg, hipStream_t stream, LaunchInfo *info)
+hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const DeviceGeom &dg, hipStream_t stream, LaunchInfo *info, const PartPlan *parts)
 {
   KParams kp = kp_in;
+  if (parts != nullptr && (parts->n == 0 || parts->n > kMaxLaunchParts))
+    return hipErrorInvalidValue;
   const bool persistent = kp.pa.pieces != nullptr;
   const bool index_pass = kp.ckpt_interval != 0 || kp.ckpt_groups != nullptr;
   const LaunchShape L = launch_shape(h, dg, persistent, persistent && kp.pa.table != nullptr ? kp.pa.table_mode : 0, kp.groups != nullptr ? kp.n_groups : 0, index_pass, persistent && kp.pa.interval == 0, persistent && kp.pa.dual != 0);
@@ -748,6 +751,38 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
       kp.pa.n_chains = h.n_chains; // (single-piece chains: n_pieces == n_chains)
       kp.pa.S = h.states;
       kp.pa.bits = h.bits;
+    }
+  }
+  if (parts != nullptr)
+  {
+    // a rank's sub-runs in one launch: only the kernels that count their units into the sub-runs (PartArgs)
+    if (spread)
+      fn = k_decode_spread<kModePack64, true>;
+    else if (grouped && L.shared && kp.groups_lean && L.mode == kModePack64)
+      fn = k_decode_grouped<kModePack64, true, true>;
+    else if (grouped && L.shared && kp.groups_lean && L.mode == kModeRank)
+      fn = k_decode_grouped<kModeRank, true, true>;
+    else
+      return hipErrorNotSupported;
+    kp.parts.n = parts->n;
+    uint32_t begin = 0;
+    for (uint32_t k = 0; k < parts->n; k++)
+    {
+      const uint32_t end = parts->chain_end[k];
+      uint32_t units = parts->group_units[k];
+      if (spread) // workgroups whose share of the chains overlaps part k (run_spread counts itself by the same rule)
+      {
+        units = 0;
+        for (uint32_t b = 0; b < launch_grid && end > begin; b++)
+        {
+          const uint32_t c0 = spread_share_begin(h.n_chains, b, launch_grid, kp.group_cum[0][launch_waves], kp.group_cum[1][launch_waves]);
+          const uint32_t c1 = spread_share_begin(h.n_chains, b + 1, launch_grid, kp.group_cum[0][launch_waves], kp.group_cum[1][launch_waves]);
+          units += c1 > c0 && c0 < end && c1 > begin ? 1 : 0;
+        }
+      }
+      kp.parts.chain_end[k] = end;
+      kp.parts.target[k] = (parts->cum[k] += units);
+      begin = end > begin ? end : begin;
     }
   }
   if (info)

@@ -109,6 +109,27 @@ __device__ __forceinline__ void store_u32_saddr(uint8_t *base, uint32_t voff, ui
     asm volatile("global_store_dword %0, %1, %2" HSRANS_STORE_POLICY : : "v"(voff), "v"(v), "s"(base) : "memory");
 }
 
+// the stores off the fast path (a run's last < 4 groups, the final partial group, single-symbol fills).  WT: written through like the
+// fast path's — the launches that publish completion words (a sharded decode's sub-runs in one launch, PartArgs) must not leave ANY
+// decoded byte dirty in an XCD's L2, because nothing flushes it before the word is published (a device-scope release fence per
+// group — buffer_wbl2, a walk of the whole L2 — was measured: 2,048 of them cost a 2^30-byte decode 190 of 200 us)
+template <bool WT>
+__device__ __forceinline__ void store_u8(uint8_t *ptr, uint32_t v)
+{
+  if (WT)
+    asm volatile("global_store_byte %0, %1, off sc0 sc1" : : "v"(ptr), "v"(v) : "memory");
+  else
+    *ptr = (uint8_t)v;
+}
+template <bool WT>
+__device__ __forceinline__ void store_u128(u32x4 *ptr, u32x4 v)
+{
+  if (WT)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(ptr), "v"(v) : "memory");
+  else
+    *ptr = v;
+}
+
 // are the 512 bytes of a histogram at stream offset `off` there to be read?
 #define HSRANS_HIST_IN_RANGE(c, off) ((off) >= (c).stream_lo && (off) <= (c).stream_len && (c).stream_len - (off) >= 512)
 
@@ -628,7 +649,7 @@ __device__ __forceinline__ uint32_t pack4(uint32_t e0, uint32_t e1, uint32_t e2,
 }
 
 // decode `steps` whole groups starting at output offset `o` (block_codec64.h:173-217)
-template <int MODE, bool FULL>
+template <int MODE, bool FULL, bool ALLWT = false> // ALLWT: every store written through (see store_u8)
 __device__ __forceinline__ void run_groups_impl(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o_ref, uint32_t steps)
 {
   uint64_t o = uni64(o_ref); // wave-uniform by construction; pinned to SGPRs
@@ -648,11 +669,19 @@ __device__ __forceinline__ void run_groups_impl(uint32_t &x, const StreamWin &sw
     uint8_t *row_base = c.out + o; // wave-uniform
     if (FULL) // scalar base + 32-bit lane offset: no 64-bit address arithmetic per store (the compiler's form adds one v_lshl_add_u64 per 4 groups)
     {
-      HSRANS_STORE_U32_SADDR((uint8_t *)uni64((uint64_t)(uintptr_t)row_base), ol.store_off, acc); // (uni64: the asm needs the base in an SGPR pair whatever the compiler thinks of its uniformity)
+      if (ALLWT)
+        store_u32_saddr<true>((uint8_t *)uni64((uint64_t)(uintptr_t)row_base), ol.store_off, acc);
+      else
+        HSRANS_STORE_U32_SADDR((uint8_t *)uni64((uint64_t)(uintptr_t)row_base), ol.store_off, acc); // (uni64: the asm needs the base in an SGPR pair whatever the compiler thinks of its uniformity)
       r.vm++;
     }
     else if (act)
-      HSRANS_STORE_U32((uint32_t *)(row_base + ol.store_off), acc);
+    {
+      if (ALLWT)
+        store_u32<true>(row_base + ol.store_off, acc);
+      else
+        HSRANS_STORE_U32((uint32_t *)(row_base + ol.store_off), acc);
+    }
     o += 4 * S;
     if (FULL)
       ring_advance_exact(sw, r, c);
@@ -664,7 +693,7 @@ __device__ __forceinline__ void run_groups_impl(uint32_t &x, const StreamWin &sw
   {
     const uint32_t e = group_step<MODE, FULL>(x, r, c, act_mask);
     if (act)
-      c.out[o + p] = (uint8_t)(e >> (8 * kSymByte));
+      store_u8<ALLWT>(c.out + o + p, (e >> (8 * kSymByte)) & 0xFFu);
     o += S;
   }
   ring_advance(sw, r, c);
@@ -893,7 +922,7 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
 
 // FAST: the call sites that carry the bulk of a launch's groups (every inlined copy of the hand-scheduled loop pins v52-v59 and
 // costs the big multi-path kernel registers: with it at every call site k_decode<3, true> went to 97 VGPRs and spilled)
-template <int MODE, bool FAST = false, bool STRICT = false, bool WT = false> // STRICT: the constant wait of run_groups_fast (the grouped launches); WT: write-through stores
+template <int MODE, bool FAST = false, bool STRICT = false, bool WT = false, bool ALLWT = false> // STRICT: the constant wait of run_groups_fast (the grouped launches); WT: write-through stores in the hand-scheduled loop; ALLWT: in what is left over too
 __device__ __forceinline__ void run_groups(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps)
 {
   if (FAST && MODE == kModePack64 && c.S == 64 && r.mirror_lanes == 0xFFFFFFFFu)
@@ -901,9 +930,9 @@ __device__ __forceinline__ void run_groups(uint32_t &x, const StreamWin &sw, Rin
   if (FAST && MODE == kModeRank && c.S == 64 && r.mirror_lanes == 0xFFFFFFFFu && uni(lds_address(c.table)) == 0)
     run_groups_fast<true, kModeRank, WT>(x, sw, r, c, o, steps); // (its rank byte's address is the slot itself: the table at LDS address 0)
   if (c.S == 64)
-    run_groups_impl<MODE, true>(x, sw, r, c, o, steps);
+    run_groups_impl<MODE, true, ALLWT>(x, sw, r, c, o, steps);
   else
-    run_groups_impl<MODE, false>(x, sw, r, c, o, steps);
+    run_groups_impl<MODE, false, ALLWT>(x, sw, r, c, o, steps);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1166,7 +1195,7 @@ __device__ __forceinline__ void run_pair_groups(uint32_t &x, const StreamWin &sw
 }
 
 // final partial group (rANS32x64_16w.cpp:252-280): only lanes whose output byte exists take part, in lane order
-template <int MODE>
+template <int MODE, bool ALLWT = false>
 __device__ __forceinline__ void run_tail(uint32_t &x, Ring &r, const WaveCtx &c, uint64_t o, uint32_t tail)
 {
   if (tail == 0)
@@ -1175,10 +1204,11 @@ __device__ __forceinline__ void run_tail(uint32_t &x, Ring &r, const WaveCtx &c,
   const bool act = c.lane < c.S && p < tail;
   const uint32_t e = group_step<MODE, false>(x, r, c, __builtin_amdgcn_ballot_w64(act));
   if (act)
-    c.out[o + p] = (uint8_t)(e >> ((MODE == kModePack64 || MODE == kModeRank || MODE == kModeSpill) ? 24 : 0));
+    store_u8<ALLWT>(c.out + o + p, (e >> ((MODE == kModePack64 || MODE == kModeRank || MODE == kModeSpill) ? 24 : 0)) & 0xFFu);
 }
 
 // single-symbol block (block_rANS32x64_16w_decode.cpp:52-60): wave-wide fill
+template <bool ALLWT = false>
 __device__ void wave_fill(const WaveCtx &c, uint64_t o, uint64_t len, uint32_t symbol)
 {
   uint8_t *p = c.out + o;
@@ -1186,17 +1216,17 @@ __device__ void wave_fill(const WaveCtx &c, uint64_t o, uint64_t len, uint32_t s
   if (head > len)
     head = len;
   if (c.lane < head)
-    p[c.lane] = (uint8_t)symbol;
+    store_u8<ALLWT>(p + c.lane, symbol & 0xFFu);
   p += head;
   len -= head;
   const uint32_t s4 = symbol * 0x01010101u;
   const u32x4 v = {s4, s4, s4, s4};
   const uint64_t vecs = len / 16;
   for (uint64_t i = c.lane; i < vecs; i += 64)
-    ((u32x4 *)p)[i] = v;
+    store_u128<ALLWT>((u32x4 *)p + i, v);
   const uint64_t done = vecs * 16;
   if (c.lane < len - done)
-    p[done + c.lane] = (uint8_t)symbol;
+    store_u8<ALLWT>(p + done + c.lane, symbol & 0xFFu);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -15,7 +15,27 @@ namespace hsrans
 // member, whose plan arrays, stream, output and status word are picked up at the start of every round (a handful of scalar loads
 // beside the group record's own): many small block_/mt_ streams then share the rounds of ONE launch instead of each launching a
 // mostly empty device (the reference's pool of per-block tasks over several files: mt_rANS32x64_16w_decode.cpp:182-224, main.cpp:841-898).
-template <int MODE, bool LEAN = false, bool FAST = false, bool BATCH = false> // FAST: the hand-scheduled 32-state pair loop too (measured in a kernel of its own: 71 VGPRs, 7 waves per SIMD — not used)
+// PARTS (round 6, k_decode_grouped<MODE, true, true>): the launch decodes a rank's sub-runs of a sharded decode and publishes a completion
+// word per sub-run (hsrans_kernels.h PartArgs; hsrans_comm.cpp).  A group carries the sub-runs it overlaps in Group::flags; when the
+// workgroup has passed the barrier that ends a round — every wave has waited for its stores first — its first lane makes them visible
+// device-wide and counts the group into those sub-runs.  Nothing is added to the decode loop: the barrier and the wait are the round's own.
+// Visibility: every decoded byte of such a launch is WRITTEN THROUGH (sc0 sc1: the hand-scheduled loop's stores and, ALLWT, everything off
+// it), and a written-through store counts down vmcnt only when memory has it; so "every wave waited for vmcnt(0), then the barrier" means
+// the group's bytes are in memory, and the counting below needs no cache maintenance.  (First version: plain `nt` stores and a device-scope
+// release fence here.  The fence is buffer_wbl2 — a walk of the XCD's whole L2, serialised among the 128 workgroups that share it: 2,048
+// groups of a 2^30-byte stream took 396 us instead of 204.)  The atomics are relaxed on purpose: an acquire / release at device scope
+// would bring the cache walk back.
+__device__ __forceinline__ void part_signal(const PartArgs &pa, uint32_t lo, uint32_t hi)
+{
+  for (uint32_t p = lo; p <= hi && p < pa.n; p++)
+  {
+    const uint32_t seen = __hip_atomic_fetch_add(pa.count + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    if (seen == pa.target[p]) // the part's last unit of this launch: every other unit's bytes were in memory before its increment
+      __hip_atomic_store(pa.done[p], pa.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+template <int MODE, bool LEAN = false, bool FAST = false, bool BATCH = false, bool PARTS = false> // FAST: the hand-scheduled 32-state pair loop too (measured in a kernel of its own: 71 VGPRs, 7 waves per SIMD — not used)
 __device__ void run_grouped(const WaveCtx &c_in, const PlanView &pv_in, const KParams &kp, uint32_t waves, uint32_t wave, const BatchGroupParams *bg = nullptr)
 {
   WaveCtx c = c_in;   // (BATCH: stream / output / status change with the group's member; otherwise these are the caller's, unchanged)
@@ -60,10 +80,20 @@ __device__ void run_grouped(const WaveCtx &c_in, const PlanView &pv_in, const KP
   const bool dynamic = group_tickets != nullptr && n_groups > gridDim.x;
   volatile uint32_t *lds_next = (volatile uint32_t *)(c.table + table_bytes_for(MODE, c.bits)); // 2 words: launch_shape reserves 64 bytes behind the table
   uint32_t gi = blockIdx.x;
+  uint32_t prev_parts = 0xFFFFFFFFu; // PARTS: the sub-runs (first | last << 8) of the group this workgroup decoded in the previous round, not yet counted
   for (uint32_t round = 0;; round++)
   {
     if (!(dynamic && round >= 1) && gi >= n_groups) // (dynamic rounds: decided below, from the published group)
+    {
+      if (PARTS && prev_parts != 0xFFFFFFFFu) // the last group of a statically ordered workgroup
+      {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+          part_signal(kp.parts, prev_parts & 0xFFu, prev_parts >> 8);
+      }
       break;
+    }
     // `advance` runs at the end of the round (every path of the loop body ends in it)
     auto advance = [&]() {
       if (!dynamic)
@@ -77,6 +107,12 @@ __device__ void run_grouped(const WaveCtx &c_in, const PlanView &pv_in, const KP
     HSRANS_GS(const uint64_t t0 = HSRANS_STAMPS(kp) ? __builtin_amdgcn_s_memrealtime() : 0;)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no stream request of the previous group may still land in the scratch slot
     __syncthreads();                                    // every wave is done with the previous group's table and rings
+    if (PARTS && prev_parts != 0xFFFFFFFFu)
+    {
+      if (threadIdx.x == 0)
+        part_signal(kp.parts, prev_parts & 0xFFu, prev_parts >> 8);
+      prev_parts = 0xFFFFFFFFu;
+    }
     if (dynamic && round >= 1)
     {
       gi = uni(lds_next[round & 1]);
@@ -85,6 +121,8 @@ __device__ void run_grouped(const WaveCtx &c_in, const PlanView &pv_in, const KP
     }
     const Group *G = groups + gi;
     const uint32_t begin = uni(G->begin), count = uni(G->count), flags = uni(G->flags);
+    if (PARTS)
+      prev_parts = flags >> kGroupPartShift;
     if (BATCH)
     {
       const uint32_t member = flags >> kGroupMemberShift;
@@ -205,11 +243,11 @@ __device__ void run_grouped(const WaveCtx &c_in, const PlanView &pv_in, const KP
       if (prio_steps != 0)
       {
         __builtin_amdgcn_s_setprio(1);
-        run_groups<MODE, true, true>(x, sw, r, c, o, prio_steps);
+        run_groups<MODE, true, true, PARTS, PARTS>(x, sw, r, c, o, prio_steps);
         __builtin_amdgcn_s_setprio(0);
       }
-      run_groups<MODE, true, true>(x, sw, r, c, o, (uint32_t)run_steps - prio_steps);
-      run_tail<MODE>(x, r, c, o, run_tail_syms);
+      run_groups<MODE, true, true, PARTS, PARTS>(x, sw, r, c, o, (uint32_t)run_steps - prio_steps);
+      run_tail<MODE, PARTS>(x, r, c, o, run_tail_syms);
       HSRANS_GS(if (HSRANS_STAMPS(kp)) {
         acc_meta += t3 - t2;
         acc_dec += __builtin_amdgcn_s_memrealtime() - t3;
@@ -219,7 +257,7 @@ __device__ void run_grouped(const WaveCtx &c_in, const PlanView &pv_in, const KP
       for (uint32_t ch = first; ch < last; ch++)
       {
         const Piece *pc = pv.pieces + uni(pv.chain_first[ch]);
-        wave_fill(c, uni64(pc->out_off), uni64(pc->fill_len), (uint32_t)uni64(pc->hist_off) & 0xFF);
+        wave_fill<PARTS>(c, uni64(pc->out_off), uni64(pc->fill_len), (uint32_t)uni64(pc->hist_off) & 0xFF);
       }
     else
       for (uint32_t ch = first; ch < last; ch++)
@@ -233,7 +271,7 @@ __device__ void run_grouped(const WaveCtx &c_in, const PlanView &pv_in, const KP
 // kernel.  A kernel of its own for the same reason as k_decode_direct: inside k_decode<MODE, true> it shared one register
 // allocation with five other launch shapes (two more VGPRs there are the difference between 8 and 7 waves per SIMD).
 // LDS: [waves x ring][table][2 next-group words, 64 B][table-build scratch, 1 KiB].
-template <int MODE, bool LEAN>
+template <int MODE, bool LEAN, bool PARTS = false>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_decode_grouped(KParams kp)
 {
   extern __shared__ u32x4 smem_v[];
@@ -262,7 +300,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   // the table build's scratch has an area of its own: a round's first stream chunks are requested before its table is built
   c.scratch_cnt = (uint16_t *)(c.table + table_bytes_for(MODE, c.bits) + 64);
   c.scratch_cum = c.scratch_cnt + 256;
-  run_grouped<MODE, LEAN>(c, pv, kp, waves, wave);
+  run_grouped<MODE, LEAN, false, false, PARTS>(c, pv, kp, waves, wave);
 }
 
 // K member streams' groups in one launch (hsrans_decode_device_batch: members that are block_/mt_ plans with checkpoints, 64 states,

@@ -19,7 +19,9 @@ namespace hsrans
 // maximal runs inside one block (fill chains — single-symbol blocks — one by one), pointing c.table at the run's table.
 // Chain c is piece c with start states c (single-piece chains: n_pieces == n_chains), so nothing but the piece records is read.
 // MODE: kModePack64 only (the rank table of 13-15 bits sits at LDS address 0 by construction: there is no second one).
-template <int MODE>
+// PARTS (round 6): the launch decodes a rank's sub-runs of a sharded decode; a workgroup that is done counts itself into every sub-run
+// its share of the chains overlaps (kernels_grouped.h part_signal; the host counted the same overlaps for PartArgs::target).
+template <int MODE, bool PARTS = false>
 __device__ void run_spread(WaveCtx &c, const PlanView &pv, const KParams &kp, uint32_t waves, uint32_t wave)
 {
   const uint32_t N = kp.pa.n_chains; // (from the launcher: reading the plan's header here is a round trip to memory before anything can start)
@@ -27,10 +29,37 @@ __device__ void run_spread(WaveCtx &c, const PlanView &pv, const KParams &kp, ui
   const uint32_t c0 = spread_share_begin(N, blockIdx.x, gridDim.x, kp.group_cum[0][waves], kp.group_cum[1][waves]);
   const uint32_t c1 = spread_share_begin(N, blockIdx.x + 1, gridDim.x, kp.group_cum[0][waves], kp.group_cum[1][waves]);
   const uint32_t count = c1 - c0;           // <= kSpreadMaxShare (the launcher checks)
+  // (with PARTS every workgroup must reach the count at the end whatever happens: a completion word nobody publishes leaves the
+  // exchange's stream waiting for ever)
+  auto count_into_parts = [&]() {
+    if (!PARTS || kp.parts.n == 0)
+      return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && c1 > c0)
+    {
+      uint32_t lo = 0, hi = 0, begin = 0;
+      bool any = false;
+      for (uint32_t p = 0; p < kp.parts.n; p++)
+      {
+        const uint32_t end = kp.parts.chain_end[p];
+        if (end > begin && c0 < end && c1 > begin) // part p = chains [begin, end)
+        {
+          lo = any ? lo : p;
+          hi = p;
+          any = true;
+        }
+        begin = end > begin ? end : begin;
+      }
+      if (any)
+        part_signal(kp.parts, lo, hi);
+    }
+  };
   if (count > kSpreadMaxShare) // (the launcher checks the same weights it hands the kernel; a share that would overrun the LDS record area must never run)
   {
     if (threadIdx.x == 0)
       atomicOr(c.status, kStatusOutOfRange);
+    count_into_parts();
     return;
   }
   const uint32_t n_rec = count + (c1 < N);  // + the chain behind the share: where the last run's words end
@@ -90,7 +119,7 @@ __device__ void run_spread(WaveCtx &c, const PlanView &pv, const KParams &kp, ui
     const Piece *p0 = lp + i;
     if (uni(p0->flags) & kPieceFill)
     {
-      wave_fill(c, uni64(p0->out_off), uni64(p0->fill_len), (uint32_t)uni64(p0->hist_off) & 0xFF);
+      wave_fill<PARTS>(c, uni64(p0->out_off), uni64(p0->fill_len), (uint32_t)uni64(p0->hist_off) & 0xFF);
       i++;
       continue;
     }
@@ -120,15 +149,16 @@ __device__ void run_spread(WaveCtx &c, const PlanView &pv, const KParams &kp, ui
     const uint64_t run_steps = (uni64(p1->out_off) - o) / c.S + uni(p1->steps);
     const uint32_t run_tail_syms = uni(p1->tail);
     ring_ready(x);
-    run_groups<MODE, true, true>(x, sw, r, c, o, (uint32_t)run_steps); // (write-through stores, counted waits: no difference here)
-    run_tail<MODE>(x, r, c, o, run_tail_syms);
+    run_groups<MODE, true, true, PARTS, PARTS>(x, sw, r, c, o, (uint32_t)run_steps); // (write-through stores, counted waits: no difference here)
+    run_tail<MODE, PARTS>(x, r, c, o, run_tail_syms);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no stream request of this run may still land in the ring the next one begins
     i = e;
   }
+  count_into_parts();
 }
 
 // LDS: [waves x ring][table A][table B][the share's piece records, (kSpreadMaxShare + 1) x 48 B]
-template <int MODE>
+template <int MODE, bool PARTS = false>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_decode_spread(KParams kp)
 {
   static_assert(MODE == kModePack64, "two tables side by side: not for the modes whose table sits at LDS address 0");
@@ -160,7 +190,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_d
   c.gtable = nullptr;
   c.scratch_cnt = nullptr; // (run_spread points the builder at a ring)
   c.scratch_cum = nullptr;
-  run_spread<MODE>(c, pv, kp, waves, wave);
+  run_spread<MODE, PARTS>(c, pv, kp, waves, wave);
 }
 
 } // namespace hsrans

@@ -193,7 +193,7 @@ class ShardedDecoder:
 
     def launch_info(self) -> dict | None:
         """Kernel geometry of what step() launches on this rank: the first sub-run's device plan (None: a rank without chains)."""
-        dp = next((p for p in self.part_dplans if p is not None), None)
+        dp = self.c.whole_plan() or next((p for p in self.part_dplans if p is not None), None)
         return dp.launch_info() if dp is not None else None
 
     def alloc_out(self, device) -> torch.Tensor:

@@ -314,17 +314,27 @@ typedef struct hsrans_sharded_info_t
   uint64_t window_begin, window_end; /* stream bytes this rank must hold at d_window (d_window[0] = stream byte window_begin) */
   uint64_t out_base, out_length;     /* output bytes this rank's d_out holds (d_out[0] = output byte out_base) */
   uint64_t decoded_length, stream_length;
+  uint32_t one_launch, reserved;     /* 1: this rank's sub-runs are decoded by ONE launch that publishes a completion word per sub-run */
 } hsrans_sharded_info_t;
 int hsrans_sharded_info(const hsrans_sharded *sharded, hsrans_sharded_info_t *info, hsrans_shard *shards /* [world * parts] or NULL */, size_t shard_capacity);
-hsrans_dplan *hsrans_sharded_part_plan(hsrans_sharded *sharded, uint32_t part); /* this rank's sub-run `part` (launch info, status); NULL: no chains */
+hsrans_dplan *hsrans_sharded_part_plan(hsrans_sharded *sharded, uint32_t part); /* this rank's sub-run `part` (launch info, status); NULL: no chains, or one launch for all */
+hsrans_dplan *hsrans_sharded_whole_plan(hsrans_sharded *sharded);               /* this rank's whole run when ONE launch decodes all its sub-runs; NULL otherwise */
 /* One decode of the stream: this rank's sub-runs are queued on `hip_stream`; with gather != 0 sub-run k's ranges go onto the links
- * (the communicator's stream waits for exactly that sub-run's kernel) while sub-run k + 1 decodes, and `hip_stream` continues when
- * the transfers are done.  A receiving root posts all its receives first.  Asynchronous; collective when gather != 0 (every rank
+ * (the communicator's stream waits for exactly that sub-run) while sub-run k + 1 decodes, and `hip_stream` continues when
+ * the transfers are done.  block_/mt_ plans with checkpoints (64 states, <= 16 sub-runs): the sub-runs are ONE launch — every block of
+ * the rank's run handed to the device in one pass, as src/mt_rANS32x64_16w_decode.cpp:182-224 hands them to its pool — that publishes a
+ * completion word per sub-run, and the communicator's stream waits for the word (hipStreamWaitValue32); other plans, or
+ * HSRANS_SHARD_ONE_LAUNCH=0 in the environment at hsrans_sharded_create: a launch per sub-run, an event behind each.  A receiving root posts all its receives first.  Asynchronous; collective when gather != 0 (every rank
  * of the communicator must make the same call). */
 #define HSRANS_SHARD_DECODE_ONLY 0         /* every rank keeps its range */
 #define HSRANS_SHARD_DECODE_AND_EXCHANGE 1 /* the step: decode, ranges exchanged behind it */
 #define HSRANS_SHARD_EXCHANGE_ONLY 2       /* the ranges of an earlier decode-only call (to time the two legs apart) */
 int hsrans_decode_sharded(hsrans_sharded *sharded, const void *d_window, void *d_out, int gather, void *hip_stream);
+/* Makes `hip_stream` (another stream than the decode's) wait until sub-run `part` of the LAST hsrans_decode_sharded call queued on this
+ * object is decoded and its bytes are visible device-wide — what the exchange does internally, for a consumer that is sharded like the
+ * decode and can start on a sub-run while the next one is still being decoded (a worker of the reference's pool picking up finished
+ * blocks: src/thread_pool.cpp:124-133).  One launch for all sub-runs: waits for the sub-run's completion word; else for its event. */
+int hsrans_sharded_wait_part(hsrans_sharded *sharded, uint32_t part, void *hip_stream);
 int hsrans_sharded_status(hsrans_sharded *sharded, void *hip_stream); /* as hsrans_dplan_status, over this rank's sub-runs */
 
 /* First decode of a stream that came WITHOUT an index (e.g. a reference-emitted mt_ stream: one chain per block,

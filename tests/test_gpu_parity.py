@@ -346,8 +346,9 @@ def test_a_process_second_pipeline_is_as_fast_as_its_first(gpu_ctx):
     assert min(rates[1:]) > 0.85 * rates[0], [round(r / 1e9, 1) for r in rates]
 
 
+@pytest.mark.parametrize("one_launch", (True, False))
 @pytest.mark.parametrize("world,root,parts,root_share", ((2, None, 3, 0.0), (8, 0, 4, 0.66), (4, 2, 2, 0.0), (8, None, 1, 0.0)))
-def test_every_ranks_gpu_side_of_a_sharded_decode_on_one_gpu(gpu_ctx, nonstat, world, root, parts, root_share):
+def test_every_ranks_gpu_side_of_a_sharded_decode_on_one_gpu(gpu_ctx, nonstat, monkeypatch, world, root, parts, root_share, one_launch):
     """No multi-GPU node here, so the N > 1 path is checked in two halves: the exchange logic on gloo (tests/test_sharded_gloo.py,
     test_bench_contract.py) and — this test — the GPU side of EVERY rank on the one GPU: each rank's slice plans, stream window,
     output window (a rank that is not the root of a gather holds only its own range), sub-runs and weighted shares, launched
@@ -355,10 +356,15 @@ def test_every_ranks_gpu_side_of_a_sharded_decode_on_one_gpu(gpu_ctx, nonstat, w
     sub-ranges into the root's buffer, in the order pipelined_gather posts them."""
     import torch
     from hypersonic_rans_amd import sharded
+    # round 6: a rank's sub-runs are ONE launch with a completion word per sub-run (mt_rANS32x64_16w_decode.cpp:182-224 hands every block to
+    # the pool in one pass); HSRANS_SHARD_ONE_LAUNCH=0 keeps round 5's launch per sub-run — both sides run here
+    monkeypatch.setenv("HSRANS_SHARD_ONE_LAUNCH", "1" if one_launch else "0")
     d = nonstat[:3_000_000]
     stream, plan = H.encode(H.MT, 64, 11, d, index_interval=32, block_size=65536)
     weights = sharded.root_weights(world, root, root_share) if (root is not None and root_share) else None
     decs = [sharded.ShardedDecoder(gpu_ctx, plan, parts=parts, weights=weights, root=root, world=world, rank=r) for r in range(world)]
+    for dec in decs:
+        assert bool(dec.c.info["one_launch"]) == (one_launch and parts > 1 and dec.count > 0), (dec.rank, dec.c.info)
     outs = []
     for dec in decs:
         d_window = dec.upload_window(stream, "cuda")
@@ -383,6 +389,51 @@ def test_every_ranks_gpu_side_of_a_sharded_decode_on_one_gpu(gpu_ctx, nonstat, w
     if root_share:
         share = (decs[root].ranges[root][1] - decs[root].ranges[root][0]) / d.size
         assert abs(share - root_share) < 0.05
+
+
+@pytest.mark.parametrize("one_launch", (True, False))
+@pytest.mark.parametrize("bits,block,interval,size", ((12, 65536, 32, 6_000_000), (14, 1 << 17, 16, 6_000_000), (11, 1 << 18, 8, 24_000_000)))
+def test_a_ranks_sub_runs_announce_their_completion(gpu_ctx, monkeypatch, one_launch, bits, block, interval, size):
+    """hsrans_sharded_wait_part — what the exchange's stream does inside hsrans_decode_sharded, reachable on one GPU: a SECOND stream waits
+    for sub-run k of the decode queued on the first (its completion word, published by the one launch that decodes all sub-runs:
+    hipStreamWaitValue32; or the event behind sub-run k's own launch) and copies the sub-run's range away at once.  Only the second
+    stream is synchronised: every copied range must already hold the decoded bytes (the output is poisoned before every step), i.e. a
+    completion word never fires before its sub-run's stores are visible device-wide.  Checked against the source bytes (the streams
+    round-trip through the oracle in the CPU suite).  The three cases reach the three kernels that count into sub-runs: the grouped
+    launch with the 8-byte table, with the rank table (14 bits), and the spread launch (few large blocks, many chains)."""
+    import torch
+    from hypersonic_rans_amd import sharded
+    monkeypatch.setenv("HSRANS_SHARD_ONE_LAUNCH", "1" if one_launch else "0")
+    d = synth.nonstationary(size, seed=5) if size < 10_000_000 else synth.enwik8_shaped(size, seed=5)
+    stream, plan = H.encode(H.MT, 64, bits, d, index_interval=interval, block_size=block)
+    src = torch.from_numpy(d).cuda()
+    world, parts = 2, 4
+    side = torch.cuda.Stream()
+    for rank in range(world):
+        dec = sharded.ShardedDecoder(gpu_ctx, plan, parts=parts, world=world, rank=rank)
+        assert bool(dec.c.info["one_launch"]) == one_launch
+        d_window = dec.upload_window(stream, "cuda")
+        out = dec.alloc_out("cuda")
+        if one_launch:
+            assert bool(dec.c.whole_plan() is not None)
+        for rep in range(4):
+            out.fill_(0xA5)
+            copy = torch.full_like(out, 0x5A)
+            torch.cuda.synchronize()
+            dec.step(d_window, out, gather=False)
+            for k in reversed(range(parts)) if rep & 1 else range(parts):  # (the waits need not come in the sub-runs' order)
+                b, e = dec.layout.sub_ranges[rank][k]
+                if e > b:
+                    dec.c.wait_part(k, side)
+                    with torch.cuda.stream(side):
+                        copy[b:e].copy_(out[b:e], non_blocking=True)
+            side.synchronize()
+            b, e = dec.ranges[rank]
+            assert torch.equal(copy[b:e], src[b:e]), (rank, rep)
+            torch.cuda.synchronize()
+            dec.check()
+        if one_launch and size > 10_000_000:
+            assert dec.launch_info()["spread"] == 1
 
 
 def test_sharded_decode_single_rank_over_rccl(gpu_ctx, zipf):

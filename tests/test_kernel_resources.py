@@ -53,7 +53,10 @@ def test_shared_table_decode_occupancy():
     assert seen == 5 + 6 + 2
     # the grouped launches' kernel (block_/mt_ plans with checkpoints): the 8-byte-table instantiations, lean and general
     grouped = {name: r for name, r in kernels.items() if re.search(r"k_decode_groupedILi[34]ELb[01]E", name)}  # 8-byte table and rank table
-    assert len(grouped) == 4
+    assert len(grouped) == 6  # + the two that count their groups into a sharded decode's sub-runs (round 6: <3, true, true>, <4, true, true>)
+    spread = {name: r for name, r in kernels.items() if "k_decode_spread" in name}
+    assert len(spread) == 2  # k_decode_spread<3> and its sub-run-counting twin
+    grouped.update(spread)
     for name, r in grouped.items():
         assert r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] == 8, (name, r)
     # the batch launches (round 5): the one-chain-per-wave form, its calibration twin, the grouped form
