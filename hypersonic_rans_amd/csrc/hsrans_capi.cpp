@@ -265,6 +265,8 @@ extern "C++" int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_si
   d->n_groups = 0;
   d->groups_lean = false;
   d->spread_min_block = 0;
+  d->block_begin.clear();
+  d->dealt_state = 0;
   {
     d->body_lo = 0;
     d->out_lo = 0;
@@ -486,6 +488,17 @@ extern "C++" int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_si
           fewest = std::min(fewest, g.count);
       }
       d->spread_min_block = ok ? fewest : 0;
+      // k_decode_dealt: the blocks as chain ranges, where every one of them is a coded block of such chains
+      bool plain = ok && !groups.empty();
+      for (size_t k = 0; k < groups.size() && plain; k++)
+        plain = !(groups[k].flags & kGroupFill) && groups[k].begin == (k ? groups[k - 1].begin + groups[k - 1].count : 0);
+      if (plain)
+      {
+        d->block_begin.reserve(groups.size() + 1);
+        for (const Group &g : groups)
+          d->block_begin.push_back(g.begin);
+        d->block_begin.push_back(h.n_chains);
+      }
     }
     const size_t want = (size_t)kGroupPartsPerCU * ctx->geom.num_cus;
     if (groups.size() < h.n_chains && groups.size() < want)
@@ -551,6 +564,61 @@ extern "C++" int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_si
   return HSRANS_OK;
 }
 
+// Plans written on the device (the GPU encoder's, an indexing decode's) have their group list there: a block's parts are consecutive groups of one
+// histogram.  One small copy (32 bytes a group) at plan creation gives k_decode_dealt's dealing the blocks as chain ranges.
+extern "C++" void dplan_blocks_from_device_groups(hsrans_dplan *d, hipStream_t s)
+{
+  d->block_begin.clear();
+  d->dealt_state = 0;
+  if (d->n_groups == 0 || d->d_groups == nullptr || !d->groups_lean || d->hdr.n_pieces != d->hdr.n_chains)
+    return;
+  try
+  {
+    std::vector<Group> groups(d->n_groups);
+    if (hipMemcpyAsync(groups.data(), d->d_groups, groups.size() * sizeof(Group), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      return;
+    }
+    std::vector<uint32_t> begins;
+    uint32_t next = 0;
+    for (size_t k = 0; k < groups.size(); k++)
+    {
+      const Group &g = groups[k];
+      if (g.count == 0) // (device builders leave unused part slots empty)
+        continue;
+      if ((g.flags & kGroupFill) || !(g.flags & kGroupMergeable) || g.begin != next || g.piece0 != g.begin)
+      {
+        if (getenv("HSRANS_DEALT_TRACE"))
+          fprintf(stderr, "hsrans dealt: group %zu of %zu: flags %x begin %u count %u piece0 %u, expected begin %u\n", k, groups.size(), g.flags, g.begin, g.count, g.piece0, next);
+        return;
+      }
+      if (begins.empty() || g.hist_off != groups[k - 1].hist_off || groups[k - 1].count == 0)
+      {
+        // (a part continues its block when the previous non-empty group has the same histogram)
+        bool cont = false;
+        for (size_t j = k; j-- > 0;)
+          if (groups[j].count != 0)
+          {
+            cont = groups[j].hist_off == g.hist_off;
+            break;
+          }
+        if (!cont)
+          begins.push_back(g.begin);
+      }
+      next = g.begin + g.count;
+    }
+    if (next != d->hdr.n_chains || begins.empty())
+      return;
+    begins.push_back(d->hdr.n_chains);
+    d->block_begin.swap(begins);
+  }
+  catch (...)
+  {
+    d->block_begin.clear();
+  }
+}
+
 // A page-locked, device-mapped host range (hipHostMalloc / hipHostRegister): the address the GPU reaches it at, else null.
 extern "C++" uint8_t *device_view_of_host(const void *ptr, size_t bytes)
 {
@@ -596,12 +664,41 @@ extern "C++" int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stre
     kp.spread = d->groups_lean ? d->spread_min_block : 0;
     // (measured at 2^30 bytes, two runs each on one box: 0 -> 0.447-0.450 ms, 300 -> 0.440, 500 -> 0.440-0.445, 700 -> 0.447-0.451, 1000 -> 0.452-0.455)
     kp.group_prio = getenv("HSRANS_GROUP_PRIO") != nullptr ? (uint32_t)atoi(getenv("HSRANS_GROUP_PRIO")) : 350;
+    // HSRANS_GROUP_PRIO_CLASS: ten per-mille values, see KParams::group_prio_class (tuning; tools/group_prio_probe.py)
+    kp.group_prio_class[9] = 0xFFFF;
+    if (const char *e = getenv("HSRANS_GROUP_PRIO_CLASS"))
+    {
+      uint32_t v[10], n = 0;
+      for (const char *p = e; n < 10 && *p; n++)
+      {
+        v[n] = (uint32_t)strtoul(p, (char **)&p, 10);
+        if (*p == ',')
+          p++;
+      }
+      if (n == 10)
+        for (uint32_t k = 0; k < 10; k++)
+          kp.group_prio_class[k] = (uint16_t)(v[k] > 1000 ? 1000 : v[k]);
+    }
     // (requesting a round's records and first chunks before its table build: measured, no gain — the other workgroups of the CU
     // fill the gap either way — so off unless asked for)
     // dynamic group order: this launch's own ticket counter (the counter sets of the persistent launches, one head of each used)
     if (d->d_counters != nullptr && getenv("HSRANS_GROUP_STATIC") == nullptr)
       kp.group_tickets = d->d_counters + (size_t)(d->epoch.fetch_add(1, std::memory_order_relaxed) % kCounterSets) * kDynQueues * kDynQueueStride;
   }
+  // lean grouped plans of coded blocks: the host-dealt one-round launch where the plan suits it (dealt once per weight set)
+  const DealtTable *dealt = nullptr;
+  if (d->n_groups && d->groups_lean && d->block_begin.size() >= 2 && d->hdr.bits <= 11 && d->hdr.states == 64)
+  {
+    uint32_t w8[8];
+    const uint64_t total_groups = (d->out_hi - d->out_lo) / 64; // (what THIS plan's chains decode: a rank's slice of a sharded stream, not the stream)
+    dealt_weights_now(d->ctx->geom, total_groups / ((uint64_t)spread_grid(d->ctx->geom) * 16), w8);
+    if (d->dealt_state == 0 || memcmp(w8, d->dealt_weights, sizeof(w8)) != 0)
+      d->dealt_state = deal_shares(d->ctx->geom, d->block_begin.data(), (uint32_t)d->block_begin.size() - 1, d->hdr.n_chains, total_groups, &d->dealt, d->dealt_weights) ? 1 : -1;
+    if (d->dealt_state == 1)
+      dealt = &d->dealt;
+  }
+  if (getenv("HSRANS_DEALT_TRACE"))
+    fprintf(stderr, "hsrans dealt: groups %u lean %d blocks %zu bits %u chains %u state %d\n", d->n_groups, (int)d->groups_lean, d->block_begin.size(), d->hdr.bits, d->hdr.n_chains, d->dealt_state);
   if (part_words != nullptr)
   {
     // a rank's sub-runs in one launch: the caller's completion words and sequence number, this plan's parts and running totals
@@ -609,9 +706,9 @@ extern "C++" int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stre
       return HSRANS_E_ARG;
     kp.parts = *part_words;
     PartPlan pp{(uint32_t)d->part_ends.size(), d->part_ends.data(), d->part_units.data(), d->part_cum.data()};
-    return launch_decode(kp, d->hdr, d->ctx->geom, s, &d->info, &pp) == hipSuccess ? HSRANS_OK : HSRANS_E_HIP;
+    return launch_decode(kp, d->hdr, d->ctx->geom, s, &d->info, &pp, dealt, d->dealt_weights) == hipSuccess ? HSRANS_OK : HSRANS_E_HIP;
   }
-  return launch_decode(kp, d->hdr, d->ctx->geom, s, &d->info) == hipSuccess ? HSRANS_OK : HSRANS_E_HIP;
+  return launch_decode(kp, d->hdr, d->ctx->geom, s, &d->info, nullptr, dealt, d->dealt_weights) == hipSuccess ? HSRANS_OK : HSRANS_E_HIP;
 }
 
 

@@ -346,6 +346,7 @@ size_t hsrans_encode_device(hsrans_ctx *ctx, int container, int states, uint32_t
   d->n_groups = grouped ? ep.n_blocks * ep.group_split : 0;
   d->groups_lean = grouped && h.states == 64; // k_plan_blocks writes mergeable runs and fill groups only
   d->spread_min_block = d->groups_lean ? ep.max_ck + 1 : 0; // (every coded block but the last has max_ck + 1 chains)
+  dplan_blocks_from_device_groups(d, s); // (k_decode_dealt's dealing wants the blocks as chain ranges: 32 bytes a group, once)
   *out_dplan = d;
   return total;
 }

@@ -447,6 +447,8 @@ try
     nd->spread_min_block = nd->groups_lean ? (uint32_t)std::min<uint64_t>(fewest, 0xFFFFFFFFu) : 0;
     if (!grouped)
       nd->d_groups = nullptr, nd->d_counters = nullptr;
+    if (grouped)
+      dplan_blocks_from_device_groups(nd, s); // (k_decode_dealt's dealing wants the blocks as chain ranges)
     if (getenv("HSRANS_DEBUG_STAMPS") && hipMalloc((void **)&nd->d_stamps, kStampWaves * 8 * 8) == hipSuccess)
       (void)hipMemset(nd->d_stamps, 0, kStampWaves * 8 * 8);
     if (trace)

@@ -95,7 +95,16 @@ struct hsrans_dplan
   // dplan_fill, which then tags every group with the parts it overlaps (Group::flags, kGroupPartShift) and counts them: part_units[k];
   // part_cum[k] = units counted into part k by all launches so far (the device's counters are never reset: launch_decode, PartPlan)
   std::vector<uint32_t> part_ends, part_units, part_cum;
+  // k_decode_dealt (kernels_dealt.h): the plan's blocks as chain ranges — block k = chains [block_begin[k], block_begin[k + 1]) — kept where the
+  // plan is a lean grouped one of coded blocks only (no single-symbol blocks); empty otherwise.  `dealt` = the shares for `dealt_weights`
+  // (dealt_state 1: valid, -1: the plan does not suit the launch with these weights, 0: not dealt yet); re-dealt when a calibration changes the weights.
+  std::vector<uint32_t> block_begin;
+  DealtTable dealt{};
+  uint32_t dealt_weights[8] = {};
+  int dealt_state = 0;
 };
+// fills d->block_begin from the device plan's group list (plans written on the device: the GPU encoder's, an indexing decode's); synchronises `s`
+void dplan_blocks_from_device_groups(hsrans_dplan *d, hipStream_t s);
 
 constexpr size_t kStampWaves = 16384;
 

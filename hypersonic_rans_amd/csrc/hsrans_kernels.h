@@ -77,6 +77,29 @@ struct PartArgs
 // part of one; sub-runs are cut at chain boundaries, so a group can straddle two of them)
 constexpr uint32_t kGroupPartShift = 16;
 
+// k_decode_dealt (kernels_dealt.h): the host-dealt one-round launch of block_/mt_ plans with checkpoints
+constexpr uint32_t kDealtGridMax = 512;
+struct DealtTable
+{
+  uint32_t begin[kDealtGridMax + 1]; // chains; begin[grid] = n_chains
+  uint16_t split[kDealtGridMax];     // chains of the share that belong to its first block (>= the share's length: one block only)
+};
+struct DealtParams
+{
+  const uint8_t *stream;
+  uint64_t stream_len, stream_lo;
+  uint8_t *out;
+  uint64_t out_cap;
+  const Piece *pieces;    // chain c = piece c with start states c (single-piece chains)
+  const uint32_t *states;
+  uint32_t *status;
+  uint64_t *stamps;       // diagnostics
+  uint32_t n_chains, bits;
+  uint16_t cum[2][17];    // a wave's part of its workgroup's share: cumulative class weights by grid half (as KParams::group_cum)
+  uint32_t gap_chains;    // what the second prologue of a wave that straddles its share's block boundary costs, in chains of this plan (run_dealt)
+  PartArgs parts;
+};
+
 // k_decode_single: a plan of ONE chain of ONE rANS piece (a raw stream without an index), filled by the host from the plan
 struct SingleArgs
 {
@@ -122,6 +145,9 @@ struct KParams
   uint32_t spread;        // grouped plans of single-piece chains: the fewest chains of a coded block that is not the last (k_decode_spread takes the launch when its longest share is shorter); 0 = never
   uint32_t groups_lean;   // 64-state plan, every group a mergeable run or fills only: the lean instantiation of k_decode_grouped
   uint32_t group_prio;    // grouped launches: per mille of its run the younger half of a workgroup's waves decodes at raised priority (s_setprio)
+  // ... per wave class (class = (workgroup in the grid's second half) * 4 + wave / (waves / 4), as everywhere): [0..7] where a group's chains are
+  // split evenly over the waves, [8..9] (by grid half) where the split already follows the class weights.  All zero: group_prio's rule.
+  uint16_t group_prio_class[10];
   // grouped launches: wave k of a workgroup in grid half h takes chains [count * cum[h][k] / cum[h][waves], count * cum[h][k+1] / cum[h][waves])
   // of its group (the same age-class weights as PersistentArgs::run_len)
   uint16_t group_cum[2][17];
@@ -208,7 +234,7 @@ struct LaunchInfo
   uint32_t grid, block, lds_bytes, waves_per_block, chains, shared_table, walk, two_level, table_mode, chains_per_wave;
   uint32_t class_weights[8]; // the per-mille run lengths of the 8 wave classes this launch was shaped with (LaunchShape::weights)
   uint32_t dynamic_groups;   // grouped launches: groups handed out by the ticket counter (1) or in static order (0)
-  uint32_t spread;           // grouped plan launched by k_decode_spread (chains dealt out evenly, two tables per workgroup)
+  uint32_t spread;           // grouped plan launched by k_decode_spread (chains dealt out evenly, two tables per workgroup); 2: by k_decode_dealt (host-dealt shares)
 };
 
 // what the launcher needs to know about the device a context lives on
@@ -338,7 +364,17 @@ struct PartPlan
   const uint32_t *group_units;
   uint32_t *cum;
 };
-hipError_t launch_decode(const KParams &kp, const PlanHeader &h, const DeviceGeom &dg, hipStream_t stream, LaunchInfo *info, const PartPlan *parts = nullptr);
+// `dealt` (may be null): the plan's shares for k_decode_dealt, from deal_shares with this device's current weights; the launcher takes that
+// kernel when it is given (the caller has checked the plan: lean grouped, 64 states, <= 11 bits, no single-symbol blocks)
+hipError_t launch_decode(const KParams &kp, const PlanHeader &h, const DeviceGeom &dg, hipStream_t stream, LaunchInfo *info, const PartPlan *parts = nullptr,
+                         const DealtTable *dealt = nullptr, const uint32_t *dealt_weights = nullptr /* the 8 class weights `dealt` was made with */);
+// The dealing of k_decode_dealt: block k = chains [block_begin[k], block_begin[k + 1]) (n_blocks + 1 entries, the last = n_chains), every one a coded
+// block of single-piece mergeable chains.  Workgroup shares by age-class weight (the one-chain-per-wave launch's, this device's own once
+// calibrated), each cut back where it would reach into a third block.  false: the plan does not suit the launch (too few chains for the
+// device's waves, shares that would have to span more than two blocks, a share beyond 65,535 chains).  weights_out: the 8 class weights used
+// (the caller's cache key: a calibration changes them).
+bool deal_shares(const DeviceGeom &dg, const uint32_t *block_begin, uint32_t n_blocks, uint32_t n_chains, uint64_t total_groups, DealtTable *out, uint32_t weights_out[8]);
+void dealt_weights_now(const DeviceGeom &dg, uint64_t run_groups, uint32_t weights_out[8]); // run_groups: groups per wave of the launch, on average
 
 } // namespace hsrans
 

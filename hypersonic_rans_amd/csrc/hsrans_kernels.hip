@@ -28,6 +28,7 @@
 //   kernels_batch.h     k_decode_batch     K independent streams in one launch of the one-chain-per-wave form
 //   kernels_grouped.h   k_decode_grouped   block_/mt_ plans with checkpoints (BASELINE config 4)
 //   kernels_spread.h    k_decode_spread    the same plans with few, large blocks: the chains dealt out evenly, two tables per workgroup
+//   kernels_dealt.h     k_decode_dealt     the same in one round with HOST-dealt shares (<= 2 blocks each), two dependent trips before the first group
 //   kernels_generic.h   k_decode           mt_ without index, block_ header walk, index-build passes
 //   kernels_dual.h      k_decode_dual      two chains per wave (13-15 bits)
 //   kernels_single.h    k_decode_single    one dependent chain (raw stream without index)
@@ -49,6 +50,7 @@
 #include "kernels_direct.h"
 #include "kernels_grouped.h"
 #include "kernels_spread.h"
+#include "kernels_dealt.h"
 #include "kernels_generic.h"
 #include "kernels_dual.h"
 #include "kernels_batch.h"
@@ -294,6 +296,12 @@ hipError_t prepare_kernels(DeviceGeom *geom)
     if (e != hipSuccess)
       return e;
   }
+  for (const void *fn : {(const void *)k_decode_dealt<true, false>, (const void *)k_decode_dealt<false, false>, (const void *)k_decode_dealt<true, true>})
+  {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
+    if (e != hipSuccess)
+      return e;
+  }
   {
     hipError_t e = hipFuncSetAttribute((const void *)k_decode_batch<kModePack64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
     if (e == hipSuccess)
@@ -362,6 +370,92 @@ uint32_t spread_longest_share(const DeviceGeom &dg, uint64_t n_chains)
   uint16_t cum[2][17];
   spread_weights(dg, cum);
   return spread_longest_share_of(dg, n_chains, cum);
+}
+
+// the class weights of a one-round launch whose waves decode `run_groups` groups each on average: the one-chain-per-wave launch's, this
+// device's own once calibrated — the set fitted nearest to that run length where several are (hsrans_ctx_calibrate_runs)
+void dealt_weights_now(const DeviceGeom &dg, uint64_t run_groups, uint32_t weights_out[8])
+{
+  direct_weights_for(dg, run_groups, weights_out);
+}
+static void cum_from_weights(const uint32_t w8[8], uint16_t (*cum_out)[17])
+{
+  for (uint32_t hf = 0; hf < 2; hf++)
+  {
+    uint32_t cum = 0;
+    for (uint32_t k = 0; k <= 16; k++)
+    {
+      cum_out[hf][k] = (uint16_t)cum;
+      cum += k < kSpreadWaves ? w8[hf * 4 + k / (kSpreadWaves / 4)] / 10 : 0;
+    }
+  }
+}
+
+static uint32_t g_dealt = 1;          // HSRANS_DEALT=0: grouped plans keep k_decode_spread / k_decode_grouped (comparison)
+static uint32_t g_dealt_min_chains = 2; // HSRANS_DEALT_MIN_CHAINS: chains per wave of the launch below which a plan is not dealt (tuning)
+static uint32_t g_dealt_wt = 1;       // HSRANS_DEALT_WT=0: k_decode_dealt's stores as `nt` instead of written through (comparison)
+
+bool deal_shares(const DeviceGeom &dg, const uint32_t *block_begin, uint32_t n_blocks, uint32_t n_chains, uint64_t total_groups, DealtTable *out, uint32_t weights_out[8])
+{
+  dealt_weights_now(dg, total_groups / ((uint64_t)spread_grid(dg) * kSpreadWaves), weights_out);
+  // (read at every dealing, not once: tools/ab_probe.py and the tests switch sides inside one process)
+  const char *e_on = getenv("HSRANS_DEALT"), *e_min = getenv("HSRANS_DEALT_MIN_CHAINS");
+  g_dealt = e_on ? (uint32_t)atoi(e_on) : 1;
+  g_dealt_min_chains = e_min && atoi(e_min) > 0 ? (uint32_t)atoi(e_min) : 2;
+  const uint32_t grid = spread_grid(dg);
+  if (!g_dealt || grid > kDealtGridMax || n_blocks == 0 || block_begin[0] != 0 || block_begin[n_blocks] != n_chains)
+    return false;
+  if ((uint64_t)n_chains < (uint64_t)grid * kSpreadWaves * g_dealt_min_chains)
+    return false;
+  // a workgroup's weight = the sum of its waves' (four waves per class; as the kernel's cumulative table has them); the first half of the grid is resident first
+  uint64_t w1 = 0, w2 = 0;
+  for (uint32_t k = 0; k < 4; k++)
+    w1 += weights_out[k] / 10, w2 += weights_out[4 + k] / 10;
+  const uint32_t fh = (grid + 1) / 2;
+  uint64_t weight_left = (uint64_t)fh * w1 + (uint64_t)(grid - fh) * w2;
+  uint32_t blk = 0; // block of the next share's first chain
+  out->begin[0] = 0;
+  for (uint32_t b = 0; b < grid; b++)
+  {
+    // what is left, by the weights that are left: a share that was cut back at a third block leaves its chains to ALL the workgroups behind
+    // it (given to the next one alone — targets as fixed fractions of the whole — shares of one grid half ranged from 1.0 to 1.5 blocks
+    // at 128 MiB in 256 KiB blocks, and the launch ended 10 us after its median wave: tools/stamps_dealt.py)
+    const uint32_t c0 = out->begin[b];
+    const uint64_t wb = b < fh ? w1 : w2;
+    uint32_t e = b + 1 == grid ? n_chains : c0 + (uint32_t)(((uint64_t)(n_chains - c0) * wb + weight_left / 2) / weight_left);
+    weight_left -= wb;
+    e = e > n_chains ? n_chains : e;
+    while (blk + 1 < n_blocks && block_begin[blk + 1] <= c0) // the block chain c0 is in
+      blk++;
+    uint32_t split = 0xFFFF;
+    if (c0 < n_chains)
+    {
+      const uint32_t end_a = block_begin[blk + 1];                                   // first block ends here
+      const uint32_t end_b = blk + 2 <= n_blocks ? block_begin[blk + 2] : n_chains; // the second one here: the share may not go on
+      e = e > end_b ? end_b : e;
+      if (e > end_a)
+      {
+        if (end_a - c0 > 0xFFFE)
+          return false;
+        split = end_a - c0;
+      }
+    }
+    if (e - c0 > 0xFFFE)
+      return false;
+    out->begin[b + 1] = e;
+    out->split[b] = (uint16_t)split;
+  }
+  for (uint32_t b = grid; b < kDealtGridMax; b++)
+    out->begin[b + 1] = n_chains, out->split[b] = 0xFFFF;
+  if (out->begin[grid] != n_chains) // the cuts at third blocks left chains over — blocks much shorter than a share: the grouped launch's case
+    return false;
+  // ... and where the cuts bent the shares too far from the weights (shares of about two blocks and more), the launch would end with its
+  // most loaded workgroup: the grouped launch's case as well
+  const double mean = (double)n_chains / (double)((uint64_t)fh * w1 + (uint64_t)(grid - fh) * w2);
+  for (uint32_t b = 0; b < grid; b++)
+    if ((double)(out->begin[b + 1] - out->begin[b]) / (double)(b < fh ? w1 : w2) > 1.6 * mean + 1.0 / (double)w2)
+      return false;
+  return true;
 }
 
 // Everything about a launch that follows from the plan header and the device alone (no pointers): the table layout, the
@@ -635,11 +729,83 @@ hipError_t launch_batch_grouped(const BatchGroupParams &bp, const BatchGroupShap
   return hipGetLastError();
 }
 
-hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const DeviceGeom &dg, hipStream_t stream, LaunchInfo *info, const PartPlan *parts)
+static hipError_t launch_dealt(const KParams &kp, const PlanHeader &h, const DeviceGeom &dg, hipStream_t stream, LaunchInfo *info, const PartPlan *parts, const DealtTable &dt,
+                               const uint32_t *w8)
+{
+  const char *e_wt = getenv("HSRANS_DEALT_WT");
+  g_dealt_wt = e_wt ? (uint32_t)atoi(e_wt) : 1;
+  DealtParams dp{};
+  dp.stream = kp.stream;
+  dp.stream_len = kp.stream_len;
+  dp.stream_lo = kp.stream_lo;
+  dp.out = kp.out;
+  dp.out_cap = kp.out_cap;
+  dp.pieces = (const Piece *)(kp.plan + plan_pieces_off(h.n_chains));
+  dp.states = (const uint32_t *)(kp.plan + plan_states_off(h.n_chains, h.n_chains));
+  dp.status = kp.status;
+  dp.stamps = kp.stamps;
+  dp.n_chains = h.n_chains;
+  dp.bits = h.bits;
+  const uint32_t grid = spread_grid(dg);
+  cum_from_weights(w8, dp.cum); // (the weights the shares were dealt with)
+  {
+    // a second prologue is ~2.5 us = ~17 groups of decoding at 8 waves per SIMD (HSRANS_DEALT_GAP_GROUPS: tuning)
+    const char *e_gap = getenv("HSRANS_DEALT_GAP_GROUPS");
+    const uint64_t gap_groups = e_gap ? (uint64_t)atoi(e_gap) : 17;
+    const uint64_t per_chain = h.interval ? h.interval : h.n_chains ? (uint64_t)h.decoded_len / 64 / h.n_chains : 0; // groups per chain: the index interval (a sliced plan keeps the stream's header)
+    dp.gap_chains = per_chain ? (uint32_t)((gap_groups + per_chain / 2) / per_chain) : 0;
+  }
+  const uint32_t lds = kSpreadWaves * kFastRingBytes + 2 * table_bytes_for(kModePack64, h.bits) + 2048;
+  if (parts != nullptr)
+  {
+    dp.parts = kp.parts;
+    dp.parts.n = parts->n;
+    uint32_t begin = 0;
+    for (uint32_t k = 0; k < parts->n; k++)
+    {
+      const uint32_t end = parts->chain_end[k];
+      uint32_t units = 0; // workgroups whose share overlaps part k (run_dealt counts itself by the same rule)
+      for (uint32_t b = 0; b < grid && end > begin; b++)
+        units += dt.begin[b + 1] > dt.begin[b] && dt.begin[b] < end && dt.begin[b + 1] > begin ? 1 : 0;
+      dp.parts.chain_end[k] = end;
+      dp.parts.target[k] = (parts->cum[k] += units);
+      begin = end > begin ? end : begin;
+    }
+  }
+  if (info)
+  {
+    *info = LaunchInfo{};
+    info->grid = grid;
+    info->block = kSpreadWaves * 64;
+    info->lds_bytes = lds;
+    info->waves_per_block = kSpreadWaves;
+    info->chains = h.n_chains;
+    info->shared_table = 1;
+    info->table_mode = (uint32_t)kModePack64;
+    info->chains_per_wave = 1;
+    for (uint32_t k = 0; k < 8; k++)
+      info->class_weights[k] = w8[k];
+    info->spread = 2;
+  }
+  (void)hipGetLastError();
+  if (parts != nullptr)
+    hipLaunchKernelGGL((k_decode_dealt<true, true>), dim3(grid), dim3(kSpreadWaves * 64), lds, stream, dp, dt);
+  else if (g_dealt_wt)
+    hipLaunchKernelGGL((k_decode_dealt<true, false>), dim3(grid), dim3(kSpreadWaves * 64), lds, stream, dp, dt);
+  else
+    hipLaunchKernelGGL((k_decode_dealt<false, false>), dim3(grid), dim3(kSpreadWaves * 64), lds, stream, dp, dt);
+  return hipGetLastError();
+}
+
+hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const DeviceGeom &dg, hipStream_t stream, LaunchInfo *info, const PartPlan *parts, const DealtTable *dealt,
+                         const uint32_t *dealt_weights)
 {
   KParams kp = kp_in;
   if (parts != nullptr && (parts->n == 0 || parts->n > kMaxLaunchParts))
     return hipErrorInvalidValue;
+  if (dealt != nullptr && dealt_weights != nullptr && kp.groups != nullptr && kp.groups_lean && kp.ckpt_interval == 0 && kp.ckpt_groups == nullptr && h.states == 64 && h.bits <= 11 &&
+      h.n_pieces == h.n_chains && 2 * (kSpreadWaves * kFastRingBytes + 2 * table_bytes_for(kModePack64, h.bits) + 2048) <= dg.max_lds)
+    return launch_dealt(kp, h, dg, stream, info, parts, *dealt, dealt_weights);
   const bool persistent = kp.pa.pieces != nullptr;
   const bool index_pass = kp.ckpt_interval != 0 || kp.ckpt_groups != nullptr;
   const LaunchShape L = launch_shape(h, dg, persistent, persistent && kp.pa.table != nullptr ? kp.pa.table_mode : 0, kp.groups != nullptr ? kp.n_groups : 0, index_pass, persistent && kp.pa.interval == 0, persistent && kp.pa.dual != 0);

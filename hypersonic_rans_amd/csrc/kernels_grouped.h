@@ -239,7 +239,13 @@ __device__ void run_grouped(const WaveCtx &c_in, const PlanView &pv_in, const KP
       // done 8 us before the younger one and waits at the round's barrier.  Unlike the one-chain-per-wave launch, whose index
       // gives the classes chains of different lengths, a block's checkpoints are where the encoder put them.
       // (not where the wave's share was already sized by its age class: 100 MB in 256 KiB blocks + G=32: 0.359 -> 0.340 with both)
-      const uint32_t prio_steps = group_prio != 0 && !weighted && wave >= waves / 2 ? (uint32_t)(run_steps * group_prio / 1000) & ~3u : 0;
+      uint32_t prio_permille = group_prio != 0 && !weighted && wave >= waves / 2 ? group_prio : 0;
+      if (!BATCH && kp.group_prio_class[9] != 0xFFFF) // (0xFFFF there: no per-class table, group_prio's rule)
+      {
+        const uint32_t per = waves >= 4 ? waves / 4 : 1;
+        prio_permille = weighted ? kp.group_prio_class[8 + half] : kp.group_prio_class[half * 4 + (wave / per < 4 ? wave / per : 3)];
+      }
+      const uint32_t prio_steps = prio_permille != 0 ? (uint32_t)(run_steps * prio_permille / 1000) & ~3u : 0;
       if (prio_steps != 0)
       {
         __builtin_amdgcn_s_setprio(1);

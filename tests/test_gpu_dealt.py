@@ -1,0 +1,95 @@
+"""k_decode_dealt (round 6): block_/mt_ plans with checkpoints decoded in ONE round with host-dealt shares — the launch a rank of a
+sharded decode runs (128 MiB of BASELINE config 4's stream) and 100 MB-class mt_ streams in >= 128 KiB blocks at any index interval.
+Every case asserts that the launch under test is the one that ran (hsrans_launch_info: spread == 2) and compares the GPU's bytes
+with the oracle's decode of the same stream (reference semantics: /root/reference/src/mt_rANS32x64_16w_decode.cpp:41-133,
+block_rANS32x64_16w_decode.cpp:36-126)."""
+import numpy as np
+import pytest
+
+import hypersonic_rans_amd as H
+from hypersonic_rans_amd import synth
+from oracle_lib import BLOCK, MT
+
+pytestmark = pytest.mark.gpu
+
+
+def shifting(n: int, seed: int, period: int) -> np.ndarray:
+    """enwik8-shaped bytes whose alphabet is re-mapped every `period` bytes: every block gets a histogram of its own, so a workgroup
+    whose share straddles two blocks really needs its two tables (and no single-symbol blocks: those keep the older launches)"""
+    d = synth.enwik8_shaped(n, seed=seed).copy()
+    for k, lo in enumerate(range(0, n, period)):
+        d[lo:lo + period] ^= np.uint8((k * 37) & 0xFF)
+    return d
+
+
+CASES = (
+    # container, bits, size, block, interval
+    (H.MT, 11, 24_000_000, 1 << 18, 8),
+    (H.MT, 11, 24_000_001, 1 << 18, 16),      # a final partial group
+    (H.MT, 10, 40_000_000, 1 << 20, 16),
+    (H.MT, 11, 33_554_432, 1 << 17, 16),      # 256 blocks for 512 workgroups: most shares inside one block
+    (H.MT, 11, 50_000_000, 3 * 65536, 4),     # many chains per wave
+    (H.BLOCK, 11, 30_000_000, 1 << 18, 16),   # block_: states carried over the block boundaries, checkpoints at them
+    (H.MT, 11, 20_000_000, 0, 16),            # the reference's adaptive block policy (blocks of >= 64 KiB where the histogram holds)
+)
+
+
+@pytest.mark.parametrize("container,bits,size,block,interval", CASES)
+def test_dealt_launch_against_the_oracle(gpu_ctx, oracle, container, bits, size, block, interval):
+    import torch
+    d = shifting(size, seed=bits + interval, period=block if block else 150_000)
+    stream, plan = H.encode(container, 64, bits, d, index_interval=interval, block_size=block)
+    r, want = oracle.decode(MT if container == H.MT else BLOCK, 64, bits, stream, size)
+    assert r == size and np.array_equal(want, d)
+    dplan = gpu_ctx.make_device_plan(plan)
+    d_in = torch.from_numpy(np.concatenate([stream, np.zeros((-stream.size) % 16 + 16, np.uint8)])).cuda()
+    d_out = torch.full((size + 64,), 0xCC, dtype=torch.uint8, device="cuda")
+    for _ in range(2):  # (the dealing is cached in the device plan: the second launch reuses it)
+        gpu_ctx.decode_device(dplan, d_in, d_out[:size], stream_length=stream.size)
+    assert gpu_ctx.status(dplan) == 0
+    info = dplan.launch_info()
+    assert info["spread"] == 2, info
+    got = d_out.cpu().numpy()
+    assert np.array_equal(got[:size], want), int(np.argmax(got[:size] != want))
+    assert (got[size:] == 0xCC).all()  # nothing written behind the output
+
+
+def test_dealt_launch_of_a_gpu_encoded_stream_and_its_device_built_plan(gpu_ctx, oracle):
+    """encode -> decode without leaving HBM: the plan is written by the encoder's kernels, the dealing reads the block list back (32
+    bytes a group) when the plan is made"""
+    import torch
+    n = 48_000_000
+    d = shifting(n, seed=3, period=1 << 18)
+    d_in = torch.from_numpy(d).cuda()
+    enc = torch.empty(H.capacity(H.MT, 64, n), dtype=torch.uint8, device="cuda")
+    for interval in (8, 32):
+        m, dplan = gpu_ctx.encode_device(H.MT, 64, 11, d_in, enc, block_size=1 << 18, index_interval=interval, want_plan=True)
+        r, want = oracle.decode(MT, 64, 11, enc[:m].cpu().numpy(), n)
+        assert r == n and np.array_equal(want, d)
+        out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        gpu_ctx.decode_device(dplan, enc, out, stream_length=m)
+        assert gpu_ctx.status(dplan) == 0 and dplan.launch_info()["spread"] == 2
+        assert torch.equal(out, d_in)
+
+
+def test_plans_the_dealt_launch_does_not_take_keep_their_launch(gpu_ctx, monkeypatch):
+    """single-symbol blocks, 12 bits, too few chains, HSRANS_DEALT=0: the older launches, same bytes"""
+    import torch
+
+    def launch_of(data, bits, block, interval):
+        stream, plan = H.encode(H.MT, 64, bits, data, index_interval=interval, block_size=block)
+        dplan = gpu_ctx.make_device_plan(plan)
+        d_in = torch.from_numpy(np.concatenate([stream, np.zeros((-stream.size) % 16 + 16, np.uint8)])).cuda()
+        out = torch.zeros(data.size, dtype=torch.uint8, device="cuda")
+        gpu_ctx.decode_device(dplan, d_in, out, stream_length=stream.size)
+        assert gpu_ctx.status(dplan) == 0 and np.array_equal(out.cpu().numpy(), data)
+        return dplan.launch_info()["spread"]
+
+    d = shifting(24_000_000, seed=9, period=1 << 18)
+    assert launch_of(d, 11, 1 << 18, 8) == 2
+    assert launch_of(d, 12, 1 << 18, 8) != 2          # two 32 KiB tables do not fit beside the rings twice per CU
+    assert launch_of(d[:3_000_000], 11, 1 << 18, 8) != 2  # fewer chains than two per wave of the device
+    runs = synth.nonstationary(24_000_000, seed=2)     # holds single-symbol blocks
+    assert launch_of(runs, 11, 1 << 16, 8) != 2
+    monkeypatch.setenv("HSRANS_DEALT", "0")
+    assert launch_of(d, 11, 1 << 18, 8) != 2

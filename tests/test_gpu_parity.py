@@ -433,7 +433,7 @@ def test_a_ranks_sub_runs_announce_their_completion(gpu_ctx, monkeypatch, one_la
             torch.cuda.synchronize()
             dec.check()
         if one_launch and size > 10_000_000:
-            assert dec.launch_info()["spread"] == 1
+            assert dec.launch_info()["spread"] == 2  # (k_decode_dealt counting its workgroups into the sub-runs)
 
 
 def test_sharded_decode_single_rank_over_rccl(gpu_ctx, zipf):

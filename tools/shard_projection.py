@@ -42,6 +42,8 @@ args = ap.parse_args()
 
 ctx = H.Context(0)
 ctx.calibrate()
+for copies in (2, 3, 5):  # class lengths fitted for runs of ~190 / 290 / 480 groups too (100 MB, 128 MiB, 256 MiB per launch): the dealt launch picks the nearest
+    ctx.calibrate_runs(copies=copies)
 n = args.size
 d_in = torch.from_numpy(synth.enwik8_shaped(n, seed=20241008)).cuda()
 COPIES = args.copies

@@ -18,6 +18,8 @@ from hypersonic_rans_amd import synth
 
 ctx = H.Context(0)
 ctx.calibrate()
+for copies in (2, 3, 5):  # class lengths fitted for runs of ~190 / 290 / 480 groups too (100 MB, 128 MiB, 256 MiB per launch): the dealt launch picks the nearest
+    ctx.calibrate_runs(copies=copies)
 d = synth.enwik8_shaped(100_000_000, seed=1)
 d_in = torch.from_numpy(d).cuda()
 COPIES = 4

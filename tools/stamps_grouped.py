@@ -58,3 +58,16 @@ print(f"per round (us): wait {np.median(us(1) / r):.2f}  build {np.median(us(2) 
 w = np.arange(len(buf) // 8)[: len(st)] % info["waves_per_block"]
 for name, col in (("wait", 1), ("decode", 4)):
     print(f"{name} per round by wave in workgroup:", " ".join(f"{np.median((us(col) / r)[w == k]):.1f}" for k in range(info["waves_per_block"])))
+# by scheduling class (grid half x wave quarter): when the waves enter, what each phase costs them, when they are done (us since the launch's first wave)
+wpb = info["waves_per_block"]
+idx = np.arange(len(buf) // 8)
+keep = buf.reshape(-1, 8).astype(np.int64)[:, 5] > 0
+wg, wv = (idx // wpb)[keep], (idx % wpb)[keep]
+half = (wg >= (info["grid"] + 1) // 2).astype(int)
+cls = half * 4 + np.minimum(wv // max(wpb // 4, 1), 3)
+print("class: waves | entry p50 | wait | build | records+chunks | decode | done p50 / max   (us; sums over the wave's rounds)")
+for k in range(8):
+    m = cls == k
+    if m.any():
+        print(f"  {k}: {m.sum():5d} | {np.median((st[m, 0] - t0) / 100.0):6.1f} | {np.median(us(1)[m]):5.1f} | {np.median(us(2)[m]):5.1f} | {np.median(us(3)[m]):5.1f} | {np.median(us(4)[m]):5.1f} | "
+              f"{np.median((st[m, 6] - t0) / 100.0):6.1f} / {((st[m, 6] - t0) / 100.0).max():6.1f}")
