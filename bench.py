@@ -37,6 +37,8 @@ from hypersonic_rans_amd import synth
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable by a copy kernel
 VALU_SLOT_NS = 1.9     # one wave64 VALU instruction of the loop's dominant (VOP3 / SGPR-operand) class per SIMD, measured
 SIMDS = 1024           # 256 CUs x 4
+COPY_PEAK_GBS = 6300.0 # what a device copy kernel reaches of the 8 TB/s (MI355X_MICROARCH.md)
+SHADER_GHZ = 2.1       # shader clock under this load (per-wave s_memtime stamps against s_memrealtime: DESIGN.md 5)
 
 
 def _cpu_model() -> str:
@@ -417,6 +419,15 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
             issue = {"valu_per_group": per_group, "slot_ns": VALU_SLOT_NS, "simds": SIMDS, "us": per_group * VALU_SLOT_NS * groups_per_launch / SIMDS * 1e-3,
                      "note": "VALU instructions per 64-symbol group (SQ_INSTS_VALU / groups) x 1.9 ns per issue slot x groups / 1,024 SIMDs: the time the "
                              "vector issue alone needs; counters from " + traffic_source}
+    lds_bound = None
+    if prof is not None and prof[1] is not None:
+        lds = prof[1]["counters"].get("SQ_LDS_IDX_ACTIVE", {}).get("mean")
+        conf = prof[1]["counters"].get("SQ_LDS_BANK_CONFLICT", {}).get("mean")
+        if lds:
+            lds_bound = {"lds_cycles_per_group_and_cu": lds / groups_per_launch, "bank_conflict_share": (conf / lds) if conf else None, "cus": SIMDS // 4, "clock_ghz": SHADER_GHZ,
+                         "us": lds / (SIMDS // 4) / (SHADER_GHZ * 1e3),
+                         "note": "LDS-array cycles (SQ_LDS_IDX_ACTIVE, summed over the CUs) / 256 CUs / 2.1 GHz: the time the CUs' LDS pipelines alone need for the table gathers and word "
+                                 "reads of one launch — with issue_bound the two units that actually bind this kernel; the HBM roofline does not (DESIGN.md 5)"}
     result = {
         "metric": "decode MiB/s (bit-exact) on 100 MB stream",
         "value": world * units * n / 2**20 / elapsed * args.steps,
@@ -480,6 +491,10 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
             "warm": {"kernel_ms_avg": float(warm_ms), "frac": alg_bytes / (warm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms_per_pair": [float(x) for x in warm_each],
                      "cache_state": "one pair replayed back to back (Infinity-Cache resident, as BENCH_r01 measured)"},
             "issue_bound": issue,
+            "lds_bound": lds_bound, "lds_bound_us": None if lds_bound is None else lds_bound["us"],
+            # against what a plain copy kernel reaches on this part (~6.3 TB/s, MI355X_MICROARCH.md) instead of the 8 TB/s pin rate
+            "frac_of_copy_peak": achieved / COPY_PEAK_GBS,
+            "binds": "vector issue + LDS gather (issue_bound / lds_bound), not HBM: traffic is ~1.03 x algorithmic and the kernel time is ~2 x the HBM time",
             "kernel": "hsrans::k_decode_batch<3>" if args.one_launch else ("hsrans::k_decode_dual<%d>" % info["table_mode"]) if info["chains_per_wave"] == 2 else
                       ("hsrans::k_decode_direct<%d>" % info["table_mode"]) if args.index == "wave" else
                       "hsrans::k_decode<%d, %s>" % (info["table_mode"], "true" if info["shared_table"] else "false"),
@@ -535,7 +550,202 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
 
     if not args.no_cpu and world == 1:  # reported baseline, N=1 only
         result["cpu_baseline"] = cpu_baseline(stream, pairs[0]["data"], S, bits)
+    # the other BASELINE configurations' 1-GPU legs, in the same driver-timed run (after everything the headline measures: they re-use and then
+    # release its buffers)
+    if world == 1 and not args.no_configs and not args.timed_only and not args.one_launch and S == 64 and bits == 11 and n == 100_000_000:
+        t0 = time.perf_counter()
+        result["configs"] = config_legs(args, ctx, dev, pairs, n)
+        result["configs_wall_s"] = time.perf_counter() - t0
+        c4 = next((c for c in result["configs"] if c.get("config") == 4 and "MiB_s" in c), None)
+        if c4 is not None:  # (the N > 1 line is another workload — this is the N = 1 value to set it against)
+            result["sharded_workload_one_gpu"] = {"MiB_s": c4["MiB_s"], "us": c4["us"], "frac_of_hbm_peak": c4["frac_of_hbm_peak"],
+                                                  "note": "`bench.py --gpus N` (N > 1) decodes ONE 2^30-byte mt_ stream sharded over N ranks: compare its `value` with THIS figure, not with the headline's"}
     return result
+
+
+def config_legs(args, ctx, dev, pairs, n: int, budget_s: float = 90.0) -> list:
+    """The 1-GPU legs of BASELINE.json's OTHER configurations, timed in the driver's own run of this file (until round 6 only the
+    headline was driver-witnessed, twenty figures were builder-run files under profiles/).  The reference's harness walks every codec over one
+    input in one process and prints a line each (src/main.cpp:841-898); this walks the configurations:
+      config 3   rANS32x64 16w raw at 12 / 14 / 15 bits on the headline's own four 100 MB inputs: one launch per stream (rotated), and the four
+                 streams in ONE launch (hsrans_decode_device_batch); at 12 bits also with the decode table left in global memory
+                 ("LDS-resident vs spilled table": HSRANS_TABLE_SPILL=1 is read when a device plan is made)
+      config 4   ONE 2^30-byte mt_ stream in 256 KiB blocks (+ a checkpoint every --configs-interval groups), GPU-encoded, decode only — what
+                 `--gpus N` shards; this is the N = 1 figure of that workload
+      config 5   the same 2^30 bytes from / to page-locked HOST memory through the C ABI's pipeline (PCIe-inclusive, marked so; one GPU)
+    Every leg: streams written by the GPU encoders (byte-identical to the host encoder's and, raw, to the reference's: tests/), output
+    compared with the source bytes before and after the timed launches, HIP events on the launch stream, the median sample behind a
+    short settle.  Fractions are of 8 TB/s on the algorithmic bytes (compressed read once + decoded written once).  Stops adding legs when
+    `budget_s` is spent (a leg that did not run is listed as skipped, never silently missing)."""
+    t_start = time.perf_counter()
+    legs = []
+    S = 64
+    P = len(pairs)
+    d_src = [torch.from_numpy(p["data"]).to(dev) for p in pairs]
+
+    def timed(fn, launches, samples=5, settle_ms=20.0):
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < settle_ms:
+            for _ in range(launches):
+                fn()
+            torch.cuda.synchronize()
+        out = []
+        for _ in range(samples):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(launches):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            out.append(a.elapsed_time(b) / launches)
+        return float(np.median(out)), [float(x) for x in out]
+
+    def kernel_name(info, batch=False):
+        if batch:
+            return "hsrans::k_decode_batch_dual<%d>" % info if isinstance(info, int) else "hsrans::k_decode_batch<3>"
+        if info["chains_per_wave"] == 2:
+            return "hsrans::k_decode_dual<%d>" % info["table_mode"]
+        return "hsrans::k_decode_direct<%d>" % info["table_mode"]
+
+    def raw_streams(bits, groups_of):
+        """the four inputs as raw streams of this width with the given index (GPU raw encoder: one wavefront, ~0.1 s per 100 MB)"""
+        out = []
+        for k in range(P):
+            d_raw = torch.empty(H.capacity(H.RAW, S, n) + 16, dtype=torch.uint8, device=dev)
+            m, dplan = ctx.encode_device_raw(S, bits, d_src[k], d_raw, index_groups=groups_of(k), want_device_plan=True)
+            out.append((d_raw, m, dplan))
+        return out
+
+    def check(outs):
+        return all(bool(torch.equal(o, d)) for o, d in zip(outs, d_src))
+
+    outs = [p["d_out"] for p in pairs]
+    for bits in (12, 14, 15):
+        if time.perf_counter() - t_start > budget_s:
+            legs.append({"config": 3, "bits": bits, "skipped": "time budget"})
+            continue
+        try:
+            groups = H.index_boundaries(S, bits, n, ctx)
+            st = raw_streams(bits, lambda k: groups)
+            k = [0]
+
+            def one():
+                i = k[0] % P
+                k[0] += 1
+                ctx.decode_device(st[i][2], st[i][0], outs[i], stream_length=st[i][1])
+
+            for o in outs:
+                o.zero_()
+            for _ in range(P):
+                one()
+            torch.cuda.synchronize()
+            ok = check(outs) and all(ctx.status(x[2]) == 0 for x in st)
+            ms, samples = timed(one, 4 * P)
+            ok = ok and check(outs)
+            alg = int(np.mean([x[1] for x in st])) + n
+            info = st[0][2].launch_info()
+            leg = {"config": 3, "workload": f"rANS32x64 16w {bits}-bit raw, {n} B, {P} streams rotated, one launch per stream, one chain per resident wavefront",
+                   "bits": bits, "us_per_stream": ms * 1e3, "MiB_s": n / 2**20 / (ms * 1e-3), "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "kernel": kernel_name(info), "table": "LDS", "compressed_bytes": int(st[0][1]), "bit_exact": bool(ok), "samples_ms": samples}
+            # the four streams in ONE launch, indexes shaped for it
+            sb = raw_streams(bits, lambda k: H.index_boundaries_batch(S, bits, [n] * P, k, ctx))
+            batch = ctx.make_batch([x[2] for x in sb])
+            b_in, b_len = [x[0] for x in sb], [x[1] for x in sb]
+            for o in outs:
+                o.zero_()
+            ctx.decode_device_batch(batch, b_in, outs, stream_lengths=b_len)
+            torch.cuda.synchronize()
+            okb = check(outs) and ctx.batch_status(batch) == [0] * P
+            msb, _ = timed(lambda: ctx.decode_device_batch(batch, b_in, outs, stream_lengths=b_len), 6)
+            okb = okb and check(outs)
+            leg["four_streams_one_launch"] = {"us_per_stream": msb / P * 1e3, "frac_of_hbm_peak": alg / (msb / P * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches": batch.info()["launches"],
+                                              "kernel": "hsrans::k_decode_batch<3>" if bits <= 12 else "hsrans::k_decode_batch_dual<%d>" % (3 if bits == 13 else 4), "bit_exact": bool(okb)}
+            if bits == 12:  # LDS-resident vs spilled table, same streams, same process
+                os.environ["HSRANS_TABLE_SPILL"] = "1"
+                try:
+                    sp = [ctx.make_device_plan(ctx.read_device_plan(x[2], capacity=1 << 26)) for x in st]
+                finally:
+                    os.environ.pop("HSRANS_TABLE_SPILL", None)
+                j = [0]
+
+                def spilled():
+                    i = j[0] % P
+                    j[0] += 1
+                    ctx.decode_device(sp[i], st[i][0], outs[i], stream_length=st[i][1])
+
+                for o in outs:
+                    o.zero_()
+                for _ in range(P):
+                    spilled()
+                torch.cuda.synchronize()
+                oks = check(outs) and all(ctx.status(x) == 0 for x in sp)
+                mss, _ = timed(spilled, P, samples=3, settle_ms=5.0)
+                leg["table_in_global_memory"] = {"us_per_stream": mss * 1e3, "frac_of_hbm_peak": alg / (mss * 1e-3) / 1e9 / HBM_PEAK_GBS, "slower_by": mss / ms,
+                                                 "kernel": "hsrans::k_decode_direct<5>", "table_mode": sp[0].launch_info()["table_mode"], "bit_exact": bool(oks)}
+                del sp
+            legs.append(leg)
+            del st, sb, batch
+        except Exception as e:  # a leg that fails is reported, the headline stands
+            legs.append({"config": 3, "bits": bits, "failed": repr(e)})
+        torch.cuda.empty_cache()
+
+    # ---- configs 4 and 5: ONE 2^30-byte mt_ stream ------------------------------------------------------------------------------------
+    big = 1 << 30
+    if time.perf_counter() - t_start > budget_s:
+        legs += [{"config": 4, "skipped": "time budget"}, {"config": 5, "skipped": "time budget"}]
+        return legs
+    try:
+        d_big = torch.cat(d_src * ((big + P * n - 1) // (P * n)))[:big].contiguous()  # the four inputs (four byte permutations) tiled: every 100 MB another histogram
+        del d_src
+        enc = torch.empty(H.capacity(H.MT, S, big), dtype=torch.uint8, device=dev)
+        t0 = time.perf_counter()
+        m, dplan = ctx.encode_device(H.MT, S, 11, d_big, enc, block_size=1 << 18, index_interval=args.configs_interval, want_plan=True)
+        t_enc = time.perf_counter() - t0
+        out = torch.zeros(big, dtype=torch.uint8, device=dev)
+        ctx.decode_device(dplan, enc, out, stream_length=m)
+        torch.cuda.synchronize()
+        ok = ctx.status(dplan) == 0 and bool(torch.equal(out, d_big))
+        ms, samples = timed(lambda: ctx.decode_device(dplan, enc, out, stream_length=m), 8)
+        ok = ok and bool(torch.equal(out, d_big))
+        info = dplan.launch_info()
+        legs.append({"config": 4, "workload": f"mt_rANS32x64 16w 11-bit, ONE {big}-byte stream in 256 KiB blocks + a checkpoint every {args.configs_interval} groups, GPU-encoded, "
+                                              "decode only, one GPU: the N = 1 figure of `bench.py --gpus N` (which shards this stream over N ranks)",
+                     "us": ms * 1e3, "MiB_s": big / 2**20 / (ms * 1e-3), "frac_of_hbm_peak": (m + big) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "compressed_bytes": int(m),
+                     "kernel": "hsrans::k_decode_dealt" if info["spread"] == 2 else "hsrans::k_decode_spread<3>" if info["spread"] == 1 else "hsrans::k_decode_grouped<%d, true>" % info["table_mode"],
+                     "launch": {k: info[k] for k in ("grid", "block", "lds_bytes", "chains", "dynamic_groups", "spread")}, "gpu_encode_ms": t_enc * 1e3, "bit_exact": bool(ok), "samples_ms": samples})
+    except Exception as e:
+        legs.append({"config": 4, "failed": repr(e)})
+        return legs
+    if time.perf_counter() - t_start > budget_s:
+        legs.append({"config": 5, "skipped": "time budget"})
+        return legs
+    try:
+        from hypersonic_rans_amd import pipeline
+        plan = ctx.read_device_plan(dplan, capacity=1 << 30)
+        host_stream = torch.empty(m, dtype=torch.uint8).pin_memory()
+        host_stream.copy_(enc[:m])
+        host_ref = d_big.cpu()
+        del enc, out, dplan, d_big
+        torch.cuda.empty_cache()
+        host_out = torch.empty(big, dtype=torch.uint8).pin_memory()
+        dec = pipeline.PipelinedHostDecoder(ctx, plan)
+        dec.decode(host_stream, host_out)
+        ok = bool(torch.equal(host_out, host_ref))
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            dec.decode(host_stream, host_out)  # synchronous: the decoded bytes are in host memory on return
+            ts.append(time.perf_counter() - t0)
+        ok = ok and bool(torch.equal(host_out, host_ref))
+        t = float(np.median(ts))
+        legs.append({"config": 5, "workload": f"the same {big}-byte mt_ stream from page-locked host memory into page-locked host memory: hsrans_hpipe (upload, decode and download of "
+                                              "consecutive slices overlapped on three HIP streams), one GPU",
+                     "pcie_inclusive": True, "ms": t * 1e3, "decoded_GB_s": big / t / 1e9, "MiB_s": big / 2**20 / t, "frac_of_pcie_d2h_63GBs": big / t / 1e9 / 63.0, "bit_exact": bool(ok),
+                     "note": "PCIe-inclusive: never the headline's value; the roofline that bounds it is the link (63 GB/s per direction), not HBM"})
+        dec.close()
+    except Exception as e:
+        legs.append({"config": 5, "failed": repr(e)})
+    return legs
 
 
 def _tiled(n: int, seed: int) -> np.ndarray:
@@ -870,6 +1080,8 @@ def main() -> None:
     ap.add_argument("--interval", type=int, default=256, help="sharded: checkpoint interval inside the blocks, in groups")
     ap.add_argument("--parts", type=int, default=4, help="sharded: sub-runs per rank; sub-run k's exchange overlaps sub-run k+1's decode")
     ap.add_argument("--root-share", type=float, default=0.0, help="sharded: the root's share of the decoded bytes (0 = balance it against the measured inbound rate)")
+    ap.add_argument("--no-configs", action="store_true", help="headline: skip the 1-GPU legs of BASELINE configs 3, 4 and 5 (result['configs'])")
+    ap.add_argument("--configs-interval", type=int, default=64, help="configs 4 / 5: checkpoint interval of the 2^30-byte mt_ stream, in groups")
     ap.add_argument("--no-replicas", action="store_true", help="sharded, N > 1: skip the weak-scaling replicas leg")
     ap.add_argument("--no-calibrate", action="store_true", help="headline: shape the index with the compiled-in class lengths instead of fitting them to this device")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")

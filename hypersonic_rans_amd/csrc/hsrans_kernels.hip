@@ -130,7 +130,9 @@ static uint32_t g_direct_weights_pair[8] = {1662, 1550, 1365, 1142, 887, 656, 45
 // blocks 0.25 -> 0.30 ms (everything is latency-bound there and half as many waves are in flight)
 static uint32_t g_private_pair = 1;
 static constexpr bool g_weights_two_level = false; // (the class weights are not applied to the two-level table mode: measured, knob removed)
-static bool g_table_spill = false;       // HSRANS_TABLE_SPILL: host-built tables stay in global memory (kModeSpill; comparison only)
+// HSRANS_TABLE_SPILL=1 (host-built tables stay in global memory: kModeSpill, BASELINE config 3's comparison side) is read whenever a table is
+// chosen — at device-plan creation — so that one process can time both sides on the same buffers (bench.py's config-3 leg)
+static bool table_spill_now() { const char *e = getenv("HSRANS_TABLE_SPILL"); return e != nullptr && e[0] != '\0' && e[0] != '0'; }
 // one-chain-per-wave plans (hsrans_index_boundaries): share of the stream (per mille) left to short chains that the ticket
 // queues hand to waves that are done early, and the length of those chains in groups
 
@@ -162,7 +164,7 @@ static KernelFn kernel_for(int mode, bool shared)
 }
 
 uint32_t pack64_max_bits() { return g_pack64_max_bits; }
-bool table_spill() { return g_table_spill; }
+bool table_spill() { return table_spill_now(); }
 
 // Which host-built decode table a plan that carries its histogram gets, and whether its launch runs two chains per wave.
 // `direct`: the plan has one chain per wave (PlanHeader::interval == 0), which is what the dual kernel is written for.
@@ -170,7 +172,7 @@ TableChoice choose_table(uint32_t bits, uint32_t states, bool direct)
 {
   read_tuning_once();
   TableChoice t{0, false};
-  if (g_table_spill)
+  if (table_spill_now())
     t.mode = kModeSpill;
   else if (direct && g_dual == 2 && states == 64 && bits <= 12) // experiment: the dual kernel below 13 bits too
   {
@@ -258,7 +260,6 @@ static void read_tuning_impl()
   read_weights("HSRANS_DIRECT_WEIGHTS6", g_direct_weights6);
   read_weights("HSRANS_DIRECT_WEIGHTS3", g_direct_weights3);
   read_weights("HSRANS_DIRECT_WEIGHTS_PAIR", g_direct_weights_pair);
-  g_table_spill = getenv("HSRANS_TABLE_SPILL") != nullptr;
   if (const char *e = getenv("HSRANS_PRIVATE_PAIR"))
     g_private_pair = (uint32_t)atoi(e);
   if (const char *e = getenv("HSRANS_DUAL"))
@@ -392,7 +393,7 @@ static void cum_from_weights(const uint32_t w8[8], uint16_t (*cum_out)[17])
 }
 
 static uint32_t g_dealt = 1;          // HSRANS_DEALT=0: grouped plans keep k_decode_spread / k_decode_grouped (comparison)
-static uint32_t g_dealt_min_chains = 2; // HSRANS_DEALT_MIN_CHAINS: chains per wave of the launch below which a plan is not dealt (tuning)
+static uint32_t g_dealt_min_chains = 1400; // HSRANS_DEALT_MIN_CHAINS: chains per 1,000 waves of the launch below which a plan is not dealt (tuning; 100 MB in 256 KiB blocks, G = 128 — 1.49 chains a wave — 58.5 us grouped, 47.4 dealt; one chain a wave leaves the class weights nothing to work with)
 static uint32_t g_dealt_wt = 1;       // HSRANS_DEALT_WT=0: k_decode_dealt's stores as `nt` instead of written through (comparison)
 
 bool deal_shares(const DeviceGeom &dg, const uint32_t *block_begin, uint32_t n_blocks, uint32_t n_chains, uint64_t total_groups, DealtTable *out, uint32_t weights_out[8])
@@ -401,11 +402,11 @@ bool deal_shares(const DeviceGeom &dg, const uint32_t *block_begin, uint32_t n_b
   // (read at every dealing, not once: tools/ab_probe.py and the tests switch sides inside one process)
   const char *e_on = getenv("HSRANS_DEALT"), *e_min = getenv("HSRANS_DEALT_MIN_CHAINS");
   g_dealt = e_on ? (uint32_t)atoi(e_on) : 1;
-  g_dealt_min_chains = e_min && atoi(e_min) > 0 ? (uint32_t)atoi(e_min) : 2;
+  g_dealt_min_chains = e_min && atoi(e_min) > 0 ? (uint32_t)atoi(e_min) : 1400;
   const uint32_t grid = spread_grid(dg);
-  if (!g_dealt || grid > kDealtGridMax || n_blocks == 0 || block_begin[0] != 0 || block_begin[n_blocks] != n_chains)
+  if (!g_dealt || !g_spread || grid > kDealtGridMax || n_blocks == 0 || block_begin[0] != 0 || block_begin[n_blocks] != n_chains)
     return false;
-  if ((uint64_t)n_chains < (uint64_t)grid * kSpreadWaves * g_dealt_min_chains)
+  if ((uint64_t)n_chains * 1000 < (uint64_t)grid * kSpreadWaves * g_dealt_min_chains)
     return false;
   // a workgroup's weight = the sum of its waves' (four waves per class; as the kernel's cumulative table has them); the first half of the grid is resident first
   uint64_t w1 = 0, w2 = 0;
@@ -453,7 +454,7 @@ bool deal_shares(const DeviceGeom &dg, const uint32_t *block_begin, uint32_t n_b
   // most loaded workgroup: the grouped launch's case as well
   const double mean = (double)n_chains / (double)((uint64_t)fh * w1 + (uint64_t)(grid - fh) * w2);
   for (uint32_t b = 0; b < grid; b++)
-    if ((double)(out->begin[b + 1] - out->begin[b]) / (double)(b < fh ? w1 : w2) > 1.6 * mean + 1.0 / (double)w2)
+    if ((double)(out->begin[b + 1] - out->begin[b]) / (double)(b < fh ? w1 : w2) > 1.25 * mean + 1.0 / (double)w2)
       return false;
   return true;
 }

@@ -88,7 +88,7 @@ def test_plans_the_dealt_launch_does_not_take_keep_their_launch(gpu_ctx, monkeyp
     d = shifting(24_000_000, seed=9, period=1 << 18)
     assert launch_of(d, 11, 1 << 18, 8) == 2
     assert launch_of(d, 12, 1 << 18, 8) != 2          # two 32 KiB tables do not fit beside the rings twice per CU
-    assert launch_of(d[:3_000_000], 11, 1 << 18, 8) != 2  # fewer chains than two per wave of the device
+    assert launch_of(d[:3_000_000], 11, 1 << 18, 8) != 2  # fewer chains than 1.4 per wave of the device
     runs = synth.nonstationary(24_000_000, seed=2)     # holds single-symbol blocks
     assert launch_of(runs, 11, 1 << 16, 8) != 2
     monkeypatch.setenv("HSRANS_DEALT", "0")

@@ -56,3 +56,12 @@ for k in range(8):
         print(f"  {k}: {np.median(us(0)[mk]):5.1f} | {np.median(us(1)[mk]):5.1f} | {np.median(us(2)[mk]):5.1f} | {np.percentile(dn, 10):5.1f} / {np.median(dn):5.1f} / {np.percentile(dn, 90):5.1f} / {dn.max():5.1f}")
 alld = us(3)[st[:, 3] > 0]
 print(f"all waves done: p50 {np.median(alld):.1f}  p99 {np.percentile(alld, 99):.1f}  max {alld.max():.1f}")
+# the launch's last waves: who they are (a late start? one workgroup? one class?)
+order = np.argsort(-us(3))
+print("slowest waves: workgroup.wave class | first group | done | decode")
+for i in order[:24]:
+    print(f"  {i // wpb:4d}.{i % wpb:<2d} c{cls[i]} | {us(2)[i]:5.1f} | {us(3)[i]:5.1f} | {us(3)[i] - us(2)[i]:5.1f}")
+wg_done = us(3).reshape(-1, wpb).max(axis=1)
+late = np.argsort(-wg_done)[:32]
+print("latest workgroups:", sorted(late.tolist()))
+print("decode time (done - first group) by class p50/p99/max:", " ".join(f"c{k}:{np.median((us(3)-us(2))[cls==k]):.1f}/{np.percentile((us(3)-us(2))[cls==k],99):.1f}/{(us(3)-us(2))[cls==k].max():.1f}" for k in range(8)))
