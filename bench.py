@@ -390,6 +390,43 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
         one_launch = batch_leg([d for _, d in shaped])
         one_launch["index"] = {"kind": "hsrans_index_boundaries_batch", "plan_bytes_per_stream": int(shaped[0][0]), "chains_per_stream": H.plan_chain_count(bplan),
                                "index_build_ms_per_stream": t_shaped / P * 1e3}
+        # ... the same streams SUBMITTED ONE BY ONE to a queue (hsrans_queue: a caller that meets its streams one after the other — the reference's
+        # loop over files, src/main.cpp:841-898 — and does not know K up front): every fourth submission flushes, the flush finds the batch it made
+        # the first time around.  Host-side submission inside the timed span; same kernels, same indexes as the leg above.
+        queue = H.api.Queue(ctx, max_members=P)
+        shaped_plans = [d for _, d in shaped]
+
+        def queued_round():
+            for k, p in enumerate(pairs):
+                queue.submit(shaped_plans[k], p["d_in"], p["d_out"], stream_length=p["stream"].size)
+
+        for p in pairs:
+            p["d_out"].zero_()
+        queued_round()
+        torch.cuda.synchronize()
+        for k, p in enumerate(pairs):
+            assert ctx.status(shaped_plans[k]) == 0 and np.array_equal(p["d_out"].cpu().numpy(), p["data"]), "queued launch: GPU output is not bit-exact"
+        rounds = max(4, args.steps // P)
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < max(3 * args.settle_ms, 1.0):
+            for _ in range(rounds):
+                queued_round()
+            torch.cuda.synchronize()
+        q_samples = []
+        for _ in range(max(5, args.repeats)):
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            for _ in range(rounds):
+                queued_round()
+            eb.record()
+            torch.cuda.synchronize()
+            q_samples.append(ea.elapsed_time(eb) / rounds)
+        for k, p in enumerate(pairs):
+            assert ctx.status(shaped_plans[k]) == 0 and np.array_equal(p["d_out"].cpu().numpy(), p["data"]), "queued launch: GPU output is not bit-exact after the timed launches"
+        q_ms = float(np.median(q_samples))
+        one_launch["queued"] = {"ms_per_stream": q_ms / P, "frac_of_hbm_peak": (int(np.mean(b_len)) + n) / (q_ms / P * 1e-3) / 1e9 / HBM_PEAK_GBS, "queue": queue.stats(),
+                                "note": f"the {P} streams submitted one by one to an hsrans_queue (max_members = {P}: the last submission flushes); the flush reuses the batch it made first"}
+        queue.close()
         # ... and with the sidecars the streams already have (made for a launch of their own)
         if args.index == "wave":
             own = batch_leg([p["dplan"] for p in pairs])
@@ -473,6 +510,8 @@ def headline(args, world, rank, dev, dev_index, ctx, dist):
                   {"value": n / 2**20 / (overlapped_ms * 1e-3), "ms_per_stream": overlapped_ms, "frac_of_hbm_peak": alg_bytes / (overlapped_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "note": f"the same {P} streams as independent work: launches alternate between two HIP streams, so a launch's prologue and tail overlap its "
                            "neighbour's decode (wall clock over 2K launches, median of 5); a step of the headline has the GPU to itself"},
+                  "independent_streams_queued": None if one_launch is None or "queued" not in one_launch else
+                  dict(one_launch["queued"], value=n / 2**20 / (one_launch["queued"]["ms_per_stream"] * 1e-3)),
                   "independent_streams_one_launch": None if one_launch is None else
                   dict(one_launch, value=n / 2**20 / (one_launch["ms_per_stream"] * 1e-3), frac_of_hbm_peak=alg_bytes / (one_launch["ms_per_stream"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        note=f"the same {P} streams decoded by ONE launch (hsrans_decode_device_batch: wave slots dealt to the streams, prologue / tail / kernel "

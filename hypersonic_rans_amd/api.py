@@ -49,6 +49,10 @@ class BatchInfo(ctypes.Structure):
                [("class_weights", _u32 * 8), ("imbalance", ctypes.c_double)]
 
 
+class QueueStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("submitted", "flushes", "launches", "batches_made", "batches_reused", "retargeted")]
+
+
 class Shard(ctypes.Structure):
     _fields_ = [("first_chain", _u32), ("chain_count", _u32), ("out_begin", ctypes.c_uint64), ("out_end", ctypes.c_uint64)]
 
@@ -153,6 +157,18 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_dplan_batch_status.argtypes = [_vp, _vp, _vp, _vp]
     L.hsrans_dplan_batch_info.restype = _i
     L.hsrans_dplan_batch_info.argtypes = [_vp, ctypes.POINTER(BatchInfo)]
+    L.hsrans_queue_create.restype = _i
+    L.hsrans_queue_create.argtypes = [_vp, _u32, ctypes.POINTER(_vp)]
+    L.hsrans_queue_destroy.restype = None
+    L.hsrans_queue_destroy.argtypes = [_vp]
+    L.hsrans_queue_submit.restype = _i
+    L.hsrans_queue_submit.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp]
+    L.hsrans_queue_flush.restype = _i
+    L.hsrans_queue_flush.argtypes = [_vp, _vp]
+    L.hsrans_queue_pending.restype = _u32
+    L.hsrans_queue_pending.argtypes = [_vp]
+    L.hsrans_queue_stats.restype = _i
+    L.hsrans_queue_stats.argtypes = [_vp, ctypes.POINTER(QueueStats)]
     L.hsrans_batch_deal.restype = ctypes.c_double
     L.hsrans_batch_deal.argtypes = [_vp, _vp, _u32, _u32, _u32, _vp, _vp]
     L.hsrans_dplan_batch_read_finish.restype = _sz
@@ -552,6 +568,55 @@ class Comm:
     def close(self):
         if getattr(self, "handle", None):
             self.ctx.L.hsrans_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Queue:
+    """hsrans_queue: streams submitted one by one, decoded by ONE batch launch per flush (the dealing cached per shape)."""
+
+    def __init__(self, ctx: "Context", max_members: int = 32):
+        self.ctx = ctx
+        h = _vp()
+        rc = ctx.L.hsrans_queue_create(ctx.handle, max_members, ctypes.byref(h))
+        if rc != 0:
+            raise HsransError(f"hsrans_queue_create failed with code {rc}")
+        self.handle = h
+        self._keep = []  # tensors and plans of the submissions still pending
+
+    def submit(self, dplan: "DevicePlan", d_stream: torch.Tensor, d_out: torch.Tensor, stream_length: int | None = None, stream: torch.cuda.Stream | None = None):
+        s = stream if stream is not None else torch.cuda.current_stream(d_out.device)
+        rc = self.ctx.L.hsrans_queue_submit(self.handle, dplan.handle, d_stream.data_ptr(), d_stream.numel() if stream_length is None else stream_length,
+                                            d_out.data_ptr(), d_out.numel(), ctypes.c_void_p(s.cuda_stream))
+        if rc != 0:
+            raise HsransError(f"hsrans_queue_submit failed with code {rc}")
+        self._keep.append((dplan, d_stream, d_out))
+        if self.pending() == 0:
+            self._keep.clear()
+
+    def flush(self, stream: torch.cuda.Stream | None = None):
+        s = stream if stream is not None else torch.cuda.current_stream()
+        rc = self.ctx.L.hsrans_queue_flush(self.handle, ctypes.c_void_p(s.cuda_stream))
+        self._keep.clear()
+        if rc != 0:
+            raise HsransError(f"hsrans_queue_flush failed with code {rc}")
+
+    def pending(self) -> int:
+        return int(self.ctx.L.hsrans_queue_pending(self.handle))
+
+    def stats(self) -> dict:
+        st = QueueStats()
+        self.ctx.L.hsrans_queue_stats(self.handle, ctypes.byref(st))
+        return {n: int(getattr(st, n)) for n, _ in QueueStats._fields_}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.L.hsrans_queue_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -265,6 +265,8 @@ extern "C++" int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_si
   d->n_groups = 0;
   d->groups_lean = false;
   d->spread_min_block = 0;
+  d->uid = next_dplan_uid(); // (a refill is another plan)
+  d->deal_sig = 0;
   d->block_begin.clear();
   d->dealt_state = 0;
   {
@@ -338,6 +340,12 @@ extern "C++" int dplan_fill(hsrans_dplan *d, const uint8_t *plan, size_t plan_si
     const uint64_t steps_total = (last.out_off - first.out_off) / h.states + last.steps;
     if (first.out_off > h.decoded_len || steps_total * h.states + last.tail > h.decoded_len - first.out_off)
       return fail(HSRANS_E_FORMAT);
+    {
+      uint64_t sig = 0x9E3779B97F4A7C15ull ^ ((uint64_t)h.states << 48) ^ ((uint64_t)h.bits << 40) ^ h.n_chains;
+      for (uint32_t i = 0; i < h.n_pieces; i++)
+        sig = (sig ^ pc[i].steps) * 0x100000001B3ull + (sig >> 29);
+      d->deal_sig = sig ? sig : 1;
+    }
     d->pa.pieces = (const Piece *)(d->d_plan + plan_pieces_off(h.n_chains));
     d->pa.states = (const uint32_t *)(d->d_plan + plan_states_off(h.n_chains, h.n_pieces));
     d->pa.n_chains = h.n_chains;

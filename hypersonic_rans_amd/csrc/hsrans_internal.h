@@ -61,9 +61,18 @@ struct hsrans_ctx
   size_t h_pin_cap = 0;
 };
 
+// every device plan (and every refill of one) has a number of its own: what hsrans_queue keys its cached batches by — an address can come back
+// with another plan behind it
+inline uint64_t next_dplan_uid()
+{
+  static std::atomic<uint64_t> n{1};
+  return n.fetch_add(1, std::memory_order_relaxed);
+}
+
 struct hsrans_dplan
 {
   hsrans_ctx *ctx = nullptr;
+  uint64_t uid = next_dplan_uid();
   PlanHeader hdr{};
   uint8_t *d_plan = nullptr;
   size_t d_plan_cap = 0;
@@ -98,6 +107,9 @@ struct hsrans_dplan
   // k_decode_dealt (kernels_dealt.h): the plan's blocks as chain ranges — block k = chains [block_begin[k], block_begin[k + 1]) — kept where the
   // plan is a lean grouped one of coded blocks only (no single-symbol blocks); empty otherwise.  `dealt` = the shares for `dealt_weights`
   // (dealt_state 1: valid, -1: the plan does not suit the launch with these weights, 0: not dealt yet); re-dealt when a calibration changes the weights.
+  // hsrans_queue: raw plans whose chains start at the same groups are dealt alike in a batch launch — a hash over (states, bits, chain count,
+  // every chain's groups), taken when the plan is filled from its host blob; 0 = none (plans written on the device, other containers)
+  uint64_t deal_sig = 0;
   std::vector<uint32_t> block_begin;
   DealtTable dealt{};
   uint32_t dealt_weights[8] = {};

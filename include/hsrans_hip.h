@@ -265,6 +265,31 @@ double hsrans_batch_deal(const uint64_t *const *chain_starts, const uint32_t *n_
 size_t hsrans_dplan_batch_read_finish(hsrans_batch *batch, uint64_t *out, size_t capacity_u64);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Open-ended submission: streams that arrive one by one.  The reference's pool takes tasks as they come (thread_pool_add,
+ * src/thread_pool.cpp:124-133) and its benchmark loop hands it file after file (src/main.cpp:841-898, :163-170); hsrans_dplan_batch_create
+ * wants all members at once.  A queue collects submissions on the host (a submit launches nothing, except that the `max_members`-th
+ * pending one flushes) and hsrans_queue_flush decodes everything pending with ONE batch launch.  What a batch costs to make (about a
+ * millisecond) is paid once per shape: the queue keeps the last 8 batches it made; the same device plans in the same order reuse theirs
+ * as it is, and OTHER raw plans of the same shapes (same decoded size and index geometry: a loop over files of one size class) reuse
+ * its dealing — only a 64-byte record per member is rewritten, asynchronously in front of the launch.  Use one `hip_stream` per queue
+ * at a time.  The buffers must stay valid until the flush's launch has run; per-member results: hsrans_dplan_status on the plans.
+ * A plan submitted again while it is still pending flushes first (a plan is one member of a launch).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct hsrans_queue hsrans_queue;
+typedef struct hsrans_queue_stats_t
+{
+  uint64_t submitted, flushes, launches; /* kernel launches made by the flushes */
+  uint64_t batches_made, batches_reused; /* flushes that had to make a batch / found theirs in the cache */
+  uint64_t retargeted;                   /* ... of the reused ones: with other plans of the same shapes */
+} hsrans_queue_stats_t;
+int hsrans_queue_create(hsrans_ctx *ctx, uint32_t max_members /* 1..32 */, hsrans_queue **out_queue);
+void hsrans_queue_destroy(hsrans_queue *queue); /* synchronises the device */
+int hsrans_queue_submit(hsrans_queue *queue, hsrans_dplan *dplan, const void *d_stream, size_t stream_length, void *d_out, size_t out_capacity, void *hip_stream);
+int hsrans_queue_flush(hsrans_queue *queue, void *hip_stream); /* asynchronous on hip_stream; nothing pending: HSRANS_OK, nothing launched */
+uint32_t hsrans_queue_pending(const hsrans_queue *queue);
+int hsrans_queue_stats(const hsrans_queue *queue, hsrans_queue_stats_t *out);
+
+/* ------------------------------------------------------------------------------------------------------------
  * ONE stream over the GPUs of a node: one process per GPU, the plan's chains cut into one contiguous run per rank, the decoded
  * ranges exchanged point to point over xGMI (RCCL ncclSend / ncclRecv groups on the communicator's own HIP stream), pipelined behind
  * the decode in `parts` sub-runs.  This is the C form of the reference's thread-pool fan-out behind the `thread_pool *` argument of

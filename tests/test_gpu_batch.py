@@ -307,3 +307,90 @@ def test_batch_argument_checks(gpu_ctx, oracle):
         gpu_ctx.decode_device_batch(batch, [m["d_in"] for m in ms], [ms[0]["d_out"], small], stream_lengths=[m["stream"].size for m in ms])
     torch.cuda.synchronize()
     assert int(ms[0]["d_out"].sum().item()) == 0, "nothing may have been launched when one member's arguments fail"
+
+
+@pytest.mark.gpu
+def test_queue_members_arriving_in_three_flushes(gpu_ctx, oracle):
+    """hsrans_queue (round 6): streams submitted ONE BY ONE, decoded by one batch launch per flush — the reference's pool takes tasks as they
+    arrive (src/thread_pool.cpp:124-133) and its loop hands it file after file (src/main.cpp:841-898, :163-170).  Ten streams of mixed kinds
+    arrive in three flushes (a flush by hand, one forced by `max_members`, a last one by hand); then the queue's three ways of finding a
+    batch: the very same plans again (reused as it is), OTHER streams of the same shapes (its dealing reused, only the member table
+    rewritten — also after the first plans were destroyed), and a plan submitted twice (flushes first).  Every member against the oracle."""
+    import torch
+    ctx = gpu_ctx
+
+    def member(container, states, bits, n, seed, **kw):
+        d = synth.enwik8_shaped(n, seed=seed)
+        if kw:
+            s, plan = H.encode(container, states, bits, d, **kw)
+        else:  # a stream without an index: a member with a launch of its own behind the shared ones
+            s = H.encode(container, states, bits, d)
+            plan = H.plan_build(container, states, bits, s)
+        r, want = oracle.decode({H.RAW: RAW, H.MT: MT, H.BLOCK: BLOCK}[container], states, bits, s, n)
+        assert r == n and np.array_equal(want, d)
+        d_in = torch.from_numpy(np.concatenate([s, np.zeros((-s.size) % 16 + 16, np.uint8)])).cuda()
+        return {"want": want, "len": s.size, "d_in": d_in, "out": torch.zeros(n, dtype=torch.uint8, device="cuda"), "dplan": ctx.make_device_plan(plan)}
+
+    def check(ms):
+        torch.cuda.synchronize()
+        for m in ms:
+            assert ctx.status(m["dplan"]) == 0
+            assert np.array_equal(m["out"].cpu().numpy(), m["want"])
+            m["out"].zero_()
+
+    mixed = [member(H.RAW, 64, 11, 3_000_000, 1, index_interval=16), member(H.RAW, 64, 12, 1_500_000, 2, index_interval=8),
+             member(H.MT, 64, 11, 2_000_000, 3, index_interval=16, block_size=65536), member(H.RAW, 32, 11, 2_000_000, 4, index_interval=16),
+             member(H.RAW, 64, 14, 2_500_000, 5, index_interval=16), member(H.RAW, 64, 11, 700_001, 6, index_interval=4),
+             member(H.MT, 64, 11, 1_000_000, 7, index_interval=8, block_size=65536), member(H.RAW, 64, 11, 5_000_000, 8, index_interval=32),
+             member(H.RAW, 64, 10, 900_000, 9), member(H.RAW, 64, 11, 2_000_000, 10, index_interval=16)]
+    q = H.api.Queue(ctx, max_members=4)
+    for m in mixed[:3]:
+        q.submit(m["dplan"], m["d_in"], m["out"], stream_length=m["len"])
+    assert q.pending() == 3 and q.stats()["flushes"] == 0  # nothing launched yet
+    q.flush()
+    for m in mixed[3:7]:  # the fourth submission flushes by itself
+        q.submit(m["dplan"], m["d_in"], m["out"], stream_length=m["len"])
+    assert q.pending() == 0 and q.stats()["flushes"] == 2
+    for m in mixed[7:]:
+        q.submit(m["dplan"], m["d_in"], m["out"], stream_length=m["len"])
+    q.flush()
+    q.flush()  # nothing pending: nothing happens
+    st = q.stats()
+    assert st["submitted"] == 10 and st["flushes"] == 3 and st["batches_made"] == 3
+    check(mixed)
+    # the same plans in the same order: their batch as it is
+    for m in mixed[:3]:
+        q.submit(m["dplan"], m["d_in"], m["out"], stream_length=m["len"])
+    q.flush()
+    assert q.stats()["batches_reused"] == 1 and q.stats()["retargeted"] == 0 and q.stats()["batches_made"] == 3
+    check(mixed[:3])
+    q.close()
+
+    # a loop over files of one size class: every flush brings OTHER streams of the same shapes
+    q = H.api.Queue(ctx, max_members=8)
+    for rnd in range(3):
+        files = [member(H.RAW, 64, 11, 4_000_000, 100 + 4 * rnd + k, index_interval=16) for k in range(4)]
+        for m in files:
+            q.submit(m["dplan"], m["d_in"], m["out"], stream_length=m["len"])
+        q.flush()
+        check(files)
+        del files  # (the plans are destroyed: the next round's may sit at the same addresses)
+    st = q.stats()
+    assert st["batches_made"] == 1 and st["batches_reused"] == 2 and st["retargeted"] == 2, st
+    # a plan that is still pending when it is submitted again: the first batch goes out first
+    a, b = member(H.RAW, 64, 11, 1_000_000, 200, index_interval=8), member(H.RAW, 64, 11, 1_000_000, 201, index_interval=8)
+    out2 = torch.zeros_like(a["out"])
+    q.submit(a["dplan"], a["d_in"], a["out"], stream_length=a["len"])
+    q.submit(b["dplan"], b["d_in"], b["out"], stream_length=b["len"])
+    flushes = q.stats()["flushes"]
+    q.submit(a["dplan"], a["d_in"], out2, stream_length=a["len"])
+    assert q.stats()["flushes"] == flushes + 1 and q.pending() == 1
+    q.flush()
+    check([a, b])
+    assert np.array_equal(out2.cpu().numpy(), a["want"])
+    # arguments
+    with pytest.raises(H.HsransError):
+        q.submit(a["dplan"], a["d_in"][1:], a["out"], stream_length=a["len"])  # misaligned stream
+    with pytest.raises(H.HsransError):
+        q.submit(a["dplan"], a["d_in"], a["out"][: 1000], stream_length=a["len"])  # output too small
+    q.close()
