@@ -824,7 +824,11 @@ try
     hsrans_dplan *ix = nullptr;
     bool have_index = launch_stream_checksum(ctx->d_in, in_length, (uint64_t *)ctx->d_enc_meta, s) == hipSuccess &&
                       hipMemcpyAsync(&sum, ctx->d_enc_meta, 8, hipMemcpyDeviceToHost, s) == hipSuccess;
-    if (have_index && container == HSRANS_RAW)
+    // HSRANS_HIP_STRICT=1: nothing of a `*_decode_hip_N` call runs on a host core — the raw stream's checkpoints are recorded by the one
+    // wavefront that decodes it (hsrans_decode_device_indexing: ~125 ms for 100 MB, once) instead of by the host SIMD decoder's pass (~35 ms)
+    const char *e_strict = getenv("HSRANS_HIP_STRICT");
+    const bool strict = e_strict != nullptr && e_strict[0] != '\0' && e_strict[0] != '0';
+    if (have_index && container == HSRANS_RAW && !strict)
     try
     {
       // a raw stream is ONE chain: the pass that records its checkpoints is the host SIMD decoder's (2-4 GB/s on one core, while the

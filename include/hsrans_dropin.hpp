@@ -28,7 +28,11 @@
 //   block_rANS32x64_decode_wrapper's runtime dispatch (block_rANS32x64_16w_decode.cpp:130-152)  ->  `*_decode_auto_N`: the same
 //       decodeFunc signature, routed at run time: a stream that is ONE dependent chain (raw / block_ without an index) goes to this
 //       library's own host SIMD decoder (AVX-512 / AVX2 / scalar by CPUID; hsrans_decode_cpu), mt_ streams go to the GPU (and
-//       to the host decoder on all cores when no gfx950 device is present).  `*_decode_hip_N` never leave the GPU.
+//       to the host decoder on all cores when no gfx950 device is present).  `*_decode_hip_N`: every decoded byte comes from the GPU
+//       kernels and nothing falls back to the host — with ONE host-side step to know about: the FIRST call on a raw stream of >= 1 MiB
+//       that comes without an index gets its checkpoints from one pass of this library's host SIMD decoder over the stream (~35 ms per
+//       100 MB, while the upload runs; the context then keeps the index: hsrans_decode_host).  HSRANS_HIP_STRICT=1 in the environment
+//       makes the one wavefront that decodes such a stream record them instead (~125 ms, once): no host core touches the stream.
 //
 // Beyond the reference's signatures: `*_decode_hip_with_index_N(in, inLen, out, outCap, plan, planLen)` take
 // the sidecar index written by `*_encode_with_index_N` (or hsrans_index_build / hsrans_index_boundaries) — with it ONE raw or block_

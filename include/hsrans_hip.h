@@ -169,7 +169,9 @@ uint32_t hsrans_ctx_host_index_chains(hsrans_ctx *ctx);
  * stream's checkpoints — memory-safe (every read stays inside in_length) but wrong.  Callers that decode hostile streams through this
  * entry switch the cache off (HSRANS_HOST_INDEX_CACHE_OFF=1) or pass their own plan.  A loop over one file (src/main.cpp:860-889) thus runs the indexed kernels from its second iteration:
  * 100 MB mt_: 0.24 -> 0.06 ms of kernel per call; raw: 125 ms -> 0.04 ms (a raw stream's index comes from the host SIMD decoder's
- * pass, ~30 ms for 100 MB, during the first call).  HSRANS_HOST_INDEX_CACHE_OFF=1 disables it. */
+ * pass, ~30 ms for 100 MB, during the first call — the one host-side step of this entry; HSRANS_HIP_STRICT=1: from the wavefront that
+ * decodes the stream instead, ~125 ms once).  HSRANS_HOST_INDEX_CACHE_OFF=1 disables the cache: every call decodes what the stream alone
+ * allows (a raw stream: one wavefront, k_decode_single). */
 size_t hsrans_decode_host(hsrans_ctx *ctx, int container, int states, uint32_t bits, const uint8_t *in, size_t in_length, uint8_t *out,
                           size_t out_capacity, const uint8_t *plan, size_t plan_size);
 

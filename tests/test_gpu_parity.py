@@ -817,6 +817,35 @@ def test_plain_host_decode_keeps_the_index_of_its_first_call(gpu_ctx, ref, nonst
     assert r == n and np.array_equal(got, d)
 
 
+@pytest.mark.parametrize("states,bits", ((64, 11), (32, 12), (64, 14)))
+def test_plain_host_decode_of_a_raw_stream_without_a_host_core(gpu_ctx, oracle, zipf, monkeypatch, states, bits):
+    """A raw stream of more than 1 MiB through the plain decodeFunc entry with NO host-side decode pass at all:
+      * HSRANS_HOST_INDEX_CACHE_OFF=1: every call decodes the stream as what it is — one dependent chain, one wavefront (k_decode_single
+        for the 8-byte-table widths: above 1 MiB the default path never reaches that kernel, because the first call leaves an index);
+      * HSRANS_HIP_STRICT=1: the first call's checkpoints are recorded by the decoding wavefront itself instead of by the host SIMD
+        decoder's pass; the second call launches the index it left.
+    Both against the oracle (rANS32x64_16w.cpp:168-283 / rANS32x32_16w.cpp:161-269)."""
+    n = (1 << 21) + 12_345
+    d = np.resize(zipf, n)
+    s = H.encode(H.RAW, states, bits, d)
+    r0, want = oracle.decode(RAW, states, bits, s, n)
+    assert r0 == n and np.array_equal(want, d)
+    monkeypatch.setenv("HSRANS_HOST_INDEX_CACHE_OFF", "1")
+    ctx = H.Context(0)
+    for _ in range(2):
+        r, got = ctx.decode_host(H.RAW, states, bits, s, n)
+        assert r == n and np.array_equal(got, want) and ctx.host_index_chains() == 0
+    monkeypatch.delenv("HSRANS_HOST_INDEX_CACHE_OFF")
+    monkeypatch.setenv("HSRANS_HIP_STRICT", "1")
+    ctx = H.Context(0)
+    r, got = ctx.decode_host(H.RAW, states, bits, s, n)
+    assert r == n and np.array_equal(got, want)
+    chains = ctx.host_index_chains()
+    assert chains > 1  # the recording wavefront left its checkpoints
+    r, got = ctx.decode_host(H.RAW, states, bits, s, n)
+    assert r == n and np.array_equal(got, want) and ctx.host_index_chains() == chains
+
+
 def hsrans_cpu_decode(container, states, bits, stream, n):
     """the library's host decoder (hsrans_decode_cpu, scalar route): a second implementation for streams no encoder wrote"""
     out = np.full(n, 0xCC, np.uint8)
