@@ -1116,7 +1116,8 @@ def main() -> None:
     ap.add_argument("--pairs", type=int, default=4, help="distinct (stream, output) pairs rotated through the timed loop")
     ap.add_argument("--block", type=int, default=1 << 18, help="sharded: block size in bytes")
     ap.add_argument("--container", choices=("mt", "block"), default="mt", help="sharded: the stream's container (BASELINE config 4 names block_; same kernel, same plan shape)")
-    ap.add_argument("--interval", type=int, default=256, help="sharded: checkpoint interval inside the blocks, in groups")
+    ap.add_argument("--interval", type=int, default=64, help="sharded: checkpoint interval inside the blocks, in groups (64: a rank of 8 holds 4 chains per wavefront — what the "
+                    "host-dealt one-round launch wants, tools/shard_projection.py: 57.3 us per rank against 59.9 at 256)")
     ap.add_argument("--parts", type=int, default=4, help="sharded: sub-runs per rank; sub-run k's exchange overlaps sub-run k+1's decode")
     ap.add_argument("--root-share", type=float, default=0.0, help="sharded: the root's share of the decoded bytes (0 = balance it against the measured inbound rate)")
     ap.add_argument("--no-configs", action="store_true", help="headline: skip the 1-GPU legs of BASELINE configs 3, 4 and 5 (result['configs'])")

@@ -408,6 +408,10 @@ bool deal_shares(const DeviceGeom &dg, const uint32_t *block_begin, uint32_t n_b
     return false;
   if ((uint64_t)n_chains * 1000 < (uint64_t)grid * kSpreadWaves * g_dealt_min_chains)
     return false;
+  // a block and more for every 8-wave workgroup slot of the grouped launch (four per CU): that launch's home ground — one block per slot and
+  // round, blocks behind the first round by ticket (256 MiB in 256 KiB blocks: 107-112 us grouped, 119-121 dealt with shares cut at two blocks)
+  if (n_blocks >= 2 * grid)
+    return false;
   // a workgroup's weight = the sum of its waves' (four waves per class; as the kernel's cumulative table has them); the first half of the grid is resident first
   uint64_t w1 = 0, w2 = 0;
   for (uint32_t k = 0; k < 4; k++)

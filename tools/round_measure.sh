@@ -2,7 +2,7 @@
 # Everything DESIGN.md §8 quotes, in one go on the GPU box:  bash tools/round_measure.sh <tag>   (outputs under gpurun_out/<tag>/)
 # (the two stamps files need the diagnostic library: make -C hypersonic_rans_amd/csrc stamps, before gpurun)
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
@@ -32,6 +32,13 @@ python tools/encode_rate.py > $OUT/encode_rate_100mb.jsonl 2> $OUT/encode.err
 HSRANS_DEBUG_STAMPS=1 python tools/encode_phase_probe.py 2>&1 | grep -v amdgpu > $OUT/encode_phases.txt   # per-block phase stamps of k_encode_blocks by blocks in flight
 timeout 120 tools/microbench/lone_wave > $OUT/encoder_lone_wave.txt 2>&1                                  # what one wavefront alone on its SIMD pays per instruction
 python tools/spread_by_interval.py > $OUT/spread_by_interval.txt 2> $OUT/spread.err                        # mt_ decode against block size and index interval
+python tools/shard_projection.py --interval 256 64 16 > $OUT/shard_projection.jsonl 2> $OUT/shard_projection.err   # every rank's GPU side of world 2 / 4 / 8 on this one GPU
+HSRANS_SHARD_ONE_LAUNCH=0 python tools/shard_projection.py --interval 64 --worlds 8 --parts 4 --label a-launch-per-sub-run >> $OUT/shard_projection.jsonl 2>> $OUT/shard_projection.err
+python tools/stamps_dealt.py --size 134217728 --interval 16 --calibrate 2>/dev/null | grep -v "amdgpu\|encode stamps" > $OUT/stamps_dealt_128mib.txt      # a rank of 8: per-class timeline of the dealt launch
+python tools/stamps_dealt.py --size 100000000 --interval 32 --calibrate 2>/dev/null | grep -v "amdgpu\|encode stamps" > $OUT/stamps_dealt_100mb.txt
+python tools/stamps_grouped.py --size 134217728 --interval 256 2>/dev/null | grep -v amdgpu > $OUT/grouped_stamps.txt                                     # the same rank on the grouped launch: older / younger workgroup of a CU
+python tools/stamps_grouped.py --size 100000000 --block 65536 --interval 64 2>/dev/null | grep -v amdgpu >> $OUT/grouped_stamps.txt
+tools/microbench/wait_value > $OUT/wait_value.txt 2>&1                                                                                                        # hipStreamWaitValue32 by memory kind
 python tools/cold_cache.py > $OUT/cold_cache.jsonl 2> $OUT/cold.err
 timeout 300 tools/microbench/stream_pattern > $OUT/stream_pattern.txt 2>&1
 python tools/stamps.py --index wave 2>/dev/null | grep -v amdgpu > $OUT/stamps_wave_warm.txt
