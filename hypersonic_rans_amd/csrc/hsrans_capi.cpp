@@ -1175,6 +1175,28 @@ int hsrans_dplan_launch_info(const hsrans_dplan *d, hsrans_launch_info *info)
   return HSRANS_OK;
 }
 
+int hsrans_dealt_shares(const hsrans_ctx *ctx, const uint32_t *block_begin, uint32_t n_blocks, uint32_t n_chains, uint64_t total_groups, uint32_t *begin_out,
+                        uint16_t *split_out)
+try
+{
+  if (block_begin == nullptr || begin_out == nullptr || split_out == nullptr || n_blocks == 0)
+    return -1;
+  for (uint32_t k = 0; k < n_blocks; k++)
+    if (block_begin[k] >= block_begin[k + 1])
+      return -1;
+  DealtTable dt{};
+  uint32_t w8[8];
+  const DeviceGeom dg = ctx ? ctx->geom : default_geom();
+  const bool ok = deal_shares(dg, block_begin, n_blocks, n_chains, total_groups, &dt, w8);
+  memcpy(begin_out, dt.begin, sizeof(dt.begin));
+  memcpy(split_out, dt.split, sizeof(dt.split));
+  return ok ? 1 : 0;
+}
+catch (...)
+{
+  return -1;
+}
+
 int hsrans_host_register(hsrans_ctx *ctx, void *ptr, size_t bytes)
 {
   if (ctx == nullptr || ptr == nullptr || bytes == 0)
