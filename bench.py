@@ -930,7 +930,8 @@ def sharded_workload(args, world, rank, dv: _Dev, dist):
         if rank == 0:  # (stderr: if a later leg dies on hardware this run has never seen, the log still holds the legs before it)
             print(f"bench.py sharded: leg {name}: {ms:.4f} ms per step over {world} rank(s)", file=sys.stderr, flush=True)
         return {"leg": name, "ms_per_step": ms, "MiB_s": n / 2**20 / (ms * 1e-3), "parts": parts, "gather": ("none" if not gather else "all" if root is None else f"root={root}"),
-                "shares": [r[1] - r[0] for r in dec.ranges], "pipelined": bool(gather and parts > 1), "per_rank": per_rank}
+                "shares": [r[1] - r[0] for r in dec.ranges], "pipelined": bool(gather and parts > 1), "per_rank": per_rank,
+                "sub_runs_in_one_launch": None if dv.rehearse else bool(dec.c.info.get("one_launch", 0))}
 
     legs = {}
     legs["none"] = leg("none", gather=False, split_legs=True)
@@ -983,7 +984,9 @@ def sharded_workload(args, world, rank, dv: _Dev, dist):
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 state / u16 word / u8 symbol (integer)", "data": "synthetic",
         "config": {"workload": f"{cname}rANS32x{S} 16w {bits}-bit, ONE {n}-byte stream in {args.block}-byte blocks + index every {args.interval} groups, chains sharded "
                                f"over {world} rank(s) by hsrans_plan_slice, decoded ranges gathered to rank 0 point-to-point over "
-                               f"{'RCCL' if not dv.rehearse else 'gloo'}, exchange pipelined behind the decode in {args.parts} sub-runs, root share {root_share:.3f}",
+                               f"{'RCCL' if not dv.rehearse else 'gloo'}, exchange pipelined behind the decode in {args.parts} sub-runs (one launch per rank, a completion word "
+                               f"per sub-run), root share {root_share:.3f}.  STRONG scaling of this one stream: compare `value` with `one_gpu_same_stream` (measured in this run) "
+                               "or with `sharded_workload_one_gpu` of the N = 1 line (`python bench.py`) — NOT with the N = 1 line's `value`, which is the 100 MB raw headline",
                    "container": cname, "states": S, "bits": bits, "decoded_bytes": n, "compressed_bytes": int(stream.size), "ratio": stream.size / n,
                    "plan_bytes": int(plan.size), "plan_over_compressed": plan.size / stream.size, "chains": H.plan_chain_count(plan), "block": args.block,
                    "index_interval_groups": args.interval, "gather": "root" if world > 1 else "none", "parts": args.parts, "root_share": root_share,
@@ -991,6 +994,7 @@ def sharded_workload(args, world, rank, dv: _Dev, dist):
         "gather": legs,
         "decode_only_MiB_s": legs["none"]["MiB_s"],
         "one_gpu_same_stream": {"ms_per_step": one_ms, "MiB_s": n / 2**20 / (one_ms * 1e-3)},
+        "sub_runs_in_one_launch": main.get("sub_runs_in_one_launch"),
         "speedup_vs_one_gpu": {k: one_ms / v["ms_per_step"] for k, v in legs.items() if k != "one"},
         "replicas": replicas,
         "per_rank": main["per_rank"],
