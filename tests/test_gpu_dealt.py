@@ -93,3 +93,59 @@ def test_plans_the_dealt_launch_does_not_take_keep_their_launch(gpu_ctx, monkeyp
     assert launch_of(runs, 11, 1 << 16, 8) != 2
     monkeypatch.setenv("HSRANS_DEALT", "0")
     assert launch_of(d, 11, 1 << 18, 8) != 2
+
+
+def test_dealt_launch_on_damaged_streams_and_plans(gpu_ctx):
+    """Streams and plans are untrusted input: the dealt launch with a valid plan over DAMAGED stream bytes (bit flips in block
+    headers, histograms, words; truncation) and with damaged plans that still pass validation must neither hang nor write outside the
+    output (guard bytes behind it) — a wrong histogram is reported (status) or decodes to other bytes, like the reference's `return 0` /
+    garbage-in-garbage-out (mt_rANS32x64_16w_decode.cpp:68-70 checks the histogram sum only); the undamaged stream decodes again after."""
+    import torch
+    n = 24_000_000
+    d = shifting(n, seed=21, period=1 << 18)
+    stream, plan = H.encode(H.MT, 64, 11, d, index_interval=16, block_size=1 << 18)
+    dplan = gpu_ctx.make_device_plan(plan)
+    pad = (-stream.size) % 16 + 16
+    d_out = torch.full((n + 4096,), 0xCC, dtype=torch.uint8, device="cuda")
+    rng = np.random.default_rng(5)
+    reported = 0
+    for it in range(40):
+        s = stream.copy()
+        kind = it % 4
+        if kind == 0:    # single bits anywhere
+            for p in rng.integers(16, s.size, 8):
+                s[p] ^= np.uint8(1 << rng.integers(0, 8))
+        elif kind == 1:  # a block's histogram (the first 512 bytes behind a header's 272)
+            off = int(rng.integers(0, s.size - 4096))
+            s[off:off + 600] = rng.integers(0, 256, 600, dtype=np.uint8)
+        elif kind == 2:  # a long run of junk
+            off = int(rng.integers(0, s.size - (1 << 20)))
+            s[off:off + (1 << 20)] = 0xFF
+        else:            # zeros over the first block
+            s[16:16 + 70_000] = 0
+        d_in = torch.from_numpy(np.concatenate([s, np.zeros(pad, np.uint8)])).cuda()
+        gpu_ctx.decode_device(dplan, d_in, d_out[:n], stream_length=s.size)
+        torch.cuda.synchronize()
+        reported += gpu_ctx.status(dplan) != 0
+        assert dplan.launch_info()["spread"] == 2
+        assert bool((d_out[n:] == 0xCC).all()), "wrote behind the output"
+    assert reported >= 10  # the damaged histograms were noticed
+    # damaged plans: whatever hsrans_dplan_create still accepts must be safe to launch
+    accepted = 0
+    for it in range(60):
+        p = plan.copy()
+        for q in rng.integers(64, p.size, 4):
+            p[q] ^= np.uint8(1 << rng.integers(0, 8))
+        try:
+            dp = gpu_ctx.make_device_plan(p)
+        except H.HsransError:
+            continue
+        accepted += 1
+        d_in = torch.from_numpy(np.concatenate([stream, np.zeros(pad, np.uint8)])).cuda()
+        gpu_ctx.decode_device(dp, d_in, d_out[:n], stream_length=stream.size)
+        torch.cuda.synchronize()
+        gpu_ctx.status(dp)
+        assert bool((d_out[n:] == 0xCC).all()), "a damaged plan wrote behind the output"
+    d_in = torch.from_numpy(np.concatenate([stream, np.zeros(pad, np.uint8)])).cuda()
+    gpu_ctx.decode_device(dplan, d_in, d_out[:n], stream_length=stream.size)
+    assert gpu_ctx.status(dplan) == 0 and np.array_equal(d_out[:n].cpu().numpy(), d)
