@@ -170,7 +170,7 @@ def load_library() -> ctypes.CDLL:
     L.hsrans_queue_stats.restype = _i
     L.hsrans_queue_stats.argtypes = [_vp, ctypes.POINTER(QueueStats)]
     L.hsrans_dealt_shares.restype = _i
-    L.hsrans_dealt_shares.argtypes = [_vp, _vp, _u32, _u32, ctypes.c_uint64, _vp, _vp]
+    L.hsrans_dealt_shares.argtypes = [_vp, _u32, _vp, _u32, _u32, ctypes.c_uint64, _vp, _vp]
     L.hsrans_batch_deal.restype = ctypes.c_double
     L.hsrans_batch_deal.argtypes = [_vp, _vp, _u32, _u32, _u32, _vp, _vp]
     L.hsrans_dplan_batch_read_finish.restype = _sz
@@ -454,11 +454,11 @@ def plan_tables(plan):
     return hdr, cf, pieces
 
 
-def dealt_shares(block_begin, total_groups: int, ctx: "Context | None" = None):
+def dealt_shares(block_begin, total_groups: int, ctx: "Context | None" = None, bits: int = 11):
     """hsrans_dealt_shares: (suits the launch?, begin[513], split[512]) for a plan whose block k is chains [block_begin[k], block_begin[k + 1])"""
     bb = np.ascontiguousarray(block_begin, dtype=np.uint32)
     begin, split = np.zeros(513, np.uint32), np.zeros(512, np.uint16)
-    rc = load_library().hsrans_dealt_shares(ctx.handle if ctx is not None else None, _p(bb), bb.size - 1, int(bb[-1]), int(total_groups), _p(begin), _p(split))
+    rc = load_library().hsrans_dealt_shares(ctx.handle if ctx is not None else None, bits, _p(bb), bb.size - 1, int(bb[-1]), int(total_groups), _p(begin), _p(split))
     if rc < 0:
         raise HsransError("hsrans_dealt_shares: bad arguments")
     return rc == 1, begin, split

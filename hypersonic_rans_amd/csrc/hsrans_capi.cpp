@@ -695,13 +695,14 @@ extern "C++" int dplan_launch(hsrans_dplan *d, const void *d_stream, size_t stre
   }
   // lean grouped plans of coded blocks: the host-dealt one-round launch where the plan suits it (dealt once per weight set)
   const DealtTable *dealt = nullptr;
-  if (d->n_groups && d->groups_lean && d->block_begin.size() >= 2 && d->hdr.bits <= 11 && d->hdr.states == 64)
+  if (d->n_groups && d->groups_lean && d->block_begin.size() >= 2 && (d->hdr.bits <= 11 || d->hdr.bits == 13 || d->hdr.bits == 14) && d->hdr.states == 64 &&
+      !(d->hdr.bits >= 13 && getenv("HSRANS_DEALT_WIDE") != nullptr && atoi(getenv("HSRANS_DEALT_WIDE")) == 0)) // (HSRANS_DEALT_WIDE=0: 13 / 14 bits keep the grouped launch: comparison)
   {
     uint32_t w8[8];
     const uint64_t total_groups = (d->out_hi - d->out_lo) / 64; // (what THIS plan's chains decode: a rank's slice of a sharded stream, not the stream)
-    dealt_weights_now(d->ctx->geom, total_groups / ((uint64_t)spread_grid(d->ctx->geom) * 16), w8);
+    dealt_weights_now(d->ctx->geom, total_groups / ((uint64_t)spread_grid(d->ctx->geom) * 16), d->hdr.bits, w8);
     if (d->dealt_state == 0 || memcmp(w8, d->dealt_weights, sizeof(w8)) != 0)
-      d->dealt_state = deal_shares(d->ctx->geom, d->block_begin.data(), (uint32_t)d->block_begin.size() - 1, d->hdr.n_chains, total_groups, &d->dealt, d->dealt_weights) ? 1 : -1;
+      d->dealt_state = deal_shares(d->ctx->geom, d->block_begin.data(), (uint32_t)d->block_begin.size() - 1, d->hdr.n_chains, total_groups, d->hdr.bits, &d->dealt, d->dealt_weights) ? 1 : -1;
     if (d->dealt_state == 1)
       dealt = &d->dealt;
   }
@@ -1175,11 +1176,11 @@ int hsrans_dplan_launch_info(const hsrans_dplan *d, hsrans_launch_info *info)
   return HSRANS_OK;
 }
 
-int hsrans_dealt_shares(const hsrans_ctx *ctx, const uint32_t *block_begin, uint32_t n_blocks, uint32_t n_chains, uint64_t total_groups, uint32_t *begin_out,
-                        uint16_t *split_out)
+int hsrans_dealt_shares(const hsrans_ctx *ctx, uint32_t bits, const uint32_t *block_begin, uint32_t n_blocks, uint32_t n_chains, uint64_t total_groups,
+                        uint32_t *begin_out, uint16_t *split_out)
 try
 {
-  if (block_begin == nullptr || begin_out == nullptr || split_out == nullptr || n_blocks == 0)
+  if (block_begin == nullptr || begin_out == nullptr || split_out == nullptr || n_blocks == 0 || bits < 10 || bits > 15)
     return -1;
   for (uint32_t k = 0; k < n_blocks; k++)
     if (block_begin[k] >= block_begin[k + 1])
@@ -1187,7 +1188,7 @@ try
   DealtTable dt{};
   uint32_t w8[8];
   const DeviceGeom dg = ctx ? ctx->geom : default_geom();
-  const bool ok = deal_shares(dg, block_begin, n_blocks, n_chains, total_groups, &dt, w8);
+  const bool ok = deal_shares(dg, block_begin, n_blocks, n_chains, total_groups, bits, &dt, w8);
   memcpy(begin_out, dt.begin, sizeof(dt.begin));
   memcpy(split_out, dt.split, sizeof(dt.split));
   return ok ? 1 : 0;

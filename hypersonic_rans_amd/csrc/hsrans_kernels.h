@@ -373,8 +373,9 @@ hipError_t launch_decode(const KParams &kp, const PlanHeader &h, const DeviceGeo
 // calibrated), each cut back where it would reach into a third block.  false: the plan does not suit the launch (too few chains for the
 // device's waves, shares that would have to span more than two blocks, a share beyond 65,535 chains).  weights_out: the 8 class weights used
 // (the caller's cache key: a calibration changes them).
-bool deal_shares(const DeviceGeom &dg, const uint32_t *block_begin, uint32_t n_blocks, uint32_t n_chains, uint64_t total_groups, DealtTable *out, uint32_t weights_out[8]);
-void dealt_weights_now(const DeviceGeom &dg, uint64_t run_groups, uint32_t weights_out[8]); // run_groups: groups per wave of the launch, on average
+bool deal_shares(const DeviceGeom &dg, const uint32_t *block_begin, uint32_t n_blocks, uint32_t n_chains, uint64_t total_groups, uint32_t bits, DealtTable *out,
+                 uint32_t weights_out[8]);
+void dealt_weights_now(const DeviceGeom &dg, uint64_t run_groups, uint32_t bits, uint32_t weights_out[8]); // run_groups: groups per wave of the launch, on average
 
 } // namespace hsrans
 

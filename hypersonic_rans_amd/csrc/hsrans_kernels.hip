@@ -297,7 +297,9 @@ hipError_t prepare_kernels(DeviceGeom *geom)
     if (e != hipSuccess)
       return e;
   }
-  for (const void *fn : {(const void *)k_decode_dealt<true, false>, (const void *)k_decode_dealt<false, false>, (const void *)k_decode_dealt<true, true>})
+  for (const void *fn : {(const void *)k_decode_dealt<true, false>, (const void *)k_decode_dealt<false, false>, (const void *)k_decode_dealt<true, true>,
+                         (const void *)k_decode_dealt_rank<13, false>, (const void *)k_decode_dealt_rank<13, true>, (const void *)k_decode_dealt_rank<14, false>,
+                         (const void *)k_decode_dealt_rank<14, true>})
   {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom->max_lds);
     if (e != hipSuccess)
@@ -375,9 +377,29 @@ uint32_t spread_longest_share(const DeviceGeom &dg, uint64_t n_chains)
 
 // the class weights of a one-round launch whose waves decode `run_groups` groups each on average: the one-chain-per-wave launch's, this
 // device's own once calibrated — the set fitted nearest to that run length where several are (hsrans_ctx_calibrate_runs)
-void dealt_weights_now(const DeviceGeom &dg, uint64_t run_groups, uint32_t weights_out[8])
+void dealt_weights_now(const DeviceGeom &dg, uint64_t run_groups, uint32_t bits, uint32_t weights_out[8])
 {
   direct_weights_for(dg, run_groups, weights_out);
+  // 13 / 14 bits (k_decode_dealt_rank): the rank loop's three dependent LDS reads per group make a wave's age count for less — the flatter
+  // class lengths fitted for the rank-table one-chain-per-wave launch (g_direct_weights6); nothing calibrates this loop per device.
+  // 100 MB in 256 KiB blocks, G = 16, rotated: 14 bits 54.1 us with the 11-bit loop's lengths, 51.3-52.1 with these; 13 bits 52.1 -> 50.0
+  // (tools/dealt_weights_probe.py)
+  if (bits >= 13)
+    for (uint32_t k = 0; k < 8; k++)
+      weights_out[k] = g_direct_weights6[k];
+  if (const char *e = getenv("HSRANS_DEALT_WEIGHTS")) // tuning: 8 per-mille class lengths for the dealt launch (read at every dealing)
+  {
+    uint32_t v[8], n = 0;
+    for (const char *p = e; n < 8 && *p; n++)
+    {
+      v[n] = (uint32_t)strtoul(p, (char **)&p, 10);
+      if (*p == ',')
+        p++;
+    }
+    if (n == 8)
+      for (uint32_t k = 0; k < 8; k++)
+        weights_out[k] = v[k] >= 10 ? v[k] : 10;
+  }
 }
 static void cum_from_weights(const uint32_t w8[8], uint16_t (*cum_out)[17])
 {
@@ -396,9 +418,10 @@ static uint32_t g_dealt = 1;          // HSRANS_DEALT=0: grouped plans keep k_de
 static uint32_t g_dealt_min_chains = 1400; // HSRANS_DEALT_MIN_CHAINS: chains per 1,000 waves of the launch below which a plan is not dealt (tuning; 100 MB in 256 KiB blocks, G = 128 — 1.49 chains a wave — 58.5 us grouped, 47.4 dealt; one chain a wave leaves the class weights nothing to work with)
 static uint32_t g_dealt_wt = 1;       // HSRANS_DEALT_WT=0: k_decode_dealt's stores as `nt` instead of written through (comparison)
 
-bool deal_shares(const DeviceGeom &dg, const uint32_t *block_begin, uint32_t n_blocks, uint32_t n_chains, uint64_t total_groups, DealtTable *out, uint32_t weights_out[8])
+bool deal_shares(const DeviceGeom &dg, const uint32_t *block_begin, uint32_t n_blocks, uint32_t n_chains, uint64_t total_groups, uint32_t bits, DealtTable *out,
+                 uint32_t weights_out[8])
 {
-  dealt_weights_now(dg, total_groups / ((uint64_t)spread_grid(dg) * kSpreadWaves), weights_out);
+  dealt_weights_now(dg, total_groups / ((uint64_t)spread_grid(dg) * kSpreadWaves), bits, weights_out);
   // (read at every dealing, not once: tools/ab_probe.py and the tests switch sides inside one process)
   const char *e_on = getenv("HSRANS_DEALT"), *e_min = getenv("HSRANS_DEALT_MIN_CHAINS");
   g_dealt = e_on ? (uint32_t)atoi(e_on) : 1;
@@ -760,7 +783,8 @@ static hipError_t launch_dealt(const KParams &kp, const PlanHeader &h, const Dev
     const uint64_t per_chain = h.interval ? h.interval : h.n_chains ? (uint64_t)h.decoded_len / 64 / h.n_chains : 0; // groups per chain: the index interval (a sliced plan keeps the stream's header)
     dp.gap_chains = per_chain ? (uint32_t)((gap_groups + per_chain / 2) / per_chain) : 0;
   }
-  const uint32_t lds = kSpreadWaves * kFastRingBytes + 2 * table_bytes_for(kModePack64, h.bits) + 2048;
+  const bool rank = h.bits >= 13; // (13 / 14 bits: two rank tables, k_decode_dealt_rank)
+  const uint32_t lds = kSpreadWaves * kFastRingBytes + 2 * table_bytes_for(rank ? kModeRank : kModePack64, h.bits) + 2048;
   if (parts != nullptr)
   {
     dp.parts = kp.parts;
@@ -786,14 +810,22 @@ static hipError_t launch_dealt(const KParams &kp, const PlanHeader &h, const Dev
     info->waves_per_block = kSpreadWaves;
     info->chains = h.n_chains;
     info->shared_table = 1;
-    info->table_mode = (uint32_t)kModePack64;
+    info->table_mode = (uint32_t)(rank ? kModeRank : kModePack64);
     info->chains_per_wave = 1;
     for (uint32_t k = 0; k < 8; k++)
       info->class_weights[k] = w8[k];
     info->spread = 2;
   }
   (void)hipGetLastError();
-  if (parts != nullptr)
+  if (rank && h.bits == 13 && parts != nullptr)
+    hipLaunchKernelGGL((k_decode_dealt_rank<13, true>), dim3(grid), dim3(kSpreadWaves * 64), lds, stream, dp, dt);
+  else if (rank && h.bits == 13)
+    hipLaunchKernelGGL((k_decode_dealt_rank<13, false>), dim3(grid), dim3(kSpreadWaves * 64), lds, stream, dp, dt);
+  else if (rank && parts != nullptr)
+    hipLaunchKernelGGL((k_decode_dealt_rank<14, true>), dim3(grid), dim3(kSpreadWaves * 64), lds, stream, dp, dt);
+  else if (rank)
+    hipLaunchKernelGGL((k_decode_dealt_rank<14, false>), dim3(grid), dim3(kSpreadWaves * 64), lds, stream, dp, dt);
+  else if (parts != nullptr)
     hipLaunchKernelGGL((k_decode_dealt<true, true>), dim3(grid), dim3(kSpreadWaves * 64), lds, stream, dp, dt);
   else if (g_dealt_wt)
     hipLaunchKernelGGL((k_decode_dealt<true, false>), dim3(grid), dim3(kSpreadWaves * 64), lds, stream, dp, dt);
@@ -808,8 +840,9 @@ hipError_t launch_decode(const KParams &kp_in, const PlanHeader &h, const Device
   KParams kp = kp_in;
   if (parts != nullptr && (parts->n == 0 || parts->n > kMaxLaunchParts))
     return hipErrorInvalidValue;
-  if (dealt != nullptr && dealt_weights != nullptr && kp.groups != nullptr && kp.groups_lean && kp.ckpt_interval == 0 && kp.ckpt_groups == nullptr && h.states == 64 && h.bits <= 11 &&
-      h.n_pieces == h.n_chains && 2 * (kSpreadWaves * kFastRingBytes + 2 * table_bytes_for(kModePack64, h.bits) + 2048) <= dg.max_lds)
+  if (dealt != nullptr && dealt_weights != nullptr && kp.groups != nullptr && kp.groups_lean && kp.ckpt_interval == 0 && kp.ckpt_groups == nullptr && h.states == 64 &&
+      (h.bits <= 11 || h.bits == 13 || h.bits == 14) && h.n_pieces == h.n_chains &&
+      2 * (kSpreadWaves * kFastRingBytes + 2 * table_bytes_for(h.bits >= 13 ? kModeRank : kModePack64, h.bits) + 2048) <= dg.max_lds)
     return launch_dealt(kp, h, dg, stream, info, parts, *dealt, dealt_weights);
   const bool persistent = kp.pa.pieces != nullptr;
   const bool index_pass = kp.ckpt_interval != 0 || kp.ckpt_groups != nullptr;

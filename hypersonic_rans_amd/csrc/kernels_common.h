@@ -749,7 +749,7 @@ __device__ __forceinline__ uint32_t fast_groups4(uint32_t &x, uint32_t &s_addr, 
 // 10 vector, 3 LDS, 3 scalar instructions.
 #define HSRANS_FAST_GROUP_RANK(P0, P1)                                                                                                               \
   "v_and_b32 %[g], %[x], %[vmask]\n\t"                                                                                                               \
-  "ds_read_u8 v" #P0 ", %[g]\n\t"                                                                                                                    \
+  "ds_read_u8 v" #P0 ", %[g] offset:%[off]\n\t"                                                                                                      \
   "v_lshrrev_b32 %[x], %[vbits], %[x]\n\t"                                                                                                           \
   "s_waitcnt lgkmcnt(0)\n\t"                                                                                                                         \
   "v_lshl_add_u32 %[t], v" #P0 ", 3, %[sent]\n\t"                                                                                                    \
@@ -769,6 +769,9 @@ __device__ __forceinline__ uint32_t fast_groups4(uint32_t &x, uint32_t &s_addr, 
   "v_lshl_or_b32 %[x], %[x], 16, %[t]\n\t"                                                                                                           \
   "s_mov_b64 exec, -1\n\t"
 
+// (TABLE_OFF: the LDS address of the rank bytes, a compile-time constant that rides in the byte gather's offset field — 0 for the launches
+// with one table at the start of the workgroup's LDS; k_decode_dealt's second table sits behind the first)
+template <uint32_t TABLE_OFF = 0>
 __device__ __forceinline__ uint32_t fast_groups4_rank(uint32_t &x, uint32_t &s_addr, const WaveCtx &c, uint32_t s_entries)
 {
   uint32_t acc, t, g, st;
@@ -777,7 +780,8 @@ __device__ __forceinline__ uint32_t fast_groups4_rank(uint32_t &x, uint32_t &s_a
                "v_perm_b32 %[t], v58, v56, %[selp]\n\t"
                "v_perm_b32 %[acc], %[t], %[acc], %[selq]"
                : [x] "+v"(x), [sa] "+s"(s_addr), [acc] "=&v"(acc), [t] "=&v"(t), [g] "=&v"(g), [st] "=&s"(st)
-               : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [sent] "s"(s_entries), [lim] "s"(kConsume), [selp] "s"(0x0c0c0703u), [selq] "s"(0x05040100u)
+               : [vmask] "v"(c.v_mask), [vbits] "v"(c.v_bits), [sent] "s"(s_entries), [lim] "s"(kConsume), [selp] "s"(0x0c0c0703u), [selq] "s"(0x05040100u),
+                 [off] "i"(TABLE_OFF)
                : "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "vcc", "scc", "memory");
   return acc;
 }
@@ -829,7 +833,7 @@ __device__ __forceinline__ void wait_after_crossing(uint32_t &t1, uint32_t &t2, 
                : "scc", "memory");
 }
 
-template <bool STRICT, int MODE = kModePack64, bool WT = false>
+template <bool STRICT, int MODE = kModePack64, bool WT = false, uint32_t TABLE_OFF = 0>
 __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o_ref, uint32_t &steps)
 {
   const OutLanes ol = out_lanes(c.lane, 64);
@@ -870,7 +874,7 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
   {
     for (; iters != 0; iters--)
     {
-      const uint32_t acc = quad_transpose(MODE == kModeRank ? fast_groups4_rank(x, s_addr, c, 1u << c.bits) : fast_groups4(x, s_addr, c, s_table), ol.sel_a, ol.sel_b);
+      const uint32_t acc = quad_transpose(MODE == kModeRank ? fast_groups4_rank<TABLE_OFF>(x, s_addr, c, TABLE_OFF + (1u << c.bits)) : fast_groups4(x, s_addr, c, s_table), ol.sel_a, ol.sel_b);
 #if HSRANS_HAVE_STAMPS && defined(HSRANS_DIAG_STORE_TIME)
       const uint64_t ds0 = __builtin_amdgcn_s_memtime();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -922,13 +926,13 @@ __device__ __forceinline__ void run_groups_fast(uint32_t &x, const StreamWin &sw
 
 // FAST: the call sites that carry the bulk of a launch's groups (every inlined copy of the hand-scheduled loop pins v52-v59 and
 // costs the big multi-path kernel registers: with it at every call site k_decode<3, true> went to 97 VGPRs and spilled)
-template <int MODE, bool FAST = false, bool STRICT = false, bool WT = false, bool ALLWT = false> // STRICT: the constant wait of run_groups_fast (the grouped launches); WT: write-through stores in the hand-scheduled loop; ALLWT: in what is left over too
+template <int MODE, bool FAST = false, bool STRICT = false, bool WT = false, bool ALLWT = false, uint32_t TABLE_OFF = 0> // STRICT: the constant wait of run_groups_fast (the grouped launches); WT: write-through stores in the hand-scheduled loop; ALLWT: in what is left over too; TABLE_OFF: where the rank table sits (fast_groups4_rank)
 __device__ __forceinline__ void run_groups(uint32_t &x, const StreamWin &sw, Ring &r, const WaveCtx &c, uint64_t &o, uint32_t steps)
 {
   if (FAST && MODE == kModePack64 && c.S == 64 && r.mirror_lanes == 0xFFFFFFFFu)
     run_groups_fast<STRICT, kModePack64, WT>(x, sw, r, c, o, steps); // the hand-scheduled loop; leaves < 4 groups
-  if (FAST && MODE == kModeRank && c.S == 64 && r.mirror_lanes == 0xFFFFFFFFu && uni(lds_address(c.table)) == 0)
-    run_groups_fast<true, kModeRank, WT>(x, sw, r, c, o, steps); // (its rank byte's address is the slot itself: the table at LDS address 0)
+  if (FAST && MODE == kModeRank && c.S == 64 && r.mirror_lanes == 0xFFFFFFFFu && uni(lds_address(c.table)) == TABLE_OFF)
+    run_groups_fast<STRICT || TABLE_OFF == 0, kModeRank, WT, TABLE_OFF>(x, sw, r, c, o, steps); // (its rank byte's address is the slot itself + TABLE_OFF: the table at that LDS address)
   if (c.S == 64)
     run_groups_impl<MODE, true, ALLWT>(x, sw, r, c, o, steps);
   else

@@ -238,6 +238,231 @@ __device__ __forceinline__ void run_dealt(const DealtParams &dp, const DealtTabl
   }
 }
 
+// build_table<kModeRank, true>'s body for counts already in cnt[0 .. 255] (as dealt_build for the 8-byte table): the slot -> symbol bytes, every
+// thread a contiguous run of dwords (one search for its first slot, then the symbol only moves forward), and the 256 eight-byte entries by
+// symbol value behind them
+__device__ __forceinline__ void rank_build_from_counts(uint8_t *table, uint16_t *cnt, uint16_t *cum, uint32_t bits, uint32_t tid, uint32_t nthreads, uint32_t *status)
+{
+  const uint32_t total = 1u << bits;
+  __syncthreads();
+  if (tid < 64)
+  {
+    const uint32_t c0 = cnt[4 * tid], c1 = cnt[4 * tid + 1], c2 = cnt[4 * tid + 2], c3 = cnt[4 * tid + 3];
+    const uint32_t sum4 = c0 + c1 + c2 + c3;
+    uint32_t incl = sum4;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      const uint32_t up = __shfl_up(incl, d, 64);
+      if (tid >= (uint32_t)d)
+        incl += up;
+    }
+    const uint32_t excl = incl - sum4;
+    cum[4 * tid] = (uint16_t)excl;
+    cum[4 * tid + 1] = (uint16_t)(excl + c0);
+    cum[4 * tid + 2] = (uint16_t)(excl + c0 + c1);
+    cum[4 * tid + 3] = (uint16_t)(excl + c0 + c1 + c2);
+    if ((uint32_t)__shfl(incl, 63, 64) != total && tid == 0)
+      atomicOr(status, kStatusBadHist);
+  }
+  __syncthreads();
+  uint32_t *sym4 = (uint32_t *)table;
+  const uint32_t dwords = total / 4;
+  const uint32_t per = (dwords + nthreads - 1) / nthreads;
+  const uint32_t q0 = tid * per, q1 = q0 + per < dwords ? q0 + per : dwords;
+  if (q0 < q1)
+  {
+    uint32_t s = 0;
+#pragma unroll
+    for (uint32_t step = 128; step >= 1; step >>= 1)
+      s += ((uint32_t)cum[s + step] <= 4 * q0) ? step : 0;
+    uint32_t next = s < 255 ? (uint32_t)cum[s + 1] : 0x10000u;
+    for (uint32_t q = q0; q < q1; q++)
+    {
+      uint32_t packed = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++)
+      {
+        const uint32_t slot = 4 * q + k;
+        while (next <= slot)
+        {
+          s++;
+          next = s < 255 ? (uint32_t)cum[s + 1] : 0x10000u;
+        }
+        packed |= s << (8 * k);
+      }
+      sym4[q] = packed;
+    }
+  }
+  uint2 *ent = (uint2 *)(table + total);
+  for (uint32_t s = tid; s < 256; s += nthreads)
+    ent[s] = make_uint2((uint32_t)cnt[s] | (s << 24), 0u - (uint32_t)cum[s]);
+  __syncthreads();
+}
+
+// The same launch for 13- and 14-bit histograms: two RANK tables per workgroup (kModeRank: a byte per slot + 256 eight-byte entries; 10 / 18 KiB
+// each, where the 8-byte-per-slot table is 64 / 128 KiB).  The hand-scheduled rank loop takes the slot as the address of its rank byte, so the
+// first table sits at LDS address 0 and the second one's address rides in the byte gather's offset field — a compile-time constant, hence a
+// kernel per width.  LDS: [table A][table B][build scratch 2 KiB][16 rings] = 79,872 bytes at 14 bits: two workgroups per CU.
+// The prologue is the plain one (piece records + start states, then the builder's own count load, then the ring): the table build is the
+// longer part at these widths anyway.
+template <uint32_t BITS, bool PARTS>
+__device__ __forceinline__ void run_dealt_rank(const DealtParams &dp, const DealtTable &dt, uint8_t *smem)
+{
+  constexpr int MODE = kModeRank;
+  constexpr uint32_t TB = table_bytes_for(kModeRank, BITS); // = the second table's LDS address
+  const uint32_t waves = blockDim.x >> 6;
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  const uint32_t b = blockIdx.x;
+  const uint32_t c0 = dt.begin[b], c1 = dt.begin[b + 1];
+  const uint32_t count = c1 - c0;
+  const uint32_t split = dt.split[b] < count ? dt.split[b] : count;
+  const bool two = split < count;
+  const uint32_t N = dp.n_chains;
+  WaveCtx c;
+  c.stream = dp.stream;
+  c.stream_len = dp.stream_len;
+  c.stream_lo = dp.stream_lo;
+  c.out = dp.out;
+  c.out_cap = dp.out_cap;
+  c.status = dp.status;
+  c.bits = BITS;
+  c.S = 64;
+  c.lane = threadIdx.x & 63;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_mask) : "s"((1u << BITS) - 1));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(c.v_bits) : "s"(BITS));
+  if (uni(lds_address(smem)) != 0 || dp.bits != BITS) // (the rank loop's addressing; the launcher picks the kernel by the plan's width)
+  {
+    if (threadIdx.x == 0)
+      atomicOr(c.status, kStatusOutOfRange);
+    return;
+  }
+  uint8_t *const table0 = smem;
+  uint16_t *const scratch0 = (uint16_t *)(smem + 2 * TB);
+  c.rings = smem + 2 * TB + 2048 + wave * kFastRingBytes;
+  c.gtable = nullptr;
+  const uint32_t half = b >= (gridDim.x + 1) / 2 ? 1 : 0;
+  const uint32_t cum_all = dp.cum[half][waves];
+  const uint32_t gap = two ? dp.gap_chains : 0;
+  const uint32_t vcount = count + gap;
+  auto real = [&](uint32_t v) { return v < split ? v : v < split + gap ? split : v - gap; };
+  const uint32_t first = c0 + real((uint32_t)((uint64_t)dp.cum[half][wave] * vcount / cum_all));
+  const uint32_t last = c0 + real((uint32_t)((uint64_t)dp.cum[half][wave + 1] * vcount / cum_all));
+  const uint32_t mid = c0 + split;
+  const kpiece_ptr pa = (kpiece_ptr)(uintptr_t)(dp.pieces + c0);
+  const kpiece_ptr pb = (kpiece_ptr)(uintptr_t)(dp.pieces + (two ? mid : c0));
+  const uint64_t hist_a = count ? pa->hist_off : 0, hist_b = count ? pb->hist_off : 0;
+  // trip 2 as in run_dealt: the counts first, then the start states and chunks 0 and 1 of the wave's first run; the two tables are built side
+  // by side (half the workgroup each) while the chunks are in flight
+  const uint32_t half_threads = blockDim.x / 2;
+  const uint32_t side = two && threadIdx.x >= half_threads ? 1 : 0;
+  const uint32_t btid = two ? threadIdx.x - side * half_threads : threadIdx.x;
+  const uint32_t bthreads = two ? half_threads : blockDim.x;
+  const uint64_t my_hist = side ? hist_b : hist_a;
+  uint32_t my_count = 0;
+  if (btid < 256 && count != 0)
+  {
+    if (HSRANS_HIST_IN_RANGE(c, my_hist))
+      my_count = *(const uint16_t *)(c.stream + my_hist + 2 * btid);
+    else if (btid == 0)
+      atomicOr(c.status, kStatusOutOfRange);
+  }
+  const uint32_t f0 = first, e0 = first < mid && mid < last ? mid : last;
+  StreamWin sw;
+  Ring r;
+  ring_bind(r, c.rings, 9, true);
+  uint32_t x = 0;
+  uint64_t words0 = 0, limit0 = 0;
+  if (f0 < e0)
+  {
+    const kpiece_ptr p0 = (kpiece_ptr)(uintptr_t)(dp.pieces + f0);
+    const kpiece_ptr pn = (kpiece_ptr)(uintptr_t)(dp.pieces + (e0 < N ? e0 : e0 - 1));
+    words0 = p0->words_off;
+    limit0 = e0 >= N ? c.stream_len : pn->hist_off != p0->hist_off ? pn->hist_off : pn->words_off;
+    x = dp.states[(uint64_t)f0 * 64 + c.lane];
+  }
+  if (count != 0 && btid < 256)
+    (scratch0 + side * 512)[btid] = (uint16_t)my_count;
+  if (f0 < e0)
+  {
+    win_open(sw, c, words0, limit0);
+    ring_begin(sw, r, c, words0, true, true);
+  }
+  if (count != 0)
+    rank_build_from_counts(table0 + side * TB, scratch0 + side * 512, scratch0 + side * 512 + 256, BITS, btid, bthreads, c.status);
+  // the wave's chains: one run, or two where they straddle the share's block boundary
+  for (uint32_t run = 0; run < 2; run++)
+  {
+    const uint32_t f = run == 0 ? f0 : e0;
+    const uint32_t e = run == 0 ? e0 : last;
+    if (f >= e)
+      continue;
+    const kpiece_ptr p0 = (kpiece_ptr)(uintptr_t)(dp.pieces + f);
+    const kpiece_ptr p1 = (kpiece_ptr)(uintptr_t)(dp.pieces + (e - 1));
+    if (run == 0)
+    {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)::"memory"); // start states, chunks 0 and 1
+      ring_begin_rest(sw, r, c);
+    }
+    else
+    {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no request of run 1 may still land in the ring run 2 begins
+      const kpiece_ptr pn = (kpiece_ptr)(uintptr_t)(dp.pieces + (e < N ? e : e - 1));
+      const uint64_t words = p0->words_off;
+      const uint64_t limit = e >= N ? c.stream_len : pn->hist_off != p0->hist_off ? pn->hist_off : pn->words_off;
+      x = dp.states[(uint64_t)f * 64 + c.lane];
+      win_open(sw, c, words, limit);
+      ring_begin(sw, r, c, words);
+      ring_ready(x);
+    }
+    uint64_t o = p0->out_off;
+    const uint64_t out_end = p1->out_off + (uint64_t)p1->steps * 64;
+    if (two && f >= mid)
+    {
+      c.table = table0 + TB;
+      c.table_b = c.table;
+      run_groups<MODE, true, true, true, PARTS, TB>(x, sw, r, c, o, (uint32_t)((out_end - o) / 64));
+    }
+    else
+    {
+      c.table = table0;
+      c.table_b = c.table;
+      run_groups<MODE, true, true, true, PARTS, 0>(x, sw, r, c, o, (uint32_t)((out_end - o) / 64));
+    }
+    run_tail<MODE, PARTS>(x, r, c, o, p1->tail);
+  }
+  if (PARTS && dp.parts.n != 0)
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && count != 0)
+    {
+      uint32_t lo = 0, hi = 0, begin = 0;
+      bool any = false;
+      for (uint32_t p = 0; p < dp.parts.n; p++)
+      {
+        const uint32_t end = dp.parts.chain_end[p];
+        if (end > begin && c0 < end && c1 > begin)
+        {
+          lo = any ? lo : p;
+          hi = p;
+          any = true;
+        }
+        begin = end > begin ? end : begin;
+      }
+      if (any)
+        part_signal(dp.parts, lo, hi);
+    }
+  }
+}
+
+template <uint32_t BITS, bool PARTS>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_decode_dealt_rank(DealtParams dp, DealtTable dt)
+{
+  extern __shared__ u32x4 smem_v[];
+  run_dealt_rank<BITS, PARTS>(dp, dt, (uint8_t *)smem_v);
+}
+
 template <bool WT, bool PARTS>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) k_decode_dealt(DealtParams dp, DealtTable dt)
 {

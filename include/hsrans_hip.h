@@ -479,8 +479,9 @@ int hsrans_dplan_launch_info(const hsrans_dplan *dplan, hsrans_launch_info *info
  * classes (the MI355X defaults; ctx != NULL: that context's fitted ones), never reaching into a third block — and split_out[b] = how many of
  * them belong to the share's first block (0xFFFF: all).  Returns 1 when the plan suits the launch, 0 when it keeps the grouped / spread
  * launch (too few chains per wave, a block and more per workgroup slot, shares bent too far by the cuts), < 0 on bad arguments. */
-int hsrans_dealt_shares(const hsrans_ctx *ctx, const uint32_t *block_begin, uint32_t n_blocks, uint32_t n_chains, uint64_t total_groups,
-                        uint32_t *begin_out /* [513] */, uint16_t *split_out /* [512] */);
+int hsrans_dealt_shares(const hsrans_ctx *ctx, uint32_t bits /* the class lengths differ between the 8-byte-table loop (<= 11) and the rank-table loop (13, 14) */,
+                        const uint32_t *block_begin, uint32_t n_blocks, uint32_t n_chains, uint64_t total_groups, uint32_t *begin_out /* [513] */,
+                        uint16_t *split_out /* [512] */);
 
 /* diagnostics: with HSRANS_DEBUG_STAMPS=1 in the environment every wavefront of a persistent / direct launch records
  * s_memtime stamps {entry, table built, stream ready, done, static share done} in 8 slots; copies up to capacity_u64 values to

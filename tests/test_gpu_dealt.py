@@ -31,6 +31,9 @@ CASES = (
     (H.MT, 11, 50_000_000, 3 * 65536, 4),     # many chains per wave
     (H.BLOCK, 11, 30_000_000, 1 << 18, 16),   # block_: states carried over the block boundaries, checkpoints at them
     (H.MT, 11, 20_000_000, 0, 16),            # the reference's adaptive block policy (blocks of >= 64 KiB where the histogram holds)
+    (H.MT, 14, 24_000_001, 1 << 18, 8),       # 13 / 14 bits: two RANK tables per workgroup, the second one's address in the gather's offset field
+    (H.MT, 13, 30_000_000, 1 << 18, 16),
+    (H.BLOCK, 14, 26_000_000, 1 << 19, 8),
 )
 
 
@@ -88,6 +91,8 @@ def test_plans_the_dealt_launch_does_not_take_keep_their_launch(gpu_ctx, monkeyp
     d = shifting(24_000_000, seed=9, period=1 << 18)
     assert launch_of(d, 11, 1 << 18, 8) == 2
     assert launch_of(d, 12, 1 << 18, 8) != 2          # two 32 KiB tables do not fit beside the rings twice per CU
+    assert launch_of(d, 15, 1 << 18, 8) != 2          # nor two 34 KiB rank tables
+    assert launch_of(d, 14, 1 << 18, 8) == 2
     assert launch_of(d[:3_000_000], 11, 1 << 18, 8) != 2  # fewer chains than 1.4 per wave of the device
     runs = synth.nonstationary(24_000_000, seed=2)     # holds single-symbol blocks
     assert launch_of(runs, 11, 1 << 16, 8) != 2

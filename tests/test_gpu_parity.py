@@ -392,7 +392,7 @@ def test_every_ranks_gpu_side_of_a_sharded_decode_on_one_gpu(gpu_ctx, nonstat, m
 
 
 @pytest.mark.parametrize("one_launch", (True, False))
-@pytest.mark.parametrize("bits,block,interval,size", ((12, 65536, 32, 6_000_000), (14, 1 << 17, 16, 6_000_000), (11, 1 << 18, 8, 24_000_000)))
+@pytest.mark.parametrize("bits,block,interval,size", ((12, 65536, 32, 6_000_000), (14, 1 << 17, 16, 6_000_000), (11, 1 << 18, 8, 24_000_000), (14, 1 << 18, 8, 24_000_000)))
 def test_a_ranks_sub_runs_announce_their_completion(gpu_ctx, monkeypatch, one_launch, bits, block, interval, size):
     """hsrans_sharded_wait_part — what the exchange's stream does inside hsrans_decode_sharded, reachable on one GPU: a SECOND stream waits
     for sub-run k of the decode queued on the first (its completion word, published by the one launch that decodes all sub-runs:
