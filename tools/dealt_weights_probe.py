@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Class lengths for the host-dealt launch at 13 / 14 bits (k_decode_dealt_rank): HSRANS_DEALT_WEIGHTS is read at every dealing, so one
+process times several sets on the same buffers (100 MB mt_, 256 KiB blocks, G = 16, four copies rotated), every set twice.
+    python tools/dealt_weights_probe.py > profiles/rNN_dealt_weights_14bit.txt"""
 import os, sys, json, time
 sys.path.insert(0, "/root/repo" if os.path.exists("/root/repo/bench.py") else ".")
 import torch
