@@ -410,10 +410,109 @@ __device__ __forceinline__ void ring_advance_exact(const StreamWin &sw, Ring &r,
 __device__ __forceinline__ uint64_t ring_pos(const StreamWin &sw, const Ring &r) { return sw.base + r.voff0 + (uint64_t)r.cur * 2; }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The 8-byte table without a search per slot (round 6).  A search is 8 DEPENDENT LDS reads per slot; with 4 slots a thread
+// (2,048 slots, 512 threads) that is 32 LDS round trips and ~140 vector instructions a wave per build — a 100 MB mt_ stream in
+// 64 KiB blocks builds ~3,000 tables a launch, a fifth of the launch's vector instructions (SQ_INSTS_VALU 21.3 M against the raw
+// stream's 17.5 M).  Instead: every symbol with a count marks its first slot with its own number (a byte per slot, kept in the
+// table's own first 2^bits bytes), and a slot's symbol is the largest mark at or before it — symbols ascend with the slots.  A
+// thread owns 4 or 8 CONSECUTIVE slots: the running maximum inside its marks, a wave-wide max-scan in DPP for the lanes before
+// it, and for the waves before it the symbol of the wave's first slot counted directly (the number of prefix sums <= that slot:
+// four ballots).  Four LDS round trips in all.  Same table as the search for every histogram that sums to 2^bits (the largest s
+// with cum[s] <= slot: zero-count symbols mark nothing); for the others the status bit is already raised and every index stays
+// in range (marks are symbols, slots beyond 2^bits are not marked).
+// ---------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr bool pack64_marks(uint32_t total, uint32_t nthreads)
+{
+  // a thread's run = 4 or 8 slots (its marks are held in two registers across the barrier that frees them for the table)
+  return (nthreads & (nthreads - 1)) == 0 && nthreads >= 64 && total >= 1024 && total / (nthreads < total / 4 ? nthreads : total / 4) <= 8;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t max_dpp(uint32_t v)
+{
+  const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true); // lanes without a source: 0
+  return v > o ? v : o;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) // inclusive, lanes 0 .. 63
+{
+  v = max_dpp<0x111, 0xF>(v); // row_shr:1
+  v = max_dpp<0x112, 0xF>(v); // row_shr:2
+  v = max_dpp<0x114, 0xF>(v); // row_shr:4
+  v = max_dpp<0x118, 0xF>(v); // row_shr:8
+  v = max_dpp<0x142, 0xA>(v); // row_bcast:15 into rows 1 and 3
+  v = max_dpp<0x143, 0xC>(v); // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ void pack64_zero_marks(uint2 *tab, uint32_t total, uint32_t tid, uint32_t nthreads)
+{
+  for (uint32_t q = tid; q < total / 4; q += nthreads)
+    ((uint32_t *)tab)[q] = 0;
+}
+// by the thread that holds four consecutive symbols' counts and the prefix sum before them (the marks are zero by now)
+__device__ __forceinline__ void pack64_mark4(uint2 *tab, uint32_t total, uint32_t s0, uint32_t excl, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3)
+{
+  uint8_t *mk = (uint8_t *)tab;
+  const uint32_t u0 = excl, u1 = u0 + c0, u2 = u1 + c1, u3 = u2 + c2;
+  if (c0 != 0 && u0 < total)
+    mk[u0] = (uint8_t)s0;
+  if (c1 != 0 && u1 < total)
+    mk[u1] = (uint8_t)(s0 + 1);
+  if (c2 != 0 && u2 < total)
+    mk[u2] = (uint8_t)(s0 + 2);
+  if (c3 != 0 && u3 < total)
+    mk[u3] = (uint8_t)(s0 + 3);
+}
+// marks, cnt[] and cum[] complete and visible -> the table; SYNC() between the last read of a mark and the first table store
+template <typename SYNC>
+__device__ __forceinline__ void pack64_from_marks(uint2 *tab, const uint16_t *cnt, const uint16_t *cum, uint32_t total, uint32_t tid, uint32_t nthreads, SYNC sync)
+{
+  const uint32_t active = nthreads < total / 4 ? nthreads : total / 4; // a multiple of 64: whole waves take part or not at all
+  const uint32_t per = total / active;                                  // 4 or 8 (pack64_marks)
+  const bool mine = tid < active;
+  uint32_t w0 = 0, w1 = 0, prev = 0; // all that is held across the barrier: the thread's marks and the largest mark before them
+  if (mine)
+  {
+    const uint32_t lane = tid & 63;
+    const uint32_t first = (tid - lane) * per; // the wave's first slot: its symbol = (number of s with cum[s] <= first) - 1
+    uint32_t before = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+      before += (uint32_t)__builtin_popcountll(__ballot((uint32_t)cum[64 * k + lane] <= first));
+    const uint32_t *mk = (const uint32_t *)tab + tid * (per / 4);
+    w0 = mk[0];
+    w1 = per == 8 ? mk[1] : 0;
+    uint32_t top = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++)
+    {
+      const uint32_t b = ((j < 4 ? w0 : w1) >> (8 * (j & 3))) & 0xFF;
+      top = b > top ? b : top;
+    }
+    const uint32_t incl = wave_scan_max(top);
+    prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138, 0xF, 0xF, true); // wave_shr:1: the lanes before this one (lane 0: 0)
+    const uint32_t base = before - 1;                                                   // cum[0] == 0 <= first: before >= 1
+    prev = prev > base ? prev : base;
+  }
+  sync(); // every mark has been read: the table may overwrite them
+  if (mine)
+  {
+    const uint32_t slot0 = tid * per;
+    uint32_t s = prev;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++)
+      if (j < per)
+      {
+        const uint32_t b = ((j < 4 ? w0 : w1) >> (8 * (j & 3))) & 0xFF;
+        s = b > s ? b : s;
+        tab[slot0 + j] = make_uint2((uint32_t)cnt[s] | (s << 24), slot0 + j - (uint32_t)cum[s]);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // decode table build (hist.cpp:291-306 make_dec_pack_hist, :356-384 inplace_make_hist_dec2, :308-324 the sum check)
 // `tid`/`nthreads` = the threads that share this table (one wave, or the whole workgroup); SYNC() orders their LDS traffic.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE, bool BLOCK_SYNC>
+template <int MODE, bool BLOCK_SYNC, bool MARKS = true> // MARKS false: the 8-byte table by a search per slot even where the marks apply (register budget of the caller)
 __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, uint32_t nthreads)
 {
   auto sync = [&]() {
@@ -441,8 +540,11 @@ __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, u
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // a stream request of the previous piece may still be landing in the scratch slot
   sync(); // scratch aliases a ring slot: everyone must be done with it
   const bool in_range = HSRANS_HIST_IN_RANGE(c, hist_off);
+  const bool marks = MARKS && MODE == kModePack64 && BLOCK_SYNC && pack64_marks(total, nthreads); // (uniform)
   for (uint32_t s = tid; s < 256; s += nthreads)
     cnt[s] = in_range ? *(const uint16_t *)(c.stream + hist_off + 2 * s) : (uint16_t)0;
+  if (marks)
+    pack64_zero_marks((uint2 *)c.table, total, tid, nthreads);
   sync();
   if (tid < 64)
   {
@@ -461,6 +563,8 @@ __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, u
     cum[4 * tid + 1] = (uint16_t)(excl + c0);
     cum[4 * tid + 2] = (uint16_t)(excl + c0 + c1);
     cum[4 * tid + 3] = (uint16_t)(excl + c0 + c1 + c2);
+    if (marks)
+      pack64_mark4((uint2 *)c.table, total, 4 * tid, excl, c0, c1, c2, c3);
     // uint32 sum must be exactly 2^bits, as inplace_complete_hist (hist.cpp:310); the decoder then returns 0.
     // A workgroup-shared build only raises the status bit and decodes on with the bogus table (every index stays
     // masked, so that is memory-safe; the host discards the output); a single-wave build stops its chain.
@@ -475,7 +579,9 @@ __device__ bool build_table(const WaveCtx &c, uint64_t hist_off, uint32_t tid, u
   // slot -> symbol: the largest s with cum[s] <= slot (zero-count symbols share cum with their successor and lose
   // the tie; trailing zero-count symbols sit at cum == total and are never hit) == hist.cpp:343-351
   // (the 8-byte table written by runs like the byte tables below — one search per thread — measured the same: 0.3715 against 0.370)
-  if (MODE == kModePack64)
+  if (MODE == kModePack64 && marks)
+    pack64_from_marks((uint2 *)c.table, cnt, cum, total, tid, nthreads, sync);
+  else if (MODE == kModePack64)
   {
     uint2 *tab = (uint2 *)c.table;
     for (uint32_t slot = tid; slot < total; slot += nthreads)

@@ -29,8 +29,11 @@ typedef const __attribute__((address_space(4))) Piece *kpiece_ptr;
 __device__ __forceinline__ void dealt_build(uint2 *tab, uint16_t *cnt, uint16_t *cum, uint32_t bits, uint32_t mine, uint32_t tid, uint32_t nthreads, uint32_t *status)
 {
   const uint32_t total = 1u << bits;
+  const bool marks = pack64_marks(total, nthreads); // (kernels_common.h: the table without a search per slot)
   if (tid < 256)
     cnt[tid] = (uint16_t)mine;
+  if (marks)
+    pack64_zero_marks(tab, total, tid, nthreads);
   __syncthreads();
   if (tid < 64)
   {
@@ -49,18 +52,23 @@ __device__ __forceinline__ void dealt_build(uint2 *tab, uint16_t *cnt, uint16_t 
     cum[4 * tid + 1] = (uint16_t)(excl + c0);
     cum[4 * tid + 2] = (uint16_t)(excl + c0 + c1);
     cum[4 * tid + 3] = (uint16_t)(excl + c0 + c1 + c2);
+    if (marks)
+      pack64_mark4(tab, total, 4 * tid, excl, c0, c1, c2, c3);
     if ((uint32_t)__shfl(incl, 63, 64) != total && tid == 0) // (hist.cpp:308-324: the decoder returns 0; here: status, the host discards the output)
       atomicOr(status, kStatusBadHist);
   }
   __syncthreads();
-  for (uint32_t slot = tid; slot < total; slot += nthreads)
-  {
-    uint32_t s = 0;
+  if (marks)
+    pack64_from_marks(tab, cnt, cum, total, tid, nthreads, []() { __syncthreads(); });
+  else
+    for (uint32_t slot = tid; slot < total; slot += nthreads)
+    {
+      uint32_t s = 0;
 #pragma unroll
-    for (uint32_t step = 128; step >= 1; step >>= 1)
-      s += ((uint32_t)cum[s + step] <= slot) ? step : 0;
-    tab[slot] = make_uint2((uint32_t)cnt[s] | (s << 24), slot - (uint32_t)cum[s]);
-  }
+      for (uint32_t step = 128; step >= 1; step >>= 1)
+        s += ((uint32_t)cum[s + step] <= slot) ? step : 0;
+      tab[slot] = make_uint2((uint32_t)cnt[s] | (s << 24), slot - (uint32_t)cum[s]);
+    }
   __syncthreads();
 }
 

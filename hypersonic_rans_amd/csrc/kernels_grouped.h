@@ -186,7 +186,7 @@ __device__ void run_grouped(const WaveCtx &c_in, const PlanView &pv_in, const KP
       run_tail_syms = uni(p1->tail);
     };
     if (!(flags & kGroupFill)) // (one call site: every inlined copy of the builder costs the kernel registers)
-      build_table<MODE, true>(c, uni64(G->hist_off), threadIdx.x, blockDim.x);
+      build_table<MODE, true, LEAN>(c, uni64(G->hist_off), threadIdx.x, blockDim.x); // (the general instantiation has no registers to spare for the marks)
     if (first >= last)
     {
       advance();
