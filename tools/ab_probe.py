@@ -12,6 +12,7 @@ import argparse
 import ctypes
 import json
 import os
+import re
 import shutil
 import sys
 import tempfile
@@ -70,7 +71,7 @@ for spec in a.variant:
     tag = parts[0]
     lib = parts[1] if len(parts) > 1 and parts[1] else "lib/libhsrans_hip.so"
     lib = lib if os.path.isabs(lib) else os.path.join(ROOT, "hypersonic_rans_amd", lib)
-    env = dict(kv.split("=", 1) for kv in parts[2].split(",")) if len(parts) > 2 and parts[2] else {}
+    env = dict(kv.split("=", 1) for kv in re.split(r",(?=[A-Z][A-Z0-9_]*=)", parts[2])) if len(parts) > 2 and parts[2] else {}  # (values may hold commas: weight lists)
     # a private copy of the file: dlopen of one path twice would give the SAME library instance (one set of tuning globals)
     private = os.path.join(tmpdir, f"{tag}.so")
     shutil.copy(lib, private)
