@@ -154,3 +154,44 @@ def test_dealt_launch_on_damaged_streams_and_plans(gpu_ctx):
     d_in = torch.from_numpy(np.concatenate([stream, np.zeros(pad, np.uint8)])).cuda()
     gpu_ctx.decode_device(dplan, d_in, d_out[:n], stream_length=stream.size)
     assert gpu_ctx.status(dplan) == 0 and np.array_equal(d_out[:n].cpu().numpy(), d)
+
+
+def _awkward(n: int, kind: str) -> np.ndarray:
+    rng = np.random.default_rng(len(kind))
+    if kind == "all_equal":      # 256 symbols, equal counts: every symbol's first slot 2^bits / 256 behind the last one's
+        return rng.integers(0, 256, n, dtype=np.uint8)
+    if kind == "ends":           # symbols 0 and 255 only: 254 zero counts between two marks
+        return np.where(rng.random(n) < 0.3, 0, 255).astype(np.uint8)
+    if kind == "one_heavy":      # one symbol nearly always, every other one rarely: 255 counts of 1 — a mark in every one of 255 neighbouring slots
+        d = np.full(n, 7, np.uint8)
+        pos = rng.choice(n, n // 400, replace=False)
+        d[pos] = rng.integers(0, 256, pos.size, dtype=np.uint8)
+        return d
+    if kind == "top_only":       # symbols 200 .. 255: no mark before slot 0's own symbol but 200 zero counts
+        return rng.integers(200, 256, n, dtype=np.uint8)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("bits", (10, 11, 12))
+@pytest.mark.parametrize("kind", ("all_equal", "ends", "one_heavy", "top_only"))
+def test_table_built_from_marks_on_awkward_histograms(gpu_ctx, oracle, bits, kind):
+    """The 8-byte table of a block is built on the device from MARKS (kernels_common.h pack64_from_marks: a symbol marks its first slot, a
+    slot's symbol is the largest mark at or before it) — 4 slots a thread in the grouped launch at 11 bits, 8 at 12 bits, 256 of its 512
+    threads at 10 bits, half a 1,024-thread workgroup per table in the dealt launch.  Histograms that stress the marks, against the oracle's
+    decode (hist.cpp:291-306 make_dec_pack_hist is what both restate): small streams take the grouped launch, the long ones the dealt one."""
+    import torch
+    for container, n, block, interval, dealt in ((H.MT, 2_000_003, 1 << 16, 16, False), (H.BLOCK, 1_500_000, 1 << 17, 8, False), (H.MT, 24_000_000, 1 << 18, 8, bits <= 11)):
+        d = _awkward(n, kind)
+        stream, plan = H.encode(container, 64, bits, d, index_interval=interval, block_size=block)
+        r, want = oracle.decode(MT if container == H.MT else BLOCK, 64, bits, stream, n)
+        assert r == n and np.array_equal(want, d)
+        dplan = gpu_ctx.make_device_plan(plan)
+        d_in = torch.from_numpy(np.concatenate([stream, np.zeros((-stream.size) % 16 + 16, np.uint8)])).cuda()
+        d_out = torch.full((n + 64,), 0xCC, dtype=torch.uint8, device="cuda")
+        gpu_ctx.decode_device(dplan, d_in, d_out[:n], stream_length=stream.size)
+        assert gpu_ctx.status(dplan) == 0
+        info = dplan.launch_info()
+        assert (info["spread"] == 2) == dealt, (info, n)
+        got = d_out.cpu().numpy()
+        assert np.array_equal(got[:n], want), (kind, bits, n, int(np.argmax(got[:n] != want)))
+        assert (got[n:] == 0xCC).all()
