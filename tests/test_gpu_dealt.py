@@ -172,15 +172,16 @@ def _awkward(n: int, kind: str) -> np.ndarray:
     raise ValueError(kind)
 
 
-@pytest.mark.parametrize("bits", (10, 11, 12))
+@pytest.mark.parametrize("bits", (10, 11, 12, 13, 14, 15))
 @pytest.mark.parametrize("kind", ("all_equal", "ends", "one_heavy", "top_only"))
 def test_table_built_from_marks_on_awkward_histograms(gpu_ctx, oracle, bits, kind):
     """The 8-byte table of a block is built on the device from MARKS (kernels_common.h pack64_from_marks: a symbol marks its first slot, a
     slot's symbol is the largest mark at or before it) — 4 slots a thread in the grouped launch at 11 bits, 8 at 12 bits, 256 of its 512
-    threads at 10 bits, half a 1,024-thread workgroup per table in the dealt launch.  Histograms that stress the marks, against the oracle's
+    threads at 10 bits, half a 1,024-thread workgroup per table in the dealt launch; from 13 bits the byte-per-slot table of the rank loop, a
+    mark per DWORD and the symbols that begin inside one patched in (rank_from_marks).  Histograms that stress the marks, against the oracle's
     decode (hist.cpp:291-306 make_dec_pack_hist is what both restate): small streams take the grouped launch, the long ones the dealt one."""
     import torch
-    for container, n, block, interval, dealt in ((H.MT, 2_000_003, 1 << 16, 16, False), (H.BLOCK, 1_500_000, 1 << 17, 8, False), (H.MT, 24_000_000, 1 << 18, 8, bits <= 11)):
+    for container, n, block, interval, dealt in ((H.MT, 2_000_003, 1 << 16, 16, False), (H.BLOCK, 1_500_000, 1 << 17, 8, False), (H.MT, 24_000_000, 1 << 18, 8, bits <= 11 or bits in (13, 14))):
         d = _awkward(n, kind)
         stream, plan = H.encode(container, 64, bits, d, index_interval=interval, block_size=block)
         r, want = oracle.decode(MT if container == H.MT else BLOCK, 64, bits, stream, n)
