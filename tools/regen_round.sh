@@ -18,4 +18,7 @@ STEPS=20 bash tools/profile.sh ${TAG}_dealt_100mb --workload sharded --size 1000
 # the mt_ GPU encoder's kernels (100 MB, 64 KiB blocks): trace only
 mkdir -p gpurun_out/prof_${TAG}_enc; TMPDIR=/tmp timeout -k 5 150 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_enc/trace -- python3 tools/debug/enc_once.py > gpurun_out/prof_${TAG}_enc/trace.log 2>&1
 mkdir -p gpurun_out/$TAG; cp $(find gpurun_out/prof_${TAG}_enc -name "*kernel_stats.csv" | head -1) gpurun_out/$TAG/encode_kernel_stats.csv
+# (on the box: the counter runs above condensed into profiles/ BEFORE bench.py runs, so that its line finds counters of these very kernels
+# and reports roofline.traffic / issue_bound / lds_bound from the same box; back in the container collect_round.py writes the same files again)
+python tools/collect_round.py $TAG > /dev/null 2>&1
 bash tools/round_measure.sh $TAG

@@ -81,17 +81,20 @@ for interval in args.interval:
 
     def run_world(world, parts):
         decs = [sharded.ShardedDecoder(ctx, plan, parts=parts, world=world, rank=r) for r in range(world)]
-        per_rank, infos = [], []
-        for dec in decs:
-            k = [0]
+        per_rank, infos = [1e30] * world, [None] * world
+        # two passes over the ranks, a rank's figure = the lower of its two medians: the first rank timed after `world` decoders were
+        # created read 10 us above the others in one regeneration (65.8 against 54.4-55.4) and like them when timed again
+        for _ in range(2):
+            for r, dec in enumerate(decs):
+                k = [0]
 
-            def step():
-                i = k[0] % COPIES
-                k[0] += 1
-                dec.decode(streams[i], outs[i], gather=False)
+                def step():
+                    i = k[0] % COPIES
+                    k[0] += 1
+                    dec.decode(streams[i], outs[i], gather=False)
 
-            per_rank.append(timed(step, args.launches, args.regions))
-            infos.append(dec.launch_info())
+                per_rank[r] = min(per_rank[r], timed(step, args.launches, args.regions))
+                infos[r] = dec.launch_info()
         # bit-exact: every rank once more into a cleared copy, then the whole output against the input
         outs[0].zero_()
         for dec in decs:
