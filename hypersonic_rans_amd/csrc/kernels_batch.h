@@ -28,7 +28,7 @@ __device__ __forceinline__ DirectPiece direct_run(const WaveCtx &c, const Persis
   DirectPiece d;
   d.words = p0[0];
   d.out = p0[1];
-  d.steps = (uint32_t)((p1[1] - d.out) / c.S) + ((kptr32)p1)[8];
+  d.steps = (uint32_t)groups_of(c.S, p1[1] - d.out) + ((kptr32)p1)[8];
   d.tail = ((kptr32)p1)[9] & 0xFFFFu;
   d.limit = last < pa.n_chains ? p1[6] : c.stream_len; // the piece behind the run's last one (Piece is 48 bytes), or the stream's end
   return d;

@@ -130,6 +130,35 @@ __device__ __forceinline__ void store_u128(u32x4 *ptr, u32x4 v)
     *ptr = v;
 }
 
+// Divisions the prologues can do without.  A 64-bit division is ~20 vector instructions behind a range check and ~100 when the operands
+// are wide, a v_rcp each, and every wave of every round did five of them (its share of the chains = weight x count / weights' sum, twice;
+// the run's groups = bytes / S): a third of what a grouped round issues outside its decode loop.
+//   groups_of(S, bytes): bytes / S for S = 32 or 64 (the two state counts there are)
+//   Recip / share_of: floor(a * n / d) with d's reciprocal taken once (host or kernel entry); exact while a * n < 2^32, else the division
+__device__ __forceinline__ uint64_t groups_of(uint32_t S, uint64_t bytes) { return S == 64 ? bytes >> 6 : S == 32 ? bytes >> 5 : bytes / S; }
+struct Recip
+{
+  uint32_t d, inv; // inv = floor((2^32 - 1) / d): __umulhi(n, inv) is n / d or one less for every n < 2^32
+};
+__host__ __device__ __forceinline__ Recip recip_of(uint32_t d)
+{
+  Recip r;
+  r.d = d ? d : 1;
+  r.inv = 0xFFFFFFFFu / r.d;
+  return r;
+}
+__device__ __forceinline__ uint32_t share_of(uint32_t a, uint32_t n, const Recip &r)
+{
+  const uint64_t wide = (uint64_t)a * n;
+  if (wide >> 32) // (more than a million chains in one unit: not a shape the launches that use this see, but exact when they do)
+    return (uint32_t)(wide / r.d);
+  const uint32_t v = (uint32_t)wide;
+  uint32_t q = __umulhi(v, r.inv);
+  if (v - q * r.d >= r.d)
+    q++;
+  return q;
+}
+
 // are the 512 bytes of a histogram at stream offset `off` there to be read?
 #define HSRANS_HIST_IN_RANGE(c, off) ((off) >= (c).stream_lo && (off) <= (c).stream_len && (c).stream_len - (off) >= 512)
 

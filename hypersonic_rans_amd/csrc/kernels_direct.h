@@ -126,7 +126,7 @@ __device__ __forceinline__ void run_direct_span(const WaveCtx &c, const KParams 
     if (HSRANS_STAMPS(kp))
       t_ready = __builtin_amdgcn_s_memrealtime();
     uint64_t o = d.out;
-    run_groups<MODE, true, false, true>(x, sw, r, c, o, (uint32_t)((run_end_out - o) / c.S));
+    run_groups<MODE, true, false, true>(x, sw, r, c, o, (uint32_t)groups_of(c.S, run_end_out - o));
     run_tail<MODE>(x, r, c, o, end == n ? last_tail : 0);
 #if HSRANS_HAVE_STAMPS
     diag_wait += r.diag_wait, diag_store += r.diag_store;

@@ -78,6 +78,9 @@ __device__ void run_grouped(const WaveCtx &c_in, const PlanView &pv_in, const KP
   // barrier r + 1.  Every workgroup draws once at the end of every round it runs, the launch as a whole exactly n_groups times:
   // ticket mod n_groups is the launch-local order whatever the counter has seen before (it is never reset).
   const bool dynamic = group_tickets != nullptr && n_groups > gridDim.x;
+  // (the shares' divisors, once per launch instead of two 64-bit divisions per round: kernels_common.h share_of)
+  const uint32_t half = blockIdx.x >= (gridDim.x + 1) / 2 ? 1 : 0;
+  const Recip by_weights = recip_of(uni(group_cum[half][waves])), by_waves = recip_of(waves);
   volatile uint32_t *lds_next = (volatile uint32_t *)(c.table + table_bytes_for(MODE, c.bits)); // 2 words: launch_shape reserves 64 bytes behind the table
   uint32_t gi = blockIdx.x;
   uint32_t prev_parts = 0xFFFFFFFFu; // PARTS: the sub-runs (first | last << 8) of the group this workgroup decoded in the previous round, not yet counted
@@ -162,12 +165,11 @@ __device__ void run_grouped(const WaveCtx &c_in, const PlanView &pv_in, const KP
       }
     };
 #endif
-    const uint32_t half = blockIdx.x >= (gridDim.x + 1) / 2 ? 1 : 0;
     // age-class weights only where a wave gets enough chains for them to mean something (else an even split)
     const bool weighted = count >= 8 * waves;
-    const uint32_t cum_all = weighted ? group_cum[half][waves] : waves;
-    const uint32_t first = begin + (uint32_t)((uint64_t)(weighted ? group_cum[half][wave] : wave) * count / cum_all);
-    const uint32_t last = begin + (uint32_t)((uint64_t)(weighted ? group_cum[half][wave + 1] : wave + 1) * count / cum_all);
+    const Recip &by = weighted ? by_weights : by_waves;
+    const uint32_t first = begin + share_of(weighted ? group_cum[half][wave] : wave, count, by);
+    const uint32_t last = begin + share_of(weighted ? group_cum[half][wave + 1] : wave + 1, count, by);
     // the wave's run of a mergeable 64-state group: chains [first, last) as one chain
     StreamWin sw;
     Ring r;
@@ -182,7 +184,7 @@ __device__ void run_grouped(const WaveCtx &c_in, const PlanView &pv_in, const KP
       win_open(sw, c, uni64(p0->words_off), limit);
       ring_begin(sw, r, c, uni64(p0->words_off));
       o = uni64(p0->out_off);
-      run_steps = (uni64(p1->out_off) - o) / c.S + uni(p1->steps);
+      run_steps = groups_of(c.S, uni64(p1->out_off) - o) + uni(p1->steps);
       run_tail_syms = uni(p1->tail);
     };
     if (!(flags & kGroupFill)) // (one call site: every inlined copy of the builder costs the kernel registers)

@@ -86,8 +86,9 @@ __device__ void run_spread(WaveCtx &c, const PlanView &pv, const KParams &kp, ui
   // the wave's chains: its age class's share of the workgroup's (kp.group_cum: the weights of the one-chain-per-wave launch)
   const uint32_t half = blockIdx.x >= (gridDim.x + 1) / 2 ? 1 : 0;
   const uint32_t cum_all = kp.group_cum[half][waves];
-  const uint32_t first = (uint32_t)((uint64_t)kp.group_cum[half][wave] * count / cum_all);
-  const uint32_t last = (uint32_t)((uint64_t)kp.group_cum[half][wave + 1] * count / cum_all);
+  const Recip by = recip_of(uni(cum_all));
+  const uint32_t first = share_of(kp.group_cum[half][wave], count, by);
+  const uint32_t last = share_of(kp.group_cum[half][wave + 1], count, by);
   // a run: chains [i, e) of one block, back to back in stream and output; `limit` = the first stream byte it cannot need: the next
   // chain's cursor when that continues the block, else the next block's histogram (a block's words end before the next block's
   // header), else the end of the stream
@@ -146,7 +147,7 @@ __device__ void run_spread(WaveCtx &c, const PlanView &pv, const KParams &kp, ui
     win_open(sw, c, uni64(p0->words_off), limit);
     ring_begin(sw, r, c, uni64(p0->words_off));
     uint64_t o = uni64(p0->out_off);
-    const uint64_t run_steps = (uni64(p1->out_off) - o) / c.S + uni(p1->steps);
+    const uint64_t run_steps = groups_of(c.S, uni64(p1->out_off) - o) + uni(p1->steps);
     const uint32_t run_tail_syms = uni(p1->tail);
     ring_ready(x);
     run_groups<MODE, true, true, PARTS, PARTS>(x, sw, r, c, o, (uint32_t)run_steps); // (write-through stores, counted waits: no difference here)
